@@ -1,0 +1,94 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # `-m gpu` on a box without a GPU is a configuration error, not a skip: fail loudly.
+    pass
+
+
+class Fixture:
+    """One tests/golden/<name>.npz written by tests/golden/make_golden.py."""
+
+    def __init__(self, name):
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+    def group(self, prefix, device="cpu"):
+        out = {}
+        for k in self.z.files:
+            if k.startswith(prefix + "/"):
+                out[k[len(prefix) + 1:]] = torch.from_numpy(self.z[k]).to(device)
+        return out
+
+    def __getitem__(self, k):
+        return self.z[k]
+
+    @property
+    def opt(self):
+        from tvqaplus_amd.synth import make_opt
+        return make_opt(**json.loads(str(self.z["opt"])))
+
+    @property
+    def mode(self):
+        return str(self.z["mode"])
+
+    def batch(self, device="cpu"):
+        from tvqaplus_amd.synth import Batch
+        i = self.group("in", device)
+        N = i["target"].shape[0]
+        Li = i["ts_label_mask"].shape[1]
+        return Batch(qas_bert=i["qas_bert"], qas_mask=i["qas_mask"], sub_bert=i["sub_bert"], sub_mask=i["sub_mask"],
+                     vid=i["vid"], vid_mask=i["vid_mask"], target=i["target"],
+                     ts_label=dict(st=i["ts_label_st"], ed=i["ts_label_ed"]), ts_label_mask=i["ts_label_mask"],
+                     qid=list(range(N)), vid_name=["v%d" % k for k in range(N)],
+                     qas=torch.zeros(N, 5, i["qas_mask"].shape[2], dtype=torch.long, device=device), att_labels=None,
+                     anno_st_idx=[0] * N, q_l=[1] * N, image_indices=[list(range(Li)) for _ in range(N)],
+                     boxes=[[] for _ in range(N)], use_hard_negatives=False, eval_object_word_ids=[])
+
+
+MODEL_CASES = ["tiny_eval", "tiny_inference", "tiny_train", "tiny_train_local", "small_local_eval",
+               "small_local_train", "small_heads_train", "small_heads_eval", "small_subonly_train",
+               "small_vidonly_train", "mid_train", "mid_eval"]
+K1_CASES = ["k1_small", "k1_mid", "k1_sub"]
+ENC_CASES = ["enc_k7", "enc_k5_heads"]
+
+
+def max_err(a, b):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.numel() == 0:
+        return 0.0
+    return float((a - b).abs().max())
+
+
+def rel_err(a, b):
+    """max |a-b| / (1 + max|b|): absolute near zero, relative for large (e.g. -1e10 mask constants)."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.numel() == 0:
+        return 0.0
+    return float(((a - b).abs() / (1.0 + b.abs())).max())
+
+
+@pytest.fixture(scope="session")
+def hip_device():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU (torch.cuda.is_available() is False)")
+    return torch.device("cuda:0")

@@ -1,0 +1,171 @@
+#!/usr/bin/env python
+"""Generate golden vectors by IMPORTING the reference (read-only) in the build container.
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+The reference Python never travels to the GPU box; these fixtures (inputs + expected outputs, data only)
+do.  Each .npz holds: ``opt`` (JSON), ``param/<state_dict key>``, ``in/<batch key>``, ``out/<name>`` and, for
+train cases, ``grad/<state_dict key>`` of  CE_sum*N/N_new + 0.5*temporal_loss  (main.py:55-60 without the
+att-loss term).  All parameters are perturbed away from their default init (LN affine != identity) so every
+term is exercised.  Dropout: opt.dropout=0 for train cases and the MultiHeadedAttention p=0.1 dropout module
+is set to p=0 in memory (the reference files are not edited).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("TVQA_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(REF, "model"))  # model/stage.py uses py2 implicit-relative imports
+sys.path.insert(0, REF)
+
+from model.stage import STAGE as RefSTAGE  # noqa: E402
+from model.context_query_attention import StructuredAttention as RefSA  # noqa: E402
+from model.encoder import StackedEncoder as RefEnc  # noqa: E402
+
+from tvqaplus_amd.synth import make_batch, make_opt  # noqa: E402
+
+
+def perturb(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            p.add_(0.15 * torch.randn(p.shape, generator=g) * (p.abs().mean() + 0.1))
+
+
+def np32(t):
+    return t.detach().cpu().numpy()
+
+
+def run_case(name, opt_kw, batch_kw, mode, seed):
+    torch.manual_seed(seed)
+    opt = make_opt(**opt_kw)
+    model = RefSTAGE(opt)
+    perturb(model, seed + 1)
+    for m in model.modules():  # fixed p=0.1 attention dropout -> 0 so train-mode outputs are deterministic
+        if isinstance(m, torch.nn.Dropout) and mode == "train":
+            m.p = 0.0
+    batch = make_batch(seed=seed + 2, wd_size=opt.embedding_size, vfeat_size=opt.vfeat_size, **batch_kw)
+    rec = {"opt": np.array(json.dumps(vars(opt))), "mode": np.array(mode),
+           "batch_kw": np.array(json.dumps(batch_kw))}
+    for k, v in model.state_dict().items():
+        rec["param/" + k] = np32(v)
+    for k in ("qas_bert", "qas_mask", "sub_bert", "sub_mask", "vid", "vid_mask", "target", "ts_label_mask"):
+        rec["in/" + k] = np32(batch[k])
+    rec["in/ts_label_st"], rec["in/ts_label_ed"] = np32(batch.ts_label["st"]), np32(batch.ts_label["ed"])
+
+    if mode == "train":
+        model.train()
+        (out, targets), att_loss, _, t_loss, t_scores, other = model.forward_main(batch)
+        loss = torch.nn.functional.cross_entropy(out, targets, reduction="sum") * (len(batch.qid) / len(targets)) \
+            + 0.5 * t_loss
+        loss.backward()
+        rec["out/logits"], rec["out/targets"] = np32(out), np32(targets)
+        rec["out/temporal_loss"], rec["out/t_scores"], rec["out/loss"] = np32(t_loss), np32(t_scores), np32(loss)
+        for k, p in model.named_parameters():
+            rec["grad/" + k] = np32(p.grad) if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+    elif mode == "eval":
+        model.eval()
+        with torch.no_grad():
+            out, att_loss, _, t_loss, t_prob, other = model.forward_main(batch)
+        rec["out/logits"], rec["out/temporal_loss"], rec["out/t_prob"] = np32(out), np32(t_loss), np32(t_prob)
+        rec["out/t_scores"] = np32(other["temporal_scores"])
+    elif mode == "inference":
+        model.eval()
+        model.inference_mode = True
+        with torch.no_grad():
+            res = model(batch)
+        rec["out/logits"], rec["out/t_prob"] = np32(res["answer"]), np32(res["t_scores"])
+        other = {}
+    for k in ("sub_raw_s", "sub_normalized_s", "vid_raw_s", "vid_normalized_s"):
+        if k in other:
+            rec["out/" + k] = np32(other[k])
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print("%-28s %8.1f KB" % (name, os.path.getsize(path) / 1024))
+
+
+def k1_case(name, N, Li, Lr, Lqa, D, seed, scale=10.0):
+    """StructuredAttention alone (model/context_query_attention.py:35-101), eval mode, with gradients."""
+    g = torch.Generator().manual_seed(seed)
+    C = torch.randn(N, 5, 1, Lqa, D, generator=g).requires_grad_()
+    Q = torch.randn(N, 1, Li, Lr, D, generator=g).requires_grad_()
+    b = make_batch(N=N, Li=Li, Lr=Lr, Lw=2, Lqa=Lqa, wd_size=4, vfeat_size=4, seed=seed, empty_frames=True)
+    c_mask, q_mask = b.qas_mask.view(N, 5, 1, Lqa), b.vid_mask.view(N, 1, Li, Lr)
+    with torch.no_grad():  # zero-norm rows exercise the 1e-12 clamp of F.normalize
+        C[0, 1, 0, 0].zero_()
+        Q[0, 0, 0, 1].zero_()
+    sa = RefSA(dropout=0.1, scale=scale).eval()
+    A, S, S_mask, S_ = sa(C, Q, c_mask, q_mask)
+    gA = torch.randn(A.shape, generator=g)
+    gS = torch.randn(S.shape, generator=g) * 0.1
+    gSn = torch.randn(S_.shape, generator=g) * 0.1
+    ((A * gA).sum() + (S * gS).sum() + (S_ * gSn).sum()).backward()
+    rec = dict(C=np32(C), Q=np32(Q), c_mask=np32(c_mask), q_mask=np32(q_mask), scale=np.float32(scale),
+               A=np32(A), S=np32(S), S_mask=np32(S_mask), S_norm=np32(S_), gA=np32(gA), gS=np32(gS), gSn=np32(gSn),
+               dC=np32(C.grad), dQ=np32(Q.grad))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print("%-28s %8.1f KB" % (name, os.path.getsize(path) / 1024))
+
+
+def encoder_case(name, M, L, D, k, n_conv, nh, seed):
+    """StackedEncoder alone (model/encoder.py:66-74) incl. the MHA query-row mask quirk, eval, with grads."""
+    torch.manual_seed(seed)
+    enc = RefEnc(n_blocks=1, n_conv=n_conv, kernel_size=k, hidden_size=D, dropout=0.1, num_heads=nh).eval()
+    perturb(enc, seed + 1)
+    g = torch.Generator().manual_seed(seed + 2)
+    x = torch.randn(M, L, D, generator=g).requires_grad_()
+    lens = torch.randint(0, L + 1, (M,), generator=g)
+    lens[0] = L
+    mask = (torch.arange(L).unsqueeze(0) < lens.unsqueeze(1)).float()
+    y = enc(x, mask)
+    gy = torch.randn(y.shape, generator=g)
+    (y * gy).sum().backward()
+    rec = dict(x=np32(x), mask=np32(mask), y=np32(y), gy=np32(gy), dx=np32(x.grad),
+               cfg=np.array(json.dumps(dict(k=k, n_conv=n_conv, nh=nh))))
+    for kk, v in enc.state_dict().items():
+        rec["param/" + kk] = np32(v)
+    for kk, p in enc.named_parameters():
+        rec["grad/" + kk] = np32(p.grad)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print("%-28s %8.1f KB" % (name, os.path.getsize(path) / 1024))
+
+
+TINY = dict(N=2, Li=2, Lr=4, Lw=5, Lqa=6)          # BASELINE.json config 1 (D=16)
+SMALL = dict(N=3, Li=7, Lr=5, Lw=9, Lqa=8, empty_frames=True)
+MID = dict(N=2, Li=6, Lr=20, Lw=50, Lqa=40)        # full per-frame shapes, D=128
+
+
+def main():
+    run_case("tiny_eval", dict(hsz=16, embedding_size=64), TINY, "eval", 11)
+    run_case("tiny_inference", dict(hsz=16, embedding_size=64), TINY, "inference", 11)
+    run_case("tiny_train", dict(hsz=16, dropout=0.0), TINY, "train", 12)
+    run_case("tiny_train_local", dict(hsz=16, embedding_size=64, dropout=0.0, add_local=True), TINY, "train", 13)
+    run_case("small_local_eval", dict(hsz=32, embedding_size=48, vfeat_size=40, add_local=True), SMALL, "eval", 21)
+    run_case("small_local_train", dict(hsz=32, embedding_size=48, vfeat_size=40, add_local=True, dropout=0.0),
+             SMALL, "train", 22)
+    run_case("small_heads_train", dict(hsz=32, embedding_size=48, vfeat_size=40, add_local=True, dropout=0.0,
+                                       input_encoder_n_heads=2, cls_encoder_n_heads=4, t_iter=1), SMALL, "train", 23)
+    run_case("small_heads_eval", dict(hsz=32, embedding_size=48, vfeat_size=40, input_encoder_n_heads=2,
+                                      cls_encoder_n_heads=4, t_iter=1), SMALL, "eval", 24)
+    run_case("small_subonly_train", dict(hsz=32, embedding_size=48, vfeat_flag=False, dropout=0.0), SMALL, "train", 25)
+    run_case("small_vidonly_train", dict(hsz=32, embedding_size=48, vfeat_size=40, sub_flag=False, dropout=0.0,
+                                         add_local=True), SMALL, "train", 26)
+    run_case("mid_train", dict(hsz=128, embedding_size=96, vfeat_size=64, dropout=0.0, add_local=True), MID, "train", 31)
+    run_case("mid_eval", dict(hsz=128, embedding_size=96, vfeat_size=64, add_local=True), MID, "eval", 32)
+    k1_case("k1_small", N=2, Li=3, Lr=5, Lqa=7, D=16, seed=41)
+    k1_case("k1_mid", N=2, Li=5, Lr=20, Lqa=40, D=128, seed=42)
+    k1_case("k1_sub", N=1, Li=3, Lr=50, Lqa=40, D=128, seed=43)
+    encoder_case("enc_k7", M=5, L=20, D=32, k=7, n_conv=2, nh=0, seed=51)
+    encoder_case("enc_k5_heads", M=6, L=11, D=32, k=5, n_conv=2, nh=4, seed=52)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,87 @@
+"""Pins the CPU oracle (oracle/stage_oracle.py) against golden vectors produced by the imported reference.
+
+Tolerance: the oracle re-expresses the same fp32 torch arithmetic, so it must agree to rounding
+(1e-5 relative-to-(1+|x|)); the north-star tolerance for the HIP path (1e-3) is applied in the -m gpu tests."""
+import json
+
+import pytest
+import torch
+
+from conftest import ENC_CASES, K1_CASES, MODEL_CASES, Fixture, rel_err
+from oracle import stage_oracle as O
+
+TOL = 1e-5
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_whole_model(name):
+    fx = Fixture(name)
+    P = fx.group("param")
+    exp = fx.group("out")
+    train = fx.mode == "train"
+    if train:
+        P = {k: (v.clone().requires_grad_() if v.is_floating_point() and not k.endswith(".pe") else v)
+             for k, v in P.items()}
+    batch = fx.batch()
+    opt = fx.opt
+    opt.mha_dropout = 0.0  # fixtures were generated with the MHA dropout module's p set to 0
+    with torch.set_grad_enabled(train):
+        out = O.stage_forward(P, opt, batch, training=train)
+    assert rel_err(out["logits"], exp["logits"]) < TOL
+    if "targets" in exp:
+        assert torch.equal(out["targets"], exp["targets"])
+    if "t_scores" in exp:
+        assert rel_err(out["t_scores"], exp["t_scores"]) < TOL
+    if "t_prob" in exp:
+        assert rel_err(torch.softmax(out["t_scores"], dim=2), exp["t_prob"]) < TOL
+    if "temporal_loss" in exp:
+        assert rel_err(out["temporal_loss"], exp["temporal_loss"]) < TOL
+    for k in ("sub_raw_s", "sub_normalized_s", "vid_raw_s", "vid_normalized_s"):
+        if k in exp:
+            assert rel_err(out[k], exp[k]) < TOL, k
+    if train:
+        loss = O.training_loss(out, n_examples=batch.target.shape[0])
+        assert rel_err(loss, exp["loss"]) < TOL
+        loss.backward()
+        G = fx.group("grad")
+        for k, g in G.items():
+            got = P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])
+            assert rel_err(got, g) < 2e-5, k
+
+
+@pytest.mark.parametrize("name", K1_CASES)
+def test_structured_attention(name):
+    fx = Fixture(name)
+    C = torch.from_numpy(fx["C"]).requires_grad_()
+    Q = torch.from_numpy(fx["Q"]).requires_grad_()
+    cm, qm = torch.from_numpy(fx["c_mask"]), torch.from_numpy(fx["q_mask"])
+    A, S, S_mask, S_ = O.structured_attention(C, Q, cm, qm, float(fx["scale"]))
+    assert rel_err(A, torch.from_numpy(fx["A"])) < TOL
+    assert rel_err(S, torch.from_numpy(fx["S"])) < TOL
+    assert torch.equal(S_mask, torch.from_numpy(fx["S_mask"]))
+    assert rel_err(S_, torch.from_numpy(fx["S_norm"])) < TOL
+    ((A * torch.from_numpy(fx["gA"])).sum() + (S * torch.from_numpy(fx["gS"])).sum()
+     + (S_ * torch.from_numpy(fx["gSn"])).sum()).backward()
+    assert rel_err(C.grad, torch.from_numpy(fx["dC"])) < 2e-5
+    assert rel_err(Q.grad, torch.from_numpy(fx["dQ"])) < 2e-5
+
+
+@pytest.mark.parametrize("name", ENC_CASES)
+def test_encoder(name):
+    fx = Fixture(name)
+    cfg = json.loads(str(fx["cfg"]))
+    P = {"enc." + k: v.requires_grad_(not k.endswith(".pe")) for k, v in fx.group("param").items()}
+    x = torch.from_numpy(fx["x"]).requires_grad_()
+    y = O.stacked_encoder(x, torch.from_numpy(fx["mask"]), P, "enc", 1, cfg["n_conv"], cfg["nh"], 0.1, False)
+    assert rel_err(y, torch.from_numpy(fx["y"])) < TOL
+    (y * torch.from_numpy(fx["gy"])).sum().backward()
+    assert rel_err(x.grad, torch.from_numpy(fx["dx"])) < 2e-5
+    for k, g in fx.group("grad").items():
+        assert rel_err(P["enc." + k].grad, g) < 2e-5, k
+
+
+def test_position_table_beyond_500():
+    """The reference crashes for L > 500 (max_len); the oracle continues the same closed form."""
+    tab = O.position_table({}, "none", 600, 32)
+    ref = O.position_table({}, "none", 500, 32)
+    assert torch.equal(tab[:500], ref)
