@@ -1,0 +1,124 @@
+/*
+ * stage_hip.h -- C ABI of libstage_hip.so: the MI355X (gfx950) kernels behind model.stage.STAGE's forward/backward.
+ *
+ * The reference (jayleicn/TVQAplus) is pure Python/PyTorch and has no FFI; the boundary a maintainer binds is the
+ * set of fused-op groups that STAGE.forward_main executes.  Every entry point below
+ * names the reference lines (relative to the reference repo root) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - all tensors are dense row-major fp32 device pointers (masks are fp32 0/1 like the reference's); `int*` where said
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call is asynchronous on that stream
+ *   - return value: 0 on success, a hipError_t (>0) from a failed launch, or a negative STAGE_ERR_* code
+ *   - dropout is counter based: (seed, element index) -> keep/drop, so the backward entry points regenerate the
+ *     forward mask from the same seed; p_drop = 0 disables it (eval mode)
+ *   - `ws`/`ws_bytes`: caller-provided device scratch, size from the matching *_ws_bytes() query
+ *   - reductions are two-stage with a fixed summation order: results are run-to-run deterministic
+ */
+#ifndef STAGE_HIP_H
+#define STAGE_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STAGE_ERR_SHAPE (-1)      /* unsupported shape (e.g. width not a multiple of 4 / 16, Lr > 64) */
+#define STAGE_ERR_WORKSPACE (-2)  /* workspace too small */
+
+/* ---- library info -------------------------------------------------------------------------------------------- */
+int stage_hip_abi_version(void);
+const char* stage_hip_error_string(int code);
+
+/* ---- K1: StructuredAttention (model/context_query_attention.py:35-101, called at model/stage.py:378) ----------
+ * Cn      (N, NA, Lqa, D)  L2-normalised (+dropout) QA/context side, produced by stage_l2norm_fwd
+ * Q       (N, Li, Lr, D)   raw region / subtitle-word side (normalised + dropped in-kernel for the similarity,
+ *                          used raw for the weighted sum, line 81)
+ * c_mask  (N, NA, Lqa), q_mask (N, Li, Lr)
+ * A       (N, NA, Li, Lqa, D) ; S_raw, S_norm (N, NA, Li, Lqa, Lr)   (raw_s / s_normalized of model/stage.py:378-380)
+ * limits: D % 16 == 0, D <= 256, Lr <= 64, NA*Lqa <= 256                                                        */
+int stage_str_attn_fwd(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A,
+                       float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D, float scale,
+                       float p_drop, unsigned long long seed, void* stream);
+size_t stage_str_attn_bwd_ws_bytes(int N, int NA, int Lqa, int D);
+/* dA (like A), dS_raw_ext (like S_raw, may be NULL: gradient arriving on raw_s from the attention loss),
+ * Qn = stage_l2norm_fwd(Q) with the forward seed.  Outputs: dS_out (like S_raw; scratch + gradient wrt raw scores),
+ * dQraw, dQn (N, Li, Lr, D) (value path / normalised path), dCn (N, NA, Lqa, D).                                 */
+int stage_str_attn_bwd(const float* dA, const float* dS_raw_ext, const float* Cn, const float* Q, const float* Qn,
+                       const float* S_norm, float* dS_out, float* dQraw, float* dQn, float* dCn, int N, int NA, int Li,
+                       int Lqa, int Lr, int D, float scale, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- F.normalize(p=2, eps) (+dropout)  (model/stage.py:256, model/context_query_attention.py:95-96) ----------- */
+int stage_l2norm_fwd(const float* x, float* y, float* norm_out /*may be NULL*/, long long rows, int K, float eps,
+                     float p_drop, unsigned long long seed, void* stream);
+int stage_l2norm_bwd(const float* dy, const float* x, float* dx, long long rows, int K, float eps, float p_drop,
+                     unsigned long long seed, int accumulate, void* stream);
+
+/* ---- nn.LayerNorm(K, eps) followed by nn.Dropout(p)  (model/stage.py:85-120,133-138, LinearWrapper :15-32,
+ *      model/encoder.py:37-41,47,52).  K % 4 == 0, K <= 1024.  mean/rstd (rows) are saved for the backward.
+ * Fused prologue: y = drop(LN(x + res)); res may be NULL.  res_period = 0: res is (rows, K) -- the residual adds of
+ * model/encoder.py:44,50 and model/stage.py:478; res_period = L: res is the (>=L, K) position table and row r uses
+ * res[r % L] (model/position_encoding.py:38-43).  sum_out (rows, K), if not NULL, receives x + res.
+ * In the backward, dx may be NULL when the input needs no gradient (raw features).                            ---- */
+int stage_layernorm_fwd(const float* x, const float* res, int res_period, float* sum_out, const float* gamma,
+                        const float* beta, float* y, float* mean, float* rstd, long long rows, int K, float eps,
+                        float p_drop, unsigned long long seed, void* stream);
+size_t stage_ln_bwd_ws_bytes(int K);
+/* dx = LN-backward(dy) + dx_add (dx_add may be NULL: gradient that reached the exported sum x + res directly) */
+int stage_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                        float* dx, const float* dx_add, float* dgamma, float* dbeta, long long rows, int K,
+                        float p_drop, unsigned long long seed, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- LayerNorm(3D) over the virtual row cat([a, b, a*b])  (model/stage.py:276-279 concat_fc, :381-385 c2q) -----
+ * a may be broadcast over `rep` (the Li frames): a_row = (row / (rep*inner)) * inner + row % inner; rep = 1: none.
+ * y (rows, 3D).  Backward returns da_full (rows, D) NOT yet reduced over rep (use stage_reduce_rep) and db (rows, D);
+ * ws sized by stage_ln_bwd_ws_bytes(3*D).  D % 4 == 0, D <= 256.                                                  */
+int stage_cat3_layernorm_fwd(const float* a, const float* b, const float* gamma, const float* beta, float* y,
+                             float* mean, float* rstd, long long rows, int D, int rep, int inner, float eps,
+                             float p_drop, unsigned long long seed, void* stream);
+int stage_cat3_layernorm_bwd(const float* dy, const float* a, const float* b, const float* mean, const float* rstd,
+                             const float* gamma, float* da_full, float* db, float* dgamma, float* dbeta, long long rows,
+                             int D, int rep, int inner, float p_drop, unsigned long long seed, void* ws,
+                             size_t ws_bytes, void* stream);
+/* out[g, inner_elems] = sum_{r<rep} in[g, r, inner_elems]  (gradient of a `.repeat`/broadcast, model/stage.py:381) */
+int stage_reduce_rep(const float* in, float* out, long long groups, int rep, long long inner_elems, void* stream);
+
+/* ---- nn.Linear / 1x1 Conv1d on the matrix cores (fp32 in, fp32 accumulate, exact f32 MFMA) --------------------
+ * Y[M,N] = epi((X .* [gate>0])[M,K] . W[N,K]^T + bias) ; epi: optional ReLU then optional + residual[M,N].
+ * (model/stage.py:88,101,110,117,136; LinearWrapper :23; model/cnn.py:27-28,44-46; model/self_attention.py:32,46,54)
+ * `gate` (M,K) fuses a ReLU backward on the input operand (dX = (dY .* [Y>0]) . W with W passed transposed).       */
+int stage_gemm_nt(const float* X, const float* gate, const float* W, const float* bias, const float* residual, float* Y,
+                  long long M, int N, int K, int relu, void* stream);
+/* dW[N,K] = sum_m (dY .* [gate>0])[m,n] X[m,k] ; db[N] = column sums (db may be NULL)                              */
+size_t stage_gemm_tn_ws_bytes(long long M, int N, int K);
+int stage_gemm_tn(const float* dY, const float* gate, const float* X, float* dW, float* db, long long M, int N, int K,
+                  void* ws, size_t ws_bytes, void* stream);
+
+/* ---- encoder block pieces (model/encoder.py:35-44, model/position_encoding.py:38-43, model/cnn.py:23-26,44) ---- */
+int stage_add_pe(const float* x, const float* pe /*(>=L, D)*/, float* y, long long M, int L, int D, void* stream);
+int stage_dwconv_fwd(const float* in, const float* w /*(D,1,k)*/, const float* bias, float* out, long long M, int L,
+                     int D, int k, void* stream);
+size_t stage_dwconv_bwd_ws_bytes(int D, int k);
+int stage_dwconv_bwd(const float* dout, const float* in, const float* w, float* din, float* dw, float* db, long long M,
+                     int L, int D, int k, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- multi-head self-attention core (model/self_attention.py:56-71) with the query-row mask quirk --------------
+ * q,k,v,out: (M, L, D) with heads interleaved along D (head h = columns [h*dk, (h+1)*dk)); mask (M, L);
+ * probs (M, nh, L, L) saved for the backward (post-softmax, pre-dropout).  L <= 64.                              */
+int stage_mha_core_fwd(const float* q, const float* k, const float* v, const float* mask, float* out, float* probs,
+                       long long M, int L, int D, int nh, float p_drop, unsigned long long seed, void* stream);
+int stage_mha_core_bwd(const float* dout, const float* q, const float* k, const float* v, const float* probs,
+                       const float* mask, float* dq, float* dk, float* dv, long long M, int L, int D, int nh,
+                       float p_drop, unsigned long long seed, void* stream);
+
+/* ---- mask_logits + max over a sequence axis (model/stage.py:503, 425, 429-432, 456-461, 532-533) ---------------
+ * x (R, L, D), mask (R, L), window (R, 2) int [st, ed) or NULL for the whole axis -> out (R, D), argmax (R, D) int */
+int stage_masked_max_fwd(const float* x, const float* mask, const int* window, float* out, int* argmax, long long R,
+                         int L, int D, void* stream);
+int stage_masked_max_bwd(const float* dout, const int* argmax, const float* mask, float* dx, long long R, int L, int D,
+                         int accumulate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STAGE_HIP_H */

@@ -1,0 +1,110 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/stage_hip.h
+declares, the ctypes signatures mirror the header, and the STAGE class has the reference's parameter schema."""
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+from conftest import MODEL_CASES, ROOT, Fixture
+
+HEADER = os.path.join(ROOT, "include", "stage_hip.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(int|size_t|const char\*)\s+(stage_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = [a.strip() for a in m.group(3).split(",")]
+        if args == ["void"]:
+            args = []
+        out[m.group(2)] = (m.group(1), args)
+    return out
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from tvqaplus_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.check_call(["make", "-C", ROOT, "-j8"], stdout=subprocess.DEVNULL)
+    return _lib
+
+
+def test_header_symbols_exported(built_lib):
+    lib = built_lib.load()
+    decl = _declared()
+    assert len(decl) >= 24
+    for name in decl:
+        assert hasattr(lib, name), name
+    assert lib.stage_hip_abi_version() == 1
+    assert lib.stage_hip_error_string(-1).decode().startswith("stage_hip")
+
+
+def test_ctypes_signatures_match_header(built_lib):
+    import ctypes
+    decl = _declared()
+    assert set(decl) == set(built_lib.SIGNATURES), set(decl) ^ set(built_lib.SIGNATURES)
+
+    def kind(c_arg: str):
+        c_arg = c_arg.strip()
+        if "*" in c_arg:
+            return ctypes.c_void_p
+        base = re.sub(r"\b\w+$", "", c_arg).strip() or c_arg  # drop the parameter name
+        return {"int": ctypes.c_int, "float": ctypes.c_float, "long long": ctypes.c_longlong,
+                "unsigned long long": ctypes.c_ulonglong, "size_t": ctypes.c_size_t}[base]
+
+    for name, (ret, args) in decl.items():
+        res, argtypes = built_lib.SIGNATURES[name]
+        assert len(args) == len(argtypes), name
+        for i, (a, t) in enumerate(zip(args, argtypes)):
+            assert kind(a) is t, (name, i, a, t)
+        exp_ret = {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "const char*": ctypes.c_char_p}[ret]
+        assert res is exp_ret, name
+
+
+def test_workspace_queries_need_no_gpu(built_lib):
+    lib = built_lib.load()
+    assert lib.stage_ln_bwd_ws_bytes(384) >= 2 * 384 * 4
+    assert lib.stage_gemm_tn_ws_bytes(960000, 128, 384) >= 128 * 384 * 4
+    assert lib.stage_dwconv_bwd_ws_bytes(128, 7) >= 8 * 128 * 4
+    assert lib.stage_str_attn_bwd_ws_bytes(16, 5, 40, 128) >= 16 * 5 * 40 * 128 * 4
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_state_dict_schema_matches_reference(name):
+    """Keys, shapes and buffer values of the drop-in class == the reference's state_dict stored in the fixture."""
+    from tvqaplus_amd.stage import STAGE
+    fx = Fixture(name)
+    model = STAGE(fx.opt)
+    ref = fx.group("param")
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    for k, v in ref.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+        if k.endswith("position_encoding.pe"):
+            assert torch.equal(sd[k], v), k
+    model.load_state_dict(ref, strict=True)
+    assert model.inference_mode is False and model.num_a == 5 and model.bridge_hsz == 300
+
+
+def test_product_refuses_cpu_tensors():
+    from tvqaplus_amd import ops
+    from tvqaplus_amd._lib import StageHipError
+    with pytest.raises(StageHipError):
+        ops.layernorm(torch.randn(4, 16), torch.ones(16), torch.zeros(16))
+    with pytest.raises(StageHipError):
+        ops.structured_attention(torch.randn(1, 5, 4, 16), torch.randn(1, 2, 3, 16), torch.ones(1, 5, 4),
+                                 torch.ones(1, 2, 3), 10.0)
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under tvqaplus_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "tvqaplus_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "stage_oracle" not in src, f

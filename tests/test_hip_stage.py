@@ -1,0 +1,155 @@
+"""-m gpu: the drop-in STAGE module (HIP path) against (a) the golden vectors captured from the reference and
+(b) the CPU oracle on fresh seeded batches, outputs and parameter gradients.  Tolerance 1e-3 (north star)."""
+import json
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import ENC_CASES, MODEL_CASES, Fixture, rel_err
+from oracle import stage_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+GTOL = 2e-3  # gradients of a ~10-layer fp32 chain, relative to (1 + |g|)
+
+
+def _model_from(fx, device):
+    from tvqaplus_amd.stage import STAGE
+    model = STAGE(fx.opt)
+    missing = model.load_state_dict(fx.group("param"), strict=True)
+    model.mha_dropout_override = 0.0  # fixtures were generated with the fixed MHA dropout zeroed
+    return model.to(device)
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_golden_whole_model(hip_device, name):
+    fx = Fixture(name)
+    model = _model_from(fx, hip_device)
+    exp = fx.group("out")
+    batch = fx.batch().to(hip_device)
+    mode = fx.mode
+    if mode == "train":
+        model.train()
+        (out, targets), att_loss, _, t_loss, t_scores, other = model.forward_main(batch)
+        assert torch.equal(targets.cpu(), exp["targets"]), "proposal set differs"
+        loss = F.cross_entropy(out, targets, reduction="sum") * (len(batch.qid) / len(targets)) + 0.5 * t_loss
+        loss.backward()
+        assert rel_err(out, exp["logits"]) < TOL
+        assert rel_err(t_scores, exp["t_scores"]) < TOL
+        assert rel_err(t_loss, exp["temporal_loss"]) < TOL
+        assert rel_err(loss, exp["loss"]) < TOL
+        G = fx.group("grad")
+        worst = ("", 0.0)
+        for k, p in model.named_parameters():
+            got = p.grad if p.grad is not None else torch.zeros_like(p)
+            e = rel_err(got, G[k])
+            if e > worst[1]:
+                worst = (k, e)
+        assert worst[1] < GTOL, "grad %s rel err %.3e" % worst
+    elif mode == "eval":
+        model.eval()
+        with torch.no_grad():
+            out, att_loss, _, t_loss, t_prob, other = model.forward_main(batch)
+        assert rel_err(out, exp["logits"]) < TOL
+        assert rel_err(t_prob, exp["t_prob"]) < TOL
+        assert rel_err(t_loss, exp["temporal_loss"]) < TOL
+        assert rel_err(other["temporal_scores"], exp["t_scores"]) < TOL
+    else:
+        model.eval()
+        model.inference_mode = True
+        with torch.no_grad():
+            res = model(batch)
+        assert set(res.keys()) == {"answer", "t_scores", "att_predictions"}
+        assert rel_err(res["answer"], exp["logits"]) < TOL
+        assert rel_err(res["t_scores"], exp["t_prob"]) < TOL
+        other = {}
+    for k in ("sub_raw_s", "sub_normalized_s", "vid_raw_s", "vid_normalized_s"):
+        if k in exp and k in other:
+            assert rel_err(other[k], exp[k]) < TOL, k
+
+
+@pytest.mark.parametrize("name", ENC_CASES)
+def test_golden_encoder(hip_device, name):
+    from tvqaplus_amd.stage import STAGE, _StackedEncoderParams
+    from tvqaplus_amd.synth import make_opt
+    fx = Fixture(name)
+    cfg = json.loads(str(fx["cfg"]))
+    P = fx.group("param")
+    D = P["stacked_encoderBlocks.0.final_layer_norm.weight"].shape[0]
+    host = STAGE(make_opt(hsz=D, embedding_size=16, vfeat_size=16))
+    host.eval()
+    enc = _StackedEncoderParams(1, cfg["n_conv"], cfg["k"], D, cfg["nh"])
+    enc.load_state_dict(P, strict=True)
+    enc = enc.to(hip_device)
+    x = torch.from_numpy(fx["x"]).to(hip_device).requires_grad_()
+    y = host._stacked_encoder(x, torch.from_numpy(fx["mask"]).to(hip_device), enc)
+    assert rel_err(y, torch.from_numpy(fx["y"])) < TOL
+    y.backward(torch.from_numpy(fx["gy"]).to(hip_device))
+    assert rel_err(x.grad, torch.from_numpy(fx["dx"])) < GTOL
+    for k, g in fx.group("grad").items():
+        p = dict(enc.named_parameters())[k]
+        assert rel_err(p.grad, g) < GTOL, k
+
+
+@pytest.mark.parametrize("kw", [
+    dict(hsz=64, add_local=True, input_encoder_n_heads=0),
+    dict(hsz=32, add_local=False, input_encoder_n_heads=4, cls_encoder_n_heads=2),
+])
+def test_oracle_fresh_batch(hip_device, kw):
+    """Fresh seeded ragged batch (not a stored fixture): HIP model vs the CPU oracle with the same parameters."""
+    from tvqaplus_amd.stage import STAGE
+    from tvqaplus_amd.synth import make_batch, make_opt
+    torch.manual_seed(77)
+    opt = make_opt(embedding_size=80, vfeat_size=52, dropout=0.0, **kw)
+    model = STAGE(opt)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.1 * torch.randn_like(p))
+    model.mha_dropout_override = 0.0
+    batch = make_batch(N=3, Li=9, Lr=11, Lw=14, Lqa=10, wd_size=80, vfeat_size=52, seed=5, empty_frames=True)
+    P = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(".pe"))
+         for k, v in model.state_dict().items()}
+    opt.mha_dropout = 0.0
+    ref = O.stage_forward(P, opt, batch, training=True)
+    ref_loss = O.training_loss(ref, n_examples=3)
+    ref_loss.backward()
+    model = model.to(hip_device).train()
+    (out, targets), _, _, t_loss, t_scores, other = model.forward_main(batch.to(hip_device))
+    assert torch.equal(targets.cpu(), ref["targets"])
+    loss = F.cross_entropy(out, targets, reduction="sum") * (3 / len(targets)) + 0.5 * t_loss
+    loss.backward()
+    assert rel_err(out, ref["logits"]) < TOL
+    assert rel_err(t_scores, ref["t_scores"]) < TOL
+    assert rel_err(loss, ref_loss) < TOL
+    for k in ("sub_raw_s", "sub_normalized_s", "vid_raw_s", "vid_normalized_s"):
+        assert rel_err(other[k], ref[k]) < TOL, k
+    for k, p in model.named_parameters():
+        g = P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert rel_err(got, g) < GTOL, k
+
+
+def test_cpu_tensors_are_rejected(hip_device):
+    """No silent fallback: the product refuses CPU tensors instead of computing on the host."""
+    from tvqaplus_amd import ops
+    from tvqaplus_amd._lib import StageHipError
+    with pytest.raises(StageHipError):
+        ops.layernorm(torch.randn(4, 16), torch.ones(16), torch.zeros(16))
+
+
+def test_train_step_with_dropout_runs(hip_device):
+    """Training mode with the default dropout 0.1: finite loss, finite grads, same seed-state advance."""
+    from tvqaplus_amd.stage import STAGE
+    from tvqaplus_amd.synth import make_batch, make_opt
+    torch.manual_seed(1)
+    opt = make_opt(hsz=32, embedding_size=64, vfeat_size=32, add_local=True, input_encoder_n_heads=2)
+    model = STAGE(opt).to(hip_device).train()
+    batch = make_batch(N=2, Li=5, Lr=6, Lw=7, Lqa=8, wd_size=64, vfeat_size=32, seed=9).to(hip_device)
+    (out, targets), _, _, t_loss, _ = model(batch)
+    loss = F.cross_entropy(out, targets, reduction="sum") + 0.5 * t_loss
+    loss.backward()
+    assert torch.isfinite(loss)
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), k

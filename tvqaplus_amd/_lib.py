@@ -1,0 +1,80 @@
+"""ctypes binding of the C-ABI HIP library (include/stage_hip.h -> tvqaplus_amd/libstage_hip.so).
+
+There is NO fallback: if the library is missing or a symbol is absent this raises, and every op in
+``tvqaplus_amd.ops`` refuses CPU tensors.  Build it with ``make`` or ``python -c 'import __graft_entry__ as g; g.build()'``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_ulonglong, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstage_hip.so")
+
+P = c_void_p  # every device pointer / stream travels as void*
+I, LL, F, U64, SZ = c_int, c_longlong, c_float, c_ulonglong, c_size_t
+
+# name -> (restype, argtypes); mirrors include/stage_hip.h one to one (tests/test_abi.py checks the two agree)
+SIGNATURES = {
+    "stage_hip_abi_version": (I, []),
+    "stage_hip_error_string": (c_char_p, [I]),
+    "stage_str_attn_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, U64, P]),
+    "stage_str_attn_bwd_ws_bytes": (SZ, [I, I, I, I]),
+    "stage_str_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, SZ, P]),
+    "stage_l2norm_fwd": (I, [P, P, P, LL, I, F, F, U64, P]),
+    "stage_l2norm_bwd": (I, [P, P, P, LL, I, F, F, U64, I, P]),
+    "stage_layernorm_fwd": (I, [P, P, I, P, P, P, P, P, P, LL, I, F, F, U64, P]),
+    "stage_ln_bwd_ws_bytes": (SZ, [I]),
+    "stage_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, LL, I, F, U64, P, SZ, P]),
+    "stage_cat3_layernorm_fwd": (I, [P, P, P, P, P, P, P, LL, I, I, I, F, F, U64, P]),
+    "stage_cat3_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, U64, P, SZ, P]),
+    "stage_reduce_rep": (I, [P, P, LL, I, LL, P]),
+    "stage_gemm_nt": (I, [P, P, P, P, P, P, LL, I, I, I, P]),
+    "stage_gemm_tn_ws_bytes": (SZ, [LL, I, I]),
+    "stage_gemm_tn": (I, [P, P, P, P, P, LL, I, I, P, SZ, P]),
+    "stage_add_pe": (I, [P, P, P, LL, I, I, P]),
+    "stage_dwconv_fwd": (I, [P, P, P, P, LL, I, I, I, P]),
+    "stage_dwconv_bwd_ws_bytes": (SZ, [I, I]),
+    "stage_dwconv_bwd": (I, [P, P, P, P, P, P, LL, I, I, I, P, SZ, P]),
+    "stage_mha_core_fwd": (I, [P, P, P, P, P, P, LL, I, I, I, F, U64, P]),
+    "stage_mha_core_bwd": (I, [P, P, P, P, P, P, P, P, P, LL, I, I, I, F, U64, P]),
+    "stage_masked_max_fwd": (I, [P, P, P, P, P, LL, I, I, P]),
+    "stage_masked_max_bwd": (I, [P, P, P, P, LL, I, I, I, P]),
+}
+
+_lib = None
+
+
+class StageHipError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load libstage_hip.so once; raise loudly if it (or any declared symbol) is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise StageHipError(
+            "tvqaplus_amd: %s not found -- the HIP extension is required (no CPU / eager fallback exists). "
+            "Build it with `make` at the repo root." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise StageHipError("tvqaplus_amd: symbol %s missing from %s" % (name, LIB_PATH)) from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().stage_hip_error_string(code)
+        msg = msg.decode() if msg else "?"
+        if "memory" in msg.lower():
+            msg += " (out of memory)"  # main.py:75-77 greps for this substring
+        raise StageHipError("%s failed: %s (code %d)" % (what, msg, code))

@@ -1,0 +1,552 @@
+// Row-wise streaming kernels of the STAGE hot path (all HBM-bound; fp32; float4 per lane; wave64):
+//   * LayerNorm (+ fused inverted dropout) forward / backward            nn.LayerNorm + nn.Dropout pairs,
+//       model/stage.py:85-91,98-104,107-120,133-138, LinearWrapper :15-32, model/encoder.py:37-41
+//   * the same over the virtual row [a, b, a*b] (never materialised)       model/stage.py:276-279, 381-385
+//   * L2 row normalisation (+dropout) forward / backward                   F.normalize, model/stage.py:256,
+//       model/context_query_attention.py:95-96
+//   * masked max over a (ranged) sequence axis forward / backward          model/stage.py:503-505, 425-432, 532-533
+//   * deterministic two-stage column reductions for the affine/bias gradients
+// One "row group" of LPR lanes (power of two, 4..64) owns one row; a wave processes 64/LPR rows at a time.
+#include "common.h"
+#include "../../include/stage_hip.h"
+
+#define MAXV 4           // float4 per lane per row  -> K <= 4*4*64 = 1024
+#define GRID_CAP 1024    // blocks of a grid-stride streaming launch (256 CU x 4)
+#define PART_CAP 512     // blocks that emit column partials (bounds the workspace)
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm forward.  MODE 0: plain row of K floats.  MODE 1: virtual row [a, b, a*b] with K = 3*D.
+// For MODE 1 the a-row may be broadcast: a_row = (row / (rep*inner)) * inner + row % inner.
+// ------------------------------------------------------------------------------------------------
+struct RowSrc {
+    const float* x;   // MODE 0: x ; MODE 1: a
+    const float* b;   // MODE 1: b ; MODE 0: optional residual added before the norm (x + res), may be NULL
+    int D;            // MODE 1: width of a / b
+    int rep, inner;   // MODE 1: broadcast description of a (rep == 1 -> none)
+                      // MODE 0: inner = residual period in rows (0: res row == row; L: res row = row % L -> pe table)
+    float* sum_out;   // MODE 0: where to write x + res (NULL: not needed)
+};
+
+__device__ __forceinline__ long a_row_of(long row, int rep, int inner) {
+    if (rep == 1) return row;
+    long g = row / ((long)rep * inner);
+    return g * inner + row % inner;
+}
+
+template <int MODE, bool DROP>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(RowSrc src, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, long rows,
+                                                     int K, float eps, int LPR, uint64_t seed, uint32_t th,
+                                                     float inv_keep) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int RPW = 64 / LPR, sub = lane / LPR, sl = lane % LPR;
+    const int K4 = K >> 2;
+    const float invK = 1.0f / (float)K;
+    for (long base = ((long)blockIdx.x * wpb + wave) * RPW; base < rows; base += (long)gridDim.x * wpb * RPW) {
+        const long row = base + sub;
+        const bool ok = row < rows;
+        float4 v[MAXV];
+        float s = 0.f;
+        if (MODE == 0) {
+#pragma unroll
+            for (int t = 0; t < MAXV; t++) {
+                int j = sl + t * LPR;
+                if (ok && j < K4) {
+                    v[t] = ld4(src.x + row * K + 4 * j);
+                    if (src.b) {
+                        const long rr = src.inner > 0 ? row % src.inner : row;
+                        v[t] = f4add(v[t], ld4(src.b + rr * K + 4 * j));
+                        if (src.sum_out) st4(src.sum_out + row * K + 4 * j, v[t]);
+                    }
+                    s += f4hsum(v[t]);
+                } else v[t] = f4zero();
+            }
+        } else {
+            // lane owns d-quads q = sl (and sl + LPR); v[0..2] = a,b,a*b of quad 0 ; v[3] unused unless D4 > LPR
+            // (MODE 1 supports D/4 <= LPR, i.e. one quad per lane: D <= 256)
+            const int D4 = src.D >> 2;
+            if (ok && sl < D4) {
+                long ar = a_row_of(row, src.rep, src.inner);
+                v[0] = ld4(src.x + ar * src.D + 4 * sl);
+                v[1] = ld4(src.b + row * src.D + 4 * sl);
+                v[2] = f4mul(v[0], v[1]);
+                s = f4hsum(v[0]) + f4hsum(v[1]) + f4hsum(v[2]);
+            } else { v[0] = v[1] = v[2] = f4zero(); }
+            v[3] = f4zero();
+        }
+        s = group_sum(s, LPR);
+        const float mu = s * invK;
+        float q = 0.f;
+        if (MODE == 0) {
+#pragma unroll
+            for (int t = 0; t < MAXV; t++) {
+                int j = sl + t * LPR;
+                if (j < K4) {
+                    float4 d = make_float4(v[t].x - mu, v[t].y - mu, v[t].z - mu, v[t].w - mu);
+                    q += f4hsum(f4mul(d, d));
+                }
+            }
+        } else {
+            if (sl < (src.D >> 2)) {
+#pragma unroll
+                for (int t = 0; t < 3; t++) {
+                    float4 d = make_float4(v[t].x - mu, v[t].y - mu, v[t].z - mu, v[t].w - mu);
+                    q += f4hsum(f4mul(d, d));
+                }
+            }
+        }
+        q = group_sum(q, LPR);
+        const float rs = 1.0f / sqrtf(q * invK + eps);
+        if (ok && sl == 0) {
+            if (mean) mean[row] = mu;
+            if (rstd) rstd[row] = rs;
+        }
+        if (!ok) continue;
+        const int nv = (MODE == 0) ? MAXV : 3;
+#pragma unroll
+        for (int t = 0; t < nv; t++) {
+            int j = (MODE == 0) ? (sl + t * LPR) : (t * (src.D >> 2) + sl);  // float4 column index inside the row
+            bool live = (MODE == 0) ? (j < K4) : (sl < (src.D >> 2));
+            if (live) {
+                float4 g = ld4(gamma + 4 * j), bb = ld4(beta + 4 * j);
+                float4 o;
+                o.x = (v[t].x - mu) * rs * g.x + bb.x;
+                o.y = (v[t].y - mu) * rs * g.y + bb.y;
+                o.z = (v[t].z - mu) * rs * g.z + bb.z;
+                o.w = (v[t].w - mu) * rs * g.w + bb.w;
+                if (DROP) o = f4mul(o, drop4(seed, (uint64_t)row * K4 + j, th, inv_keep));
+                st4(y + row * K + 4 * j, o);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward: dx (MODE 0) or da_full/db (MODE 1) + per-block partial dgamma/dbeta.
+// part layout: [gridDim.x][2][K]  (0: dgamma, 1: dbeta), reduced by colreduce_kernel.
+// ------------------------------------------------------------------------------------------------
+template <int MODE, bool DROP>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(RowSrc src, const float* __restrict__ dy,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, float* __restrict__ dx,
+                                                     float* __restrict__ db_out, float* __restrict__ part, long rows,
+                                                     int K, int LPR, uint64_t seed, uint32_t th, float inv_keep) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [wpb*RPW][2][K]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int RPW = 64 / LPR, sub = lane / LPR, sl = lane % LPR;
+    const int K4 = K >> 2;
+    const float invK = 1.0f / (float)K;
+    float4 ag[MAXV], ab[MAXV];
+#pragma unroll
+    for (int t = 0; t < MAXV; t++) ag[t] = ab[t] = f4zero();
+    const int D4 = (MODE == 1) ? (src.D >> 2) : 0;
+
+    for (long base = ((long)blockIdx.x * wpb + wave) * RPW; base < rows; base += (long)gridDim.x * wpb * RPW) {
+        const long row = base + sub;
+        const bool ok = row < rows;
+        float4 xh[MAXV], g[MAXV], av = f4zero(), bv = f4zero();
+        float mu = 0.f, rs = 0.f;
+        if (ok) { mu = mean[row]; rs = rstd[row]; }
+        float s1 = 0.f, s2 = 0.f;
+        const int nv = (MODE == 0) ? MAXV : 3;
+        if (MODE == 1 && ok && sl < D4) {
+            long ar = a_row_of(row, src.rep, src.inner);
+            av = ld4(src.x + ar * src.D + 4 * sl);
+            bv = ld4(src.b + row * src.D + 4 * sl);
+        }
+#pragma unroll
+        for (int t = 0; t < nv; t++) {
+            int j = (MODE == 0) ? (sl + t * LPR) : (t * D4 + sl);
+            bool live = ok && ((MODE == 0) ? (j < K4) : (sl < D4));
+            if (live) {
+                float4 xv;
+                if (MODE == 0) xv = ld4(src.x + row * K + 4 * j);
+                else xv = (t == 0) ? av : ((t == 1) ? bv : f4mul(av, bv));
+                float4 d = ld4(dy + row * K + 4 * j);
+                if (DROP) d = f4mul(d, drop4(seed, (uint64_t)row * K4 + j, th, inv_keep));
+                float4 gm = ld4(gamma + 4 * j);
+                xh[t] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                g[t] = f4mul(d, gm);
+                s1 += f4hsum(g[t]);
+                s2 += f4hsum(f4mul(g[t], xh[t]));
+                ag[t] = f4add(ag[t], f4mul(d, xh[t]));
+                ab[t] = f4add(ab[t], d);
+            } else { xh[t] = g[t] = f4zero(); }
+        }
+        s1 = group_sum(s1, LPR) * invK;
+        s2 = group_sum(s2, LPR) * invK;
+        if (!ok) continue;
+        float4 dz[3];
+#pragma unroll
+        for (int t = 0; t < nv; t++) {
+            int j = (MODE == 0) ? (sl + t * LPR) : (t * D4 + sl);
+            bool live = (MODE == 0) ? (j < K4) : (sl < D4);
+            if (live) {
+                float4 o;
+                o.x = rs * (g[t].x - s1 - xh[t].x * s2);
+                o.y = rs * (g[t].y - s1 - xh[t].y * s2);
+                o.z = rs * (g[t].z - s1 - xh[t].z * s2);
+                o.w = rs * (g[t].w - s1 - xh[t].w * s2);
+                if (MODE == 0) {
+                    if (dx) {
+                        if (src.b) o = f4add(o, ld4(src.b + row * K + 4 * j));  // + gradient of the exported sum
+                        st4(dx + row * K + 4 * j, o);
+                    }
+                }
+                else dz[t] = o;
+            }
+        }
+        if (MODE == 1 && sl < D4) {
+            // z = [a, b, a*b]:  da = dz0 + dz2*b ; db = dz1 + dz2*a
+            st4(dx + row * src.D + 4 * sl, f4add(dz[0], f4mul(dz[2], bv)));
+            st4(db_out + row * src.D + 4 * sl, f4add(dz[1], f4mul(dz[2], av)));
+        }
+    }
+    // block reduction of the per-lane column partials
+    const int slot = wave * RPW + sub;
+    float* sg = smem + (size_t)slot * 2 * K;
+    const int nv2 = (MODE == 0) ? MAXV : 3;
+#pragma unroll
+    for (int t = 0; t < nv2; t++) {
+        int j = (MODE == 0) ? (sl + t * LPR) : (t * D4 + sl);
+        bool live = (MODE == 0) ? (j < K4) : (sl < D4);
+        if (live) {
+            st4(sg + 4 * j, ag[t]);
+            st4(sg + K + 4 * j, ab[t]);
+        }
+    }
+    __syncthreads();
+    const int nslots = wpb * RPW;
+    for (int c = threadIdx.x; c < 2 * K; c += blockDim.x) {
+        float acc = 0.f;
+        for (int s = 0; s < nslots; s++) acc += smem[(size_t)s * 2 * K + c];
+        part[(size_t)blockIdx.x * 2 * K + c] = acc;
+    }
+}
+
+// out[c] = sum_b part[b*stride + c]   (fixed order -> deterministic)
+__global__ void colreduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nb, long stride, int C) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float acc = 0.f;
+    for (int b = 0; b < nb; b++) acc += part[(size_t)b * stride + c];
+    out[c] = acc;
+}
+
+static int ln_lpr(int K4) {
+    int l = stage_pow2_ceil(K4);
+    if (l < 4) l = 4;
+    if (l > 64) l = 64;
+    return l;
+}
+
+extern "C" size_t stage_ln_bwd_ws_bytes(int K) { return (size_t)PART_CAP * 2 * (size_t)K * sizeof(float); }
+
+template <int MODE>
+static int ln_fwd_launch(RowSrc src, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                         long long rows, int K, int LPR, float eps, float p_drop, unsigned long long seed,
+                         hipStream_t st) {
+    const int rows_per_block = 4 * (64 / LPR);
+    const int grid = stage_grid_for(rows, rows_per_block, GRID_CAP * 4);
+    if (p_drop > 0.f)
+        hipLaunchKernelGGL((ln_fwd_kernel<MODE, true>), dim3(grid), dim3(256), 0, st, src, gamma, beta, y, mean, rstd,
+                           (long)rows, K, eps, LPR, (uint64_t)seed, drop_thresh16(p_drop), 1.0f / (1.0f - p_drop));
+    else
+        hipLaunchKernelGGL((ln_fwd_kernel<MODE, false>), dim3(grid), dim3(256), 0, st, src, gamma, beta, y, mean, rstd,
+                           (long)rows, K, eps, LPR, (uint64_t)0, 0u, 1.0f);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int MODE>
+static int ln_bwd_launch(RowSrc src, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                         float* dx, float* db_out, float* dgamma, float* dbeta, long long rows, int K, int LPR,
+                         float p_drop, unsigned long long seed, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (ws_bytes < stage_ln_bwd_ws_bytes(K)) return STAGE_ERR_WORKSPACE;
+    if (rows <= 0) {
+        (void)hipMemsetAsync(dgamma, 0, sizeof(float) * K, st);
+        (void)hipMemsetAsync(dbeta, 0, sizeof(float) * K, st);
+        return 0;
+    }
+    const int rows_per_block = 4 * (64 / LPR);
+    const int grid = stage_grid_for(rows, rows_per_block * 8, PART_CAP);
+    const size_t lds = (size_t)rows_per_block * 2 * K * sizeof(float);
+    float* part = (float*)ws;
+    if (p_drop > 0.f)
+        hipLaunchKernelGGL((ln_bwd_kernel<MODE, true>), dim3(grid), dim3(256), lds, st, src, dy, mean, rstd, gamma, dx,
+                           db_out, part, (long)rows, K, LPR, (uint64_t)seed, drop_thresh16(p_drop),
+                           1.0f / (1.0f - p_drop));
+    else
+        hipLaunchKernelGGL((ln_bwd_kernel<MODE, false>), dim3(grid), dim3(256), lds, st, src, dy, mean, rstd, gamma, dx,
+                           db_out, part, (long)rows, K, LPR, (uint64_t)0, 0u, 1.0f);
+    STAGE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colreduce_kernel, dim3((K + 255) / 256), dim3(256), 0, st, part, dgamma, grid, (long)2 * K, K);
+    hipLaunchKernelGGL(colreduce_kernel, dim3((K + 255) / 256), dim3(256), 0, st, part + K, dbeta, grid, (long)2 * K, K);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int stage_layernorm_fwd(const float* x, const float* res, int res_period, float* sum_out, const float* gamma,
+                                   const float* beta, float* y, float* mean, float* rstd, long long rows, int K,
+                                   float eps, float p_drop, unsigned long long seed, void* stream) {
+    if (rows <= 0) return 0;
+    if (K % 4 != 0 || K > 4 * MAXV * 64) return STAGE_ERR_SHAPE;
+    RowSrc src{x, res, 0, 1, res_period, sum_out};
+    return ln_fwd_launch<0>(src, gamma, beta, y, mean, rstd, rows, K, ln_lpr(K / 4), eps, p_drop, seed,
+                            (hipStream_t)stream);
+}
+
+extern "C" int stage_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                                   const float* gamma, float* dx, const float* dx_add, float* dgamma, float* dbeta,
+                                   long long rows, int K, float p_drop, unsigned long long seed, void* ws,
+                                   size_t ws_bytes, void* stream) {
+    if (K % 4 != 0 || K > 4 * MAXV * 64) return STAGE_ERR_SHAPE;
+    RowSrc src{x, dx_add, 0, 1, 0, nullptr};
+    return ln_bwd_launch<0>(src, dy, mean, rstd, gamma, dx, nullptr, dgamma, dbeta, rows, K, ln_lpr(K / 4), p_drop,
+                            seed, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// y[rows, 3D] = drop(LN([a, b, a*b]))     a: [rows/(rep) , D] broadcast over `rep` (see a_row_of), b: [rows, D]
+extern "C" int stage_cat3_layernorm_fwd(const float* a, const float* b, const float* gamma, const float* beta,
+                                        float* y, float* mean, float* rstd, long long rows, int D, int rep, int inner,
+                                        float eps, float p_drop, unsigned long long seed, void* stream) {
+    if (rows <= 0) return 0;
+    if (D % 4 != 0 || D > 256 || rep < 1 || inner < 1) return STAGE_ERR_SHAPE;
+    RowSrc src{a, b, D, rep, inner, nullptr};
+    return ln_fwd_launch<1>(src, gamma, beta, y, mean, rstd, rows, 3 * D, ln_lpr(D / 4), eps, p_drop, seed,
+                            (hipStream_t)stream);
+}
+
+// da_full[rows, D] (NOT yet reduced over `rep`), db[rows, D], dgamma/dbeta[3D]
+extern "C" int stage_cat3_layernorm_bwd(const float* dy, const float* a, const float* b, const float* mean,
+                                        const float* rstd, const float* gamma, float* da_full, float* db,
+                                        float* dgamma, float* dbeta, long long rows, int D, int rep, int inner,
+                                        float p_drop, unsigned long long seed, void* ws, size_t ws_bytes,
+                                        void* stream) {
+    if (D % 4 != 0 || D > 256 || rep < 1 || inner < 1) return STAGE_ERR_SHAPE;
+    RowSrc src{a, b, D, rep, inner, nullptr};
+    return ln_bwd_launch<1>(src, dy, mean, rstd, gamma, da_full, db, dgamma, dbeta, rows, 3 * D, ln_lpr(D / 4),
+                            p_drop, seed, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[g, inner, D] = sum_{r < rep} in[g, r, inner, D]      (undoes a broadcast over `rep`; deterministic)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_rep_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                         long groups, int rep, long inner4) {
+    const long total = groups * inner4;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long g = e / inner4, q = e % inner4;
+        const float* p = in + (g * rep * inner4 + q) * 4;
+        float4 acc = f4zero();
+        for (int r = 0; r < rep; r++) acc = f4add(acc, ld4(p + (long)r * inner4 * 4));
+        st4(out + e * 4, acc);
+    }
+}
+
+extern "C" int stage_reduce_rep(const float* in, float* out, long long groups, int rep, long long inner_elems,
+                                void* stream) {
+    if (groups <= 0 || inner_elems <= 0) return 0;
+    if (inner_elems % 4 != 0) return STAGE_ERR_SHAPE;
+    const long inner4 = inner_elems / 4;
+    const int grid = stage_grid_for(groups * inner4, 256, GRID_CAP * 4);
+    hipLaunchKernelGGL(reduce_rep_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, out, (long)groups, rep,
+                       inner4);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// L2 row normalisation  y = drop(x / max(||x||, eps))   (F.normalize p=2, eps 1e-12) and its backward.
+// ------------------------------------------------------------------------------------------------
+template <bool DROP>
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         float* __restrict__ nrm, long rows, int K, float eps, int LPR,
+                                                         uint64_t seed, uint32_t th, float inv_keep) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int RPW = 64 / LPR, sub = lane / LPR, sl = lane % LPR;
+    const int K4 = K >> 2;
+    for (long base = ((long)blockIdx.x * wpb + wave) * RPW; base < rows; base += (long)gridDim.x * wpb * RPW) {
+        const long row = base + sub;
+        const bool ok = row < rows;
+        float4 v[MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < MAXV; t++) {
+            int j = sl + t * LPR;
+            if (ok && j < K4) {
+                v[t] = ld4(x + row * K + 4 * j);
+                s += f4hsum(f4mul(v[t], v[t]));
+            } else v[t] = f4zero();
+        }
+        s = group_sum(s, LPR);
+        const float n = fmaxf(sqrtf(s), eps);
+        if (!ok) continue;
+        if (nrm && sl == 0) nrm[row] = n;
+#pragma unroll
+        for (int t = 0; t < MAXV; t++) {
+            int j = sl + t * LPR;
+            if (j < K4) {
+                float4 o = make_float4(v[t].x / n, v[t].y / n, v[t].z / n, v[t].w / n);
+                if (DROP) o = f4mul(o, drop4(seed, (uint64_t)row * K4 + j, th, inv_keep));
+                st4(y + row * K + 4 * j, o);
+            }
+        }
+    }
+}
+
+// dx = (g - xh * <xh, g>) / n   with g = dy * dropmask, xh = x / n, n = max(||x||, eps); if ||x|| <= eps the clamp is
+// a constant and dx = g / eps (what autograd gives for clamp_min).
+template <bool DROP>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         float* __restrict__ dx, long rows, int K, float eps, int LPR,
+                                                         uint64_t seed, uint32_t th, float inv_keep, int accumulate) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int RPW = 64 / LPR, sub = lane / LPR, sl = lane % LPR;
+    const int K4 = K >> 2;
+    for (long base = ((long)blockIdx.x * wpb + wave) * RPW; base < rows; base += (long)gridDim.x * wpb * RPW) {
+        const long row = base + sub;
+        const bool ok = row < rows;
+        float4 v[MAXV], g[MAXV];
+        float s = 0.f, dot = 0.f;
+#pragma unroll
+        for (int t = 0; t < MAXV; t++) {
+            int j = sl + t * LPR;
+            if (ok && j < K4) {
+                v[t] = ld4(x + row * K + 4 * j);
+                g[t] = ld4(dy + row * K + 4 * j);
+                if (DROP) g[t] = f4mul(g[t], drop4(seed, (uint64_t)row * K4 + j, th, inv_keep));
+                s += f4hsum(f4mul(v[t], v[t]));
+                dot += f4hsum(f4mul(v[t], g[t]));
+            } else v[t] = g[t] = f4zero();
+        }
+        s = group_sum(s, LPR);
+        dot = group_sum(dot, LPR);
+        if (!ok) continue;
+        const float nr = sqrtf(s);
+        const bool clamped = !(nr > eps);
+        const float n = clamped ? eps : nr;
+        const float c = clamped ? 0.f : dot / (n * n * n);  // <x,g>/n^3
+#pragma unroll
+        for (int t = 0; t < MAXV; t++) {
+            int j = sl + t * LPR;
+            if (j < K4) {
+                float4 o = make_float4(g[t].x / n - v[t].x * c, g[t].y / n - v[t].y * c, g[t].z / n - v[t].z * c,
+                                       g[t].w / n - v[t].w * c);
+                float* p = dx + row * K + 4 * j;
+                if (accumulate) o = f4add(o, ld4(p));
+                st4(p, o);
+            }
+        }
+    }
+}
+
+extern "C" int stage_l2norm_fwd(const float* x, float* y, float* norm_out, long long rows, int K, float eps,
+                                float p_drop, unsigned long long seed, void* stream) {
+    if (rows <= 0) return 0;
+    if (K % 4 != 0 || K > 4 * MAXV * 64) return STAGE_ERR_SHAPE;
+    const int LPR = ln_lpr(K / 4);
+    const int grid = stage_grid_for(rows, 4 * (64 / LPR), GRID_CAP * 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (p_drop > 0.f)
+        hipLaunchKernelGGL((l2norm_fwd_kernel<true>), dim3(grid), dim3(256), 0, st, x, y, norm_out, (long)rows, K, eps,
+                           LPR, (uint64_t)seed, drop_thresh16(p_drop), 1.0f / (1.0f - p_drop));
+    else
+        hipLaunchKernelGGL((l2norm_fwd_kernel<false>), dim3(grid), dim3(256), 0, st, x, y, norm_out, (long)rows, K,
+                           eps, LPR, (uint64_t)0, 0u, 1.0f);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int stage_l2norm_bwd(const float* dy, const float* x, float* dx, long long rows, int K, float eps,
+                                float p_drop, unsigned long long seed, int accumulate, void* stream) {
+    if (rows <= 0) return 0;
+    if (K % 4 != 0 || K > 4 * MAXV * 64) return STAGE_ERR_SHAPE;
+    const int LPR = ln_lpr(K / 4);
+    const int grid = stage_grid_for(rows, 4 * (64 / LPR), GRID_CAP * 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (p_drop > 0.f)
+        hipLaunchKernelGGL((l2norm_bwd_kernel<true>), dim3(grid), dim3(256), 0, st, dy, x, dx, (long)rows, K, eps, LPR,
+                           (uint64_t)seed, drop_thresh16(p_drop), 1.0f / (1.0f - p_drop), accumulate);
+    else
+        hipLaunchKernelGGL((l2norm_bwd_kernel<false>), dim3(grid), dim3(256), 0, st, dy, x, dx, (long)rows, K, eps,
+                           LPR, (uint64_t)0, 0u, 1.0f, accumulate);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Masked max over the sequence axis with an optional per-row window:
+//   out[r, d] = max_{l in [st_r, ed_r)} ( x[r,l,d]*m[r,l] + (1-m[r,l])*(-1e10) ),  idx = first arg max
+// (mask_logits + torch.max: model/stage.py:503, 425, 429-432, 532-533).  An empty window is an error in the
+// reference (torch.max of an empty tensor) and yields -inf / idx -1 here.
+// Backward: dx[r, idx, d] = dout[r,d] * m[r, idx]; zero elsewhere (the whole dx is written).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void masked_max_fwd_kernel(const float* __restrict__ x, const float* __restrict__ m,
+                                                             const int* __restrict__ win, float* __restrict__ out,
+                                                             int* __restrict__ idx, long R, int L, int D4) {
+    const long total = R * D4;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long r = e / D4;
+        const int q = (int)(e % D4);
+        int st = 0, ed = L;
+        if (win) { st = max(0, win[2 * r]); ed = min(L, win[2 * r + 1]); }
+        float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        int4 bi = make_int4(-1, -1, -1, -1);
+        const float* px = x + (r * L) * (long)D4 * 4 + 4 * q;
+        for (int l = st; l < ed; l++) {
+            const float mk = m[r * L + l];
+            float4 v = ld4(px + (long)l * D4 * 4);
+            const float off = (1.0f - mk) * STAGE_NEG;
+            v = make_float4(v.x * mk + off, v.y * mk + off, v.z * mk + off, v.w * mk + off);
+            if (v.x > best.x) { best.x = v.x; bi.x = l; }
+            if (v.y > best.y) { best.y = v.y; bi.y = l; }
+            if (v.z > best.z) { best.z = v.z; bi.z = l; }
+            if (v.w > best.w) { best.w = v.w; bi.w = l; }
+        }
+        st4(out + e * 4, best);
+        *reinterpret_cast<int4*>(idx + e * 4) = bi;
+    }
+}
+
+__global__ __launch_bounds__(256) void masked_max_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ idx,
+                                                             const float* __restrict__ m, float* __restrict__ dx,
+                                                             long R, int L, int D4, int accumulate) {
+    const long total = R * L * D4;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(e % D4);
+        const long rl = e / D4;
+        const int l = (int)(rl % L);
+        const long r = rl / L;
+        const int4 bi = *reinterpret_cast<const int4*>(idx + (r * D4 + q) * 4);
+        const float4 g = ld4(dout + (r * D4 + q) * 4);
+        const float mk = m[rl];
+        float4 o = make_float4(bi.x == l ? g.x * mk : 0.f, bi.y == l ? g.y * mk : 0.f, bi.z == l ? g.z * mk : 0.f,
+                               bi.w == l ? g.w * mk : 0.f);
+        if (accumulate) o = f4add(o, ld4(dx + e * 4));
+        st4(dx + e * 4, o);
+    }
+}
+
+extern "C" int stage_masked_max_fwd(const float* x, const float* mask, const int* window, float* out, int* argmax,
+                                    long long R, int L, int D, void* stream) {
+    if (R <= 0) return 0;
+    if (D % 4 != 0 || L < 1) return STAGE_ERR_SHAPE;
+    const int grid = stage_grid_for(R * (D / 4), 256, GRID_CAP * 8);
+    hipLaunchKernelGGL(masked_max_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mask, window, out,
+                       argmax, (long)R, L, D / 4);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int stage_masked_max_bwd(const float* dout, const int* argmax, const float* mask, float* dx, long long R,
+                                    int L, int D, int accumulate, void* stream) {
+    if (R <= 0) return 0;
+    if (D % 4 != 0 || L < 1) return STAGE_ERR_SHAPE;
+    const int grid = stage_grid_for(R * L * (D / 4), 256, GRID_CAP * 8);
+    hipLaunchKernelGGL(masked_max_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dout, argmax, mask, dx,
+                       (long)R, L, D / 4, accumulate);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,367 @@
+"""Autograd-aware host wrappers around the C-ABI HIP kernels (one ``torch.autograd.Function`` per fused group).
+
+PyTorch is plumbing here: it owns device memory (``torch.empty``), the stream (``torch.cuda.current_stream``) and
+the autograd tape.  All arithmetic of the hot path happens in ``libstage_hip.so`` through ``ctypes``; tensors cross
+the boundary as raw device pointers.  CPU tensors are rejected -- there is no fallback path.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+EPS_LN = 1e-5
+EPS_L2 = 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# plumbing
+# ---------------------------------------------------------------------------------------------------------------
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.StageHipError("tvqaplus_amd.ops: %s is a %s tensor; the HIP path needs device tensors "
+                                 "(there is no CPU fallback)" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s: expected %s, got %s" % (name, dtype, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+_WS = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    """Stream-ordered scratch, grown on demand (all ops of one process run on one stream)."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def _call(name: str, *args):
+    lib = _lib.load()
+    _lib.check(getattr(lib, name)(*args), name)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# LayerNorm (+ fused residual add / position table, + fused dropout)
+# ---------------------------------------------------------------------------------------------------------------
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, res_period: int, want_sum: bool, p: float, seed: int):
+        x = _chk(x, "x")
+        K = x.shape[-1]
+        rows = x.numel() // K
+        res_c = None if res is None else _chk(res, "res")
+        gamma, beta = _chk(gamma, "gamma"), _chk(beta, "beta")
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        s = torch.empty_like(x) if (want_sum and res_c is not None) else None
+        _call("stage_layernorm_fwd", _ptr(x), _ptr(res_c), int(res_period), _ptr(s), _ptr(gamma), _ptr(beta), _ptr(y),
+              _ptr(mean), _ptr(rstd), rows, K, EPS_LN, float(p), int(seed), _stream())
+        if res_c is not None and s is None:
+            # backward needs the normalised input; recompute-free path requires the sum -> always keep it when training
+            raise RuntimeError("internal: layernorm with residual requires want_sum=True")
+        xin = s if res_c is not None else x
+        ctx.save_for_backward(xin, mean, rstd, gamma)
+        ctx.p, ctx.seed = float(p), int(seed)
+        ctx.has_res = res_c is not None
+        ctx.res_full = res_c is not None and res_period == 0
+        if s is None:
+            s = y.new_empty(0)
+        return y, s
+
+    @staticmethod
+    def backward(ctx, dy, dsum):
+        xin, mean, rstd, gamma = ctx.saved_tensors
+        K = xin.shape[-1]
+        rows = xin.numel() // K
+        dy = _chk(dy, "dy")
+        x_needs = ctx.needs_input_grad[0]
+        res_needs = ctx.needs_input_grad[1] and ctx.res_full
+        need_dx = x_needs or res_needs
+        dx = torch.empty_like(xin) if need_dx else None
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        lib = _lib.load()
+        wsb = lib.stage_ln_bwd_ws_bytes(K)
+        ws = _workspace(wsb, xin.device)
+        dadd = None  # gradient arriving through the exported sum (next residual branch), fused into the dx store
+        if dx is not None and ctx.has_res and dsum is not None and dsum.numel() == dx.numel():
+            dadd = _chk(dsum, "dsum")
+        _call("stage_layernorm_bwd", _ptr(dy), _ptr(xin), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dx), _ptr(dadd),
+              _ptr(dgamma), _ptr(dbeta), rows, K, ctx.p, ctx.seed, _ptr(ws), wsb, _stream())
+        return (dx if x_needs else None), (dx if res_needs else None), dgamma, dbeta, None, None, None, None
+
+
+def layernorm(x, gamma, beta, p: float = 0.0, seed: int = 0, res=None, res_period: int = 0
+              ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """y = drop(LN(x + res)); returns (y, x + res or None)."""
+    y, s = _LayerNorm.apply(x, res, gamma, beta, res_period, res is not None, p, seed)
+    return y, (s if res is not None else None)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# LayerNorm over cat([a, b, a*b])
+# ---------------------------------------------------------------------------------------------------------------
+class _Cat3LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, gamma, beta, rep: int, inner: int, p: float, seed: int):
+        a, b = _chk(a, "a"), _chk(b, "b")
+        D = b.shape[-1]
+        rows = b.numel() // D
+        gamma, beta = _chk(gamma, "gamma"), _chk(beta, "beta")
+        assert a.numel() * rep == b.numel(), (a.shape, b.shape, rep)
+        y = torch.empty(b.shape[:-1] + (3 * D,), dtype=torch.float32, device=b.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=b.device)
+        rstd = torch.empty_like(mean)
+        _call("stage_cat3_layernorm_fwd", _ptr(a), _ptr(b), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd),
+              rows, D, int(rep), int(inner), EPS_LN, float(p), int(seed), _stream())
+        ctx.save_for_backward(a, b, mean, rstd, gamma)
+        ctx.cfg = (int(rep), int(inner), float(p), int(seed))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b, mean, rstd, gamma = ctx.saved_tensors
+        rep, inner, p, seed = ctx.cfg
+        D = b.shape[-1]
+        rows = b.numel() // D
+        dy = _chk(dy, "dy")
+        da_full = torch.empty_like(b)
+        db = torch.empty_like(b)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        lib = _lib.load()
+        wsb = lib.stage_ln_bwd_ws_bytes(3 * D)
+        ws = _workspace(wsb, b.device)
+        _call("stage_cat3_layernorm_bwd", _ptr(dy), _ptr(a), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(gamma),
+              _ptr(da_full), _ptr(db), _ptr(dgamma), _ptr(dbeta), rows, D, rep, inner, p, seed, _ptr(ws), wsb,
+              _stream())
+        if rep > 1:
+            da = torch.empty_like(a)
+            groups = a.numel() // (inner * D)
+            _call("stage_reduce_rep", _ptr(da_full), _ptr(da), groups, rep, inner * D, _stream())
+        else:
+            da = da_full.view(a.shape)
+        return da, db, dgamma, dbeta, None, None, None, None
+
+
+def cat3_layernorm(a, b, gamma, beta, rep: int = 1, inner: int = 1, p: float = 0.0, seed: int = 0):
+    return _Cat3LayerNorm.apply(a, b, gamma, beta, rep, inner, p, seed)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Linear (+bias, +ReLU) on the matrix cores
+# ---------------------------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, relu: bool):
+        x = _chk(x, "x")
+        w2 = _chk(w, "w").reshape(w.shape[0], -1)  # (N, K) ; pointwise Conv1d weights are (N, K, 1)
+        N, K = w2.shape
+        assert x.shape[-1] == K, (x.shape, w.shape)
+        M = x.numel() // K
+        bias_c = None if bias is None else _chk(bias, "bias")
+        y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+        _call("stage_gemm_nt", _ptr(x), None, _ptr(w2), _ptr(bias_c), None, _ptr(y), M, N, K, int(relu), _stream())
+        ctx.save_for_backward(x, w2, y if relu else None)
+        ctx.relu = relu
+        ctx.wshape = w.shape
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w2, y = ctx.saved_tensors
+        N, K = w2.shape
+        M = x.numel() // K
+        dy = _chk(dy, "dy")
+        gate = y if ctx.relu else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = w2.t().contiguous()  # (K, N): dX = (dY .* gate) . W  ==  NT with the transposed weight
+            dx = torch.empty_like(x)
+            _call("stage_gemm_nt", _ptr(dy), _ptr(gate), _ptr(wt), None, None, _ptr(dx), M, K, N, 0, _stream())
+        dw = torch.empty_like(w2)
+        db = torch.empty(N, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        lib = _lib.load()
+        wsb = lib.stage_gemm_tn_ws_bytes(M, N, K)
+        ws = _workspace(wsb, x.device)
+        _call("stage_gemm_tn", _ptr(dy), _ptr(gate), _ptr(x), _ptr(dw), _ptr(db), M, N, K, _ptr(ws), wsb, _stream())
+        return dx, dw.view(ctx.wshape), db, None
+
+
+def linear(x, w, bias=None, relu: bool = False):
+    return _Linear.apply(x, w, bias, relu)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# depthwise Conv1d along L
+# ---------------------------------------------------------------------------------------------------------------
+class _DWConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x = _chk(x, "x")  # (M, L, D)
+        M, L, D = x.shape
+        w, bias = _chk(w, "w"), _chk(bias, "bias")
+        k = w.shape[-1]
+        y = torch.empty_like(x)
+        _call("stage_dwconv_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), M, L, D, k, _stream())
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        M, L, D = x.shape
+        k = w.shape[-1]
+        dy = _chk(dy, "dy")
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        db = torch.empty(D, dtype=torch.float32, device=x.device)
+        lib = _lib.load()
+        wsb = lib.stage_dwconv_bwd_ws_bytes(D, k)
+        ws = _workspace(wsb, x.device)
+        _call("stage_dwconv_bwd", _ptr(dy), _ptr(x), _ptr(w), _ptr(dx), _ptr(dw), _ptr(db), M, L, D, k, _ptr(ws), wsb,
+              _stream())
+        return dx, dw, db
+
+
+def dwconv(x, w, bias):
+    return _DWConv.apply(x, w, bias)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# L2 normalisation of raw features (no gradient needed: inputs are data) -- model/stage.py:256
+# ---------------------------------------------------------------------------------------------------------------
+def l2norm(x: torch.Tensor, p: float = 0.0, seed: int = 0) -> torch.Tensor:
+    x = _chk(x, "x")
+    K = x.shape[-1]
+    y = torch.empty_like(x)
+    _call("stage_l2norm_fwd", _ptr(x), _ptr(y), None, x.numel() // K, K, EPS_L2, float(p), int(seed), _stream())
+    return y
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# K1: StructuredAttention
+# ---------------------------------------------------------------------------------------------------------------
+class _StrAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, C, Q, c_mask, q_mask, scale: float, p: float, seed_c: int, seed_q: int):
+        C, Q = _chk(C, "C"), _chk(Q, "Q")                    # (N, NA, Lqa, D), (N, Li, Lr, D)
+        c_mask, q_mask = _chk(c_mask, "c_mask"), _chk(q_mask, "q_mask")
+        N, NA, Lqa, D = C.shape
+        _, Li, Lr, _ = Q.shape
+        Cn = torch.empty_like(C)
+        _call("stage_l2norm_fwd", _ptr(C), _ptr(Cn), None, N * NA * Lqa, D, EPS_L2, float(p), int(seed_c), _stream())
+        A = torch.empty(N, NA, Li, Lqa, D, dtype=torch.float32, device=C.device)
+        S = torch.empty(N, NA, Li, Lqa, Lr, dtype=torch.float32, device=C.device)
+        Sn = torch.empty_like(S)
+        _call("stage_str_attn_fwd", _ptr(Cn), _ptr(Q), _ptr(c_mask), _ptr(q_mask), _ptr(A), _ptr(S), _ptr(Sn), N, NA, Li,
+              Lqa, Lr, D, float(scale), float(p), int(seed_q), _stream())
+        ctx.save_for_backward(C, Q, Cn, Sn)
+        ctx.cfg = (float(scale), float(p), int(seed_c), int(seed_q))
+        ctx.mark_non_differentiable(Sn)
+        return A, S, Sn
+
+    @staticmethod
+    def backward(ctx, dA, dS, _dSn):
+        C, Q, Cn, Sn = ctx.saved_tensors
+        scale, p, seed_c, seed_q = ctx.cfg
+        N, NA, Lqa, D = C.shape
+        _, Li, Lr, _ = Q.shape
+        dA = _chk(dA, "dA") if dA is not None else torch.zeros(N, NA, Li, Lqa, D, device=C.device)
+        dS_ext = _chk(dS, "dS") if dS is not None else None
+        Qn = torch.empty_like(Q)
+        _call("stage_l2norm_fwd", _ptr(Q), _ptr(Qn), None, N * Li * Lr, D, EPS_L2, p, seed_q, _stream())
+        dS_out = torch.empty_like(Sn)
+        dQ = torch.empty_like(Q)       # receives the value-path gradient, then the normalised-path one on top
+        dQn = torch.empty_like(Q)
+        dCn = torch.empty_like(C)
+        lib = _lib.load()
+        wsb = lib.stage_str_attn_bwd_ws_bytes(N, NA, Lqa, D)
+        ws = _workspace(wsb, C.device)
+        _call("stage_str_attn_bwd", _ptr(dA), _ptr(dS_ext), _ptr(Cn), _ptr(Q), _ptr(Qn), _ptr(Sn), _ptr(dS_out),
+              _ptr(dQ), _ptr(dQn), _ptr(dCn), N, NA, Li, Lqa, Lr, D, scale, _ptr(ws), wsb, _stream())
+        _call("stage_l2norm_bwd", _ptr(dQn), _ptr(Q), _ptr(dQ), N * Li * Lr, D, EPS_L2, p, seed_q, 1, _stream())
+        dC = torch.empty_like(C)
+        _call("stage_l2norm_bwd", _ptr(dCn), _ptr(C), _ptr(dC), N * NA * Lqa, D, EPS_L2, p, seed_c, 0, _stream())
+        return dC, dQ, None, None, None, None, None, None
+
+
+def structured_attention(C, Q, c_mask, q_mask, scale: float, p: float = 0.0, seed_c: int = 0, seed_q: int = 0):
+    """C (N,NA,Lqa,D), Q (N,Li,Lr,D), c_mask (N,NA,Lqa), q_mask (N,Li,Lr) -> A (N,NA,Li,Lqa,D), raw S, normalised S."""
+    return _StrAttn.apply(C, Q, c_mask, q_mask, scale, p, seed_c, seed_q)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# masked max over a sequence axis (optionally windowed)
+# ---------------------------------------------------------------------------------------------------------------
+class _MaskedMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask, window):
+        x, mask = _chk(x, "x"), _chk(mask, "mask")  # (R, L, D), (R, L)
+        R, L, D = x.shape
+        win = None if window is None else _chk(window, "window", torch.int32)
+        out = torch.empty(R, D, dtype=torch.float32, device=x.device)
+        idx = torch.empty(R, D, dtype=torch.int32, device=x.device)
+        _call("stage_masked_max_fwd", _ptr(x), _ptr(mask), _ptr(win), _ptr(out), _ptr(idx), R, L, D, _stream())
+        ctx.save_for_backward(idx, mask)
+        ctx.shape = (R, L, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        idx, mask = ctx.saved_tensors
+        R, L, D = ctx.shape
+        dout = _chk(dout, "dout")
+        dx = torch.empty(R, L, D, dtype=torch.float32, device=dout.device)
+        _call("stage_masked_max_bwd", _ptr(dout), _ptr(idx), _ptr(mask), _ptr(dx), R, L, D, 0, _stream())
+        return dx, None, None
+
+
+def masked_max(x, mask, window=None):
+    return _MaskedMax.apply(x, mask, window)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# multi-head attention core
+# ---------------------------------------------------------------------------------------------------------------
+class _MHACore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask, nh: int, p: float, seed: int):
+        q, k, v, mask = _chk(q, "q"), _chk(k, "k"), _chk(v, "v"), _chk(mask, "mask")
+        M, L, D = q.shape
+        out = torch.empty_like(q)
+        probs = torch.empty(M, nh, L, L, dtype=torch.float32, device=q.device)
+        _call("stage_mha_core_fwd", _ptr(q), _ptr(k), _ptr(v), _ptr(mask), _ptr(out), _ptr(probs), M, L, D, nh, float(p),
+              int(seed), _stream())
+        ctx.save_for_backward(q, k, v, probs, mask)
+        ctx.cfg = (nh, float(p), int(seed))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, probs, mask = ctx.saved_tensors
+        nh, p, seed = ctx.cfg
+        M, L, D = q.shape
+        dout = _chk(dout, "dout")
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        _call("stage_mha_core_bwd", _ptr(dout), _ptr(q), _ptr(k), _ptr(v), _ptr(probs), _ptr(mask), _ptr(dq), _ptr(dk),
+              _ptr(dv), M, L, D, nh, p, seed, _stream())
+        return dq, dk, dv, None, None, None, None
+
+
+def mha_core(q, k, v, mask, nh: int, p: float = 0.0, seed: int = 0):
+    return _MHACore.apply(q, k, v, mask, nh, p, seed)

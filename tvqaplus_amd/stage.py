@@ -1,0 +1,414 @@
+"""MI355X-native STAGE: drop-in for ``model.stage.STAGE`` of jayleicn/TVQAplus (model/stage.py:55-348).
+
+Same constructor (``STAGE(opt)``), same parameter / buffer names and shapes (``load_state_dict(strict=True)`` of a
+reference checkpoint works, inference.py:87-89), same ``forward(batch)`` return conventions (model/stage.py:192-197,
+297-312, 345-348).  The tensor path runs entirely on the HIP kernels of ``libstage_hip.so`` via ``tvqaplus_amd.ops``;
+the torch ``nn`` modules below are parameter *containers* only (they are never called), which is what gives the
+reference's state_dict keys and default initialisers for free.
+
+Scope: the model forward/backward.  The host-side supervised-attention loss and box prediction
+(model/stage.py:557-806) live in ``tvqaplus_amd.att_host`` and are pure host logic on top of ``vid_raw_s``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+NEG = -1e10
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# parameter containers (names mirror the reference's attribute names -> identical state_dict keys)
+# ---------------------------------------------------------------------------------------------------------------
+class _PositionTable(nn.Module):
+    """model/position_encoding.py:19-31: fixed sinusoid table registered as buffer ``pe`` (max_len, D)."""
+
+    def __init__(self, n_filters: int, max_len: int = 500):
+        super().__init__()
+        self.register_buffer("pe", self.table(max_len, n_filters))
+        self._ext: Optional[torch.Tensor] = None
+
+    @staticmethod
+    def table(L: int, D: int) -> torch.Tensor:
+        pos = torch.arange(0, L).float().unsqueeze(1)
+        div = torch.exp(torch.arange(0, D, 2).float() * -(math.log(10000.0) / D))
+        pe = torch.zeros(L, D)
+        pe[:, 0::2] = torch.sin(pos * div)
+        pe[:, 1::2] = torch.cos(pos * div)
+        return pe
+
+    def rows(self, L: int) -> torch.Tensor:
+        """First L rows; beyond the 500 registered positions (where the reference crashes, SURVEY.md note 3) the
+        same closed form is continued and cached."""
+        if L <= self.pe.shape[0]:
+            return self.pe
+        if self._ext is None or self._ext.shape[0] < L or self._ext.device != self.pe.device:
+            self._ext = self.table(L, self.pe.shape[1]).to(self.pe.device)
+        return self._ext
+
+
+class _DWSepConv(nn.Module):
+    """model/cnn.py:23-28 parameters: depthwise Conv1d(C,C,k,groups=C,pad=k//2) + pointwise Conv1d(C,C_out,1)."""
+
+    def __init__(self, in_ch: int, out_ch: int, k: int):
+        super().__init__()
+        self.depthwise_conv = nn.Conv1d(in_ch, in_ch, kernel_size=k, groups=in_ch, padding=k // 2)
+        self.pointwise_conv = nn.Conv1d(in_ch, out_ch, kernel_size=1, padding=0)
+
+
+class _MHAParams(nn.Module):
+    """model/self_attention.py:19-33: four Linear(D, D); attention-probability dropout fixed at 0.1."""
+
+    def __init__(self, nh: int, d_model: int):
+        super().__init__()
+        assert d_model % nh == 0
+        self.nh = nh
+        self.linears = nn.ModuleList([nn.Linear(d_model, d_model) for _ in range(4)])
+        self.p_attn_drop = 0.1
+
+
+class _EncoderBlockParams(nn.Module):
+    """model/encoder.py:11-27."""
+
+    def __init__(self, n_conv: int, kernel_size: int, n_filters: int, num_heads: int):
+        super().__init__()
+        self.n_conv, self.num_heads = n_conv, num_heads
+        self.position_encoding = _PositionTable(n_filters)
+        self.layer_norm = nn.ModuleList([nn.LayerNorm(n_filters) for _ in range(n_conv)])
+        self.final_layer_norm = nn.LayerNorm(n_filters)
+        self.conv = nn.ModuleList([_DWSepConv(n_filters, n_filters, kernel_size) for _ in range(n_conv)])
+        if num_heads != 0:
+            self.multi_head_attn = _MHAParams(num_heads, n_filters)
+            self.attn_layer_norm = nn.LayerNorm(n_filters)
+
+
+class _StackedEncoderParams(nn.Module):
+    """model/encoder.py:55-64."""
+
+    def __init__(self, n_blocks, n_conv, kernel_size, hidden_size, num_heads):
+        super().__init__()
+        self.stacked_encoderBlocks = nn.ModuleList(
+            [_EncoderBlockParams(n_conv, kernel_size, hidden_size, num_heads) for _ in range(n_blocks)])
+
+
+class _LinearWrapperParams(nn.Module):
+    """model/stage.py:15-25: ``conv`` = Sequential(LayerNorm, Dropout, Linear)."""
+
+    def __init__(self, in_hsz, out_hsz, dropout, relu):
+        super().__init__()
+        self.relu = relu
+        self.conv = nn.Sequential(nn.LayerNorm(in_hsz), nn.Dropout(dropout), nn.Linear(in_hsz, out_hsz))
+
+
+class _ConvLinearParams(nn.Module):
+    """model/stage.py:35-48: ``conv`` = Sequential(LayerNorm, Dropout, DepthwiseSeparableConv(k=3))."""
+
+    def __init__(self, in_hsz, out_hsz, dropout):
+        super().__init__()
+        self.conv = nn.Sequential(nn.LayerNorm(in_hsz), nn.Dropout(dropout), _DWSepConv(in_hsz, out_hsz, 3))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the model
+# ---------------------------------------------------------------------------------------------------------------
+class STAGE(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.inference_mode = False
+        self.sub_flag = opt.sub_flag
+        self.vfeat_flag = opt.vfeat_flag
+        self.vfeat_size = opt.vfeat_size
+        self.t_iter = opt.t_iter
+        self.extra_span_length = opt.extra_span_length
+        self.add_local = opt.add_local
+        self.use_sup_att = opt.use_sup_att
+        self.num_negatives = opt.num_negatives
+        self.negative_pool_size = opt.negative_pool_size
+        self.num_hard = opt.num_hard
+        self.drop_topk = opt.drop_topk
+        self.margin = opt.margin
+        self.att_loss_type = opt.att_loss_type
+        self.scale = opt.scale
+        self.alpha = opt.alpha
+        self.dropout = opt.dropout
+        self.hsz = opt.hsz
+        self.bsz = None
+        self.num_seg = None
+        self.num_a = 5
+        self.flag_cnt = self.sub_flag + self.vfeat_flag
+        self.wd_size = opt.embedding_size
+        self.bridge_hsz = 300
+
+        def bridge(in_size):  # model/stage.py:85-91 / 98-104
+            return nn.Sequential(nn.LayerNorm(in_size), nn.Dropout(self.dropout), nn.Linear(in_size, self.bridge_hsz),
+                                 nn.ReLU(True), nn.LayerNorm(self.bridge_hsz))
+
+        self.bert_word_encoding_fc = bridge(self.wd_size)
+        if self.sub_flag:
+            print("Activate sub branch")
+        if self.vfeat_flag:
+            print("Activate vid branch")
+            self.vid_fc = bridge(self.vfeat_size)
+        if self.flag_cnt == 2:  # model/stage.py:106-113
+            self.concat_fc = nn.Sequential(nn.LayerNorm(3 * self.hsz), nn.Dropout(self.dropout),
+                                           nn.Linear(3 * self.hsz, self.hsz), nn.ReLU(True), nn.LayerNorm(self.hsz))
+        self.input_embedding = nn.Sequential(nn.Dropout(self.dropout), nn.Linear(self.bridge_hsz, self.hsz),
+                                             nn.ReLU(True), nn.LayerNorm(self.hsz))
+        self.input_encoder = _StackedEncoderParams(opt.input_encoder_n_blocks, opt.input_encoder_n_conv,
+                                                   opt.input_encoder_kernel_size, self.hsz,
+                                                   opt.input_encoder_n_heads)
+        # str_attn has no parameters (model/stage.py:129-131)
+        self.c2q_down_projection = nn.Sequential(nn.LayerNorm(3 * self.hsz), nn.Dropout(self.dropout),
+                                                 nn.Linear(3 * self.hsz, self.hsz), nn.ReLU(True))
+        self.cls_encoder = _StackedEncoderParams(opt.cls_encoder_n_blocks, opt.cls_encoder_n_conv,
+                                                 opt.cls_encoder_kernel_size, self.hsz, opt.cls_encoder_n_heads)
+        self.cls_projection_layers = nn.ModuleList(
+            [_LinearWrapperParams(self.hsz, self.hsz, self.dropout, relu=True)]
+            + [_ConvLinearParams(self.hsz, self.hsz, self.dropout) for _ in range(self.t_iter)])
+        self.temporal_scoring_st_layers = nn.ModuleList(
+            [_LinearWrapperParams(self.hsz, 1, self.dropout, relu=False) for _ in range(self.t_iter + 1)])
+        self.temporal_scoring_ed_layers = nn.ModuleList(
+            [_LinearWrapperParams(self.hsz, 1, self.dropout, relu=False) for _ in range(self.t_iter + 1)])
+        self.temporal_criterion = nn.CrossEntropyLoss(reduction="sum")
+        self.classifier = _LinearWrapperParams(self.hsz * 2 if self.add_local else self.hsz, 1, self.dropout,
+                                               relu=False)
+        self._seed_state = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x1234567) & 0xFFFFFFFFFFFFFFFF
+        self.mha_dropout_override: Optional[float] = None  # tests: the reference's fixed 0.1 can be zeroed
+
+    # ---- dropout bookkeeping ---------------------------------------------------------------------------------
+    def _p(self) -> float:
+        return float(self.dropout) if self.training else 0.0
+
+    def _seed(self) -> int:
+        """A fresh 63-bit stream id per dropout site per forward (host-side LCG: no device sync)."""
+        self._seed_state = (self._seed_state * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        return self._seed_state >> 1
+
+    # ---- building blocks ---------------------------------------------------------------------------------------
+    def _ln(self, x, ln: nn.LayerNorm, drop: bool = False, res=None, res_period: int = 0):
+        return ops.layernorm(x, ln.weight, ln.bias, p=self._p() if drop else 0.0, seed=self._seed() if drop else 0,
+                             res=res, res_period=res_period)
+
+    def _encoder_block(self, x, mask, blk: _EncoderBlockParams):
+        """model/encoder.py:29-52.  x (M, L, D).  Residual adds are deferred into the next LayerNorm's prologue."""
+        M, L, D = x.shape
+        pending, cur, period = x, blk.position_encoding.rows(L), L  # first LN sees x + pe[:L]
+        for i in range(blk.n_conv):
+            y, cur = self._ln(pending, blk.layer_norm[i], drop=(i % 2 == 0), res=cur, res_period=period)
+            period = 0
+            c = blk.conv[i]
+            h = ops.dwconv(y, c.depthwise_conv.weight, c.depthwise_conv.bias)
+            pending = ops.linear(h, c.pointwise_conv.weight, c.pointwise_conv.bias, relu=True)
+        if blk.num_heads != 0:
+            y, cur = self._ln(pending, blk.attn_layer_norm, res=cur, res_period=period)
+            period = 0
+            mha = blk.multi_head_attn
+            q = ops.linear(y, mha.linears[0].weight, mha.linears[0].bias)
+            k = ops.linear(y, mha.linears[1].weight, mha.linears[1].bias)
+            v = ops.linear(y, mha.linears[2].weight, mha.linears[2].bias)
+            p_attn = mha.p_attn_drop if self.mha_dropout_override is None else self.mha_dropout_override
+            p_attn = p_attn if self.training else 0.0
+            a = ops.mha_core(q, k, v, mask, mha.nh, p=p_attn, seed=self._seed() if p_attn > 0 else 0)
+            pending = ops.linear(a, mha.linears[3].weight, mha.linears[3].bias)
+        y, _ = self._ln(pending, blk.final_layer_norm, res=cur, res_period=period)
+        return y
+
+    def _stacked_encoder(self, x, mask, enc: _StackedEncoderParams):
+        for blk in enc.stacked_encoderBlocks:
+            x = self._encoder_block(x, mask, blk)
+        return x
+
+    def base_encoder(self, data, data_mask, init_encoder, downsize_encoder, input_encoder, l2_normalize=False):
+        """model/stage.py:350-363 (+ the F.normalize of :256 when l2_normalize)."""
+        M, L, _ = data.shape
+        if l2_normalize:
+            data = ops.l2norm(data)
+        y, _ = self._ln(data, init_encoder[0], drop=True)
+        y = ops.linear(y, init_encoder[2].weight, init_encoder[2].bias, relu=True)
+        y, _ = self._ln(y, init_encoder[4], drop=True)            # LN(300) then input_embedding's Dropout
+        y = ops.linear(y, downsize_encoder[1].weight, downsize_encoder[1].bias, relu=True)
+        y, _ = self._ln(y, downsize_encoder[3])
+        return self._stacked_encoder(y.view(M, L, -1), data_mask, input_encoder)
+
+    def qa_ctx_attention(self, qa_embed, ctx_embed, qa_mask, ctx_mask):
+        """model/stage.py:365-387.  qa_embed (N,5,Lqa,D), ctx_embed (N,Li,Lr,D), qa_mask (N,5,Lqa), ctx_mask (N,Li,Lr)."""
+        N, NA, Lqa, D = qa_embed.shape
+        Li = ctx_embed.shape[1]
+        p = self._p()
+        u_a, raw_s, s_norm = ops.structured_attention(qa_embed, ctx_embed, qa_mask, ctx_mask, self.scale, p=p,
+                                                      seed_c=self._seed(), seed_q=self._seed())
+        proj = self.c2q_down_projection
+        z = ops.cat3_layernorm(qa_embed.reshape(N * NA * Lqa, D), u_a.view(-1, D), proj[0].weight, proj[0].bias,
+                               rep=Li, inner=Lqa, p=p, seed=self._seed())
+        mixed = ops.linear(z, proj[2].weight, proj[2].bias, relu=True).view(N, NA, Li, Lqa, D)
+        # (s_mask.sum(-1) != 0) with s_mask = qa_mask (x) ctx_mask
+        mixed_mask = ((qa_mask != 0).view(N, NA, 1, Lqa) & (ctx_mask.sum(-1) != 0).view(N, 1, Li, 1)).float()
+        return mixed, mixed_mask, raw_s, s_norm
+
+    # ---- span proposals (model/stage.py:389-467, model/model_utils.py:37-123) ----------------------------------
+    @staticmethod
+    def _best_span(p_st, p_ed):
+        """Upper-triangular arg max of p_st (x) p_ed per row, on device.  (R, Li) x2 -> st, ed, conf (R,)."""
+        R, Li = p_st.shape
+        prod = torch.triu(p_st.unsqueeze(2) * p_ed.unsqueeze(1))
+        conf, flat = prod.view(R, -1).max(dim=1)
+        return flat // Li, flat % Li, conf
+
+    def get_proposals(self, max_statement, max_statement_mask, temporal_scores, targets, ts_labels,
+                      iou_thd=0.5, ce_prob_thd=0.01, extra_span_length=3):
+        N, NA, Li, D = max_statement.shape
+        x = max_statement.reshape(N * NA, Li, D)
+        m = max_statement_mask.reshape(N * NA, Li)
+        glob = ops.masked_max(x, m)                                               # (N*5, D)
+        if self.training:
+            ca = F.softmax(temporal_scores[torch.arange(N, device=targets.device), targets].detach(), dim=1)
+            st, ed, conf = self._best_span(ca[:, :, 0], ca[:, :, 1])
+            # one small D2H copy per step: the number of proposals (N_new) is data dependent by construction
+            host = torch.stack([st.float(), ed.float(), conf, ts_labels["st"].float(), ts_labels["ed"].float()]).tolist()
+            src, wins = [], []
+            for n in range(N):
+                gs, ge = int(host[3][n]), int(host[4][n]) + 1
+                spans = [(gs, ge)]
+                if host[2][n] >= ce_prob_thd:
+                    ps, pe = int(host[0][n]), int(host[1][n]) + 1
+                    inter = max(0, min(pe, ge) - max(ps, gs))
+                    union = max(pe, ge) - min(ps, gs)
+                    if union != 0 and inter / union >= iou_thd:
+                        spans.append((ps, pe))
+                for (s, e) in spans:
+                    src.append(n)
+                    wins.append((max(0, s - extra_span_length), e + extra_span_length))
+            src_t = torch.tensor(src, device=x.device, dtype=torch.long)
+            win_t = torch.tensor(wins, device=x.device, dtype=torch.int32)       # (N_new, 2)
+            xg = max_statement[src_t].reshape(-1, Li, D)                          # (N_new*5, Li, D)
+            mg = max_statement_mask.reshape(N, NA, Li)[src_t].reshape(-1, Li)
+            wg = win_t.unsqueeze(1).expand(-1, NA, -1).reshape(-1, 2).contiguous()
+            loc = ops.masked_max(xg, mg, wg).view(-1, NA, D)
+            pooled = torch.cat([loc, glob.view(N, NA, D)[src_t]], dim=-1)         # (N_new, 5, 2D)
+            return pooled, targets[src_t]
+        ts = F.softmax(temporal_scores, dim=2).view(N * NA, Li, 2)
+        st, ed, _ = self._best_span(ts[:, :, 0], ts[:, :, 1])
+        win = torch.stack([(st - extra_span_length).clamp(min=0), ed + 1 + extra_span_length], dim=1).int().contiguous()
+        loc = ops.masked_max(x, m, win)
+        return torch.cat([loc, glob], dim=-1).view(N, NA, 2 * D), targets
+
+    def _linear_wrapper(self, x, lw: _LinearWrapperParams, res=None):
+        y, s = self._ln(x, lw.conv[0], drop=True, res=res)
+        return ops.linear(y, lw.conv[2].weight, lw.conv[2].bias, relu=lw.relu), s
+
+    def classfier_head_multi_proposal(self, statement, statement_mask, targets, ts_labels, ts_labels_mask,
+                                      extra_span_length=3):
+        """model/stage.py:484-537."""
+        N, NA, Li, Lqa = statement_mask.shape
+        D = statement.shape[-1]
+        x = statement.reshape(N * NA * Li, Lqa, D)
+        m = statement_mask.reshape(N * NA * Li, Lqa).contiguous()
+        x = self._stacked_encoder(x, m, self.cls_encoder)
+        mx = ops.masked_max(x, m)                                                       # :503
+        mx_mask = (m.sum(1) != 0).float().view(N, NA, Li, 1)                             # :504
+        enc = mx.view(N * NA * Li, D)
+        # residual_temporal_predictor, layer 0 (:469-482).  Layers >= 1 (t_iter > 0) never reach any output or
+        # gradient because of the `[:1]` slice at :516 (0.5*(t0 + mean([t0])) == t0 exactly), so they are skipped.
+        h, _ = self._linear_wrapper(enc, self.cls_projection_layers[0])
+        st_lw, ed_lw = self.temporal_scoring_st_layers[0], self.temporal_scoring_ed_layers[0]
+        t_st, first = self._linear_wrapper(h, st_lw, res=enc)                            # first = enc + h
+        t_ed, _ = self._linear_wrapper(first, ed_lw)
+        t_scores = torch.cat([t_st, t_ed], dim=-1).view(N, NA, Li, 2)
+        tm = ts_labels_mask.view(N, 1, Li, 1)
+        t_scores = t_scores * tm + (1 - tm) * NEG                                        # :521 mask_logits
+        first = first.view(N, NA, Li, D)
+        if self.add_local:
+            pooled, targets = self.get_proposals(first, mx_mask, t_scores, targets, ts_labels,
+                                                 extra_span_length=extra_span_length)
+        else:
+            pooled = ops.masked_max(first.view(N * NA, Li, D), mx_mask.view(N * NA, Li)).view(N, NA, D)
+        logits, _ = self._linear_wrapper(pooled.reshape(-1, pooled.shape[-1]), self.classifier)
+        return logits.view(-1, NA), targets, t_scores
+
+    def get_ts_loss(self, temporal_scores, ts_labels, answer_indices):
+        """model/stage.py:539-555."""
+        bsz = len(answer_indices)
+        ca = temporal_scores[torch.arange(bsz, device=answer_indices.device), answer_indices]
+        loss_st = self.temporal_criterion(ca[:, :, 0], ts_labels["st"])
+        loss_ed = self.temporal_criterion(ca[:, :, 1], ts_labels["ed"])
+        return (loss_st + loss_ed) / 2.
+
+    # ---- forward ----------------------------------------------------------------------------------------------
+    def forward(self, batch):
+        if self.inference_mode:
+            return self.forward_main(batch)
+        out, att_loss, att_predictions, temporal_loss, temporal_predictions, _ = self.forward_main(batch)
+        return out, att_loss, att_predictions, temporal_loss, temporal_predictions
+
+    def forward_main(self, batch):
+        """model/stage.py:199-348."""
+        self.bsz = len(batch.qid)
+        N, NA, D = self.bsz, self.num_a, self.hsz
+        qas_mask = batch.qas_mask.view(N, NA, -1).float()
+        a_embed = self.base_encoder(batch.qas_bert.view(N * NA, -1, self.wd_size), qas_mask.view(N * NA, -1),
+                                    self.bert_word_encoding_fc, self.input_embedding, self.input_encoder)
+        a_embed = a_embed.view(N, NA, -1, D)
+        attended_sub = attended_vid = attended_vid_mask = attended_sub_mask = None
+        other_outputs: Dict[str, torch.Tensor] = {}
+        if self.sub_flag:
+            Li, Lw = batch.sub_bert.shape[1:3]
+            sub_mask = batch.sub_mask.view(N, Li, Lw).float()
+            sub_embed = self.base_encoder(batch.sub_bert.view(N * Li, Lw, -1), sub_mask.view(N * Li, Lw),
+                                          self.bert_word_encoding_fc, self.input_embedding, self.input_encoder)
+            attended_sub, attended_sub_mask, raw, norm = self.qa_ctx_attention(
+                a_embed, sub_embed.view(N, Li, Lw, D), qas_mask, sub_mask)
+            other_outputs["sub_normalized_s"], other_outputs["sub_raw_s"] = norm, raw
+        if self.vfeat_flag:
+            Li, Lr = batch.vid.shape[1:3]
+            vid_mask = batch.vid_mask.view(N, Li, Lr).float()
+            vid_embed = self.base_encoder(batch.vid.view(N * Li, Lr, -1), vid_mask.view(N * Li, Lr), self.vid_fc,
+                                          self.input_embedding, self.input_encoder, l2_normalize=True)
+            attended_vid, attended_vid_mask, raw, norm = self.qa_ctx_attention(
+                a_embed, vid_embed.view(N, Li, Lr, D), qas_mask, vid_mask)
+            other_outputs["vid_normalized_s"], other_outputs["vid_raw_s"] = norm, raw
+        if self.flag_cnt == 2:
+            fc = self.concat_fc
+            z = ops.cat3_layernorm(attended_sub.view(-1, D), attended_vid.view(-1, D), fc[0].weight, fc[0].bias,
+                                   p=self._p(), seed=self._seed())
+            z = ops.linear(z, fc[2].weight, fc[2].bias, relu=True)
+            z, _ = self._ln(z, fc[4])
+            statement, statement_mask = z.view(attended_vid.shape), attended_vid_mask
+        elif self.sub_flag:
+            statement, statement_mask = attended_sub, attended_sub_mask
+        elif self.vfeat_flag:
+            statement, statement_mask = attended_vid, attended_vid_mask
+        else:
+            raise NotImplementedError
+        out, target, t_scores = self.classfier_head_multi_proposal(
+            statement, statement_mask, batch.target, batch.ts_label, batch.ts_label_mask.float(),
+            extra_span_length=self.extra_span_length)
+        assert len(out) == len(target)
+        other_outputs["temporal_scores"] = t_scores
+
+        if self.inference_mode:
+            from .att_host import get_att_prediction
+            return {
+                "answer": out,
+                "t_scores": F.softmax(t_scores, dim=2),
+                "att_predictions": get_att_prediction(
+                    scores=other_outputs["vid_raw_s"], object_vocab=batch.eval_object_word_ids, words=batch.qas,
+                    vid_names=batch.vid_name, qids=batch.qid, img_indices=batch.image_indices, boxes=batch.boxes,
+                    start_indices=batch.anno_st_idx) if self.vfeat_flag else None,
+            }
+
+        att_loss = 0
+        att_predictions = None
+        if self.use_sup_att and self.training and self.vfeat_flag:
+            from .att_host import get_att_loss
+            att_loss, att_predictions = get_att_loss(self, other_outputs["vid_raw_s"], batch)
+        temporal_loss = self.get_ts_loss(t_scores, batch.ts_label, batch.target)
+        if self.training:
+            return [out, target], att_loss, att_predictions, temporal_loss, t_scores, other_outputs
+        return out, att_loss, att_predictions, temporal_loss, F.softmax(t_scores, dim=2), other_outputs
