@@ -140,6 +140,10 @@ def encoder_case(name, M, L, D, k, n_conv, nh, seed):
 
 TINY = dict(N=2, Li=2, Lr=4, Lw=5, Lqa=6)          # BASELINE.json config 1 (D=16)
 SMALL = dict(N=3, Li=7, Lr=5, Lw=9, Lqa=8, empty_frames=True)
+# Train (gradient) cases avoid frames whose regions are all masked while the frame itself is valid: such a frame turns
+# into an all -1e10 row entering a LayerNorm, where the reference's own fp32 backward is rounding noise (torch's CPU
+# kernel returns dx = 0 and a 1e5-scale dgamma for a constant row) -- there is nothing well defined to match.
+SMALL_T = dict(N=3, Li=7, Lr=5, Lw=9, Lqa=8)
 MID = dict(N=2, Li=6, Lr=20, Lw=50, Lqa=40)        # full per-frame shapes, D=128
 
 
@@ -150,14 +154,14 @@ def main():
     run_case("tiny_train_local", dict(hsz=16, embedding_size=64, dropout=0.0, add_local=True), TINY, "train", 13)
     run_case("small_local_eval", dict(hsz=32, embedding_size=48, vfeat_size=40, add_local=True), SMALL, "eval", 21)
     run_case("small_local_train", dict(hsz=32, embedding_size=48, vfeat_size=40, add_local=True, dropout=0.0),
-             SMALL, "train", 22)
+             SMALL_T, "train", 22)
     run_case("small_heads_train", dict(hsz=32, embedding_size=48, vfeat_size=40, add_local=True, dropout=0.0,
-                                       input_encoder_n_heads=2, cls_encoder_n_heads=4, t_iter=1), SMALL, "train", 23)
+                                       input_encoder_n_heads=2, cls_encoder_n_heads=4, t_iter=1), SMALL_T, "train", 23)
     run_case("small_heads_eval", dict(hsz=32, embedding_size=48, vfeat_size=40, input_encoder_n_heads=2,
                                       cls_encoder_n_heads=4, t_iter=1), SMALL, "eval", 24)
-    run_case("small_subonly_train", dict(hsz=32, embedding_size=48, vfeat_flag=False, dropout=0.0), SMALL, "train", 25)
+    run_case("small_subonly_train", dict(hsz=32, embedding_size=48, vfeat_flag=False, dropout=0.0), SMALL_T, "train", 25)
     run_case("small_vidonly_train", dict(hsz=32, embedding_size=48, vfeat_size=40, sub_flag=False, dropout=0.0,
-                                         add_local=True), SMALL, "train", 26)
+                                         add_local=True), SMALL_T, "train", 26)
     run_case("mid_train", dict(hsz=128, embedding_size=96, vfeat_size=64, dropout=0.0, add_local=True), MID, "train", 31)
     run_case("mid_eval", dict(hsz=128, embedding_size=96, vfeat_size=64, add_local=True), MID, "eval", 32)
     k1_case("k1_small", N=2, Li=3, Lr=5, Lqa=7, D=16, seed=41)

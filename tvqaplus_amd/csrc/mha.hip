@@ -133,6 +133,8 @@ extern "C" int stage_mha_core_fwd(const float* q, const float* k, const float* v
     const size_t lds = ((size_t)3 * L * (dk + 1) + (size_t)L * (L + 1)) * sizeof(float);
     uint32_t th = p_drop > 0.f ? drop_thresh16(p_drop) : 0u;
     if (p_drop > 0.f && th == 0u) th = 1u;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)mha_core_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(mha_core_fwd_kernel, dim3((unsigned)(M * nh)), dim3(256), lds, (hipStream_t)stream, q, k, v, mask,
                        out, probs, L, D, nh, (uint64_t)seed, th, p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f);
     STAGE_LAUNCH_CHECK();
@@ -148,6 +150,8 @@ extern "C" int stage_mha_core_bwd(const float* dout, const float* q, const float
     const size_t lds = ((size_t)4 * L * (dk + 1) + (size_t)2 * L * (L + 1)) * sizeof(float);
     uint32_t th = p_drop > 0.f ? drop_thresh16(p_drop) : 0u;
     if (p_drop > 0.f && th == 0u) th = 1u;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)mha_core_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(mha_core_bwd_kernel, dim3((unsigned)(M * nh)), dim3(256), lds, (hipStream_t)stream, dout, q, k, v,
                        probs, mask, dq, dk_out, dv, L, D, nh, (uint64_t)seed, th,
                        p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f);

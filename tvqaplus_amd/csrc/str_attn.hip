@@ -130,8 +130,9 @@ __global__ __launch_bounds__(512) void str_attn_fwd_kernel(
         // ---- (d) mask, softmax over regions, store S / S_ ; acc becomes the stage-2 B operand ----
 #pragma unroll
         for (int t = 0; t < TPW; t++) {
+#pragma clang fp contract(off)  // scale*raw must be ONE rounded value for both the max and the exponent (see below)
             float mx = -INFINITY;
-            float msk[RT][4];
+            float msk[RT][4], xs[RT][4];
 #pragma unroll
             for (int rt = 0; rt < RT; rt++)
 #pragma unroll
@@ -140,7 +141,10 @@ __global__ __launch_bounds__(512) void str_attn_fwd_kernel(
                     msk[rt][k] = cmv[t] * qm[R];
                     const float raw = acc[t][rt][k] - 1e10f * (1.0f - msk[rt][k]);
                     acc[t][rt][k] = raw;
-                    if (R < Lr) mx = fmaxf(mx, raw * scale);
+                    // a contracted fma(raw, scale, -mx) would see -1e11 exactly vs the rounded max: exp(-2048) = 0,
+                    // 0/0 on fully masked rows.  Contraction is off in this block and the product is kept.
+                    xs[rt][k] = raw * scale;
+                    if (R < Lr) mx = fmaxf(mx, xs[rt][k]);
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(512) void str_attn_fwd_kernel(
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int R = rt * 16 + 4 * g + k;
-                    p[rt][k] = (R < Lr) ? expf(acc[t][rt][k] * scale - mx) : 0.f;
+                    p[rt][k] = (R < Lr) ? expf(xs[rt][k] - mx) : 0.f;
                     sum += p[rt][k];
                 }
             sum += __shfl_xor(sum, 16);
@@ -232,6 +236,10 @@ static int launch_fwd(const float* Cn, const float* Q, const float* cm, const fl
     uint32_t th = p_drop > 0.f ? drop_thresh16(p_drop) : 0u;
     if (p_drop > 0.f && th == 0u) th = 1u;
     const float ik = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    if (lds > 64 * 1024) {  // above the default dynamic-LDS cap the limit must be raised per kernel (160 KiB/CU)
+        (void)hipFuncSetAttribute((const void*)str_attn_fwd_kernel<RT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)str_attn_fwd_kernel<RT, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     if (D <= 128)
         hipLaunchKernelGGL((str_attn_fwd_kernel<RT, 8>), dim3(grid), dim3(64 * nw), lds, st, Cn, Q, cm, qm, A, S, Sn, N,
                            NA, Li, Lqa, Lr, D, scale, FPB, (uint64_t)seed, th, ik);
@@ -410,6 +418,10 @@ extern "C" int stage_str_attn_bwd(const float* dA, const float* dS_raw_ext, cons
     const int RT = (Lr + 15) / 16;
     const size_t lds = (size_t)RT * 16 * (D + 4) * sizeof(float);
     const dim3 grid(N * Li), block(64 * nw);
+    if (lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void*)str_attn_bwd_ds_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)str_attn_bwd_ds_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     switch (RT) {
         case 1: hipLaunchKernelGGL((str_attn_bwd_ds_kernel<1>), grid, block, lds, st, dA, Q, S_norm, dS_raw_ext, dS_out, N, NA, Li, Lqa, Lr, D, scale); break;
         case 2: hipLaunchKernelGGL((str_attn_bwd_ds_kernel<2>), grid, block, lds, st, dA, Q, S_norm, dS_raw_ext, dS_out, N, NA, Li, Lqa, Lr, D, scale); break;
