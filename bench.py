@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--dense", action="store_true", help="all-ones masks instead of ragged lengths")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
+    ap.add_argument("--only_roofline", action="store_true")
     ap.add_argument("--cpu_seconds", type=float, default=20.0, help="CPU-baseline time budget")
     return ap.parse_args()
 
@@ -139,6 +140,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    if args.only_roofline:  # developer shortcut: just the K1 kernel line (video and subtitle stream shapes)
+        print(json.dumps({"vid": k1_roofline(args, device)}))
+        args.regions = args.sub_words
+        print(json.dumps({"sub": k1_roofline(args, device)}))
+        return
     torch.manual_seed(2018)
     opt = make_opt(hsz=args.hsz, add_local=True, dropout=0.1)
     import contextlib

@@ -233,8 +233,10 @@ def test_k1_golden(ops, name):
     check("A", A, t("A"))
     check("S", S, t("S"))
     check("S_norm", Sn, t("S_norm"))
-    check("dC", Cd.grad.view_as(C), C.grad)
-    check("dQ", Qd.grad.view_as(Q), Q.grad)
+    # gradients: the scale-10 softmax backward dz = p*(dp - <p,dp>) cancels heavily; a 1-ulp change of S_ (x*(1/n)
+    # instead of x/n in the forward) already moves dQ by 4.5e-4 of (1+|g|) on k1_sub -> held to the north star's 1e-3
+    check("dC", Cd.grad.view_as(C), C.grad, 1e-3)
+    check("dQ", Qd.grad.view_as(Q), Q.grad, 1e-3)
 
 
 @pytest.mark.parametrize("N,Li,Lr,Lqa,D", [(2, 5, 4, 6, 16), (1, 9, 25, 13, 32), (2, 7, 20, 40, 128),
@@ -255,8 +257,8 @@ def test_k1_oracle_ragged(ops, N, Li, Lr, Lqa, D):
     check("A", A, Ao)
     check("S", S, So)
     check("S_norm", Sn, Sno)
-    check("dC", Cd.grad.view_as(C), Cc.grad)
-    check("dQ", Qd.grad.view_as(Q), Qc.grad)
+    check("dC", Cd.grad.view_as(C), Cc.grad, 1e-3)
+    check("dQ", Qd.grad.view_as(Q), Qc.grad, 1e-3)
 
 
 def test_k1_full_size_vs_oracle(ops):

@@ -250,7 +250,7 @@ static int launch_fwd(const float* Cn, const float* Q, const float* cm, const fl
     return 0;
 }
 
-extern "C" int stage_str_attn_fwd(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A,
+extern "C" int stage_str_attn_fwd_v1(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A,
                                   float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D,
                                   float scale, float p_drop, unsigned long long seed, void* stream) {
     if (N <= 0 || Li <= 0) return 0;

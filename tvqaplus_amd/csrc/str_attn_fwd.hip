@@ -1,0 +1,396 @@
+// K1 forward, production version -- StructuredAttention (model/context_query_attention.py:35-101).
+//
+//   Cn = drop(C / max(|C|,1e-12))  (pre-pass, rowops.hip)      C : (N, NA, Lqa, D)   broadcast over the Li frames
+//   Qn = drop(Q / max(|Q|,1e-12))  (in-kernel, per frame)      Q : (N, Li, Lr, D)    broadcast over the NA answers
+//   S  = Cn.Qn^T - 1e10*(1 - cm (x) qm)        raw_s           (N, NA, Li, Lqa, Lr)
+//   S_ = softmax(scale*S, -1) * (cm (x) qm)    normalised      (N, NA, Li, Lqa, Lr)
+//   A  = S_ . Q   (un-normalised Q)                            (N, NA, Li, Lqa, D)
+//
+// Fast path for D = 128 (hsz of every published STAGE config); other widths use the generic kernel in str_attn.hip.
+//
+// "One wave owns one frame".  A work item is (frame, slice of the NA*Lqa context rows); wave w of the grid walks the
+// items w, w + #waves, ...  It stages the frame's Lr x 128 region tile into its OWN slice of LDS (raw rows, 1/|row|,
+// region mask) and streams the 16-row context tiles of its slice past it; the Cn fragments of tile t+1 are loaded from
+// L2 into a second register set while tile t computes, and are "consumed" (waited for) BEFORE tile t's stores are
+// issued, so no s_waitcnt ever drains a freshly issued store.  There is no workgroup barrier (waves of a workgroup only
+// share the LDS allocation), all trip counts of the MFMA loops are compile-time, and invalid context rows of the last
+// tile alias the last valid row (identical values written twice) so the tile body is branch free.
+//   stage 1  S^T tile (regions x ctx) = Qn . Cn^T   on v_mfma_f32_16x16x4_f32 (A = raw rows from LDS * 1/|q|, B = Cn regs)
+//            -> each lane owns one context column and 4 regions per region tile: masked softmax = per-lane loop + two
+//               cross-lane-group shuffles, and the weights are ALREADY the B operand of stage 2 (any k-permutation
+//               is legal when A and B agree) -- no LDS round trip.
+//   stage 2  A^T tile (d x ctx) = Qraw^T . S_^T     -> each lane owns 4 consecutive d of one context row: 16-B stores.
+// Region permutation of the LAST region tile (PERM): tile row 4g+k holds region base + g + 4k instead of base + 4g + k,
+// so the valid regions fill whole k-steps and stage 2 runs only KL of them (Lr = 20: 5 k-steps instead of 8).  Rows
+// >= Lr alias one shared all-zero LDS row.  HBM traffic = algorithmic bytes: Q is read once per frame (the other slices
+// of the frame hit L2), Cn is L2 resident, A / S / S_ are written once.
+#include <stdlib.h>
+#include "common.h"
+#include "../../include/stage_hip.h"
+
+extern "C" int stage_str_attn_fwd_v1(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A,
+                                     float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D,
+                                     float scale, float p_drop, unsigned long long seed, void* stream);
+
+#define DD 128          // row width
+#define LDQ (DD + 4)    // padded LDS row stride (floats): ds_read_b128 of 16 rows x one chunk is conflict free
+#define NCH 8           // 4-float chunks per lane group (DD / 16)
+#define D4 32           // float4 per row
+
+__device__ __forceinline__ int dchunk(int g, int m) {
+    // 4-float chunk owned by lane group g at step m; groups 0/1 (2/3) sit 16 chunks apart (distinct 16-B LDS slots)
+    return m + NCH * (g >> 1) + 2 * NCH * (g & 1);
+}
+
+template <int RT, int KL, bool PERM, bool TRAIN, bool VEC_S>
+__global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
+    const float* __restrict__ Cn, const float* __restrict__ Q, const float* __restrict__ cmask,
+    const float* __restrict__ qmask, float* __restrict__ A, float* __restrict__ S, float* __restrict__ Sn, int N,
+    int NA, int Li, int Lqa, int Lr, float scale, int slices, int tiles_per_slice, uint64_t seed, uint32_t th,
+    float inv_keep, unsigned int* __restrict__ ticket, unsigned long long* __restrict__ tim) {
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = tim ? __builtin_readcyclecounter() : 0;
+#define TICK(ph) do { if (tim) { unsigned long long tn = __builtin_readcyclecounter(); tacc[ph] += tn - tlast; tlast = tn; } } while (0)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // floats per wave: Lr rows + one zero row, rinv[RT*16], qm[RT*16], context mask of the slice [tiles_per_slice*16]
+    const int WB = (Lr + 1) * LDQ + 2 * RT * 16 + tiles_per_slice * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int c15 = lane & 15, g = lane >> 4;
+    float* Qr = lds + wave * WB;
+    float* rinv = Qr + (Lr + 1) * LDQ;
+    float* qm = rinv + RT * 16;
+    float* cms = qm + RT * 16;
+    const int CR = NA * Lqa, CT = (CR + 15) >> 4;
+    constexpr int base_last = (RT - 1) * 16;
+    const int sq = lane & 31, srow = lane >> 5;     // staging: 32 lanes per row, 2 rows per pass
+
+    for (int i = lane; i < LDQ; i += 64) Qr[Lr * LDQ + i] = 0.f;      // shared zero row
+    for (int i = lane; i < 2 * RT * 16; i += 64) rinv[i] = 0.f;       // zero tails of rinv / qm
+
+    // region (and LDS row, clamped to the zero row) this lane feeds as stage-1 A operand, per region tile
+    int arow[RT], areg[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+        const int r = (PERM && rt == RT - 1) ? base_last + (c15 >> 2) + 4 * (c15 & 3) : rt * 16 + c15;
+        areg[rt] = r;
+        arow[rt] = r < Lr ? r : Lr;
+    }
+    // regions held by this lane after stage 1 (C layout) and their LDS rows for stage 2
+    int Rk[RT][4], Rrow[RT][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            Rk[rt][k] = (PERM && rt == RT - 1) ? base_last + g + 4 * k : rt * 16 + 4 * g + k;
+            Rrow[rt][k] = (Rk[rt][k] < Lr ? Rk[rt][k] : Lr) * LDQ;
+        }
+
+    const long n_items = (long)N * Li * slices;
+    const long n_waves = (long)gridDim.x * wpb;
+    // dynamic distribution: every wave starts on its own item, then draws tickets (one relaxed atomic per item), so the
+    // last items are picked up by whichever wave is free -- a static stride leaves 4800 items / 2048 waves at 78 %
+    long item = (long)blockIdx.x * wpb + wave;
+    for (; item < n_items; item = n_waves + (long)__builtin_amdgcn_readfirstlane(
+                                lane == 0 ? (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0)) {
+        const long frame = item / slices;           // n*Li + i
+        const int slice = (int)(item % slices);
+        const int n = (int)(frame / Li), i = (int)(frame % Li);
+        const int tile0 = slice * tiles_per_slice;
+        const int tile1 = min(CT, tile0 + tiles_per_slice);
+
+        TICK(5);
+        // ---- stage the frame: raw rows -> LDS, 1/|row| (x * (1/n) instead of x / n: 1 ulp), region mask ----
+        unsigned long long anyb = 0ull;
+        for (int r0 = 0; r0 < Lr; r0 += 16) {  // 16 rows per batch: all loads of a batch are in flight together
+            float4 v[8];
+            float pmv[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int r = r0 + 2 * j + srow;
+                v[j] = r < Lr ? ld4(Q + (frame * Lr + r) * DD + 4 * sq) : f4zero();
+                pmv[j] = (r < Lr && sq == 0) ? qmask[frame * Lr + r] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int r = r0 + 2 * j + srow;
+                const float ss = group_sum(f4hsum(f4mul(v[j], v[j])), 32);
+                if (r < Lr) st4(&Qr[r * LDQ + 4 * sq], v[j]);
+                if (r < Lr && sq == 0) {
+                    rinv[r] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+                    qm[r] = pmv[j];
+                }
+                anyb |= __ballot(pmv[j] != 0.f);
+            }
+        }
+        // context mask of this slice -> LDS (rows past the end alias the last valid row); keeps the tile loop free of
+        // compiler-tracked global loads (each would force an s_waitcnt that also drains the stores in flight)
+        for (int j = lane; j < (tile1 - tile0) * 16; j += 64) cms[j] = cmask[(long)n * CR + min(tile0 * 16 + j, CR - 1)];
+        if (anyb == 0ull) {
+            // no valid region in this frame: S = -1e10 (cos - 1e10 rounds to -1e10), S_ = 0, A = 0 for the whole slice
+            const int c_lo = tile0 * 16, c_hi = min(CR, tile1 * 16);
+            for (int c = c_lo + (lane >> 5); c < c_hi; c += 2) {
+                const long orow = ((long)(n * NA + c / Lqa) * Li + i) * Lqa + c % Lqa;
+                st4(A + orow * DD + 4 * sq, f4zero());
+                for (int r = sq; r < Lr; r += 32) { S[orow * Lr + r] = STAGE_NEG; Sn[orow * Lr + r] = 0.f; }
+            }
+            continue;
+        }
+        TICK(0);
+        float ri[RT], qmk[RT][4];
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            ri[rt] = rinv[areg[rt]];
+#pragma unroll
+            for (int k = 0; k < 4; k++) qmk[rt][k] = qm[Rk[rt][k]];
+        }
+
+        // Cn fragments are fetched by loads the compiler does not track, so that WE choose the wait: vmcnt is in-order,
+        // the fragments of tile t+1 are issued before tile t's stores and awaited with vmcnt(NST), NST = number of stores
+        // every tile is guaranteed to issue afterwards -- they stay in flight, only older traffic is waited for.
+        auto issue_cf = [&](f32x4 (&cf)[NCH], int tile) {
+            const int c = min(tile * 16 + c15, CR - 1);  // rows past the end alias the last valid row
+            const float* src = Cn + ((long)n * CR + c) * DD;
+#pragma unroll
+            for (int m = 0; m < NCH; m++) {
+                const float* p = src + 4 * dchunk(g, m);
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cf[m]) : "v"(p) : "memory");
+            }
+        };
+        // Two context tiles per step: their MFMA chains, LDS reads and softmax shuffle/exp chains are independent, so
+        // the in-order instruction stream of the wave always has something to issue.  One Cn register set: the
+        // fragments of the next pair are issued right after stage 1 has read the current ones (before this pair's
+        // stores) and awaited at the top of the next step.
+        auto do_pair = [&](f32x4 (&cf)[2][NCH], int t0, int t1, bool more, int nt0, int nt1) {
+            long orow[2];
+            float cmv[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int tile = u ? t1 : t0;
+                const int c = min(tile * 16 + c15, CR - 1);
+                orow[u] = ((long)(n * NA + c / Lqa) * Li + i) * Lqa + c % Lqa;
+                cmv[u] = cms[(tile - tile0) * 16 + c15];
+            }
+            f32x4 acc[2][RT];
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) acc[u][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // ---- stage 1 ----
+#pragma unroll
+            for (int m = 0; m < NCH; m++) {
+                float4 qv[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) {
+                    const int ch = dchunk(g, m);
+                    qv[rt] = f4scale(ld4(&Qr[arow[rt] * LDQ + 4 * ch]), ri[rt]);
+                    if (TRAIN) qv[rt] = f4mul(qv[rt], drop4(seed, (uint64_t)(frame * Lr + areg[rt]) * D4 + ch, th, inv_keep));
+                }
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int u = 0; u < 2; u++) acc[u][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[rt].x, cf[u][m][0], acc[u][rt], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int u = 0; u < 2; u++) acc[u][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[rt].y, cf[u][m][1], acc[u][rt], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int u = 0; u < 2; u++) acc[u][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[rt].z, cf[u][m][2], acc[u][rt], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int u = 0; u < 2; u++) acc[u][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[rt].w, cf[u][m][3], acc[u][rt], 0, 0, 0);
+            }
+            TICK(2);
+            if (more) {  // the MFMAs above have read cf (in-order issue): refill it for the next pair
+                issue_cf(cf[0], nt0);
+                issue_cf(cf[1], nt1);
+            }
+            float rv[2][RT][4], pv[2][RT][4];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {  // ---- mask + softmax over regions; pv becomes the stage-2 B operand ----
+#pragma clang fp contract(off)  // scale*raw must be ONE rounded value for both the max and the exponent: a contracted
+                                // fma(raw, scale, -mx) sees -1e11 exactly vs the rounded max -> exp(-2048) = 0 -> 0/0
+                float mx = -INFINITY;
+                float msk[RT][4], xs[RT][4];
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        msk[rt][k] = cmv[u] * qmk[rt][k];
+                        rv[u][rt][k] = acc[u][rt][k] - 1e10f * (1.0f - msk[rt][k]);
+                        xs[rt][k] = rv[u][rt][k] * scale;
+                        if (Rk[rt][k] < Lr) mx = fmaxf(mx, xs[rt][k]);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                float sum = 0.f;
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        pv[u][rt][k] = (Rk[rt][k] < Lr) ? expf(xs[rt][k] - mx) : 0.f;
+                        sum += pv[u][rt][k];
+                    }
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                const float rsum = 1.0f / sum;
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) pv[u][rt][k] = pv[u][rt][k] * rsum * msk[rt][k];
+            }
+            // ---- stores of S / S_ ----
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) {
+                    if (PERM && rt == RT - 1) {
+#pragma unroll
+                        for (int k = 0; k < KL; k++)
+                            if (Rk[rt][k] < Lr) {
+                                S[orow[u] * Lr + Rk[rt][k]] = rv[u][rt][k];
+                                Sn[orow[u] * Lr + Rk[rt][k]] = pv[u][rt][k];
+                            }
+                    } else if (VEC_S) {
+                        st4(S + orow[u] * Lr + rt * 16 + 4 * g, make_float4(rv[u][rt][0], rv[u][rt][1], rv[u][rt][2], rv[u][rt][3]));
+                        st4(Sn + orow[u] * Lr + rt * 16 + 4 * g, make_float4(pv[u][rt][0], pv[u][rt][1], pv[u][rt][2], pv[u][rt][3]));
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            S[orow[u] * Lr + Rk[rt][k]] = rv[u][rt][k];
+                            Sn[orow[u] * Lr + Rk[rt][k]] = pv[u][rt][k];
+                        }
+                    }
+                }
+            TICK(3);
+            // ---- stage 2: A^T tiles: per 16-wide d tile, one accumulator chain per context tile ----
+#pragma unroll
+            for (int dt = 0; dt < NCH; dt++) {
+                f32x4 o[2];
+                o[0] = o[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int k = 0; k < ((rt == RT - 1) ? KL : 4); k++) {
+                        const float q = Qr[Rrow[rt][k] + dt * 16 + c15];
+#pragma unroll
+                        for (int u = 0; u < 2; u++) o[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(q, pv[u][rt][k], o[u], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+                    st4(A + orow[u] * DD + dt * 16 + 4 * g, make_float4(o[u][0], o[u][1], o[u][2], o[u][3]));
+            }
+        };
+
+        // stores every PAIR issues for sure (lane-predicated stores of a permuted last region tile are not counted)
+        constexpr int NST_RAW = 2 * (8 + (VEC_S ? 2 : 8) * (PERM ? RT - 1 : RT));
+        constexpr int NST = NST_RAW > 60 ? 60 : NST_RAW;  // vmcnt is a 6-bit field; a smaller count only waits longer
+#define WAIT_CF(n_after)                                                                                             \
+    asm volatile("s_waitcnt vmcnt(%16)"                                                                              \
+                 : "+v"(cf[0][0]), "+v"(cf[0][1]), "+v"(cf[0][2]), "+v"(cf[0][3]), "+v"(cf[0][4]), "+v"(cf[0][5]),   \
+                   "+v"(cf[0][6]), "+v"(cf[0][7]), "+v"(cf[1][0]), "+v"(cf[1][1]), "+v"(cf[1][2]), "+v"(cf[1][3]),   \
+                   "+v"(cf[1][4]), "+v"(cf[1][5]), "+v"(cf[1][6]), "+v"(cf[1][7])                                    \
+                 : "n"(n_after)                                                                                      \
+                 : "memory")
+        f32x4 cf[2][NCH];
+        issue_cf(cf[0], tile0);
+        issue_cf(cf[1], min(tile0 + 1, tile1 - 1));
+        WAIT_CF(0);
+        TICK(1);
+        for (int t = tile0; t < tile1; t += 2) {
+            const bool more = t + 2 < tile1;
+            // an odd tail recomputes the last tile in the second slot: identical values are stored twice
+            do_pair(cf, t, min(t + 1, tile1 - 1), more, t + 2, min(t + 3, tile1 - 1));
+            TICK(4);
+            if (more) WAIT_CF(NST);  // only this pair's stores may still be in flight
+            TICK(1);
+        }
+#undef WAIT_CF
+    }
+    if (tim && lane == 0) for (int ph = 0; ph < 6; ph++) atomicAdd(tim + ph, tacc[ph]);
+#undef TICK
+}
+
+// One zeroed ticket word per launch out of a small device-resident ring (stream-ordered memset; launches of one process
+// run on one stream, the ring only guards against a handful of launches being in flight on different streams).
+static unsigned int* next_ticket(hipStream_t st) {
+    static unsigned int* ring = nullptr;
+    static unsigned int slot = 0;
+    if (!ring && hipMalloc((void**)&ring, 64 * sizeof(unsigned int)) != hipSuccess) return nullptr;
+    unsigned int* t = ring + (slot++ & 63u);
+    if (hipMemsetAsync(t, 0, sizeof(unsigned int), st) != hipSuccess) return nullptr;
+    return t;
+}
+
+template <int RT, int KL, bool PERM, bool TRAIN, bool VEC_S>
+static int launch_d128_t(const float* Cn, const float* Q, const float* cm, const float* qm, float* A, float* S, float* Sn,
+                         int N, int NA, int Li, int Lqa, int Lr, float scale, float p_drop, unsigned long long seed,
+                         hipStream_t st) {
+    const int CR = NA * Lqa, CT = (CR + 15) / 16;
+    // slices of the context tiles: enough work items (frames x slices) to balance ~2048 waves, >= 3 tiles per item
+    int slices = 1;
+    if (getenv("STAGE_K1_SLICES")) slices = atoi(getenv("STAGE_K1_SLICES"));
+    else while (slices < 4 && (long)N * Li * slices < 8192 && CT / (slices + 1) >= 3) slices++;
+    const int tps = (CT + slices - 1) / slices;
+    slices = (CT + tps - 1) / tps;
+    const size_t wave_bytes = ((size_t)(Lr + 1) * LDQ + 2 * RT * 16 + (size_t)tps * 16) * sizeof(float);
+    int wpb = 4;
+    while (wpb > 1 && wpb * wave_bytes > 80 * 1024) wpb >>= 1;   // keep >= 2 workgroups per CU when the tile is large
+    const size_t lds = wpb * wave_bytes;
+    auto kern = str_attn_fwd_d128_kernel<RT, KL, PERM, TRAIN, VEC_S>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const long items = (long)N * Li * slices;
+    int waves_per_cu = (int)((160 * 1024) / wave_bytes);
+    if (waves_per_cu > 8) waves_per_cu = 8;
+    if (getenv("STAGE_K1_WPC")) waves_per_cu = atoi(getenv("STAGE_K1_WPC"));
+    if (waves_per_cu < 1) waves_per_cu = 1;
+    long blocks = (256L * waves_per_cu + wpb - 1) / wpb;         // one resident round of waves; they stride the items
+    if (blocks * wpb > items) blocks = (items + wpb - 1) / wpb;
+    uint32_t th = TRAIN ? drop_thresh16(p_drop) : 0u;
+    if (TRAIN && th == 0u) th = 1u;
+    const float ik = TRAIN ? 1.0f / (1.0f - p_drop) : 1.0f;
+    unsigned int* ticket = next_ticket(st);
+    if (!ticket) return (int)hipErrorOutOfMemory;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * wpb), lds, st, Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr,
+                       scale, slices, tps, (uint64_t)seed, th, ik, ticket, (unsigned long long*)(getenv("STAGE_K1_TIM") ? strtoull(getenv("STAGE_K1_TIM"), 0, 0) : 0ull));
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int RT, bool TRAIN>
+static int launch_d128(const float* Cn, const float* Q, const float* cm, const float* qm, float* A, float* S, float* Sn,
+                       int N, int NA, int Li, int Lqa, int Lr, float scale, float p_drop, unsigned long long seed,
+                       hipStream_t st) {
+    const int rem = Lr - 16 * (RT - 1);
+    const bool vec = (Lr & 3) == 0;
+#define ARGS Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st
+    if (rem == 16) return vec ? launch_d128_t<RT, 4, false, TRAIN, true>(ARGS) : launch_d128_t<RT, 4, false, TRAIN, false>(ARGS);
+    switch ((rem + 3) / 4) {
+        case 1: return vec ? launch_d128_t<RT, 1, true, TRAIN, true>(ARGS) : launch_d128_t<RT, 1, true, TRAIN, false>(ARGS);
+        case 2: return vec ? launch_d128_t<RT, 2, true, TRAIN, true>(ARGS) : launch_d128_t<RT, 2, true, TRAIN, false>(ARGS);
+        case 3: return vec ? launch_d128_t<RT, 3, true, TRAIN, true>(ARGS) : launch_d128_t<RT, 3, true, TRAIN, false>(ARGS);
+        default: return vec ? launch_d128_t<RT, 4, true, TRAIN, true>(ARGS) : launch_d128_t<RT, 4, true, TRAIN, false>(ARGS);
+    }
+#undef ARGS
+}
+
+extern "C" int stage_str_attn_fwd(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A,
+                                  float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D,
+                                  float scale, float p_drop, unsigned long long seed, void* stream) {
+    if (N <= 0 || Li <= 0) return 0;
+    if (D % 16 != 0 || D > 256 || Lr < 1 || Lr > 64 || Lqa < 1 || NA < 1) return STAGE_ERR_SHAPE;
+    if (D != DD || getenv("STAGE_K1_GENERIC"))
+        return stage_str_attn_fwd_v1(Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, D, scale, p_drop, seed,
+                                     stream);
+    hipStream_t st = (hipStream_t)stream;
+    const bool train = p_drop > 0.f;
+#define ARGS Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st
+    switch ((Lr + 15) / 16) {
+        case 1: return train ? launch_d128<1, true>(ARGS) : launch_d128<1, false>(ARGS);
+        case 2: return train ? launch_d128<2, true>(ARGS) : launch_d128<2, false>(ARGS);
+        case 3: return train ? launch_d128<3, true>(ARGS) : launch_d128<3, false>(ARGS);
+        default: return train ? launch_d128<4, true>(ARGS) : launch_d128<4, false>(ARGS);
+    }
+#undef ARGS
+}
