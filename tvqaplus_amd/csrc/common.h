@@ -73,6 +73,38 @@ __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4
 __device__ __forceinline__ float4 f4scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 __device__ __forceinline__ float f4hsum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
 
+// out[c] = sum_b part[b*stride + c] for c < C, fixed summation order (deterministic).  64 columns x 16 row groups per
+// workgroup: the nb partial rows are read 16-way parallel (independent loads in flight) and combined by an LDS tree.
+// Optional remap (k > 0): column c = t*D + d of a depthwise-conv partial goes to dw[d*k + t] (t < k) or db[d] (t == k).
+__global__ __launch_bounds__(1024) static void stage_colreduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                                      float* __restrict__ out2, int nb, long stride,
+                                                                      int C, int D, int k) {
+    __shared__ float sm[16][64];
+    const int x = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + x;
+    float acc = 0.f;
+    if (c < C) {
+#pragma unroll 4
+        for (int b = r; b < nb; b += 16) acc += part[(size_t)b * stride + c];
+    }
+    sm[r][x] = acc;
+    __syncthreads();
+    if (r == 0 && c < C) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) s += sm[j][x];
+        if (k > 0) {
+            const int t = c / D, d = c % D;
+            if (t < k) out[d * k + t] = s;
+            else out2[d] = s;
+        } else out[c] = s;
+    }
+}
+static inline void stage_colreduce(const float* part, float* out, float* out2, int nb, long stride, int C, int D, int k,
+                                   hipStream_t st) {
+    hipLaunchKernelGGL(stage_colreduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, part, out, out2, nb, stride, C, D, k);
+}
+
 static inline int stage_pow2_ceil(int v) {
     int p = 1;
     while (p < v) p <<= 1;

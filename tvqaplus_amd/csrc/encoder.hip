@@ -158,8 +158,7 @@ extern "C" int stage_dwconv_bwd(const float* dout, const float* in, const float*
     hipLaunchKernelGGL(dwconv_bwd_kernel, dim3(grid), dim3(256), lds * sizeof(float), st, dout, in, w, din,
                        (float*)ws, (long)(M * L), L, D, k);
     STAGE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dwconv_final_kernel, dim3(((k + 1) * D + 255) / 256), dim3(256), 0, st, (const float*)ws, dw, db,
-                       grid, D, k);
+    stage_colreduce((const float*)ws, dw, db, grid, (long)(k + 1) * D, (k + 1) * D, D, k, st);
     STAGE_LAUNCH_CHECK();
     return 0;
 }

@@ -233,6 +233,7 @@ __global__ void slab_reduce_kernel(const float* __restrict__ part, float* __rest
     long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float acc = 0.f;
+#pragma unroll 8
     for (int b = 0; b < nb; b++) acc += part[(size_t)b * C + c];
     out[c] = acc;
 }

@@ -281,8 +281,8 @@ static int ln_bwd_launch(RowSrc src, const float* dy, const float* mean, const f
         hipLaunchKernelGGL((ln_bwd_kernel<MODE, false>), dim3(grid), dim3(256), lds, st, src, dy, mean, rstd, gamma, dx,
                            db_out, part, (long)rows, K, LPR, (uint64_t)0, 0u, 1.0f);
     STAGE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colreduce_kernel, dim3((K + 255) / 256), dim3(256), 0, st, part, dgamma, grid, (long)2 * K, K);
-    hipLaunchKernelGGL(colreduce_kernel, dim3((K + 255) / 256), dim3(256), 0, st, part + K, dbeta, grid, (long)2 * K, K);
+    stage_colreduce(part, dgamma, nullptr, grid, (long)2 * K, K, 0, 0, st);
+    stage_colreduce(part + K, dbeta, nullptr, grid, (long)2 * K, K, 0, 0, st);
     STAGE_LAUNCH_CHECK();
     return 0;
 }

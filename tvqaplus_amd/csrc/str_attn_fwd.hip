@@ -229,12 +229,12 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
                 for (int rt = 0; rt < RT; rt++)
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        pv[u][rt][k] = (Rk[rt][k] < Lr) ? expf(xs[rt][k] - mx) : 0.f;
+                        pv[u][rt][k] = (Rk[rt][k] < Lr) ? __expf(xs[rt][k] - mx) : 0.f;  // v_exp_f32 path: ~1e-6 relative
                         sum += pv[u][rt][k];
                     }
                 sum += __shfl_xor(sum, 16);
                 sum += __shfl_xor(sum, 32);
-                const float rsum = 1.0f / sum;
+                const float rsum = __builtin_amdgcn_rcpf(sum);  // 1 ulp
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++)
 #pragma unroll
