@@ -16,6 +16,7 @@
 //   stage 2  A^T tile (d x ctx) = Qraw^T . S_^T     on the same MFMA -> each lane owns 4 consecutive d of one context
 //            row: 16-byte stores of A.
 // HBM traffic = algorithmic bytes: Q read once per frame, Cn re-read from L2 per chunk, A / S / S_ written once.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/stage_hip.h"
 
@@ -398,7 +399,13 @@ __global__ void str_attn_slab_sum_kernel(const float* __restrict__ part, float* 
     st4(out + e * 4, acc);
 }
 
-#define DC_CHUNKS 8
+#define DC_CHUNKS 16
+
+// MFMA versions of B2 / B3 for D % 64 == 0 (str_attn_bwd_mfma.hip)
+int stage_str_attn_bwd_dq_mfma(const float* dA, const float* Sn, const float* dS, const float* Cn, float* dQraw,
+                                          float* dQn, int N, int NA, int Li, int Lqa, int Lr, int D, void* stream);
+int stage_str_attn_bwd_dc_mfma(const float* dS, const float* Qn, float* part, int N, int NA, int Li, int Lqa,
+                                          int Lr, int D, int max_chunks, int* nchunks_out, void* stream);
 
 extern "C" size_t stage_str_attn_bwd_ws_bytes(int N, int NA, int Lqa, int D) {
     return (size_t)DC_CHUNKS * N * NA * Lqa * D * sizeof(float);
@@ -429,15 +436,25 @@ extern "C" int stage_str_attn_bwd(const float* dA, const float* dS_raw_ext, cons
         default: hipLaunchKernelGGL((str_attn_bwd_ds_kernel<4>), grid, block, lds, st, dA, Q, S_norm, dS_raw_ext, dS_out, N, NA, Li, Lqa, Lr, D, scale); break;
     }
     STAGE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(str_attn_bwd_dq_kernel, dim3(N * Li), dim3(256), 0, st, dA, S_norm, dS_out, Cn, dQraw, dQn, N, NA,
-                       Li, Lqa, Lr, D);
-    STAGE_LAUNCH_CHECK();
-    const int fpc = (Li + DC_CHUNKS - 1) / DC_CHUNKS;
-    const int nchunks = (Li + fpc - 1) / fpc;
+    static const bool scalar_bwd = getenv("STAGE_K1_BWD_SCALAR") != nullptr;   // developer switch: pre-MFMA B2/B3
+    const bool mfma = (D % 64 == 0) && !scalar_bwd;
     const long total = (long)N * CR * (D / 4);
-    hipLaunchKernelGGL(str_attn_bwd_dc_kernel, dim3((unsigned)((total + 255) / 256), nchunks), dim3(256), 0, st, dS_out,
-                       Qn, (float*)ws, N, NA, Li, Lqa, Lr, D, fpc);
-    STAGE_LAUNCH_CHECK();
+    int nchunks;
+    if (mfma) {
+        int rc = stage_str_attn_bwd_dq_mfma(dA, S_norm, dS_out, Cn, dQraw, dQn, N, NA, Li, Lqa, Lr, D, stream);
+        if (rc) return rc;
+        rc = stage_str_attn_bwd_dc_mfma(dS_out, Qn, (float*)ws, N, NA, Li, Lqa, Lr, D, DC_CHUNKS, &nchunks, stream);
+        if (rc) return rc;
+    } else {
+        hipLaunchKernelGGL(str_attn_bwd_dq_kernel, dim3(N * Li), dim3(256), 0, st, dA, S_norm, dS_out, Cn, dQraw, dQn, N,
+                           NA, Li, Lqa, Lr, D);
+        STAGE_LAUNCH_CHECK();
+        const int fpc = (Li + DC_CHUNKS - 1) / DC_CHUNKS;
+        nchunks = (Li + fpc - 1) / fpc;
+        hipLaunchKernelGGL(str_attn_bwd_dc_kernel, dim3((unsigned)((total + 255) / 256), nchunks), dim3(256), 0, st,
+                           dS_out, Qn, (float*)ws, N, NA, Li, Lqa, Lr, D, fpc);
+        STAGE_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(str_attn_slab_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        (const float*)ws, dCn, nchunks, total);
     STAGE_LAUNCH_CHECK();
