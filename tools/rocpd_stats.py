@@ -17,3 +17,13 @@ for n, cnt, t, mn, mx in rows[: int(sys.argv[2]) if len(sys.argv) > 2 else 40]:
     n = re.sub(r"\(.*", "", n)[:90]
     print("%-90s %7d %12.1f %10.1f %10.1f %10.1f %6.2f" % (n, cnt, t / 1e3, t / 1e3 / cnt, mn / 1e3, mx / 1e3, 100.0 * t / tot))
 print("TOTAL kernel time us: %.1f" % (tot / 1e3))
+# optional: argv[3] = substring -> list individual dispatches (chronological) of matching kernels with grid size
+if len(sys.argv) > 3:
+    pat = sys.argv[3]
+    gcols = [x for x in cols if "grid" in x or "workgroup" in x]
+    q = "select s.%s, d.start, d.end-d.start, %s from %s d join %s s on d.kernel_id=s.id order by d.start" % (
+        namecol, ",".join("d." + x for x in gcols), kd, ks)
+    print("individual dispatches matching", pat, gcols)
+    for row in c.execute(q):
+        if pat in row[0]:
+            print("%-40s %10.1f us  %s" % (re.sub(r"\(.*", "", row[0])[:40], row[2] / 1e3, row[3:]))

@@ -32,6 +32,26 @@ __device__ __forceinline__ float4 load4_guard(const float* __restrict__ base, lo
     if (col + 3 < ncols) v.w = p[3];
     return v;
 }
+// branch-free variant (16-B aligned operands, ncols % 4 == 0): clamp the address, select zero afterwards -- the guarded
+// form compiles to an exec-masked branch + s_waitcnt per load, which serialises the whole fetch
+__device__ __forceinline__ float4 load4_clamp_f(const float* __restrict__ base, long row, long ld, int col, long nrows,
+                                                int ncols) {
+    const long r = row < nrows ? row : nrows - 1;
+    const int c = col < ncols ? col : ncols - 4;
+    float4 v = ld4(base + r * ld + c);
+    const bool ok = row < nrows && col < ncols;
+    v.x = ok ? v.x : 0.f;
+    v.y = ok ? v.y : 0.f;
+    v.z = ok ? v.z : 0.f;
+    v.w = ok ? v.w : 0.f;
+    return v;
+}
+template <bool FAST>
+__device__ __forceinline__ float4 load4_f(const float* __restrict__ base, long row, long ld, int col, long nrows, int ncols,
+                                          bool vec) {
+    if (FAST) return load4_clamp_f(base, row, ld, col, nrows, ncols);
+    return load4_guard(base, row, ld, col, nrows, ncols, vec);
+}
 __device__ __forceinline__ float4 gate4(float4 v, float4 g) {
     return make_float4(g.x > 0.f ? v.x : 0.f, g.y > 0.f ? v.y : 0.f, g.z > 0.f ? v.z : 0.f, g.w > 0.f ? v.w : 0.f);
 }
@@ -39,6 +59,7 @@ __device__ __forceinline__ float4 gate4(float4 v, float4 g) {
 // ------------------------------------------------------------------------------------------------
 // NT:  Y = epi(Xg . W^T + bias)
 // ------------------------------------------------------------------------------------------------
+template <bool FAST>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict__ X, const float* __restrict__ G,
                                                          const float* __restrict__ W, const float* __restrict__ bias,
                                                          const float* __restrict__ R, float* __restrict__ Y, long M,
@@ -48,8 +69,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, h = lane >> 5;
-    const long m0 = (long)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // 1-D grid, n-tile fastest: the workgroups that share a row block of X are dispatched back to back (L2 hits)
+    const int n_tiles = (N + BN - 1) / BN;
+    const long m0 = (long)(blockIdx.x / n_tiles) * BM;
+    const int n0 = (int)(blockIdx.x % n_tiles) * BN;
     const int lrow = tid >> 3, lcol = (tid & 7) * 4;  // staging: 32 rows x 8 float4 per pass, 4 passes
 
     f32x16 acc[2][2];
@@ -60,19 +83,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    float4 pa[4], pb[4];
-    auto fetch = [&](int k0) {
+    float4 pa[4], pb[4], pg[4];
+    auto fetch = [&](int k0) {   // loads only (gate applied in stash): one burst, one wait
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-            const long row = m0 + lrow + 32 * p;
-            pa[p] = load4_guard(X, row, K, k0 + lcol, M, K, vecX);
-            if (G) pa[p] = gate4(pa[p], load4_guard(G, row, K, k0 + lcol, M, K, vecX));
-            pb[p] = load4_guard(W, n0 + lrow + 32 * p, K, k0 + lcol, N, K, vecW);
+            pa[p] = load4_f<FAST>(X, m0 + lrow + 32 * p, K, k0 + lcol, M, K, vecX);
+            pb[p] = load4_f<FAST>(W, n0 + lrow + 32 * p, K, k0 + lcol, N, K, vecW);
+        }
+        if (G) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) pg[p] = load4_f<FAST>(G, m0 + lrow + 32 * p, K, k0 + lcol, M, K, vecX);
         }
     };
     auto stash = [&]() {
 #pragma unroll
         for (int p = 0; p < 4; p++) {
+            if (G) pa[p] = gate4(pa[p], pg[p]);
             st4(&As[(lrow + 32 * p) * LDS_STRIDE + lcol], pa[p]);
             st4(&Bs[(lrow + 32 * p) * LDS_STRIDE + lcol], pb[p]);
         }
@@ -143,9 +169,13 @@ extern "C" int stage_gemm_nt(const float* X, const float* gate, const float* W, 
     if (K <= 0) return STAGE_ERR_SHAPE;
     const int vecX = (K % 4 == 0) && (((uintptr_t)X & 15) == 0) && (!gate || ((uintptr_t)gate & 15) == 0);
     const int vecW = (K % 4 == 0) && (((uintptr_t)W & 15) == 0);
-    dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
-    hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, gate, W, bias, residual, Y, (long)M,
-                       N, K, relu, vecX, vecW);
+    dim3 grid((unsigned)(((M + BM - 1) / BM) * ((N + BN - 1) / BN)));
+    if (vecX && vecW && K >= 4)
+        hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, X, gate, W, bias, residual, Y,
+                           (long)M, N, K, relu, vecX, vecW);
+    else
+        hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, X, gate, W, bias, residual, Y,
+                           (long)M, N, K, relu, vecX, vecW);
     STAGE_LAUNCH_CHECK();
     return 0;
 }
@@ -153,8 +183,9 @@ extern "C" int stage_gemm_nt(const float* X, const float* gate, const float* W, 
 // ------------------------------------------------------------------------------------------------
 // TN:  partial[s][n][k] = sum_{m in slab s} Yg[m,n] X[m,k] ; partial_b[s][n] = sum_{m in slab s} Yg[m,n]
 // ------------------------------------------------------------------------------------------------
-#define TN_MAX_SPLIT 128
+#define TN_MAX_SPLIT 1024
 
+template <bool FAST>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const float* __restrict__ dY, const float* __restrict__ G,
                                                          const float* __restrict__ X, float* __restrict__ part,
                                                          float* __restrict__ part_b, long M, int N, int K,
@@ -180,19 +211,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const float* __restrict
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     float4 bsum = f4zero();
 
-    float4 py[4], px[4];
-    auto fetch = [&](long mb) {
+    float4 py[4], px[4], pg[4];
+    auto fetch = [&](long mb) {   // loads only (gate applied in stash): one burst, one wait
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-            const long row = mb + lrow + 8 * p;
-            py[p] = load4_guard(dY, row, N, n0 + lcol, mend, N, vecY);
-            if (G) py[p] = gate4(py[p], load4_guard(G, row, N, n0 + lcol, mend, N, vecY));
-            px[p] = load4_guard(X, row, K, k0 + lcol, mend, K, vecX);
+            py[p] = load4_f<FAST>(dY, mb + lrow + 8 * p, N, n0 + lcol, mend, N, vecY);
+            px[p] = load4_f<FAST>(X, mb + lrow + 8 * p, K, k0 + lcol, mend, K, vecX);
+        }
+        if (G) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) pg[p] = load4_f<FAST>(G, mb + lrow + 8 * p, N, n0 + lcol, mend, N, vecY);
         }
     };
     auto stash = [&]() {
 #pragma unroll
         for (int p = 0; p < 4; p++) {
+            if (G) py[p] = gate4(py[p], pg[p]);
             st4(&Ys[(lrow + 8 * p) * BM + lcol], py[p]);
             st4(&Xs[(lrow + 8 * p) * BN + lcol], px[p]);
             bsum = f4add(bsum, py[p]);
@@ -245,15 +279,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const float* __restrict
     }
 }
 
-__global__ void slab_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nb, long C) {
-    long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float acc = 0.f;
-#pragma unroll 8
-    for (int b = 0; b < nb; b++) acc += part[(size_t)b * C + c];
-    out[c] = acc;
-}
-
 static int tn_splits(long long M, int N, int K) {
     const long tiles = (long)((N + BM - 1) / BM) * ((K + BN - 1) / BN);
     long s = (1024 + tiles - 1) / tiles;
@@ -287,12 +312,16 @@ extern "C" int stage_gemm_tn(const float* dY, const float* gate, const float* X,
     const int vecY = (N % 4 == 0) && (((uintptr_t)dY & 15) == 0) && (!gate || ((uintptr_t)gate & 15) == 0);
     const int vecX = (K % 4 == 0) && (((uintptr_t)X & 15) == 0);
     dim3 grid((N + BM - 1) / BM, (K + BN - 1) / BN, S);
-    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, st, dY, gate, X, part, db ? part_b : (float*)nullptr,
-                       (long)M, N, K, rps, vecY, vecX);
+    if (vecY && vecX && N >= 4 && K >= 4)
+        hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, st, dY, gate, X, part, db ? part_b : (float*)nullptr,
+                           (long)M, N, K, rps, vecY, vecX);
+    else
+        hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, st, dY, gate, X, part, db ? part_b : (float*)nullptr,
+                           (long)M, N, K, rps, vecY, vecX);
     STAGE_LAUNCH_CHECK();
     const long C = (long)N * K;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, part, dW, S, C);
-    if (db) hipLaunchKernelGGL(slab_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part_b, db, S, (long)N);
+    stage_colreduce(part, dW, nullptr, S, C, (int)C, 1, 0, st);
+    if (db) stage_colreduce(part_b, db, nullptr, S, (long)N, N, 1, 0, st);
     STAGE_LAUNCH_CHECK();
     return 0;
 }

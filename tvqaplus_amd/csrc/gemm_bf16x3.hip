@@ -53,6 +53,27 @@ __device__ __forceinline__ float4 load4_guard_b(const float* __restrict__ base, 
     if (col + 3 < ncols) v.w = p[3];
     return v;
 }
+// branch-free variant for 16-B aligned operands with ncols % 4 == 0: clamp the address, select zero afterwards.  The
+// guarded form above compiles to one exec-masked branch + s_waitcnt per load (loads serialised); this one lets the
+// compiler issue a whole fetch back to back under a single wait.
+__device__ __forceinline__ float4 load4_clamp(const float* __restrict__ base, long row, long ld, int col, long nrows,
+                                              int ncols) {
+    const long r = row < nrows ? row : nrows - 1;
+    const int c = col < ncols ? col : ncols - 4;
+    float4 v = ld4(base + r * ld + c);
+    const bool ok = row < nrows && col < ncols;
+    v.x = ok ? v.x : 0.f;
+    v.y = ok ? v.y : 0.f;
+    v.z = ok ? v.z : 0.f;
+    v.w = ok ? v.w : 0.f;
+    return v;
+}
+template <bool FAST>
+__device__ __forceinline__ float4 load4_b(const float* __restrict__ base, long row, long ld, int col, long nrows, int ncols,
+                                          bool vec) {
+    if (FAST) return load4_clamp(base, row, ld, col, nrows, ncols);
+    return load4_guard_b(base, row, ld, col, nrows, ncols, vec);
+}
 __device__ __forceinline__ float4 gate4_b(float4 v, float4 g) {
     return make_float4(g.x > 0.f ? v.x : 0.f, g.y > 0.f ? v.y : 0.f, g.z > 0.f ? v.z : 0.f, g.w > 0.f ? v.w : 0.f);
 }
@@ -79,7 +100,7 @@ __device__ __forceinline__ void mma_terms(f32x16 (&acc)[2][2], const bf16x8 (&a)
 // ------------------------------------------------------------------------------------------------
 // NT:  Y = epi(Xg . W^T + bias)
 // ------------------------------------------------------------------------------------------------
-template <int NSPLIT>
+template <int NSPLIT, bool FAST>
 __global__ __launch_bounds__(256, 2) void gemm_nt_split_kernel(const float* __restrict__ X, const float* __restrict__ G,
                                                                const float* __restrict__ W,
                                                                const float* __restrict__ bias,
@@ -101,14 +122,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_split_kernel(const float* __re
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    float4 pa[4], pb[4];
-    auto fetch = [&](int k0) {
+    float4 pa[4], pb[4], pg[4];
+    auto fetch = [&](int k0) {   // loads only (the gate is applied in stash): one uninterrupted burst, one wait
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-            const long row = m0 + lrow + 32 * p;
-            pa[p] = load4_guard_b(X, row, K, k0 + lcol, M, K, vecX);
-            if (G) pa[p] = gate4_b(pa[p], load4_guard_b(G, row, K, k0 + lcol, M, K, vecX));
-            pb[p] = load4_guard_b(W, n0 + lrow + 32 * p, K, k0 + lcol, N, K, vecW);
+            pa[p] = load4_b<FAST>(X, m0 + lrow + 32 * p, K, k0 + lcol, M, K, vecX);
+            pb[p] = load4_b<FAST>(W, n0 + lrow + 32 * p, K, k0 + lcol, N, K, vecW);
+        }
+        if (G) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) pg[p] = load4_b<FAST>(G, m0 + lrow + 32 * p, K, k0 + lcol, M, K, vecX);
         }
     };
     auto stash = [&]() {
@@ -116,8 +139,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_split_kernel(const float* __re
         for (int p = 0; p < 4; p++) {
             const int off = (lrow + 32 * p) * XS + lcol;
             unsigned s01[NSPLIT], s23[NSPLIT];
-            splitn<NSPLIT>(pa[p].x, pa[p].y, s01);
-            splitn<NSPLIT>(pa[p].z, pa[p].w, s23);
+            const float4 av = G ? gate4_b(pa[p], pg[p]) : pa[p];
+            splitn<NSPLIT>(av.x, av.y, s01);
+            splitn<NSPLIT>(av.z, av.w, s23);
 #pragma unroll
             for (int s = 0; s < NSPLIT; s++) *reinterpret_cast<uint2*>(&Ap[s * PLANE + off]) = make_uint2(s01[s], s23[s]);
             splitn<NSPLIT>(pb[p].x, pb[p].y, s01);
@@ -182,12 +206,13 @@ extern "C" int stage_gemm_nt_bf16x3(const float* X, const float* gate, const flo
     const int vecX = (K % 4 == 0) && (((uintptr_t)X & 15) == 0) && (!gate || ((uintptr_t)gate & 15) == 0);
     const int vecW = (K % 4 == 0) && (((uintptr_t)W & 15) == 0);
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
-    if (split_depth() == 2)
-        hipLaunchKernelGGL(gemm_nt_split_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, X, gate, W, bias, residual, Y,
-                           (long)M, N, K, relu, vecX, vecW);
-    else
-        hipLaunchKernelGGL(gemm_nt_split_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, X, gate, W, bias, residual, Y,
-                           (long)M, N, K, relu, vecX, vecW);
+    const bool fast = vecX && vecW && K >= 4;
+#define LAUNCH_NT(NS, F)                                                                                              \
+    hipLaunchKernelGGL((gemm_nt_split_kernel<NS, F>), grid, dim3(256), 0, (hipStream_t)stream, X, gate, W, bias, residual, \
+                       Y, (long)M, N, K, relu, vecX, vecW)
+    if (split_depth() == 2) { if (fast) LAUNCH_NT(2, true); else LAUNCH_NT(2, false); }
+    else { if (fast) LAUNCH_NT(3, true); else LAUNCH_NT(3, false); }
+#undef LAUNCH_NT
     STAGE_LAUNCH_CHECK();
     return 0;
 }
@@ -197,7 +222,7 @@ extern "C" int stage_gemm_nt_bf16x3(const float* X, const float* gate, const flo
 // ------------------------------------------------------------------------------------------------
 #define TN_MAX_SPLIT 128
 
-template <int NSPLIT>
+template <int NSPLIT, bool FAST>
 __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(const float* __restrict__ dY, const float* __restrict__ G,
                                                                const float* __restrict__ X, float* __restrict__ part,
                                                                float* __restrict__ part_b, long M, int N, int K,
@@ -223,17 +248,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(const float* __re
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     float4 bsum = f4zero();
 
-    float4 py[2][2], px[2][2];  // [pass][row of the pair]
-    auto fetch = [&](long mb) {
+    float4 py[2][2], px[2][2], pg[2][2];  // [pass][row of the pair]
+    auto fetch = [&](long mb) {   // loads only; the gate is applied in stash
 #pragma unroll
         for (int p = 0; p < 2; p++)
 #pragma unroll
             for (int e = 0; e < 2; e++) {
                 const long row = mb + 16 * p + 2 * mp + e;
-                py[p][e] = load4_guard_b(dY, row, N, n0 + c4, mend, N, vecY);
-                if (G) py[p][e] = gate4_b(py[p][e], load4_guard_b(G, row, N, n0 + c4, mend, N, vecY));
-                px[p][e] = load4_guard_b(X, row, K, k0 + c4, mend, K, vecX);
+                py[p][e] = load4_b<FAST>(dY, row, N, n0 + c4, mend, N, vecY);
+                px[p][e] = load4_b<FAST>(X, row, K, k0 + c4, mend, K, vecX);
             }
+        if (G) {
+#pragma unroll
+            for (int p = 0; p < 2; p++)
+#pragma unroll
+                for (int e = 0; e < 2; e++)
+                    pg[p][e] = load4_b<FAST>(G, mb + 16 * p + 2 * mp + e, N, n0 + c4, mend, N, vecY);
+        }
     };
     auto put = [&](unsigned short* P, int col, int m, float a, float b) {
         unsigned s[NSPLIT];
@@ -245,6 +276,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(const float* __re
 #pragma unroll
         for (int p = 0; p < 2; p++) {
             const int m = 16 * p + 2 * mp;
+            if (G) {
+                py[p][0] = gate4_b(py[p][0], pg[p][0]);
+                py[p][1] = gate4_b(py[p][1], pg[p][1]);
+            }
             put(Ap, c4 + 0, m, py[p][0].x, py[p][1].x);
             put(Ap, c4 + 1, m, py[p][0].y, py[p][1].y);
             put(Ap, c4 + 2, m, py[p][0].z, py[p][1].z);
@@ -343,12 +378,13 @@ extern "C" int stage_gemm_tn_bf16x3(const float* dY, const float* gate, const fl
     const int vecY = (N % 4 == 0) && (((uintptr_t)dY & 15) == 0) && (!gate || ((uintptr_t)gate & 15) == 0);
     const int vecX = (K % 4 == 0) && (((uintptr_t)X & 15) == 0);
     dim3 grid((N + BM - 1) / BM, (K + BN - 1) / BN, S);
-    if (split_depth() == 2)
-        hipLaunchKernelGGL(gemm_tn_split_kernel<2>, grid, dim3(256), 0, st, dY, gate, X, part, db ? part_b : (float*)nullptr,
-                           (long)M, N, K, rps, vecY, vecX);
-    else
-        hipLaunchKernelGGL(gemm_tn_split_kernel<3>, grid, dim3(256), 0, st, dY, gate, X, part, db ? part_b : (float*)nullptr,
-                           (long)M, N, K, rps, vecY, vecX);
+    const bool fast = vecY && vecX && N >= 4 && K >= 4;
+#define LAUNCH_TN(NS, F)                                                                                                 \
+    hipLaunchKernelGGL((gemm_tn_split_kernel<NS, F>), grid, dim3(256), 0, st, dY, gate, X, part,                          \
+                       db ? part_b : (float*)nullptr, (long)M, N, K, rps, vecY, vecX)
+    if (split_depth() == 2) { if (fast) LAUNCH_TN(2, true); else LAUNCH_TN(2, false); }
+    else { if (fast) LAUNCH_TN(3, true); else LAUNCH_TN(3, false); }
+#undef LAUNCH_TN
     STAGE_LAUNCH_CHECK();
     const long C = (long)N * K;
     hipLaunchKernelGGL(slab_reduce_b_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, part, dW, S, C);
