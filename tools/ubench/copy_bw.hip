@@ -75,6 +75,28 @@ __global__ __launch_bounds__(256, 2) void k_tile(const float* __restrict__ X, fl
         for (int q = 0; q < 16; q++) { p[q].x += 1.f; *(float4*)(Y + (m0 + (tid >> 5) + 8 * q) * 128 + (tid & 31) * 4) = p[q]; }
     }
 }
+// mode 5: wave-private 32-row tiles, A operand loaded straight in MFMA layout (lane = (row, k-half), 16 B per lane:
+// 32 rows x 32 B per instruction), MFMA C-layout dword stores
+template <int PREF>
+__global__ __launch_bounds__(512, 2) void k_direct(const float* __restrict__ X, float* __restrict__ Y, long M) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+    const long nw = (long)gridDim.x * (blockDim.x >> 6), w0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    for (long t = w0; t < M / 32; t += nw) {
+        const float* xr = X + (t * 32 + l31) * 128 + 4 * h;
+        float4 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = *(const float4*)(xr + 8 * i);
+        float acc[4][16];
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[nt][r] = v[(nt * 4 + (r >> 2)) & 15].x + v[r].y * (float)nt;
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) Y[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 128 + nt * 32 + l31] = acc[nt][r];
+    }
+}
 template <typename F> void timeit(const char* name, F f, double bytes) {
     hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
     for (int r = 0; r < 3; r++) f();
@@ -92,5 +114,7 @@ int main() {
     timeit("tile: 1 chunk in flight, dword stores", [&] { hipLaunchKernelGGL(k_tile<2>, dim3(M / 128), dim3(256), 0, 0, X, Y, M); }, 2 * B);
     timeit("tile: 4 chunks up front, dword stores", [&] { hipLaunchKernelGGL(k_tile<3>, dim3(M / 128), dim3(256), 0, 0, X, Y, M); }, 2 * B);
     timeit("tile: full rows float4 in/out", [&] { hipLaunchKernelGGL(k_tile<4>, dim3(M / 128), dim3(256), 0, 0, X, Y, M); }, 2 * B);
+    for (int blocks : {256, 512})
+        { char n[64]; sprintf(n, "direct MFMA-layout loads, blocks=%d x512", blocks); timeit(n, [&] { hipLaunchKernelGGL(k_direct<0>, dim3(blocks), dim3(512), 0, 0, X, Y, M); }, 2 * B); }
     return 0;
 }

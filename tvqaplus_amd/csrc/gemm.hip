@@ -156,6 +156,8 @@ extern "C" int stage_gemm_nt_bf16x3(const float* X, const float* gate, const flo
                                     const float* residual, float* Y, long long M, int N, int K, int relu, void* stream);
 extern "C" int stage_gemm_tn_bf16x3(const float* dY, const float* gate, const float* X, float* dW, float* db, long long M,
                                     int N, int K, void* ws, size_t ws_bytes, void* stream);
+int stage_gemm_nt_stream(const float* X, const float* gate, const float* W, const float* bias, const float* residual,
+                         float* Y, long long M, int N, int K, int relu, void* stream);   // gemm_stream.hip
 static bool gemm_exact_f32() {
     static int mode = -1;
     if (mode < 0) mode = getenv("STAGE_GEMM_F32") ? 1 : 0;
@@ -164,8 +166,16 @@ static bool gemm_exact_f32() {
 
 extern "C" int stage_gemm_nt(const float* X, const float* gate, const float* W, const float* bias,
                              const float* residual, float* Y, long long M, int N, int K, int relu, void* stream) {
-    if (!gemm_exact_f32()) return stage_gemm_nt_bf16x3(X, gate, W, bias, residual, Y, M, N, K, relu, stream);
     if (M <= 0 || N <= 0) return 0;
+    if (K <= 0) return STAGE_ERR_SHAPE;
+    if (!gemm_exact_f32()) {
+        static const bool tiled_only = getenv("STAGE_GEMM_TILED") != nullptr;   // developer switch
+        if (!tiled_only) {
+            const int rc = stage_gemm_nt_stream(X, gate, W, bias, residual, Y, M, N, K, relu, stream);
+            if (rc <= 0) return rc;                      // 1 = shape not handled by the streaming kernel
+        }
+        return stage_gemm_nt_bf16x3(X, gate, W, bias, residual, Y, M, N, K, relu, stream);
+    }
     if (K <= 0) return STAGE_ERR_SHAPE;
     const int vecX = (K % 4 == 0) && (((uintptr_t)X & 15) == 0) && (!gate || ((uintptr_t)gate & 15) == 0);
     const int vecW = (K % 4 == 0) && (((uintptr_t)W & 15) == 0);

@@ -1,0 +1,289 @@
+// Streaming NT GEMM for the tall-skinny Linear / 1x1-conv shapes of the STAGE path (M ~ 1e5..1e6 rows, N, K ~ 128..768):
+//     Y[M,N] = epi( (X (*) gate)[M,K] . W[N,K]^T + bias )           same contract as stage_gemm_nt (gemm.hip)
+// fp32 accuracy through the exact 3-way bf16 split (see gemm_bf16x3.hip), but organised for HBM streaming:
+//   * the weight tile (128 output columns x 128 k) is split ONCE per workgroup into its three bf16 planes and stays in
+//     LDS (102 KB); for K <= 128 it is never reloaded while the workgroup walks its row tiles;
+//   * the X operand never touches LDS: every wave owns 32-row tiles and loads them straight from HBM in MFMA operand
+//     layout (lane = (row, k-half), 16 B per lane).  The MFMA contraction order is free as long as both operands agree,
+//     so k is permuted inside every 16-group such that a lane's two float4 loads (k = 8c + 4h + 0..3, c = 0,1) form its
+//     8-element operand; the LDS image of W is written with the same permutation.  tools/ubench/copy_bw.hip measures
+//     this access shape at 5.6 TB/s copy bandwidth, the same as fully row-contiguous loads;
+//   * no workgroup barrier in the row loop (K <= 128): 8 waves per CU drift freely, so loads, the split VALU work, the
+//     matrix cores and the stores of different waves overlap; the next 32-k line is prefetched while one is multiplied.
+// K > 128 walks K in 128-wide chunks with a barrier pair per chunk (weight chunk reload), accumulators stay in registers.
+#include <stdlib.h>
+#include "common.h"
+#include "../../include/stage_hip.h"
+
+#define SBN 128                 // output columns per workgroup
+#define SKC 128                 // k per resident weight chunk
+#define SWS (SKC + 8)           // bf16 per LDS row of a plane (272 B: 16-lane ds_read_b128 groups hit distinct slots)
+#define SPLANE (SBN * SWS)      // bf16 elements per plane
+#define SWAVES 8
+
+typedef __bf16 sbf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned s_cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// (a, b) -> three packed bf16 pairs (a low half): exact residual splits, a == a1 + a2 + a3
+__device__ __forceinline__ void s_split3(float a, float b, unsigned (&out)[3]) {
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        out[s] = s_cvt_pk_bf16(a, b);
+        a -= __uint_as_float(out[s] << 16);
+        b -= __uint_as_float(out[s] & 0xFFFF0000u);
+    }
+}
+__device__ __forceinline__ float4 s_load4(const float* __restrict__ base, long row, long ld, int col, long nrows, int ncols) {
+    const long r = row < nrows ? row : nrows - 1;
+    const int c = col < ncols ? col : ncols - 4;
+    float4 v = ld4(base + r * ld + c);
+    const bool ok = row < nrows && col < ncols;
+    v.x = ok ? v.x : 0.f;
+    v.y = ok ? v.y : 0.f;
+    v.z = ok ? v.z : 0.f;
+    v.w = ok ? v.w : 0.f;
+    return v;
+}
+// address-clamped load WITHOUT the zero select (a select at the load site forces an s_waitcnt right behind the load)
+__device__ __forceinline__ float4 s_load4_raw(const float* __restrict__ base, long row, long ld, int col, long nrows, int ncols) {
+    const long r = row < nrows ? row : nrows - 1;
+    const int c = col < ncols ? col : ncols - 4;
+    return ld4(base + r * ld + c);
+}
+__device__ __forceinline__ float4 s_keep4(float4 v, bool ok) {
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+__device__ __forceinline__ float4 s_gate4(float4 v, float4 g) {
+    return make_float4(g.x > 0.f ? v.x : 0.f, g.y > 0.f ? v.y : 0.f, g.z > 0.f ? v.z : 0.f, g.w > 0.f ? v.w : 0.f);
+}
+
+template <bool HAS_GATE, bool HAS_RES>
+__global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const float* __restrict__ X,
+                                                                        const float* __restrict__ G,
+                                                                        const float* __restrict__ W,
+                                                                        const float* __restrict__ bias,
+                                                                        const float* __restrict__ R, float* __restrict__ Y,
+                                                                        long M, int N, int K, int relu) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short Wp[];   // [3][SBN][SWS] bf16, k permuted per 16-group
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * SBN;
+    const int nkc = (K + SKC - 1) / SKC;
+    const long MT = (M + 31) >> 5;                       // 32-row wave tiles
+    const long n_bt = (MT + SWAVES - 1) / SWAVES;        // workgroup iterations
+
+    // weight chunk kc -> LDS planes.  float4 group q of a row covers k = 4q..4q+3 = 16u + 8c + 4h' + e  (q = 4u + 2c + h')
+    // and lands at plane position 16u + 8h' + 4c + e, i.e. lane-half h' finds its 8 operand values contiguous.
+    auto load_w = [&](int kc) {
+        for (int e = tid; e < SBN * (SKC / 4); e += 64 * SWAVES) {
+            const int n = e >> 5, q = e & 31;
+            const float4 v = s_load4(W, n0 + n, K, kc * SKC + 4 * q, N, K);
+            unsigned s01[3], s23[3];
+            s_split3(v.x, v.y, s01);
+            s_split3(v.z, v.w, s23);
+            const int pos = 16 * (q >> 2) + 8 * (q & 1) + 4 * ((q >> 1) & 1);
+#pragma unroll
+            for (int s = 0; s < 3; s++) *reinterpret_cast<uint2*>(&Wp[s * SPLANE + n * SWS + pos]) = make_uint2(s01[s], s23[s]);
+        }
+    };
+
+    // X (and gate) lines in flight: two 32-k line buffers, ping-ponged inside a tile.  vmcnt retires in issue order on
+    // gfx9, so a load issued after the 64 epilogue stores of a tile cannot be consumed before those stores are
+    // acknowledged: the first two lines of the NEXT tile are therefore requested BEFORE the stores of the current one.
+    // The compiler's own s_waitcnt bookkeeping cannot express "older than 64 stores" (it falls back to vmcnt(0..2) at the
+    // loop head, draining the stores), so the X/gate loads are issued as asm and awaited with hand-counted vmcnt values.
+    // Rule for every count below: it must not exceed the number of VMEM instructions (of any kind) issued after the
+    // awaited loads -- a smaller count only waits longer.
+    constexpr int NL = HAS_GATE ? 8 : 4;                   // loads per fetch
+    f32x4 xa[2][4], ga[2][4];
+    auto fetch = [&](int buf, long row, int k_line) {   // K % 32 == 0: one address per lane, immediate offsets
+        const long off = (row < M ? row : M - 1) * K + k_line + 4 * h;
+        const float* px = X + off;
+        const float* pg = G + off;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(xa[buf][c]) : "v"(px), "n"(32 * c) : "memory");
+            if (HAS_GATE)
+                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(ga[buf][c]) : "v"(pg), "n"(32 * c) : "memory");
+        }
+    };
+#define WAIT_LINE(buf, n)                                                                                              \
+    do {                                                                                                               \
+        if constexpr (HAS_GATE)                                                                                        \
+            asm volatile("s_waitcnt vmcnt(%8)"                                                                         \
+                         : "+v"(xa[buf][0]), "+v"(xa[buf][1]), "+v"(xa[buf][2]), "+v"(xa[buf][3]), "+v"(ga[buf][0]),   \
+                           "+v"(ga[buf][1]), "+v"(ga[buf][2]), "+v"(ga[buf][3])                                        \
+                         : "n"(n)                                                                                      \
+                         : "memory");                                                                                  \
+        else                                                                                                           \
+            asm volatile("s_waitcnt vmcnt(%4)"                                                                         \
+                         : "+v"(xa[buf][0]), "+v"(xa[buf][1]), "+v"(xa[buf][2]), "+v"(xa[buf][3])                      \
+                         : "n"(n)                                                                                      \
+                         : "memory");                                                                                  \
+    } while (0)
+    // bias of the 128 output columns goes to LDS once: a register loaded from global before the row loop makes the
+    // compiler guard every epilogue with s_waitcnt vmcnt(0) (which would also drain the stores and the prefetch)
+    float* bias_s = reinterpret_cast<float*>(Wp + 3 * SPLANE);
+    if (tid < SBN) bias_s[tid] = (bias && n0 + tid < N) ? bias[n0 + tid] : 0.f;
+    // Units of work of a wave: (tile, k-chunk).  Lines 0 and 1 of the NEXT unit are always requested right after line 3 of
+    // the current one has been consumed (straight-line code: asm results defined inside a branch get merged by register
+    // copies, and a copy of a register whose load is still in flight copies garbage).  When the next unit is a new tile,
+    // that request therefore precedes the 64 stores of the current tile ("steady": the waits then use vmcnt(63)).
+    const bool full_cols = n0 + SBN <= N;                 // this workgroup stores all 4 column tiles: 64 stores per tile
+    bool w_loaded = false, first = true;
+    fetch(0, ((long)blockIdx.x * SWAVES + wave) * 32 + l31, 0);
+    fetch(1, ((long)blockIdx.x * SWAVES + wave) * 32 + l31, 32);
+    for (long bt = blockIdx.x; bt < n_bt; bt += gridDim.x) {
+        const long t = bt * SWAVES + wave;               // this wave's tile (may be past the end: then it only syncs)
+        const bool live = t < MT;
+        const long row = t * 32 + l31;
+        f32x16 acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[nt][r] = 0.f;
+
+        for (int kc = 0; kc < nkc; kc++) {
+            const int kb = kc * SKC;
+            if (nkc > 1 || !w_loaded) {
+                __syncthreads();                         // everyone done with the previous chunk
+                load_w(kc);
+                __syncthreads();
+                w_loaded = true;
+            }
+            if (!live) continue;
+            auto mul_line = [&](int buf, int L) {
+#pragma unroll
+                for (int up = 0; up < 2; up++) {          // two 16-k MFMA steps per line
+                    float4 v0 = make_float4(xa[buf][2 * up][0], xa[buf][2 * up][1], xa[buf][2 * up][2], xa[buf][2 * up][3]);
+                    float4 v1 = make_float4(xa[buf][2 * up + 1][0], xa[buf][2 * up + 1][1], xa[buf][2 * up + 1][2],
+                                            xa[buf][2 * up + 1][3]);
+                    if (HAS_GATE) {
+                        const f32x4 g0 = ga[buf][2 * up], g1 = ga[buf][2 * up + 1];
+                        v0 = s_gate4(v0, make_float4(g0[0], g0[1], g0[2], g0[3]));
+                        v1 = s_gate4(v1, make_float4(g1[0], g1[1], g1[2], g1[3]));
+                    }
+                    unsigned p0[3], p1[3], p2[3], p3[3];
+                    s_split3(v0.x, v0.y, p0);
+                    s_split3(v0.z, v0.w, p1);
+                    s_split3(v1.x, v1.y, p2);
+                    s_split3(v1.z, v1.w, p3);
+                    sbf16x8 a[3];
+#pragma unroll
+                    for (int s = 0; s < 3; s++) a[s] = __builtin_bit_cast(sbf16x8, make_uint4(p0[s], p1[s], p2[s], p3[s]));
+                    const int koff = 16 * (2 * L + up) + 8 * h;
+#pragma unroll
+                    for (int nt = 0; nt < 4; nt++) {
+                        sbf16x8 b[3];
+#pragma unroll
+                        for (int s = 0; s < 3; s++)
+                            b[s] = __builtin_bit_cast(sbf16x8, *reinterpret_cast<const uint4*>(&Wp[s * SPLANE + (nt * 32 + l31) * SWS + koff]));
+                        // kept cross terms, smallest first
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[nt], 0, 0, 0);
+                    }
+                }
+            };
+            // In flight (issue order): [line 0][line 1] {64 stores of the previous tile, if steady}.
+            // Not steady: the exact counts are applied first by an untied wait inside the (uniform) branch; the tied
+            // waits that carry the registers stay outside of any branch.
+            const bool steady = kc == 0 && !first && full_cols;
+            if (!steady) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");   // newer than line 0: line 1
+            WAIT_LINE(0, 63);
+            mul_line(0, 0);
+            fetch(0, row, kb + 64);
+            if (!steady) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");   // newer than line 1: line 2
+            WAIT_LINE(1, 63);                                                         // steady: 64 stores + line 2
+            mul_line(1, 1);
+            fetch(1, row, kb + 96);
+            WAIT_LINE(0, NL);                                                         // newer than line 2: line 3
+            mul_line(0, 2);
+            WAIT_LINE(1, 0);
+            mul_line(1, 3);
+            // lines 0, 1 of the next unit (same tile / next chunk, or next tile / chunk 0; clamped past the end)
+            const bool last_chunk = kc + 1 == nkc;
+            const long nrow = last_chunk ? ((bt + gridDim.x) * SWAVES + wave) * 32 + l31 : row;
+            const int nk = last_chunk ? 0 : kb + SKC;
+            fetch(0, nrow, nk);
+            fetch(1, nrow, nk + 32);
+            first = false;
+        }
+        if (!live) continue;
+        // epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+        // Straight-line stores: a residual load or a per-row guard inside this loop makes the compiler put an
+        // s_waitcnt vmcnt(0) in front of every store (each store then waits for the previous one to be acknowledged).
+        const bool full = t * 32 + 32 <= M;
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+            const int n = n0 + nt * 32 + l31;
+            if (n >= N) continue;
+            const float bsv = bias_s[nt * 32 + l31];
+            float* yp = Y + (t * 32 + 4 * h) * N + n;
+            float rv[16];
+            if (HAS_RES) {
+                const float* rp = R + (t * 32 + 4 * h) * N + n;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int dm = (r & 3) + 8 * (r >> 2);
+                    rv[r] = (full || t * 32 + 4 * h + dm < M) ? rp[(long)dm * N] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                float v = acc[nt][r] + bsv;
+                if (relu) v = fmaxf(v, 0.f);
+                if (HAS_RES) v += rv[r];
+                acc[nt][r] = v;
+            }
+            if (full) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) yp[(long)((r & 3) + 8 * (r >> 2)) * N] = acc[nt][r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int dm = (r & 3) + 8 * (r >> 2);
+                    if (t * 32 + 4 * h + dm < M) yp[(long)dm * N] = acc[nt][r];
+                }
+            }
+        }
+    }
+}
+
+// returns 1 if the shape/alignment is not handled here (caller falls back to the tiled kernel), 0 on launch, <0 on error
+int stage_gemm_nt_stream(const float* X, const float* gate, const float* W, const float* bias, const float* residual,
+                         float* Y, long long M, int N, int K, int relu, void* stream) {
+    const bool vec = (K % 4 == 0) && K >= 4 && (((uintptr_t)X & 15) == 0) && (((uintptr_t)W & 15) == 0) &&
+                     (!gate || ((uintptr_t)gate & 15) == 0);
+    if (!vec || M < 4096 || K % SKC != 0) return 1;   // K in {128, 384, 768, 2048} on the STAGE path
+    const int lds = 3 * SPLANE * (int)sizeof(unsigned short) + SBN * (int)sizeof(float);
+    const long MT = (M + 31) / 32, n_bt = (MT + SWAVES - 1) / SWAVES;
+    const int n_tiles = (N + SBN - 1) / SBN;
+    long gx = 256 / n_tiles;                              // one resident workgroup per CU; the column tiles of a row
+    if (gx < 1) gx = 1;                                   // range run side by side (X re-reads hit L2 / MALL)
+    if (gx > n_bt) gx = n_bt;
+    dim3 grid((unsigned)gx, (unsigned)n_tiles), block(64 * SWAVES);
+#define LAUNCH_ST(GT, RS)                                                                                              \
+    do {                                                                                                               \
+        static bool attr_done = false;                                                                                 \
+        if (!attr_done) {                                                                                              \
+            (void)hipFuncSetAttribute((const void*)gemm_nt_stream_kernel<GT, RS>,                                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                \
+            attr_done = true;                                                                                          \
+        }                                                                                                              \
+        hipLaunchKernelGGL((gemm_nt_stream_kernel<GT, RS>), grid, block, lds, (hipStream_t)stream, X, gate, W, bias,   \
+                           residual, Y, (long)M, N, K, relu);                                                          \
+    } while (0)
+    if (gate) { if (residual) LAUNCH_ST(true, true); else LAUNCH_ST(true, false); }
+    else { if (residual) LAUNCH_ST(false, true); else LAUNCH_ST(false, false); }
+#undef LAUNCH_ST
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
