@@ -32,6 +32,10 @@ extern "C" int stage_str_attn_fwd_v1(const float* Cn, const float* Q, const floa
                                      float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D,
                                      float scale, float p_drop, unsigned long long seed, void* stream);
 
+int stage_str_attn_fwd_reg(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A,
+                           float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D, float scale,
+                           float p_drop, unsigned long long seed, void* stream);
+
 #define DD 128          // row width
 #define LDQ (DD + 4)    // padded LDS row stride (floats): ds_read_b128 of 16 rows x one chunk is conflict free
 #define NCH 8           // 4-float chunks per lane group (DD / 16)
@@ -283,8 +287,10 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
             }
         };
 
-        // stores every PAIR issues for sure (lane-predicated stores of a permuted last region tile are not counted)
-        constexpr int NST_RAW = 2 * (8 + (VEC_S ? 2 : 8) * (PERM ? RT - 1 : RT));
+        // stores every PAIR issues after the next fragments were requested -- EXACT count (an undercount makes every
+        // step wait for some of its own stores to be acknowledged; the lane-predicated stores of a permuted last region
+        // tile are always issued: for k < KL region base + g + 4k is valid at least for g = 0)
+        constexpr int NST_RAW = 2 * (8 + (VEC_S ? 2 : 8) * (PERM ? RT - 1 : RT) + (PERM ? 2 * KL : 0));
         constexpr int NST = NST_RAW > 60 ? 60 : NST_RAW;  // vmcnt is a 6-bit field; a smaller count only waits longer
 #define WAIT_CF(n_after)                                                                                             \
     asm volatile("s_waitcnt vmcnt(%16)"                                                                              \
@@ -383,6 +389,11 @@ extern "C" int stage_str_attn_fwd(const float* Cn, const float* Q, const float* 
     if (D != DD || getenv("STAGE_K1_GENERIC"))
         return stage_str_attn_fwd_v1(Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, D, scale, p_drop, seed,
                                      stream);
+    if (!getenv("STAGE_K1_LDS")) {   // register-resident kernel for Lr <= 32 (str_attn_fwd_reg.hip); 1 = not handled
+        const int rc = stage_str_attn_fwd_reg(Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, D, scale, p_drop,
+                                              seed, stream);
+        if (rc != 1) return rc;
+    }
     hipStream_t st = (hipStream_t)stream;
     const bool train = p_drop > 0.f;
 #define ARGS Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st

@@ -1,0 +1,362 @@
+// K1 forward, register-resident version for D = 128 and Lr <= 32 (the video stream: 20 regions per frame) --
+// StructuredAttention (model/context_query_attention.py:35-101).  Same math and output contract as str_attn_fwd.hip:
+//
+//   S  = Cn.Qn^T - 1e10*(1 - cm (x) qm) ,  S_ = softmax(scale*S, -1) * (cm (x) qm) ,  A = S_ . Q
+//
+// No LDS at all.  A work item is (frame, slice of the NA*Lqa context rows), one wave per item.  Both views of the frame's
+// region tile live in registers for the whole item, loaded from global directly in MFMA operand layout:
+//   qa  stage-1 A operand   lane (c15, g): region row c15 (permuted for the last region tile), 16 B at chunk 4m+g:
+//                           normalised (x * 1/|row|, the norm is two cross-lane-group shuffles) and dropped ONCE per item
+//   q2  stage-2 B operand   lane (c15, g): raw region row Rk(g, k), 16 B at d = 64b + 4 c15  (d-permutation: output
+//                           column j of tile e is d = 64b + 4j + e, so one float4 feeds four 16-wide tiles)
+// and the 16-row context tiles stream past them:
+//   stage 1  S^T tile (regions x ctx) = Qn . Cn^T  (v_mfma_f32_16x16x4_f32; B = Cn fragments, prefetched one tile ahead by
+//            asm loads that are issued BEFORE the tile's stores and awaited with a counted vmcnt -- vmcnt retires in
+//            issue order, a compiler-tracked load behind the stores would drain them)
+//            -> lane (c15, g) owns context row c15 and 4 regions per region tile: masked softmax in registers, and the
+//               weights ARE the A operand of stage 2 (contraction index g <-> region Rk(g, k); both operands agree)
+//   stage 2  A tile (ctx x d) = S_ . Q -> lane owns 4 consecutive d of context rows 4g+reg: 16-B stores, 256 B per row.
+// Region permutation of the LAST region tile (PERM/KL) as in str_attn_fwd.hip: tile row 4g+k holds region base + g + 4k.
+#include <stdlib.h>
+#include "common.h"
+#include "../../include/stage_hip.h"
+
+#ifndef K1_ABL
+#define K1_ABL 0        // developer ablation bits (tools/ubench/k1_abl.hip): 1 no A stores, 2 no S stores, 4 no stage-2 MFMA,
+#endif                  // 8 no stage-1 MFMA -- results are wrong with any bit set, timing experiments only
+#define RD 128          // row width (floats)
+#define RNCH 8          // 4-float chunks per lane group
+
+template <int RT, int KL, bool PERM, bool TRAIN, bool VEC_S>
+__global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
+    const float* __restrict__ Cn, const float* __restrict__ Q, const float* __restrict__ cmask,
+    const float* __restrict__ qmask, float* __restrict__ A, float* __restrict__ S, float* __restrict__ Sn, int N,
+    int NA, int Li, int Lqa, int Lr, float scale, int slices, int tiles_per_slice, uint64_t seed, uint32_t th,
+    float inv_keep, unsigned int* __restrict__ ticket, int static_rounds) {
+    constexpr int NK2 = (RT - 1) * 4 + KL;            // stage-2 k-steps (4 regions each)
+    constexpr int base_last = (RT - 1) * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int c15 = lane & 15, g = lane >> 4;
+    const int CR = NA * Lqa, CT = (CR + 15) >> 4;
+    const float inv_lqa = 1.0f / (float)Lqa;
+
+    // region fed by this lane as stage-1 A row (i = c15), per region tile
+    int areg[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+        areg[rt] = (PERM && rt == RT - 1) ? base_last + (c15 >> 2) + 4 * (c15 & 3) : rt * 16 + c15;
+    // region held by this lane in register k of region tile rt after stage 1 (C layout: row 4g + k); recomputed where
+    // needed (8 live index registers are 8 too many here), validity kept as one bit mask
+    auto Rk = [&](int rt, int k) -> int { return (PERM && rt == RT - 1) ? base_last + g + 4 * k : rt * 16 + 4 * g + k; };
+    unsigned vmask = 0u;
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) vmask |= (Rk(rt, k) < Lr ? 1u : 0u) << (rt * 4 + k);
+
+    // output row of context row c of example n, frame i:  ((n*NA + a)*Li + i)*Lqa + w ,  c = a*Lqa + w
+    auto out_row = [&](int n, int i, int c) -> long {
+        const int a = (int)(((float)c + 0.5f) * inv_lqa);      // exact for c < 2^22
+        return ((long)(n * NA + a) * Li + i) * Lqa + (c - a * Lqa);
+    };
+
+    const long n_items = (long)N * Li * slices;
+    const long n_waves = (long)gridDim.x * wpb;
+    // Work distribution: the first `static_rounds` rounds are a plain stride (item = wave + round * #waves), only the
+    // tail is handed out by tickets (one relaxed atomic per item, drawn at the top of the PREVIOUS item so that its
+    // return travels with the frame loads).  All-dynamic costs ~85 us here: every atomic hits the same L2 word (~9 ns
+    // each, 2048 of them queued at kernel start) and, vmcnt being in-order, the frame loads behind it cannot retire
+    // before it returns.  All-static leaves the waves resident for only ~74 % of the kernel with ragged frames (items
+    // without a valid region are almost free).
+    long item = (long)blockIdx.x * wpb + wave;
+    int round = 0;
+    while (item < n_items) {
+        round++;
+        long next_item;
+        if ((K1_ABL & 256) || round < static_rounds) {
+            next_item = item + n_waves;
+        } else {
+            const unsigned drawn = lane == 0 ? __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            next_item = (long)static_rounds * n_waves + (long)__builtin_amdgcn_readfirstlane((int)drawn);
+        }
+        const long frame = item / slices;           // n*Li + i
+        const int slice = (int)(item % slices);
+        const int n = (int)(frame / Li), i = (int)(frame % Li);
+        const int tile0 = slice * tiles_per_slice;
+        const int tile1 = min(CT, tile0 + tiles_per_slice);
+        const float* qf = Q + frame * Lr * RD;
+
+        // ---- the frame's operands (compiler-tracked loads: the one full vmcnt drain per item) ----
+        float4 qa[RT][RNCH];
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            const int rc = min(areg[rt], Lr - 1);
+#pragma unroll
+            for (int m = 0; m < RNCH; m++) qa[rt][m] = (K1_ABL & 128) ? make_float4(rc, m, g, 1.f) : ld4(qf + rc * RD + 4 * (4 * m + g));
+        }
+        float4 q2[NK2][2];
+        float qmk[RT][4];
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+            for (int k = 0; k < ((rt == RT - 1) ? KL : 4); k++) {
+                const int rc = min(Rk(rt, k), Lr - 1);
+#pragma unroll
+                for (int b = 0; b < 2; b++) q2[rt * 4 + k][b] = (K1_ABL & 128) ? make_float4(rc, b, c15, 1.f) : ld4(qf + rc * RD + 64 * b + 4 * c15);
+            }
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) qmk[rt][k] = (K1_ABL & 128) ? 1.f : qmask[frame * Lr + min(Rk(rt, k), Lr - 1)];
+        unsigned long long anyb = 0ull;
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (!((vmask >> (rt * 4 + k)) & 1u)) qmk[rt][k] = 0.f;
+                anyb |= __ballot(qmk[rt][k] != 0.f);
+            }
+        if (anyb == 0ull) {
+            // no valid region in this frame: S = -1e10 (cos - 1e10 rounds to -1e10), S_ = 0, A = 0 for the whole slice
+            const int c_lo = tile0 * 16, c_hi = min(CR, tile1 * 16);
+            const int sq = lane & 31;
+            for (int c = c_lo + (lane >> 5); c < c_hi; c += 2) {
+                const long orow = out_row(n, i, c);
+                st4(A + orow * RD + 4 * sq, f4zero());
+                for (int r = sq; r < Lr; r += 32) { S[orow * Lr + r] = STAGE_NEG; Sn[orow * Lr + r] = 0.f; }
+            }
+            item = next_item;
+            continue;
+        }
+        // rows >= Lr of the region tile are zero operands (their scores are masked out of the softmax anyway)
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+            for (int k = 0; k < ((rt == RT - 1) ? KL : 4); k++)
+                if (!((vmask >> (rt * 4 + k)) & 1u)) q2[rt * 4 + k][0] = q2[rt * 4 + k][1] = f4zero();
+        // normalise (x * 1/|row|: 1 ulp from x / |row|) and drop the stage-1 operand once
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            float ss = 0.f;
+#pragma unroll
+            for (int m = 0; m < RNCH; m++) ss += f4hsum(f4mul(qa[rt][m], qa[rt][m]));
+            ss += __shfl_xor(ss, 16);
+            ss += __shfl_xor(ss, 32);
+            const float ri = areg[rt] < Lr ? 1.0f / fmaxf(sqrtf(ss), 1e-12f) : 0.f;
+#pragma unroll
+            for (int m = 0; m < RNCH; m++) {
+                qa[rt][m] = f4scale(qa[rt][m], ri);
+                if (TRAIN)
+                    qa[rt][m] = f4mul(qa[rt][m], drop4(seed, (uint64_t)(frame * Lr + areg[rt]) * 32 + 4 * m + g, th, inv_keep));
+            }
+        }
+
+        // ---- Cn fragments + context mask of a tile: untracked loads, counted waits ----
+        f32x4 cf[RNCH];
+        float cmv;
+        auto issue_cf = [&](int tile) {
+            const int c = min(tile * 16 + c15, CR - 1);  // rows past the end alias the last valid row
+            const float* src = Cn + ((long)n * CR + c) * RD + 4 * g;
+            const float* pm = cmask + (long)n * CR + c;
+#pragma unroll
+            for (int m = 0; m < RNCH; m++)
+                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(cf[m]) : "v"(src), "n"(64 * m) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "=v"(cmv) : "v"(pm) : "memory");
+        };
+        // Stores every tile issues AFTER the next tile's fragments were requested.  The count must be EXACT to be useful:
+        // an undercount of 2 makes every tile wait for two of its own stores to be acknowledged (~ the HBM write
+        // latency per tile), an overcount would read stale fragments.  The lane-predicated stores of a permuted last
+        // region tile are always issued: for k < KL region base + g + 4k is valid at least for g = 0, so the exec mask
+        // is never empty.
+        constexpr int NST = 8 + (VEC_S ? 2 : 8) * (PERM ? RT - 1 : RT) + (PERM ? 2 * KL : 0);
+#define WAIT_CF(n_after)                                                                                            \
+    asm volatile("s_waitcnt vmcnt(%9)"                                                                              \
+                 : "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(cf[4]), "+v"(cf[5]), "+v"(cf[6]),       \
+                   "+v"(cf[7]), "+v"(cmv)                                                                           \
+                 : "n"(n_after)                                                                                     \
+                 : "memory")
+        issue_cf(tile0);
+        WAIT_CF(0);
+        for (int t = tile0; t < ((K1_ABL & 64) ? tile0 + 1 : tile1); t++) {
+            // ---- stage 1 ----
+            f32x4 acc[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < ((K1_ABL & 8) ? 1 : RNCH); m++) {
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[rt][m].x, cf[m][0], acc[rt], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[rt][m].y, cf[m][1], acc[rt], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[rt][m].z, cf[m][2], acc[rt], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[rt][m].w, cf[m][3], acc[rt], 0, 0, 0);
+            }
+            const float cm_cur = cmv;
+            // the MFMAs above have read cf (in-order issue): request the next tile now, before this tile's stores.
+            // Unconditional (the last step re-requests its own tile): an asm result defined inside a branch is merged
+            // by register copies, and copying a register whose load is still in flight copies garbage.
+            if (!(K1_ABL & 32)) issue_cf(min(t + 1, tile1 - 1));
+
+            const int c = min(t * 16 + c15, CR - 1);
+            const long orow = out_row(n, i, c);
+            float rv[RT][4], pv[RT][4];
+            {   // ---- mask + softmax over regions; pv becomes the stage-2 A operand ----
+#pragma clang fp contract(off)  // scale*raw must be ONE rounded value for both the max and the exponent: a contracted
+                                // fma(raw, scale, -mx) sees -1e11 exactly vs the rounded max -> exp(-2048) = 0 -> 0/0
+                float mx = -INFINITY;
+                float msk[RT][4], xs[RT][4];
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        msk[rt][k] = cm_cur * qmk[rt][k];
+                        rv[rt][k] = acc[rt][k] - 1e10f * (1.0f - msk[rt][k]);
+                        xs[rt][k] = rv[rt][k] * scale;
+                        if (((vmask >> (rt * 4 + k)) & 1u)) mx = fmaxf(mx, xs[rt][k]);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                float sum = 0.f;
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        pv[rt][k] = (((vmask >> (rt * 4 + k)) & 1u)) ? __expf(xs[rt][k] - mx) : 0.f;  // v_exp_f32 path: ~1e-6 relative
+                        sum += pv[rt][k];
+                    }
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                const float rsum = __builtin_amdgcn_rcpf(sum);  // 1 ulp
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) pv[rt][k] = pv[rt][k] * rsum * msk[rt][k];
+            }
+            // ---- stores of S / S_ (context row c15 of the tile) ----
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                if (PERM && rt == RT - 1) {
+#pragma unroll
+                    for (int k = 0; k < KL; k++)
+                        if (((vmask >> (rt * 4 + k)) & 1u)) {
+                            S[orow * Lr + Rk(rt, k)] = rv[rt][k];
+                            Sn[orow * Lr + Rk(rt, k)] = pv[rt][k];
+                        }
+                } else if (VEC_S) {
+                    if ((K1_ABL & 2) && rv[rt][0] != 1.2345e30f) continue;
+                    st4(S + orow * Lr + rt * 16 + 4 * g, make_float4(rv[rt][0], rv[rt][1], rv[rt][2], rv[rt][3]));
+                    st4(Sn + orow * Lr + rt * 16 + 4 * g, make_float4(pv[rt][0], pv[rt][1], pv[rt][2], pv[rt][3]));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        S[orow * Lr + Rk(rt, k)] = rv[rt][k];
+                        Sn[orow * Lr + Rk(rt, k)] = pv[rt][k];
+                    }
+                }
+            }
+            // ---- stage 2: A tile (ctx x d), one 64-wide d block at a time (4 independent accumulator chains) ----
+            // C layout: lane (c15, g) holds context rows 4g + reg, columns d = 64b + 4 c15 + e
+            long arow4[4];
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++)   // rows past the end alias the last valid row
+                arow4[reg] = out_row(n, i, min(t * 16 + 4 * g + reg, CR - 1)) * RD + 4 * c15;
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                f32x4 o[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int k = 0; k < ((K1_ABL & 4) ? (rt == 0 ? 1 : 0) : ((rt == RT - 1) ? KL : 4)); k++) {
+                        const float4 q = q2[rt * 4 + k][b];
+                        const float p = pv[rt][k];
+                        o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, q.x, o[0], 0, 0, 0);
+                        o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, q.y, o[1], 0, 0, 0);
+                        o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, q.z, o[2], 0, 0, 0);
+                        o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, q.w, o[3], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++)
+                    if (!(K1_ABL & 1) || o[0][reg] == 1.2345e30f)
+                        st4(A + arow4[reg] + 64 * b, make_float4(o[0][reg], o[1][reg], o[2][reg], o[3][reg]));
+            }
+            if (!(K1_ABL & 32)) WAIT_CF(NST);   // only this tile's stores may still be in flight
+        }
+#undef WAIT_CF
+        item = next_item;
+    }
+}
+
+// One zeroed ticket word per launch out of a small device-resident ring (stream-ordered memset; the ring only guards
+// against a handful of launches being in flight on different streams).
+static unsigned int* reg_next_ticket(hipStream_t st) {
+    static unsigned int* ring = nullptr;
+    static unsigned int slot = 0;
+    if (!ring && hipMalloc((void**)&ring, 64 * sizeof(unsigned int)) != hipSuccess) return nullptr;
+    unsigned int* t = ring + (slot++ & 63u);
+    if (hipMemsetAsync(t, 0, sizeof(unsigned int), st) != hipSuccess) return nullptr;
+    return t;
+}
+
+template <int RT, int KL, bool PERM, bool TRAIN, bool VEC_S>
+static int launch_reg_t(const float* Cn, const float* Q, const float* cm, const float* qm, float* A, float* S, float* Sn,
+                        int N, int NA, int Li, int Lqa, int Lr, float scale, float p_drop, unsigned long long seed,
+                        hipStream_t st) {
+    const int CR = NA * Lqa, CT = (CR + 15) / 16;
+    // slices of the context tiles: enough work items (frames x slices) to balance ~2048 waves, >= 3 tiles per item
+    int slices = 1;
+    if (getenv("STAGE_K1_SLICES")) slices = atoi(getenv("STAGE_K1_SLICES"));
+    else while (slices < 4 && (long)N * Li * slices < 8192 && CT / (slices + 1) >= 3) slices++;
+    if (slices < 1) slices = 1;
+    const int tps = (CT + slices - 1) / slices;
+    slices = (CT + tps - 1) / tps;
+    const long items = (long)N * Li * slices;
+    long blocks = 512;                                           // 256 CUs x 8 waves, 4 waves per workgroup
+    if (blocks * 4 > items) blocks = (items + 3) / 4;
+    uint32_t th = TRAIN ? drop_thresh16(p_drop) : 0u;
+    if (TRAIN && th == 0u) th = 1u;
+    const float ik = TRAIN ? 1.0f / (1.0f - p_drop) : 1.0f;
+    unsigned int* ticket = reg_next_ticket(st);
+    if (!ticket) return (int)hipErrorOutOfMemory;
+    // ~70 % of the items by static stride, the tail by tickets (at least one dynamic round)
+    int static_rounds = (int)((items * 7) / (blocks * 4 * 10));
+    if (getenv("STAGE_K1_STATIC")) static_rounds = atoi(getenv("STAGE_K1_STATIC"));
+    if (static_rounds < 1) static_rounds = 1;
+    hipLaunchKernelGGL((str_attn_fwd_reg_kernel<RT, KL, PERM, TRAIN, VEC_S>), dim3((unsigned)blocks), dim3(256), 0, st, Cn, Q,
+                       cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, slices, tps, (uint64_t)seed, th, ik, ticket, static_rounds);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int RT, bool TRAIN>
+static int launch_reg(const float* Cn, const float* Q, const float* cm, const float* qm, float* A, float* S, float* Sn,
+                      int N, int NA, int Li, int Lqa, int Lr, float scale, float p_drop, unsigned long long seed,
+                      hipStream_t st) {
+    const int rem = Lr - 16 * (RT - 1);
+    const bool vec = (Lr & 3) == 0;
+#define ARGS Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st
+    if (rem == 16) return vec ? launch_reg_t<RT, 4, false, TRAIN, true>(ARGS) : launch_reg_t<RT, 4, false, TRAIN, false>(ARGS);
+    switch ((rem + 3) / 4) {
+        case 1: return vec ? launch_reg_t<RT, 1, true, TRAIN, true>(ARGS) : launch_reg_t<RT, 1, true, TRAIN, false>(ARGS);
+        case 2: return vec ? launch_reg_t<RT, 2, true, TRAIN, true>(ARGS) : launch_reg_t<RT, 2, true, TRAIN, false>(ARGS);
+        case 3: return vec ? launch_reg_t<RT, 3, true, TRAIN, true>(ARGS) : launch_reg_t<RT, 3, true, TRAIN, false>(ARGS);
+        default: return vec ? launch_reg_t<RT, 4, true, TRAIN, true>(ARGS) : launch_reg_t<RT, 4, true, TRAIN, false>(ARGS);
+    }
+#undef ARGS
+}
+
+// returns 1 when the shape is not handled here (caller falls back to the LDS-staged kernel), 0 on launch, other = error
+int stage_str_attn_fwd_reg(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A,
+                           float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D, float scale,
+                           float p_drop, unsigned long long seed, void* stream) {
+    if (D != RD || Lr > 32 || (long)NA * Lqa >= (1 << 22)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    const bool train = p_drop > 0.f;
+#define ARGS Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st
+    if (Lr <= 16) return train ? launch_reg<1, true>(ARGS) : launch_reg<1, false>(ARGS);
+    return train ? launch_reg<2, true>(ARGS) : launch_reg<2, false>(ARGS);
+#undef ARGS
+}
