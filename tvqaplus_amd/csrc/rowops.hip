@@ -7,6 +7,7 @@
 //   * masked max over a (ranged) sequence axis forward / backward          model/stage.py:503-505, 425-432, 532-533
 //   * deterministic two-stage column reductions for the affine/bias gradients
 // One "row group" of LPR lanes (power of two, 4..64) owns one row; a wave processes 64/LPR rows at a time.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/stage_hip.h"
 
@@ -225,6 +226,187 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(RowSrc src, const float* __
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast variants for the shapes the STAGE path actually runs (K = 4*LPR for MODE 0, D = 4*LPR for MODE 1: every lane owns
+// the same column quad(s) of every row it touches).  Same arithmetic, same summation order as the generic kernels above;
+// what changes is the memory schedule: UR row slots per wave iteration, all loads of an iteration issued back to back
+// from clamped addresses (a guarded load compiles to an exec branch + s_waitcnt per load and serialises the row), the
+// affine parameters live in registers for the whole kernel, stores are the only predicated memory operations.
+// ------------------------------------------------------------------------------------------------
+#define LN_UR 4
+__device__ __forceinline__ long a_row_fast(long row, int rep, int inner) {
+    if (rep == 1) return row;
+    const unsigned r = (unsigned)row, ri = (unsigned)(rep * inner);   // rows < 2^31 on this path (checked by the launcher)
+    const unsigned gq = r / ri;
+    return (long)(gq * (unsigned)inner + r % (unsigned)inner);
+}
+
+template <int MODE, bool DROP>
+__global__ __launch_bounds__(256) void ln_fwd_fast_kernel(RowSrc src, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ y,
+                                                          float* __restrict__ mean, float* __restrict__ rstd, long rows,
+                                                          int K, float eps, int LPR, uint64_t seed, uint32_t th,
+                                                          float inv_keep) {
+    constexpr int NQ = (MODE == 0) ? 1 : 3;          // column quads per lane
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int RPW = 64 / LPR, sub = lane / LPR, sl = lane % LPR;
+    const int K4 = K >> 2, D = (MODE == 0) ? K : src.D, D4 = D >> 2;
+    const float invK = 1.0f / (float)K;
+    float4 gm[NQ], bt[NQ];
+#pragma unroll
+    for (int t = 0; t < NQ; t++) { gm[t] = ld4(gamma + 4 * (t * D4 + sl)); bt[t] = ld4(beta + 4 * (t * D4 + sl)); }
+    const long step = (long)gridDim.x * wpb * RPW * LN_UR;
+    for (long base = ((long)blockIdx.x * wpb + wave) * RPW * LN_UR; base < rows; base += step) {
+        float4 v[LN_UR][NQ], rv[LN_UR];
+        long row[LN_UR];
+#pragma unroll
+        for (int u = 0; u < LN_UR; u++) {
+            row[u] = base + u * RPW + sub;
+            const long rc = row[u] < rows ? row[u] : rows - 1;
+            if (MODE == 0) {
+                v[u][0] = ld4(src.x + rc * K + 4 * sl);
+                if (src.b) rv[u] = ld4(src.b + (src.inner > 0 ? (long)((unsigned)rc % (unsigned)src.inner) : rc) * K + 4 * sl);
+            } else {
+                v[u][0] = ld4(src.x + a_row_fast(rc, src.rep, src.inner) * D + 4 * sl);
+                v[u][1] = ld4(src.b + rc * D + 4 * sl);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LN_UR; u++) {
+            const bool ok = row[u] < rows;
+            float s;
+            if (MODE == 0) {
+                if (src.b) {
+                    v[u][0] = f4add(v[u][0], rv[u]);
+                    if (src.sum_out && ok) st4(src.sum_out + row[u] * K + 4 * sl, v[u][0]);
+                }
+                s = f4hsum(v[u][0]);
+            } else {
+                v[u][2] = f4mul(v[u][0], v[u][1]);
+                s = f4hsum(v[u][0]) + f4hsum(v[u][1]) + f4hsum(v[u][2]);
+            }
+            s = group_sum(s, LPR);
+            const float mu = s * invK;
+            float q = 0.f;
+#pragma unroll
+            for (int t = 0; t < NQ; t++) {
+                const float4 d = make_float4(v[u][t].x - mu, v[u][t].y - mu, v[u][t].z - mu, v[u][t].w - mu);
+                q += f4hsum(f4mul(d, d));
+            }
+            q = group_sum(q, LPR);
+            const float rs = 1.0f / sqrtf(q * invK + eps);
+            if (ok && sl == 0) {
+                if (mean) mean[row[u]] = mu;
+                if (rstd) rstd[row[u]] = rs;
+            }
+#pragma unroll
+            for (int t = 0; t < NQ; t++) {
+                const int j = t * D4 + sl;
+                float4 o;
+                o.x = (v[u][t].x - mu) * rs * gm[t].x + bt[t].x;
+                o.y = (v[u][t].y - mu) * rs * gm[t].y + bt[t].y;
+                o.z = (v[u][t].z - mu) * rs * gm[t].z + bt[t].z;
+                o.w = (v[u][t].w - mu) * rs * gm[t].w + bt[t].w;
+                if (DROP) o = f4mul(o, drop4(seed, (uint64_t)row[u] * K4 + j, th, inv_keep));
+                if (ok) st4(y + row[u] * K + 4 * j, o);
+            }
+        }
+    }
+}
+
+template <int MODE, bool DROP>
+__global__ __launch_bounds__(256) void ln_bwd_fast_kernel(RowSrc src, const float* __restrict__ dy,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, float* __restrict__ dx,
+                                                          float* __restrict__ db_out, float* __restrict__ part, long rows,
+                                                          int K, int LPR, uint64_t seed, uint32_t th, float inv_keep) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [wpb*RPW][2][K]
+    constexpr int NQ = (MODE == 0) ? 1 : 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int RPW = 64 / LPR, sub = lane / LPR, sl = lane % LPR;
+    const int K4 = K >> 2, D = (MODE == 0) ? K : src.D, D4 = D >> 2;
+    const float invK = 1.0f / (float)K;
+    float4 gm[NQ], ag[NQ], ab[NQ];
+#pragma unroll
+    for (int t = 0; t < NQ; t++) { gm[t] = ld4(gamma + 4 * (t * D4 + sl)); ag[t] = ab[t] = f4zero(); }
+    const long step = (long)gridDim.x * wpb * RPW * LN_UR;
+    for (long base = ((long)blockIdx.x * wpb + wave) * RPW * LN_UR; base < rows; base += step) {
+        float4 xv[LN_UR][2], d[LN_UR][NQ], ra[LN_UR];
+        float mu[LN_UR], rs[LN_UR];
+        long row[LN_UR];
+#pragma unroll
+        for (int u = 0; u < LN_UR; u++) {
+            row[u] = base + u * RPW + sub;
+            const long rc = row[u] < rows ? row[u] : rows - 1;
+            mu[u] = mean[rc];
+            rs[u] = rstd[rc];
+            if (MODE == 0) {
+                xv[u][0] = ld4(src.x + rc * K + 4 * sl);
+                if (dx && src.b) ra[u] = ld4(src.b + rc * K + 4 * sl);
+            } else {
+                xv[u][0] = ld4(src.x + a_row_fast(rc, src.rep, src.inner) * D + 4 * sl);
+                xv[u][1] = ld4(src.b + rc * D + 4 * sl);
+            }
+#pragma unroll
+            for (int t = 0; t < NQ; t++) d[u][t] = ld4(dy + rc * K + 4 * (t * D4 + sl));
+        }
+#pragma unroll
+        for (int u = 0; u < LN_UR; u++) {
+            const bool ok = row[u] < rows;
+            float4 xh[NQ], g[NQ];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < NQ; t++) {
+                const float4 x = (MODE == 0 || t == 0) ? xv[u][0] : ((t == 1) ? xv[u][1] : f4mul(xv[u][0], xv[u][1]));
+                float4 dd = d[u][t];
+                if (DROP) dd = f4mul(dd, drop4(seed, (uint64_t)row[u] * K4 + t * D4 + sl, th, inv_keep));
+                if (!ok) dd = f4zero();              // rows past the end were read from a clamped address
+                xh[t] = make_float4((x.x - mu[u]) * rs[u], (x.y - mu[u]) * rs[u], (x.z - mu[u]) * rs[u], (x.w - mu[u]) * rs[u]);
+                g[t] = f4mul(dd, gm[t]);
+                s1 += f4hsum(g[t]);
+                s2 += f4hsum(f4mul(g[t], xh[t]));
+                ag[t] = f4add(ag[t], f4mul(dd, xh[t]));
+                ab[t] = f4add(ab[t], dd);
+            }
+            s1 = group_sum(s1, LPR) * invK;
+            s2 = group_sum(s2, LPR) * invK;
+            float4 dz[NQ];
+#pragma unroll
+            for (int t = 0; t < NQ; t++) {
+                dz[t].x = rs[u] * (g[t].x - s1 - xh[t].x * s2);
+                dz[t].y = rs[u] * (g[t].y - s1 - xh[t].y * s2);
+                dz[t].z = rs[u] * (g[t].z - s1 - xh[t].z * s2);
+                dz[t].w = rs[u] * (g[t].w - s1 - xh[t].w * s2);
+            }
+            if (MODE == 0) {
+                if (dx && ok) {
+                    if (src.b) dz[0] = f4add(dz[0], ra[u]);  // + gradient of the exported sum
+                    st4(dx + row[u] * K + 4 * sl, dz[0]);
+                }
+            } else if (ok) {
+                // z = [a, b, a*b]:  da = dz0 + dz2*b ; db = dz1 + dz2*a
+                st4(dx + row[u] * D + 4 * sl, f4add(dz[0], f4mul(dz[NQ - 1], xv[u][1])));
+                st4(db_out + row[u] * D + 4 * sl, f4add(dz[NQ > 1 ? 1 : 0], f4mul(dz[NQ - 1], xv[u][0])));
+            }
+        }
+    }
+    // block reduction of the per-lane column partials (same slot layout and order as the generic kernel)
+    const int slot = wave * RPW + sub;
+    float* sg = smem + (size_t)slot * 2 * K;
+#pragma unroll
+    for (int t = 0; t < NQ; t++) {
+        st4(sg + 4 * (t * D4 + sl), ag[t]);
+        st4(sg + K + 4 * (t * D4 + sl), ab[t]);
+    }
+    __syncthreads();
+    const int nslots = wpb * RPW;
+    for (int c = threadIdx.x; c < 2 * K; c += blockDim.x) {
+        float acc = 0.f;
+        for (int s = 0; s < nslots; s++) acc += smem[(size_t)s * 2 * K + c];
+        part[(size_t)blockIdx.x * 2 * K + c] = acc;
+    }
+}
+
 // out[c] = sum_b part[b*stride + c]   (fixed order -> deterministic)
 __global__ void colreduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nb, long stride, int C) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -248,6 +430,18 @@ static int ln_fwd_launch(RowSrc src, const float* gamma, const float* beta, floa
                          long long rows, int K, int LPR, float eps, float p_drop, unsigned long long seed,
                          hipStream_t st) {
     const int rows_per_block = 4 * (64 / LPR);
+    const int q4 = (MODE == 0) ? K / 4 : src.D / 4;
+    if (q4 == LPR && rows < (1ll << 31) && !getenv("STAGE_LN_GENERIC")) {   // every lane owns fixed column quads: fast schedule
+        const int gridf = stage_grid_for(rows, rows_per_block * LN_UR, GRID_CAP * 2);
+        if (p_drop > 0.f)
+            hipLaunchKernelGGL((ln_fwd_fast_kernel<MODE, true>), dim3(gridf), dim3(256), 0, st, src, gamma, beta, y, mean,
+                               rstd, (long)rows, K, eps, LPR, (uint64_t)seed, drop_thresh16(p_drop), 1.0f / (1.0f - p_drop));
+        else
+            hipLaunchKernelGGL((ln_fwd_fast_kernel<MODE, false>), dim3(gridf), dim3(256), 0, st, src, gamma, beta, y, mean,
+                               rstd, (long)rows, K, eps, LPR, (uint64_t)0, 0u, 1.0f);
+        STAGE_LAUNCH_CHECK();
+        return 0;
+    }
     const int grid = stage_grid_for(rows, rows_per_block, GRID_CAP * 4);
     if (p_drop > 0.f)
         hipLaunchKernelGGL((ln_fwd_kernel<MODE, true>), dim3(grid), dim3(256), 0, st, src, gamma, beta, y, mean, rstd,
@@ -273,7 +467,16 @@ static int ln_bwd_launch(RowSrc src, const float* dy, const float* mean, const f
     const int grid = stage_grid_for(rows, rows_per_block * 8, PART_CAP);
     const size_t lds = (size_t)rows_per_block * 2 * K * sizeof(float);
     float* part = (float*)ws;
-    if (p_drop > 0.f)
+    const int q4 = (MODE == 0) ? K / 4 : src.D / 4;
+    const bool fast = q4 == LPR && rows < (1ll << 31) && !getenv("STAGE_LN_GENERIC");
+    if (fast && p_drop > 0.f)
+        hipLaunchKernelGGL((ln_bwd_fast_kernel<MODE, true>), dim3(grid), dim3(256), lds, st, src, dy, mean, rstd, gamma, dx,
+                           db_out, part, (long)rows, K, LPR, (uint64_t)seed, drop_thresh16(p_drop),
+                           1.0f / (1.0f - p_drop));
+    else if (fast)
+        hipLaunchKernelGGL((ln_bwd_fast_kernel<MODE, false>), dim3(grid), dim3(256), lds, st, src, dy, mean, rstd, gamma, dx,
+                           db_out, part, (long)rows, K, LPR, (uint64_t)0, 0u, 1.0f);
+    else if (p_drop > 0.f)
         hipLaunchKernelGGL((ln_bwd_kernel<MODE, true>), dim3(grid), dim3(256), lds, st, src, dy, mean, rstd, gamma, dx,
                            db_out, part, (long)rows, K, LPR, (uint64_t)seed, drop_thresh16(p_drop),
                            1.0f / (1.0f - p_drop));
