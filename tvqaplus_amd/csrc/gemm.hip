@@ -158,6 +158,8 @@ extern "C" int stage_gemm_tn_bf16x3(const float* dY, const float* gate, const fl
                                     int N, int K, void* ws, size_t ws_bytes, void* stream);
 int stage_gemm_nt_stream(const float* X, const float* gate, const float* W, const float* bias, const float* residual,
                          float* Y, long long M, int N, int K, int relu, void* stream);   // gemm_stream.hip
+int stage_gemm_tn_stream(const float* dY, const float* gate, const float* X, float* part, float* part_b, long long M, int N,
+                         int K, int S, long rows_per_split, void* stream);   // gemm_stream.hip
 static bool gemm_exact_f32() {
     static int mode = -1;
     if (mode < 0) mode = getenv("STAGE_GEMM_F32") ? 1 : 0;
@@ -322,7 +324,13 @@ extern "C" int stage_gemm_tn(const float* dY, const float* gate, const float* X,
     const int vecY = (N % 4 == 0) && (((uintptr_t)dY & 15) == 0) && (!gate || ((uintptr_t)gate & 15) == 0);
     const int vecX = (K % 4 == 0) && (((uintptr_t)X & 15) == 0);
     dim3 grid((N + BM - 1) / BM, (K + BN - 1) / BN, S);
-    if (vecY && vecX && N >= 4 && K >= 4)
+    static const bool tn_tiled = getenv("STAGE_GEMM_TN_TILED") != nullptr;   // developer switch
+    int handled = 1;
+    if (!gemm_exact_f32() && !tn_tiled)
+        handled = stage_gemm_tn_stream(dY, gate, X, part, db ? part_b : (float*)nullptr, M, N, K, S, rps, stream);
+    if (handled < 0 || handled > 1) return handled;
+    if (handled == 0) {
+    } else if (vecY && vecX && N >= 4 && K >= 4)
         hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, st, dY, gate, X, part, db ? part_b : (float*)nullptr,
                            (long)M, N, K, rps, vecY, vecX);
     else

@@ -287,3 +287,159 @@ int stage_gemm_nt_stream(const float* X, const float* gate, const float* W, cons
     STAGE_LAUNCH_CHECK();
     return 0;
 }
+
+// =====================================================================================================================
+// Streaming TN GEMM (weight gradients):  part[s][n][k] = sum_{m in slab s} (dY (*) gate)[m,n] X[m,k] ,
+//                                        part_b[s][n]  = sum_{m in slab s} (dY (*) gate)[m,n]
+// The contraction runs over ROWS, so an MFMA operand lane (column c, k-half h) needs 8 consecutive rows of one column.
+// Instead of transposing through LDS (the split-bf16 tiled TN kernel loses to the fp32 one on exactly that), every lane
+// loads its 8 values with 8 dword loads: a load instruction then covers 2 rows x 128 contiguous bytes -- full cache
+// lines, 4x more VMEM instructions than dwordx4 but no LDS, no barrier, no transpose.  The loads are buffer loads
+// (resource + wave-uniform row offset in an SGPR + constant 32-bit lane offset): no 64-bit per-lane address arithmetic
+// in the loop, and rows past the end of the tensor read as 0.  Each wave owns a 64 x 64 patch of the 128 x 128 output tile
+// of its workgroup (2 x 2 MFMA tiles, exact 3-way bf16 split on v_mfma_f32_32x32x16_bf16) and walks the rows of its slab
+// 16 at a time with the next step's 32 (48 with gate) loads in flight.
+// =====================================================================================================================
+__device__ __forceinline__ float s_buf_load(__amdgpu_buffer_rsrc_t r, int voff_bytes, int soff_bytes) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff_bytes, soff_bytes, 0));
+}
+
+template <bool HAS_GATE>
+__global__ __launch_bounds__(256, 2) void gemm_tn_stream_kernel(const float* __restrict__ dY, const float* __restrict__ G,
+                                                                const float* __restrict__ X, float* __restrict__ part,
+                                                                float* __restrict__ part_b, long M, int N, int K,
+                                                                long rows_per_split) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int pn = wave >> 1, pk = wave & 1;
+    const int n_base = blockIdx.x * 128 + pn * 64, k_base = blockIdx.y * 128 + pk * 64;
+    const int split = blockIdx.z;
+    const long mbeg = (long)split * rows_per_split;
+    const long mend = min(M, mbeg + rows_per_split);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)dY, 0, (int)(M * N * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)(M * K * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_GATE ? G : dY), 0, (int)(M * N * 4), 0x00020000);
+    // this lane's two dY columns and two X columns (clamped for the address, zeroed by the flag) as byte offsets inside
+    // a 16-row step
+    int yoff[2], xoff[2];
+    bool nok[2], kok[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int n = n_base + 32 * t + l31, k = k_base + 32 * t + l31;
+        nok[t] = n < N;
+        kok[t] = k < K;
+        yoff[t] = (8 * h * N + (nok[t] ? n : N - 1)) * 4;
+        xoff[t] = (8 * h * K + (kok[t] ? k : K - 1)) * 4;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    float bsum[2] = {0.f, 0.f};
+
+    float ya[2][2][8], xa[2][2][8], ga[2][2][8];   // [buffer][tile][row]
+    auto fetch = [&](int buf, long m0) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int sy = (int)((m0 + r) * N * 4), sx = (int)((m0 + r) * K * 4);   // wave-uniform row offsets (bytes)
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                ya[buf][t][r] = s_buf_load(ry, yoff[t], sy);
+                xa[buf][t][r] = s_buf_load(rx, xoff[t], sx);
+                if (HAS_GATE) ga[buf][t][r] = s_buf_load(rg, yoff[t], sy);
+            }
+        }
+    };
+    auto step = [&](int buf, long m0) {
+        const bool full = m0 + 16 <= mend;
+        sbf16x8 a[2][3], b[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            float yv[8], xv[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const bool rok = full || (m0 + 8 * h + r < mend);   // rows of the next slab / past the end contribute 0
+                float y = ya[buf][t][r];
+                if (HAS_GATE) y = ga[buf][t][r] > 0.f ? y : 0.f;
+                yv[r] = (rok && nok[t]) ? y : 0.f;
+                xv[r] = (rok && kok[t]) ? xa[buf][t][r] : 0.f;
+                bsum[t] += yv[r];
+            }
+            unsigned p[4][3], q[4][3];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                s_split3(yv[2 * i], yv[2 * i + 1], p[i]);
+                s_split3(xv[2 * i], xv[2 * i + 1], q[i]);
+            }
+#pragma unroll
+            for (int s = 0; s < 3; s++) {
+                a[t][s] = __builtin_bit_cast(sbf16x8, make_uint4(p[0][s], p[1][s], p[2][s], p[3][s]));
+                b[t][s] = __builtin_bit_cast(sbf16x8, make_uint4(q[0][s], q[1][s], q[2][s], q[3][s]));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                // kept cross terms, smallest first
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+            }
+    };
+    if (mbeg < mend) {
+        fetch(0, mbeg);
+        for (long m0 = mbeg; m0 < mend; m0 += 32) {
+            if (m0 + 16 < mend) fetch(1, m0 + 16);
+            step(0, m0);
+            if (m0 + 16 < mend) {
+                if (m0 + 32 < mend) fetch(0, m0 + 32);
+                step(1, m0 + 16);
+            }
+        }
+    }
+    // C/D layout of the 32x32 MFMA: col = lane & 31 (k), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (n)
+    float* po = part + (size_t)split * N * K;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int k = k_base + 32 * j + l31;
+            if (k >= K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int n = n_base + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (n < N) po[(size_t)n * K + k] = acc[i][j][r];
+            }
+        }
+    if (part_b && blockIdx.y == 0 && pk == 0) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const float s = bsum[t] + __shfl_xor(bsum[t], 32);
+            const int n = n_base + 32 * t + l31;
+            if (h == 0 && n < N) part_b[(size_t)split * N + n] = s;
+        }
+    }
+}
+
+// same slab rule / workspace layout as stage_gemm_tn (gemm.hip); returns 1 if not handled here
+int stage_gemm_tn_stream(const float* dY, const float* gate, const float* X, float* part, float* part_b, long long M, int N,
+                         int K, int S, long rows_per_split, void* stream) {
+    // buffer addressing: every operand must be smaller than 2 GiB
+    if (M < 4096 || M * (long long)N * 4 >= (1ll << 31) || M * (long long)K * 4 >= (1ll << 31)) return 1;
+    dim3 grid((N + 127) / 128, (K + 127) / 128, S);
+    if (gate)
+        hipLaunchKernelGGL(gemm_tn_stream_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dY, gate, X, part, part_b,
+                           (long)M, N, K, rows_per_split);
+    else
+        hipLaunchKernelGGL(gemm_tn_stream_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dY, gate, X, part, part_b,
+                           (long)M, N, K, rows_per_split);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
