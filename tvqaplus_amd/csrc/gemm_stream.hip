@@ -100,15 +100,23 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
     // awaited loads -- a smaller count only waits longer.
     constexpr int NL = HAS_GATE ? 8 : 4;                   // loads per fetch
     f32x4 xa[2][4], ga[2][4];
-    auto fetch = [&](int buf, long row, int k_line) {   // K % 32 == 0: one address per lane, immediate offsets
-        const long off = (row < M ? row : M - 1) * K + k_line + 4 * h;
-        const float* px = X + off;
-        const float* pg = G + off;
+    // buffer loads: resource + 32-bit lane offset + immediate.  A ragged last chunk (K % 128 != 0) reads past the end of
+    // its row -- into the next row, or as 0 past the end of the tensor -- and is zeroed at use (mul_line).
+    typedef int s_rsrc_t __attribute__((ext_vector_type(4)));
+    auto make_rsrc = [&](const float* p) -> s_rsrc_t {
+        const unsigned long long a = (unsigned long long)p;
+        return (s_rsrc_t){(int)(unsigned)a, (int)(unsigned)((a >> 32) & 0xffffu), (int)(M * K * 4), 0x00020000};
+    };
+    const s_rsrc_t rsx = make_rsrc(X), rsg = make_rsrc(HAS_GATE ? G : X);
+    auto fetch = [&](int buf, long row, int k_line) {   // one offset per lane, immediate offsets for the 4 chunks
+        const int off = (int)(((row < M ? row : M - 1) * K + k_line + 4 * h) * 4);
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(xa[buf][c]) : "v"(px), "n"(32 * c) : "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3"
+                         : "=v"(xa[buf][c]) : "v"(off), "s"(rsx), "n"(32 * c) : "memory");
             if (HAS_GATE)
-                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(ga[buf][c]) : "v"(pg), "n"(32 * c) : "memory");
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3"
+                             : "=v"(ga[buf][c]) : "v"(off), "s"(rsg), "n"(32 * c) : "memory");
         }
     };
 #define WAIT_LINE(buf, n)                                                                                              \
@@ -162,6 +170,10 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
                     float4 v0 = make_float4(xa[buf][2 * up][0], xa[buf][2 * up][1], xa[buf][2 * up][2], xa[buf][2 * up][3]);
                     float4 v1 = make_float4(xa[buf][2 * up + 1][0], xa[buf][2 * up + 1][1], xa[buf][2 * up + 1][2],
                                             xa[buf][2 * up + 1][3]);
+                    if (K & (SKC - 1)) {   // ragged last chunk: columns past K hold the next row's data (or 0)
+                        v0 = s_keep4(v0, kb + 32 * L + 16 * up + 4 * h < K);
+                        v1 = s_keep4(v1, kb + 32 * L + 16 * up + 8 + 4 * h < K);
+                    }
                     if (HAS_GATE) {
                         const f32x4 g0 = ga[buf][2 * up], g1 = ga[buf][2 * up + 1];
                         v0 = s_gate4(v0, make_float4(g0[0], g0[1], g0[2], g0[3]));
@@ -262,7 +274,7 @@ int stage_gemm_nt_stream(const float* X, const float* gate, const float* W, cons
                          float* Y, long long M, int N, int K, int relu, void* stream) {
     const bool vec = (K % 4 == 0) && K >= 4 && (((uintptr_t)X & 15) == 0) && (((uintptr_t)W & 15) == 0) &&
                      (!gate || ((uintptr_t)gate & 15) == 0);
-    if (!vec || M < 4096 || K % SKC != 0) return 1;   // K in {128, 384, 768, 2048} on the STAGE path
+    if (!vec || M < 4096 || K < 64 || M * (long long)K * 4 >= (1ll << 31)) return 1;   // buffer addressing: < 2 GiB
     const int lds = 3 * SPLANE * (int)sizeof(unsigned short) + SBN * (int)sizeof(float);
     const long MT = (M + 31) / 32, n_bt = (MT + SWAVES - 1) / SWAVES;
     const int n_tiles = (N + SBN - 1) / SBN;
