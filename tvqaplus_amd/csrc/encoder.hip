@@ -3,6 +3,7 @@
 //   * depthwise Conv1d(k, groups=D, zero padding k//2) along L of (M, L, D) tensors, forward and backward
 // The 1x1 pointwise conv + ReLU + residual is stage_gemm_nt's epilogue; the LayerNorms are rowops.hip.
 // Padded sequence positions are NOT masked anywhere here (bug-compatible with the reference).
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/stage_hip.h"
 
@@ -114,6 +115,125 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sliding-window versions (the ones that run): a thread owns one float4 column of one chunk of DWC positions of one
+// sequence and walks it, keeping the k taps of `in` (and of `dout` in the backward) in registers: every element is
+// loaded once per chunk (+ a halo of k-1 rows) by straight-line loads from clamped addresses, instead of 2k+1 guarded
+// loads per output element.  Same arithmetic order over the taps as the kernels above.
+// ------------------------------------------------------------------------------------------------
+#define DWC 32   // positions per chunk
+
+template <int KT>
+__global__ __launch_bounds__(256) void dwconv_fwd_sw_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            long M, int L, int D) {
+    constexpr int pad = KT / 2;
+    const int D4 = D >> 2, rpi = blockDim.x / D4;
+    const int q = threadIdx.x % D4, rsub = threadIdx.x / D4;
+    if (rsub >= rpi) return;
+    float4 wt[KT];
+#pragma unroll
+    for (int t = 0; t < KT; t++)
+        wt[t] = make_float4(w[(4 * q + 0) * KT + t], w[(4 * q + 1) * KT + t], w[(4 * q + 2) * KT + t], w[(4 * q + 3) * KT + t]);
+    const float4 bq = ld4(bias + 4 * q);
+    const int chunks = (L + DWC - 1) / DWC;
+    const long items = M * chunks;
+    for (long it = (long)blockIdx.x * rpi + rsub; it < items; it += (long)gridDim.x * rpi) {
+        const long m = it / chunks;
+        const int l0 = (int)(it % chunks) * DWC, l1 = min(L, l0 + DWC);
+        const float* base = in + (m * L) * D + 4 * q;
+        float4 win[KT];   // win[t] = in[l + t - pad] for the current l
+#pragma unroll
+        for (int t = 0; t < KT - 1; t++) {
+            const int ll = l0 + t - pad;
+            const float4 v = ld4(base + (long)min(max(ll, 0), L - 1) * D);
+            win[t + 1] = (ll >= 0 && ll < L) ? v : f4zero();
+        }
+#pragma unroll 4
+        for (int l = l0; l < l1; l++) {
+#pragma unroll
+            for (int t = 0; t < KT - 1; t++) win[t] = win[t + 1];
+            const int ll = l + pad;
+            const float4 v = ld4(base + (long)min(ll, L - 1) * D);
+            win[KT - 1] = ll < L ? v : f4zero();
+            float4 acc = bq;
+#pragma unroll
+            for (int t = 0; t < KT; t++) acc = f4add(acc, f4mul(win[t], wt[t]));
+            st4(out + ((m * L + l) * D + 4 * q), acc);
+        }
+    }
+}
+
+template <int KT>
+__global__ __launch_bounds__(256) void dwconv_bwd_sw_kernel(const float* __restrict__ dout, const float* __restrict__ in,
+                                                            const float* __restrict__ w, float* __restrict__ din,
+                                                            float* __restrict__ part, long M, int L, int D) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // reduction scratch [rpi][KT + 1][D]
+    constexpr int pad = KT / 2;
+    const int D4 = D >> 2, rpi = blockDim.x / D4;
+    const int q = threadIdx.x % D4, rsub = threadIdx.x / D4;
+    const bool active = rsub < rpi;
+    float4 aw[KT], ab = f4zero();
+#pragma unroll
+    for (int t = 0; t < KT; t++) aw[t] = f4zero();
+    if (active) {
+        float4 wt[KT];
+#pragma unroll
+        for (int t = 0; t < KT; t++)
+            wt[t] = make_float4(w[(4 * q + 0) * KT + t], w[(4 * q + 1) * KT + t], w[(4 * q + 2) * KT + t], w[(4 * q + 3) * KT + t]);
+        const int chunks = (L + DWC - 1) / DWC;
+        const long items = M * chunks;
+        for (long it = (long)blockIdx.x * rpi + rsub; it < items; it += (long)gridDim.x * rpi) {
+            const long m = it / chunks;
+            const int l0 = (int)(it % chunks) * DWC, l1 = min(L, l0 + DWC);
+            const float* bi = in + (m * L) * D + 4 * q;
+            const float* bo = dout + (m * L) * D + 4 * q;
+            float4 wi[KT], wo[KT];   // wi[t] = in[l + t - pad], wo[t] = dout[l + t - pad]
+#pragma unroll
+            for (int t = 0; t < KT - 1; t++) {
+                const int ll = l0 + t - pad;
+                const long ro = (long)min(max(ll, 0), L - 1) * D;
+                const float4 vi = ld4(bi + ro), vo = ld4(bo + ro);
+                const bool ok = ll >= 0 && ll < L;
+                wi[t + 1] = ok ? vi : f4zero();
+                wo[t + 1] = ok ? vo : f4zero();
+            }
+#pragma unroll 2
+            for (int l = l0; l < l1; l++) {
+#pragma unroll
+                for (int t = 0; t < KT - 1; t++) { wi[t] = wi[t + 1]; wo[t] = wo[t + 1]; }
+                const int ll = l + pad;
+                const long ro = (long)min(ll, L - 1) * D;
+                const float4 vi = ld4(bi + ro), vo = ld4(bo + ro);
+                wi[KT - 1] = ll < L ? vi : f4zero();
+                wo[KT - 1] = ll < L ? vo : f4zero();
+                const float4 go = wo[pad];
+                ab = f4add(ab, go);
+                float4 gi = f4zero();
+#pragma unroll
+                for (int t = 0; t < KT; t++) {
+                    aw[t] = f4add(aw[t], f4mul(go, wi[t]));                 // dw[t] += dout[l] * in[l + t - pad]
+                    gi = f4add(gi, f4mul(wo[KT - 1 - t], wt[t]));           // din[l] += dout[l - t + pad] * w[t]
+                }
+                st4(din + ((m * L + l) * D + 4 * q), gi);
+            }
+        }
+    }
+    // block reduce: scratch [rpi][(KT+1)][D]
+    if (active) {
+#pragma unroll
+        for (int t = 0; t < KT; t++) st4(&sm[((size_t)rsub * (KT + 1) + t) * D + 4 * q], aw[t]);
+        st4(&sm[((size_t)rsub * (KT + 1) + KT) * D + 4 * q], ab);
+    }
+    __syncthreads();
+    const int C = (KT + 1) * D;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int r = 0; r < rpi; r++) s += sm[(size_t)r * C + c];
+        part[(size_t)blockIdx.x * C + c] = s;
+    }
+}
+
 // dw[d*k + t] = sum_b part[b][t][d] ; db[d] = sum_b part[b][k][d]
 __global__ void dwconv_final_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
                                     int nb, int D, int k) {
@@ -131,6 +251,21 @@ extern "C" int stage_dwconv_fwd(const float* in, const float* w, const float* bi
                                 int D, int k, void* stream) {
     if (M <= 0) return 0;
     if (D % 4 != 0 || k < 1 || k > KMAX || (k & 1) == 0) return STAGE_ERR_SHAPE;
+    if (D / 4 <= 256 && !getenv("STAGE_DWCONV_GENERIC")) {
+        const int rpi = 256 / (D / 4);
+        const long items = (long)M * ((L + DWC - 1) / DWC);
+        const int gridw = stage_grid_for(items, rpi, GRID_CAP * 4);
+        hipStream_t st = (hipStream_t)stream;
+        switch (k) {
+            case 1: hipLaunchKernelGGL(dwconv_fwd_sw_kernel<1>, dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D); break;
+            case 3: hipLaunchKernelGGL(dwconv_fwd_sw_kernel<3>, dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D); break;
+            case 5: hipLaunchKernelGGL(dwconv_fwd_sw_kernel<5>, dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D); break;
+            case 7: hipLaunchKernelGGL(dwconv_fwd_sw_kernel<7>, dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D); break;
+            default: hipLaunchKernelGGL(dwconv_fwd_sw_kernel<9>, dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D); break;
+        }
+        STAGE_LAUNCH_CHECK();
+        return 0;
+    }
     const int grid = stage_grid_for(M * L * (D / 4), 256, GRID_CAP);
     hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(grid), dim3(256), (size_t)(k + 1) * D * sizeof(float),
                        (hipStream_t)stream, in, w, bias, out, (long)(M * L), L, D, k);
@@ -151,12 +286,26 @@ extern "C" int stage_dwconv_bwd(const float* dout, const float* in, const float*
         return 0;
     }
     const int rpi = 256 / (D / 4);
-    const int grid = stage_grid_for(M * L, rpi * 8, DW_PART_CAP);
+    int grid;
     size_t lds = (size_t)k * D;
     const size_t red = (size_t)rpi * (k + 1) * D;
     if (red > lds) lds = red;
-    hipLaunchKernelGGL(dwconv_bwd_kernel, dim3(grid), dim3(256), lds * sizeof(float), st, dout, in, w, din,
-                       (float*)ws, (long)(M * L), L, D, k);
+    if (!getenv("STAGE_DWCONV_GENERIC")) {
+        const long items = (long)M * ((L + DWC - 1) / DWC);
+        grid = stage_grid_for(items, rpi, DW_PART_CAP);
+        const size_t ldb = red * sizeof(float);
+        switch (k) {
+            case 1: hipLaunchKernelGGL(dwconv_bwd_sw_kernel<1>, dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D); break;
+            case 3: hipLaunchKernelGGL(dwconv_bwd_sw_kernel<3>, dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D); break;
+            case 5: hipLaunchKernelGGL(dwconv_bwd_sw_kernel<5>, dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D); break;
+            case 7: hipLaunchKernelGGL(dwconv_bwd_sw_kernel<7>, dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D); break;
+            default: hipLaunchKernelGGL(dwconv_bwd_sw_kernel<9>, dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D); break;
+        }
+    } else {
+        grid = stage_grid_for(M * L, rpi * 8, DW_PART_CAP);
+        hipLaunchKernelGGL(dwconv_bwd_kernel, dim3(grid), dim3(256), lds * sizeof(float), st, dout, in, w, din,
+                           (float*)ws, (long)(M * L), L, D, k);
+    }
     STAGE_LAUNCH_CHECK();
     stage_colreduce((const float*)ws, dw, db, grid, (long)(k + 1) * D, (k + 1) * D, D, k, st);
     STAGE_LAUNCH_CHECK();
