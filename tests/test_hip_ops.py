@@ -38,7 +38,8 @@ def ops(hip_device):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("rows,K", [(7, 16), (33, 128), (10, 300), (5, 768), (1000, 128), (3, 48), (129, 32)])
+@pytest.mark.parametrize("rows,K", [(7, 16), (33, 128), (10, 300), (5, 768), (1000, 128), (3, 48), (129, 32),
+                                     (4099, 128), (5003, 64), (2500, 256)])
 def test_layernorm_plain(ops, rows, K):
     g = torch.Generator().manual_seed(rows * 1000 + K)
     x = torch.randn(rows, K, generator=g) * 2 + 0.5
@@ -79,7 +80,8 @@ def test_layernorm_fused_add(ops, M, L, K, period):
     check("dbeta", bd.grad, bc.grad)
 
 
-@pytest.mark.parametrize("G,rep,inner,D", [(3, 1, 5, 16), (4, 6, 7, 32), (2, 3, 40, 128), (10, 2, 6, 64)])
+@pytest.mark.parametrize("G,rep,inner,D", [(3, 1, 5, 16), (4, 6, 7, 32), (2, 3, 40, 128), (10, 2, 6, 64),
+                                           (5, 7, 123, 128), (3, 1, 1001, 128)])
 def test_cat3_layernorm(ops, G, rep, inner, D):
     g = torch.Generator().manual_seed(G * 100 + rep)
     a = torch.randn(G * inner, D, generator=g)
@@ -102,7 +104,11 @@ def test_cat3_layernorm(ops, G, rep, inner, D):
 
 @pytest.mark.parametrize("M,N,K,relu", [(5, 16, 16, True), (300, 128, 384, True), (257, 300, 768, True),
                                          (1000, 128, 300, False), (77, 1, 128, False), (130, 48, 20, True),
-                                         (4100, 128, 128, True), (64, 5, 7, False)])
+                                         (4100, 128, 128, True), (64, 5, 7, False),
+                                         # M >= 4096: the streaming kernels (ragged last row tile, partial column
+                                         # tiles, several K chunks, ragged last K chunk, several column tiles)
+                                         (5000, 300, 768, True), (4133, 128, 300, False), (8200, 384, 128, True),
+                                         (4097, 128, 384, True), (6000, 44, 132, False), (4096, 128, 64, True)])
 def test_linear(ops, M, N, K, relu):
     g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g)
@@ -127,6 +133,23 @@ def test_linear(ops, M, N, K, relu):
     check("db", bd.grad, bc.grad)
 
 
+@pytest.mark.parametrize("M,N,K", [(4200, 128, 128), (4111, 96, 260)])
+def test_gemm_nt_gate_residual_c_abi(ops, M, N, K):
+    """stage_gemm_nt with the gate and the residual operand (not reachable through ops.linear) straight through the C-ABI."""
+    from tvqaplus_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + K)
+    x, gate = torch.randn(M, K, generator=g), torch.randn(M, K, generator=g)
+    w, b, res = torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    xd, gd, wd, bd, rd = (t.cuda().contiguous() for t in (x, gate, w, b, res))
+    y = torch.empty(M, N, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.stage_gemm_nt(xd.data_ptr(), gd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr(), y.data_ptr(),
+                                 M, N, K, 1, st), "stage_gemm_nt")
+    ref = torch.relu(F.linear((x * (gate > 0)).double(), w.double(), b.double())) + res.double()
+    check("y", y, ref.float())
+
+
 def test_linear_is_transpose_safe(ops):
     """A = I with an asymmetric weight: catches swapped MFMA output rows/cols."""
     K = 64
@@ -136,7 +159,8 @@ def test_linear_is_transpose_safe(ops):
     check("y", y, w.t())
 
 
-@pytest.mark.parametrize("M,L,D,k", [(3, 5, 16, 7), (6, 20, 128, 7), (5, 40, 128, 5), (2, 9, 32, 3), (4, 2, 16, 5)])
+@pytest.mark.parametrize("M,L,D,k", [(3, 5, 16, 7), (6, 20, 128, 7), (5, 40, 128, 5), (2, 9, 32, 3), (4, 2, 16, 5),
+                                     (3, 100, 64, 9), (2, 33, 128, 1), (7, 64, 128, 3), (40, 300, 128, 7)])
 def test_dwconv(ops, M, L, D, k):
     g = torch.Generator().manual_seed(M * L + k)
     x = torch.randn(M, L, D, generator=g)
