@@ -241,31 +241,43 @@ __device__ __forceinline__ long a_row_fast(long row, int rep, int inner) {
     return (long)(gq * (unsigned)inner + r % (unsigned)inner);
 }
 
-template <int MODE, bool DROP>
+template <int MODE, bool DROP, int NQ0>
 __global__ __launch_bounds__(256) void ln_fwd_fast_kernel(RowSrc src, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ y,
                                                           float* __restrict__ mean, float* __restrict__ rstd, long rows,
                                                           int K, float eps, int LPR, uint64_t seed, uint32_t th,
                                                           float inv_keep) {
-    constexpr int NQ = (MODE == 0) ? 1 : 3;          // column quads per lane
+    constexpr int NQ = (MODE == 0) ? NQ0 : 3;        // column quads per lane (MODE 0: quad sl + t*LPR, the last may be ragged)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int RPW = 64 / LPR, sub = lane / LPR, sl = lane % LPR;
     const int K4 = K >> 2, D = (MODE == 0) ? K : src.D, D4 = D >> 2;
     const float invK = 1.0f / (float)K;
+    int jq[NQ], jc[NQ];
+    bool jok[NQ];
     float4 gm[NQ], bt[NQ];
 #pragma unroll
-    for (int t = 0; t < NQ; t++) { gm[t] = ld4(gamma + 4 * (t * D4 + sl)); bt[t] = ld4(beta + 4 * (t * D4 + sl)); }
+    for (int t = 0; t < NQ; t++) {
+        jq[t] = (MODE == 0) ? sl + t * LPR : t * D4 + sl;
+        jok[t] = jq[t] < K4;
+        jc[t] = jok[t] ? jq[t] : K4 - 1;
+        gm[t] = ld4(gamma + 4 * jc[t]);
+        bt[t] = ld4(beta + 4 * jc[t]);
+    }
     const long step = (long)gridDim.x * wpb * RPW * LN_UR;
     for (long base = ((long)blockIdx.x * wpb + wave) * RPW * LN_UR; base < rows; base += step) {
-        float4 v[LN_UR][NQ], rv[LN_UR];
+        float4 v[LN_UR][NQ], rv[LN_UR][(MODE == 0) ? NQ : 1];
         long row[LN_UR];
 #pragma unroll
         for (int u = 0; u < LN_UR; u++) {
             row[u] = base + u * RPW + sub;
             const long rc = row[u] < rows ? row[u] : rows - 1;
             if (MODE == 0) {
-                v[u][0] = ld4(src.x + rc * K + 4 * sl);
-                if (src.b) rv[u] = ld4(src.b + (src.inner > 0 ? (long)((unsigned)rc % (unsigned)src.inner) : rc) * K + 4 * sl);
+                const long rr = src.b ? (src.inner > 0 ? (long)((unsigned)rc % (unsigned)src.inner) : rc) : 0;
+#pragma unroll
+                for (int t = 0; t < NQ; t++) {
+                    v[u][t] = ld4(src.x + rc * K + 4 * jc[t]);
+                    if (src.b) rv[u][t] = ld4(src.b + rr * K + 4 * jc[t]);
+                }
             } else {
                 v[u][0] = ld4(src.x + a_row_fast(rc, src.rep, src.inner) * D + 4 * sl);
                 v[u][1] = ld4(src.b + rc * D + 4 * sl);
@@ -274,13 +286,17 @@ __global__ __launch_bounds__(256) void ln_fwd_fast_kernel(RowSrc src, const floa
 #pragma unroll
         for (int u = 0; u < LN_UR; u++) {
             const bool ok = row[u] < rows;
-            float s;
+            float s = 0.f;
             if (MODE == 0) {
-                if (src.b) {
-                    v[u][0] = f4add(v[u][0], rv[u]);
-                    if (src.sum_out && ok) st4(src.sum_out + row[u] * K + 4 * sl, v[u][0]);
+#pragma unroll
+                for (int t = 0; t < NQ; t++) {
+                    if (src.b) {
+                        v[u][t] = f4add(v[u][t], rv[u][t]);
+                        if (src.sum_out && ok && jok[t]) st4(src.sum_out + row[u] * K + 4 * jq[t], v[u][t]);
+                    }
+                    if (!jok[t]) v[u][t] = f4zero();
+                    s += f4hsum(v[u][t]);
                 }
-                s = f4hsum(v[u][0]);
             } else {
                 v[u][2] = f4mul(v[u][0], v[u][1]);
                 s = f4hsum(v[u][0]) + f4hsum(v[u][1]) + f4hsum(v[u][2]);
@@ -291,7 +307,7 @@ __global__ __launch_bounds__(256) void ln_fwd_fast_kernel(RowSrc src, const floa
 #pragma unroll
             for (int t = 0; t < NQ; t++) {
                 const float4 d = make_float4(v[u][t].x - mu, v[u][t].y - mu, v[u][t].z - mu, v[u][t].w - mu);
-                q += f4hsum(f4mul(d, d));
+                if (jok[t]) q += f4hsum(f4mul(d, d));
             }
             q = group_sum(q, LPR);
             const float rs = 1.0f / sqrtf(q * invK + eps);
@@ -301,37 +317,45 @@ __global__ __launch_bounds__(256) void ln_fwd_fast_kernel(RowSrc src, const floa
             }
 #pragma unroll
             for (int t = 0; t < NQ; t++) {
-                const int j = t * D4 + sl;
                 float4 o;
                 o.x = (v[u][t].x - mu) * rs * gm[t].x + bt[t].x;
                 o.y = (v[u][t].y - mu) * rs * gm[t].y + bt[t].y;
                 o.z = (v[u][t].z - mu) * rs * gm[t].z + bt[t].z;
                 o.w = (v[u][t].w - mu) * rs * gm[t].w + bt[t].w;
-                if (DROP) o = f4mul(o, drop4(seed, (uint64_t)row[u] * K4 + j, th, inv_keep));
-                if (ok) st4(y + row[u] * K + 4 * j, o);
+                if (DROP) o = f4mul(o, drop4(seed, (uint64_t)row[u] * K4 + jq[t], th, inv_keep));
+                if (ok && jok[t]) st4(y + row[u] * K + 4 * jq[t], o);
             }
         }
     }
 }
 
-template <int MODE, bool DROP>
+template <int MODE, bool DROP, int NQ0>
 __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(RowSrc src, const float* __restrict__ dy,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, float* __restrict__ dx,
                                                           float* __restrict__ db_out, float* __restrict__ part, long rows,
                                                           int K, int LPR, uint64_t seed, uint32_t th, float inv_keep) {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [wpb*RPW][2][K]
-    constexpr int NQ = (MODE == 0) ? 1 : 3;
+    constexpr int NQ = (MODE == 0) ? NQ0 : 3;
+    constexpr int NX = (MODE == 0) ? NQ0 : 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int RPW = 64 / LPR, sub = lane / LPR, sl = lane % LPR;
     const int K4 = K >> 2, D = (MODE == 0) ? K : src.D, D4 = D >> 2;
     const float invK = 1.0f / (float)K;
+    int jq[NQ], jc[NQ];
+    bool jok[NQ];
     float4 gm[NQ], ag[NQ], ab[NQ];
 #pragma unroll
-    for (int t = 0; t < NQ; t++) { gm[t] = ld4(gamma + 4 * (t * D4 + sl)); ag[t] = ab[t] = f4zero(); }
+    for (int t = 0; t < NQ; t++) {
+        jq[t] = (MODE == 0) ? sl + t * LPR : t * D4 + sl;
+        jok[t] = jq[t] < K4;
+        jc[t] = jok[t] ? jq[t] : K4 - 1;
+        gm[t] = ld4(gamma + 4 * jc[t]);
+        ag[t] = ab[t] = f4zero();
+    }
     const long step = (long)gridDim.x * wpb * RPW * LN_UR;
     for (long base = ((long)blockIdx.x * wpb + wave) * RPW * LN_UR; base < rows; base += step) {
-        float4 xv[LN_UR][2], d[LN_UR][NQ], ra[LN_UR];
+        float4 xv[LN_UR][NX], d[LN_UR][NQ], ra[LN_UR][(MODE == 0) ? NQ : 1];
         float mu[LN_UR], rs[LN_UR];
         long row[LN_UR];
 #pragma unroll
@@ -341,14 +365,17 @@ __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(RowSrc src, const floa
             mu[u] = mean[rc];
             rs[u] = rstd[rc];
             if (MODE == 0) {
-                xv[u][0] = ld4(src.x + rc * K + 4 * sl);
-                if (dx && src.b) ra[u] = ld4(src.b + rc * K + 4 * sl);
+#pragma unroll
+                for (int t = 0; t < NQ; t++) {
+                    xv[u][t] = ld4(src.x + rc * K + 4 * jc[t]);
+                    if (dx && src.b) ra[u][t] = ld4(src.b + rc * K + 4 * jc[t]);
+                }
             } else {
                 xv[u][0] = ld4(src.x + a_row_fast(rc, src.rep, src.inner) * D + 4 * sl);
                 xv[u][1] = ld4(src.b + rc * D + 4 * sl);
             }
 #pragma unroll
-            for (int t = 0; t < NQ; t++) d[u][t] = ld4(dy + rc * K + 4 * (t * D4 + sl));
+            for (int t = 0; t < NQ; t++) d[u][t] = ld4(dy + rc * K + 4 * jc[t]);
         }
 #pragma unroll
         for (int u = 0; u < LN_UR; u++) {
@@ -357,10 +384,10 @@ __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(RowSrc src, const floa
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int t = 0; t < NQ; t++) {
-                const float4 x = (MODE == 0 || t == 0) ? xv[u][0] : ((t == 1) ? xv[u][1] : f4mul(xv[u][0], xv[u][1]));
+                const float4 x = (MODE == 0) ? xv[u][t] : ((t == 0) ? xv[u][0] : ((t == 1) ? xv[u][1] : f4mul(xv[u][0], xv[u][1])));
                 float4 dd = d[u][t];
-                if (DROP) dd = f4mul(dd, drop4(seed, (uint64_t)row[u] * K4 + t * D4 + sl, th, inv_keep));
-                if (!ok) dd = f4zero();              // rows past the end were read from a clamped address
+                if (DROP) dd = f4mul(dd, drop4(seed, (uint64_t)row[u] * K4 + jq[t], th, inv_keep));
+                if (!ok || !jok[t]) dd = f4zero();   // rows / quads past the end were read from a clamped address
                 xh[t] = make_float4((x.x - mu[u]) * rs[u], (x.y - mu[u]) * rs[u], (x.z - mu[u]) * rs[u], (x.w - mu[u]) * rs[u]);
                 g[t] = f4mul(dd, gm[t]);
                 s1 += f4hsum(g[t]);
@@ -380,12 +407,15 @@ __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(RowSrc src, const floa
             }
             if (MODE == 0) {
                 if (dx && ok) {
-                    if (src.b) dz[0] = f4add(dz[0], ra[u]);  // + gradient of the exported sum
-                    st4(dx + row[u] * K + 4 * sl, dz[0]);
+#pragma unroll
+                    for (int t = 0; t < NQ; t++) {
+                        if (src.b) dz[t] = f4add(dz[t], ra[u][t]);  // + gradient of the exported sum
+                        if (jok[t]) st4(dx + row[u] * K + 4 * jq[t], dz[t]);
+                    }
                 }
             } else if (ok) {
                 // z = [a, b, a*b]:  da = dz0 + dz2*b ; db = dz1 + dz2*a
-                st4(dx + row[u] * D + 4 * sl, f4add(dz[0], f4mul(dz[NQ - 1], xv[u][1])));
+                st4(dx + row[u] * D + 4 * sl, f4add(dz[0], f4mul(dz[NQ - 1], xv[u][NX - 1])));
                 st4(db_out + row[u] * D + 4 * sl, f4add(dz[NQ > 1 ? 1 : 0], f4mul(dz[NQ - 1], xv[u][0])));
             }
         }
@@ -394,10 +424,11 @@ __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(RowSrc src, const floa
     const int slot = wave * RPW + sub;
     float* sg = smem + (size_t)slot * 2 * K;
 #pragma unroll
-    for (int t = 0; t < NQ; t++) {
-        st4(sg + 4 * (t * D4 + sl), ag[t]);
-        st4(sg + K + 4 * (t * D4 + sl), ab[t]);
-    }
+    for (int t = 0; t < NQ; t++)
+        if (jok[t]) {
+            st4(sg + 4 * jq[t], ag[t]);
+            st4(sg + K + 4 * jq[t], ab[t]);
+        }
     __syncthreads();
     const int nslots = wpb * RPW;
     for (int c = threadIdx.x; c < 2 * K; c += blockDim.x) {
@@ -431,14 +462,23 @@ static int ln_fwd_launch(RowSrc src, const float* gamma, const float* beta, floa
                          hipStream_t st) {
     const int rows_per_block = 4 * (64 / LPR);
     const int q4 = (MODE == 0) ? K / 4 : src.D / 4;
-    if (q4 == LPR && rows < (1ll << 31) && !getenv("STAGE_LN_GENERIC")) {   // every lane owns fixed column quads: fast schedule
+    const int nq = (MODE == 0) ? (q4 + LPR - 1) / LPR : (q4 == LPR ? 1 : 0);   // quads per lane; MODE 1 needs D/4 == LPR
+    if (nq >= 1 && nq <= 4 && rows < (1ll << 31) && !getenv("STAGE_LN_GENERIC")) {   // fixed column quads per lane
         const int gridf = stage_grid_for(rows, rows_per_block * LN_UR, GRID_CAP * 2);
-        if (p_drop > 0.f)
-            hipLaunchKernelGGL((ln_fwd_fast_kernel<MODE, true>), dim3(gridf), dim3(256), 0, st, src, gamma, beta, y, mean,
-                               rstd, (long)rows, K, eps, LPR, (uint64_t)seed, drop_thresh16(p_drop), 1.0f / (1.0f - p_drop));
-        else
-            hipLaunchKernelGGL((ln_fwd_fast_kernel<MODE, false>), dim3(gridf), dim3(256), 0, st, src, gamma, beta, y, mean,
-                               rstd, (long)rows, K, eps, LPR, (uint64_t)0, 0u, 1.0f);
+        const bool dr = p_drop > 0.f;
+        const uint64_t sd = dr ? (uint64_t)seed : 0;
+        const uint32_t th = dr ? drop_thresh16(p_drop) : 0u;
+        const float ik = dr ? 1.0f / (1.0f - p_drop) : 1.0f;
+#define LN_FWD_FAST(DR, NQV)                                                                                           \
+    hipLaunchKernelGGL((ln_fwd_fast_kernel<MODE, DR, NQV>), dim3(gridf), dim3(256), 0, st, src, gamma, beta, y, mean, rstd, \
+                       (long)rows, K, eps, LPR, sd, th, ik)
+        switch (MODE == 0 ? nq : 1) {
+            case 1: if (dr) LN_FWD_FAST(true, 1); else LN_FWD_FAST(false, 1); break;
+            case 2: if (dr) LN_FWD_FAST(true, 2); else LN_FWD_FAST(false, 2); break;
+            case 3: if (dr) LN_FWD_FAST(true, 3); else LN_FWD_FAST(false, 3); break;
+            default: if (dr) LN_FWD_FAST(true, 4); else LN_FWD_FAST(false, 4); break;
+        }
+#undef LN_FWD_FAST
         STAGE_LAUNCH_CHECK();
         return 0;
     }
@@ -468,14 +508,24 @@ static int ln_bwd_launch(RowSrc src, const float* dy, const float* mean, const f
     const size_t lds = (size_t)rows_per_block * 2 * K * sizeof(float);
     float* part = (float*)ws;
     const int q4 = (MODE == 0) ? K / 4 : src.D / 4;
-    const bool fast = q4 == LPR && rows < (1ll << 31) && !getenv("STAGE_LN_GENERIC");
-    if (fast && p_drop > 0.f)
-        hipLaunchKernelGGL((ln_bwd_fast_kernel<MODE, true>), dim3(grid), dim3(256), lds, st, src, dy, mean, rstd, gamma, dx,
-                           db_out, part, (long)rows, K, LPR, (uint64_t)seed, drop_thresh16(p_drop),
-                           1.0f / (1.0f - p_drop));
-    else if (fast)
-        hipLaunchKernelGGL((ln_bwd_fast_kernel<MODE, false>), dim3(grid), dim3(256), lds, st, src, dy, mean, rstd, gamma, dx,
-                           db_out, part, (long)rows, K, LPR, (uint64_t)0, 0u, 1.0f);
+    const int nq = (MODE == 0) ? (q4 + LPR - 1) / LPR : (q4 == LPR ? 1 : 0);
+    const bool fast = nq >= 1 && nq <= 4 && rows < (1ll << 31) && !getenv("STAGE_LN_GENERIC");
+    if (fast) {
+        const bool dr = p_drop > 0.f;
+        const uint64_t sd = dr ? (uint64_t)seed : 0;
+        const uint32_t th = dr ? drop_thresh16(p_drop) : 0u;
+        const float ik = dr ? 1.0f / (1.0f - p_drop) : 1.0f;
+#define LN_BWD_FAST(DR, NQV)                                                                                            \
+    hipLaunchKernelGGL((ln_bwd_fast_kernel<MODE, DR, NQV>), dim3(grid), dim3(256), lds, st, src, dy, mean, rstd, gamma, dx, \
+                       db_out, part, (long)rows, K, LPR, sd, th, ik)
+        switch (MODE == 0 ? nq : 1) {
+            case 1: if (dr) LN_BWD_FAST(true, 1); else LN_BWD_FAST(false, 1); break;
+            case 2: if (dr) LN_BWD_FAST(true, 2); else LN_BWD_FAST(false, 2); break;
+            case 3: if (dr) LN_BWD_FAST(true, 3); else LN_BWD_FAST(false, 3); break;
+            default: if (dr) LN_BWD_FAST(true, 4); else LN_BWD_FAST(false, 4); break;
+        }
+#undef LN_BWD_FAST
+    }
     else if (p_drop > 0.f)
         hipLaunchKernelGGL((ln_bwd_kernel<MODE, true>), dim3(grid), dim3(256), lds, st, src, dy, mean, rstd, gamma, dx,
                            db_out, part, (long)rows, K, LPR, (uint64_t)seed, drop_thresh16(p_drop),
