@@ -54,6 +54,12 @@ __device__ __forceinline__ float4 drop4(uint64_t seed, uint64_t idx4, uint32_t t
     m.w = ((uint32_t)(h >> 48) & 0xFFFFu) >= thresh16 ? inv_keep : 0.f;
     return m;
 }
+// keep bits (bit i set <=> element 4*idx4 + i is kept) of the same stream as drop4
+__device__ __forceinline__ uint32_t drop4_bits(uint64_t seed, uint64_t idx4, uint32_t thresh16) {
+    const uint64_t h = mix64(seed, idx4);
+    return (((uint32_t)(h) & 0xFFFFu) >= thresh16 ? 1u : 0u) | (((uint32_t)(h >> 16) & 0xFFFFu) >= thresh16 ? 2u : 0u) |
+           (((uint32_t)(h >> 32) & 0xFFFFu) >= thresh16 ? 4u : 0u) | (((uint32_t)(h >> 48) & 0xFFFFu) >= thresh16 ? 8u : 0u);
+}
 // single element `e` (global element index): same stream as drop4(seed, e/4)[e%4]
 __device__ __forceinline__ float drop1(uint64_t seed, uint64_t e, uint32_t thresh16, float inv_keep) {
     uint64_t h = mix64(seed, e >> 2);

@@ -140,9 +140,20 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
         }
         TICK(0);
         float ri[RT], qmk[RT][4];
+        // TRAIN: the dropout keep bits of this lane's stage-1 operand elements (RT rows x 8 chunks x 4) are hashed ONCE
+        // per item (the 64-bit mixes are quarter-rate integer multiplies: per tile pair they cost more than the MFMAs
+        // and spilled the kernel); the tile loop expands them with one v_bfe_i32 + v_and per element
+        unsigned kb[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; rt++) {
             ri[rt] = rinv[areg[rt]];
+            kb[rt] = 0u;
+            if (TRAIN) {
+                ri[rt] *= inv_keep;
+#pragma unroll
+                for (int m = 0; m < NCH; m++)
+                    kb[rt] |= drop4_bits(seed, (uint64_t)(frame * Lr + areg[rt]) * D4 + dchunk(g, m), th) << (4 * m);
+            }
 #pragma unroll
             for (int k = 0; k < 4; k++) qmk[rt][k] = qm[Rk[rt][k]];
         }
@@ -186,7 +197,13 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
                 for (int rt = 0; rt < RT; rt++) {
                     const int ch = dchunk(g, m);
                     qv[rt] = f4scale(ld4(&Qr[arow[rt] * LDQ + 4 * ch]), ri[rt]);
-                    if (TRAIN) qv[rt] = f4mul(qv[rt], drop4(seed, (uint64_t)(frame * Lr + areg[rt]) * D4 + ch, th, inv_keep));
+                    if (TRAIN) {
+                        const int kbits = (int)kb[rt];
+                        qv[rt].x = __int_as_float(__float_as_int(qv[rt].x) & __builtin_amdgcn_sbfe(kbits, 4 * m + 0, 1));
+                        qv[rt].y = __int_as_float(__float_as_int(qv[rt].y) & __builtin_amdgcn_sbfe(kbits, 4 * m + 1, 1));
+                        qv[rt].z = __int_as_float(__float_as_int(qv[rt].z) & __builtin_amdgcn_sbfe(kbits, 4 * m + 2, 1));
+                        qv[rt].w = __int_as_float(__float_as_int(qv[rt].w) & __builtin_amdgcn_sbfe(kbits, 4 * m + 3, 1));
+                    }
                 }
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++)
