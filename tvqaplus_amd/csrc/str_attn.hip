@@ -344,6 +344,88 @@ __global__ __launch_bounds__(512) void str_attn_bwd_ds_kernel(
     }
 }
 
+// B1 for D = 128 and Lr % 4 == 0 (both streams of the published configs): same tiling, but compile-time trip counts, all
+// global loads of a tile (8 dA fragments, the S_ quads, the external dS quads) issued up front from clamped addresses,
+// 16-byte S_ loads / dS stores (register k of region tile rt holds region rt*16 + 4g + k: 4 consecutive floats).
+template <int RT, bool HAS_EXT>
+__global__ __launch_bounds__(512) void str_attn_bwd_ds_d128_kernel(
+    const float* __restrict__ dA, const float* __restrict__ Q, const float* __restrict__ Sn,
+    const float* __restrict__ dS_ext, float* __restrict__ dS, int N, int NA, int Li, int Lqa, int Lr, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int D = 128, LDQ = D + 4, NC = 8, D4 = 32;
+    float* Qr = lds;  // [RT*16][LDQ]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c15 = lane & 15, g = lane >> 4;
+    const int CR = NA * Lqa;
+    const long frame = blockIdx.x;  // n*Li + i
+    const int n = (int)(frame / Li), i = (int)(frame % Li);
+    for (int e = tid; e < RT * 16 * D4; e += blockDim.x) {
+        const int r = e / D4, q = e % D4;
+        const float4 v = ld4(Q + (frame * Lr + min(r, Lr - 1)) * D + 4 * q);
+        st4(&Qr[r * LDQ + 4 * q], r < Lr ? v : f4zero());
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TPW; t++) {
+        const int c = (wave * TPW + t) * 16 + c15;
+        const bool cvalid = c < CR;
+        const int cc = cvalid ? c : CR - 1;
+        const long orow = ((long)(n * NA + cc / Lqa) * Li + i) * Lqa + cc % Lqa;
+        float4 gv[NC];
+        float2 pq[RT][2], eq[RT][2];   // 8-byte pieces: regions rt*16 + 4g + {0,1} and {2,3} (Lr even -> 8-byte aligned)
+#pragma unroll
+        for (int m = 0; m < NC; m++) gv[m] = ld4(dA + orow * D + 4 * dchunk(g, m, NC));
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                const int r0 = min(rt * 16 + 4 * g + 2 * hh, Lr - 2);
+                pq[rt][hh] = *reinterpret_cast<const float2*>(Sn + orow * Lr + r0);
+                if (HAS_EXT) eq[rt][hh] = *reinterpret_cast<const float2*>(dS_ext + orow * Lr + r0);
+            }
+        }
+        f32x4 acc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < NC; m++) {
+            const float gj[4] = {gv[m].x, gv[m].y, gv[m].z, gv[m].w};
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                const float4 qv = ld4(&Qr[(rt * 16 + c15) * LDQ + 4 * dchunk(g, m, NC)]);
+                const float qj[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qj[j], gj[j], acc[rt], 0, 0, 0);
+            }
+        }
+        // acc[rt][k] = dP[c][R = rt*16 + 4g + k]
+        float p[RT][4], dot = 0.f;
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            const bool rok0 = rt * 16 + 4 * g < Lr, rok1 = rt * 16 + 4 * g + 2 < Lr;
+            p[rt][0] = rok0 ? pq[rt][0].x : 0.f;
+            p[rt][1] = rok0 ? pq[rt][0].y : 0.f;
+            p[rt][2] = rok1 ? pq[rt][1].x : 0.f;
+            p[rt][3] = rok1 ? pq[rt][1].y : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) dot += p[rt][k] * acc[rt][k];
+        }
+        dot += __shfl_xor(dot, 16);
+        dot += __shfl_xor(dot, 32);
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                float2 o = make_float2(scale * p[rt][2 * hh] * (acc[rt][2 * hh] - dot),
+                                       scale * p[rt][2 * hh + 1] * (acc[rt][2 * hh + 1] - dot));
+                if (HAS_EXT) { o.x += eq[rt][hh].x; o.y += eq[rt][hh].y; }
+                const int r0 = rt * 16 + 4 * g + 2 * hh;
+                if (cvalid && r0 < Lr) *reinterpret_cast<float2*>(dS + orow * Lr + r0) = o;
+            }
+        }
+    }
+}
+
 // B2: one workgroup per frame; thread (r, q) walks the NA*Lqa context rows in order.
 __global__ __launch_bounds__(256) void str_attn_bwd_dq_kernel(const float* __restrict__ dA, const float* __restrict__ Sn,
                                                               const float* __restrict__ dS, const float* __restrict__ Cn,
@@ -429,6 +511,27 @@ extern "C" int stage_str_attn_bwd(const float* dA, const float* dS_raw_ext, cons
         (void)hipFuncSetAttribute((const void*)str_attn_bwd_ds_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)str_attn_bwd_ds_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
+    static const bool ds_generic = getenv("STAGE_K1_DS_GENERIC") != nullptr;   // developer switch
+    if (D == 128 && (Lr & 1) == 0 && Lr >= 2 && !ds_generic) {
+#define LAUNCH_DS(RTV)                                                                                                  \
+    do {                                                                                                                \
+        if (lds > 64 * 1024) {                                                                                          \
+            (void)hipFuncSetAttribute((const void*)str_attn_bwd_ds_d128_kernel<RTV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            (void)hipFuncSetAttribute((const void*)str_attn_bwd_ds_d128_kernel<RTV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        }                                                                                                               \
+        if (dS_raw_ext)                                                                                                 \
+            hipLaunchKernelGGL((str_attn_bwd_ds_d128_kernel<RTV, true>), grid, block, lds, st, dA, Q, S_norm, dS_raw_ext, dS_out, N, NA, Li, Lqa, Lr, scale); \
+        else                                                                                                            \
+            hipLaunchKernelGGL((str_attn_bwd_ds_d128_kernel<RTV, false>), grid, block, lds, st, dA, Q, S_norm, dS_raw_ext, dS_out, N, NA, Li, Lqa, Lr, scale); \
+    } while (0)
+        switch (RT) {
+            case 1: LAUNCH_DS(1); break;
+            case 2: LAUNCH_DS(2); break;
+            case 3: LAUNCH_DS(3); break;
+            default: LAUNCH_DS(4); break;
+        }
+#undef LAUNCH_DS
+    } else
     switch (RT) {
         case 1: hipLaunchKernelGGL((str_attn_bwd_ds_kernel<1>), grid, block, lds, st, dA, Q, S_norm, dS_raw_ext, dS_out, N, NA, Li, Lqa, Lr, D, scale); break;
         case 2: hipLaunchKernelGGL((str_attn_bwd_ds_kernel<2>), grid, block, lds, st, dA, Q, S_norm, dS_raw_ext, dS_out, N, NA, Li, Lqa, Lr, D, scale); break;
