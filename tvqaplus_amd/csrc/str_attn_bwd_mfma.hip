@@ -110,25 +110,43 @@ __global__ __launch_bounds__(256) void str_attn_bwd_dc_mfma_kernel(const float* 
 #pragma unroll
                 for (int e = 0; e < 4; e++) acc[u][b][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        for (int i = fa; i < fb; i++) {
-            const float* qrow = Qn + (((long)n * Li + i) * Lr) * D;
-
-            for (int kr = 0; kr < KR; kr++) {
-                const int r = 4 * kr + g;
-                const bool rok = r < Lr;
-                float a_op[2];
+        // steps s = (frame - fa) * KR + kr, software pipelined: the operands of step s + 1 are requested (straight-line,
+        // clamped addresses) before the MFMAs of step s; two register sets, loop unrolled by two
+        const int nsteps = (fb - fa) * KR;
+        auto fetch = [&](int sidx, float (&a_op)[2], float4 (&q)[NB]) {
+            const int sc = sidx < nsteps ? sidx : nsteps - 1;
+            const int i = fa + sc / KR, kr = sc % KR;
+            const int r = min(4 * kr + g, Lr - 1);
 #pragma unroll
-                for (int u = 0; u < 2; u++) a_op[u] = (cok[u] && rok) ? dS[(obase[u] + (long)i * Lqa) * Lr + r] : 0.f;
+            for (int u = 0; u < 2; u++) a_op[u] = dS[(obase[u] + (long)i * Lqa) * Lr + r];
+            const float* qrow = Qn + (((long)n * Li + i) * Lr + r) * D + 4 * c15;
 #pragma unroll
-                for (int b = 0; b < NB; b++) {
-                    const float4 q = rok ? ld4(qrow + (long)r * D + 64 * b + 4 * c15) : f4zero();
-                    const float qv[4] = {q.x, q.y, q.z, q.w};
+            for (int b = 0; b < NB; b++) q[b] = ld4(qrow + 64 * b);
+        };
+        auto mul = [&](int sidx, const float (&a_op)[2], const float4 (&q)[NB]) {
+            const bool ok = sidx < nsteps && 4 * (sidx % KR) + g < Lr;
+            float av[2];
 #pragma unroll
-                    for (int u = 0; u < 2; u++)
+            for (int u = 0; u < 2; u++) av[u] = (ok && cok[u]) ? a_op[u] : 0.f;
 #pragma unroll
-                        for (int e = 0; e < 4; e++)
-                            acc[u][b][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_op[u], qv[e], acc[u][b][e], 0, 0, 0);
-                }
+            for (int b = 0; b < NB; b++) {
+                const float qv[4] = {q[b].x, q[b].y, q[b].z, q[b].w};
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        acc[u][b][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], qv[e], acc[u][b][e], 0, 0, 0);
+            }
+        };
+        if (nsteps > 0) {
+            float a0[2], a1[2];
+            float4 q0[NB], q1[NB];
+            fetch(0, a0, q0);
+            for (int sidx = 0; sidx < nsteps; sidx += 2) {
+                fetch(sidx + 1, a1, q1);
+                mul(sidx, a0, q0);
+                fetch(sidx + 2, a0, q0);
+                mul(sidx + 1, a1, q1);
             }
         }
         // C layout: row = 4g + reg (context row inside the tile), col j = c15 -> d = 64b + 4 c15 + e
