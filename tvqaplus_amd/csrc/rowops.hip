@@ -534,8 +534,8 @@ static int ln_bwd_launch(RowSrc src, const float* dy, const float* mean, const f
         hipLaunchKernelGGL((ln_bwd_kernel<MODE, false>), dim3(grid), dim3(256), lds, st, src, dy, mean, rstd, gamma, dx,
                            db_out, part, (long)rows, K, LPR, (uint64_t)0, 0u, 1.0f);
     STAGE_LAUNCH_CHECK();
-    stage_colreduce(part, dgamma, nullptr, grid, (long)2 * K, K, 0, 0, st);
-    stage_colreduce(part + K, dbeta, nullptr, grid, (long)2 * K, K, 0, 0, st);
+    // one launch for both: column c = t*K + d of the [2][K] partial rows goes to dgamma[d] (t = 0) or dbeta[d] (t = 1)
+    stage_colreduce(part, dgamma, dbeta, grid, (long)2 * K, 2 * K, K, 1, st);
     STAGE_LAUNCH_CHECK();
     return 0;
 }
