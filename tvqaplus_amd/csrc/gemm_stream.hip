@@ -61,7 +61,7 @@ __device__ __forceinline__ float4 s_gate4(float4 v, float4 g) {
     return make_float4(g.x > 0.f ? v.x : 0.f, g.y > 0.f ? v.y : 0.f, g.z > 0.f ? v.z : 0.f, g.w > 0.f ? v.w : 0.f);
 }
 
-template <bool HAS_GATE, bool HAS_RES>
+template <bool HAS_GATE, bool HAS_RES, bool WPRE>
 __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const float* __restrict__ X,
                                                                         const float* __restrict__ G,
                                                                         const float* __restrict__ W,
@@ -90,6 +90,38 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
             for (int s = 0; s < 3; s++) *reinterpret_cast<uint2*>(&Wp[s * SPLANE + n * SWS + pos]) = make_uint2(s01[s], s23[s]);
         }
     };
+
+    // K > 128 with WPRE: the NEXT weight chunk is requested (untracked loads, 8 float4 per thread) before the current chunk
+    // is multiplied and split into the LDS planes after the barrier that ends the chunk, so its L2 latency hides behind
+    // 192 MFMAs per wave instead of stalling all 8 waves between two barriers.
+    f32x4 wr[8];
+    const bool multi = WPRE && nkc > 1;
+    auto w_issue = [&](int kc) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int e = tid + j * 64 * SWAVES, n = e >> 5, q = e & 31;
+            const float* pw = W + (long)min(n0 + n, N - 1) * K + min(kc * SKC + 4 * q, K - 4);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wr[j]) : "v"(pw) : "memory");
+        }
+    };
+    auto w_stash = [&](int kc) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int e = tid + j * 64 * SWAVES, n = e >> 5, q = e & 31;
+            const bool ok = n0 + n < N && kc * SKC + 4 * q < K;
+            unsigned s01[3], s23[3];
+            s_split3(ok ? wr[j][0] : 0.f, ok ? wr[j][1] : 0.f, s01);
+            s_split3(ok ? wr[j][2] : 0.f, ok ? wr[j][3] : 0.f, s23);
+            const int pos = 16 * (q >> 2) + 8 * (q & 1) + 4 * ((q >> 1) & 1);
+#pragma unroll
+            for (int s = 0; s < 3; s++) *reinterpret_cast<uint2*>(&Wp[s * SPLANE + n * SWS + pos]) = make_uint2(s01[s], s23[s]);
+        }
+    };
+#define WAIT_W(n)                                                                                                      \
+    asm volatile("s_waitcnt vmcnt(%8)"                                                                                 \
+                 : "+v"(wr[0]), "+v"(wr[1]), "+v"(wr[2]), "+v"(wr[3]), "+v"(wr[4]), "+v"(wr[5]), "+v"(wr[6]), "+v"(wr[7]) \
+                 : "n"(n)                                                                                              \
+                 : "memory")
 
     // X (and gate) lines in flight: two 32-k line buffers, ping-ponged inside a tile.  vmcnt retires in issue order on
     // gfx9, so a load issued after the 64 epilogue stores of a tile cannot be consumed before those stores are
@@ -142,7 +174,8 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
     // copies, and a copy of a register whose load is still in flight copies garbage).  When the next unit is a new tile,
     // that request therefore precedes the 64 stores of the current tile ("steady": the waits then use vmcnt(63)).
     const bool full_cols = n0 + SBN <= N;                 // this workgroup stores all 4 column tiles: 64 stores per tile
-    bool w_loaded = false, first = true;
+    bool w_loaded = false, first = true, after_stores = false;
+    if (multi) w_issue(0);
     fetch(0, ((long)blockIdx.x * SWAVES + wave) * 32 + l31, 0);
     fetch(1, ((long)blockIdx.x * SWAVES + wave) * 32 + l31, 32);
     for (long bt = blockIdx.x; bt < n_bt; bt += gridDim.x) {
@@ -157,7 +190,18 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
 
         for (int kc = 0; kc < nkc; kc++) {
             const int kb = kc * SKC;
-            if (nkc > 1 || !w_loaded) {
+            if (multi) {
+                __syncthreads();                         // everyone done with the previous chunk
+                // younger than the weight request: lines 0/1 of this unit (2 NL; the lines requested while the previous
+                // chunk was multiplied were awaited there) and, after a tile end, its 64 stores; nothing for a wave
+                // without tiles.  Exact counts in untied waits, the tied wait carries the registers.
+                if (!live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (!after_stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
+                WAIT_W(63);
+                w_stash(kc);
+                __syncthreads();
+                w_issue(kc + 1 == nkc ? 0 : kc + 1);
+            } else if (nkc > 1 || !w_loaded) {
                 __syncthreads();                         // everyone done with the previous chunk
                 load_w(kc);
                 __syncthreads();
@@ -208,11 +252,18 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
             // Not steady: the exact counts are applied first by an untied wait inside the (uniform) branch; the tied
             // waits that carry the registers stay outside of any branch.
             const bool steady = kc == 0 && !first && full_cols;
-            if (!steady) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");   // newer than line 0: line 1
+            // (multi: the 8 weight loads of the next chunk were requested after lines 0/1 as well)
+            if (!steady) {
+                if (multi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL + 8) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");          // newer than line 0: line 1
+            }
             WAIT_LINE(0, 63);
             mul_line(0, 0);
             fetch(0, row, kb + 64);
-            if (!steady) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");   // newer than line 1: line 2
+            if (!steady) {
+                if (multi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL + 8) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");          // newer than line 1: line 2
+            }
             WAIT_LINE(1, 63);                                                         // steady: 64 stores + line 2
             mul_line(1, 1);
             fetch(1, row, kb + 96);
@@ -227,6 +278,7 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
             fetch(0, nrow, nk);
             fetch(1, nrow, nk + 32);
             first = false;
+            after_stores = last_chunk && full_cols;   // this wave is live: its 64 epilogue stores follow
         }
         if (!live) continue;
         // epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
@@ -286,11 +338,11 @@ int stage_gemm_nt_stream(const float* X, const float* gate, const float* W, cons
     do {                                                                                                               \
         static bool attr_done = false;                                                                                 \
         if (!attr_done) {                                                                                              \
-            (void)hipFuncSetAttribute((const void*)gemm_nt_stream_kernel<GT, RS>,                                      \
+            (void)hipFuncSetAttribute((const void*)gemm_nt_stream_kernel<GT, RS, !(GT && RS)>,                                      \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                \
             attr_done = true;                                                                                          \
         }                                                                                                              \
-        hipLaunchKernelGGL((gemm_nt_stream_kernel<GT, RS>), grid, block, lds, (hipStream_t)stream, X, gate, W, bias,   \
+        hipLaunchKernelGGL((gemm_nt_stream_kernel<GT, RS, !(GT && RS)>), grid, block, lds, (hipStream_t)stream, X, gate, W, bias,   \
                            residual, Y, (long)M, N, K, relu);                                                          \
     } while (0)
     if (gate) { if (residual) LAUNCH_ST(true, true); else LAUNCH_ST(true, false); }
