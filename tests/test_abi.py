@@ -108,3 +108,41 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "stage_oracle" not in src, f
+
+
+def test_kernels_with_untracked_loads_do_not_spill(built_lib):
+    """Kernels that issue inline-asm loads and await them with hand-counted s_waitcnt must not spill: a spilled
+    register whose load is still in flight stores stale data (finding 3).  The streaming GEMMs, the K1 forward
+    kernels that run at the published shapes and their callers' objects are checked through the code-object metadata."""
+    import glob
+    import re
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        pytest.skip("ROCm LLVM tools not available")
+    # kernel-name pattern -> must have vgpr_spill_count == 0
+    must_be_clean = {
+        "gemm_stream": [r"gemm_nt_stream_kernel", r"gemm_tn_stream_kernel"],
+        # video-stream shapes of the published configs (RT = 2, KL = 1, PERM), eval and training variants
+        "str_attn_fwd_reg": [r"str_attn_fwd_reg_kernelILi2ELi1ELb1ELb0E"],
+    }
+    for stem, patterns in must_be_clean.items():
+        obj = os.path.join(ROOT, "build", stem + ".o")
+        if not os.path.exists(obj):
+            subprocess.check_call(["make", "-C", ROOT, "build/%s.o" % stem], stdout=subprocess.DEVNULL)
+        subprocess.check_call([os.path.join(llvm, "llvm-objdump"), "--offloading", obj], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+        bundles = glob.glob(obj + ".*amdgcn*")
+        assert bundles, "no device code object in " + obj
+        try:
+            notes = subprocess.check_output([os.path.join(llvm, "llvm-readelf"), "--notes", bundles[0]]).decode()
+        finally:
+            for f in glob.glob(obj + ".0.*"):
+                os.remove(f)
+        names = re.findall(r"\.name:\s+(\S+)", notes)
+        spills = re.findall(r"\.vgpr_spill_count:\s+(\d+)", notes)
+        assert len(names) == len(spills) and names
+        for pat in patterns:
+            hits = [(n, int(s)) for n, s in zip(names, spills) if re.search(pat, n)]
+            assert hits, "no kernel matches " + pat
+            for n, sp in hits:
+                assert sp == 0, "%s spills %d VGPRs" % (n, sp)
