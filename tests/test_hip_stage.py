@@ -160,3 +160,45 @@ def test_train_step_with_dropout_runs(hip_device):
     for k, p in model.named_parameters():
         if p.grad is not None:
             assert torch.isfinite(p.grad).all(), k
+
+
+def test_full_size_batch_split_invariance(hip_device):
+    """BASELINE.json's full configuration (B=16, 300 frames x 20 regions, 50 subtitle words, 40 QA words, hsz=128):
+    examples are independent, so the outputs of the full batch must equal the outputs of its two halves and the summed
+    loss gradients must add up -- a size-independent property that runs every production kernel (streaming GEMMs,
+    register-resident K1, sliding-window convs, fast LayerNorms) at the sizes the bench measures.  Eval mode (no dropout:
+    the counter-based masks are indexed by global element position and would differ between the splits)."""
+    from tvqaplus_amd import parallel
+    from tvqaplus_amd.stage import STAGE
+    from tvqaplus_amd.synth import make_batch, make_opt
+    torch.manual_seed(3)
+    opt = make_opt(hsz=128, add_local=True, dropout=0.0)
+    model = STAGE(opt).to(hip_device).eval()
+    model.mha_dropout_override = 0.0
+    batch = make_batch(N=16, Li=300, Lr=20, Lw=50, Lqa=40, seed=2018).to(hip_device)
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def run(b):
+        for p in params:
+            p.grad = None
+        out, _, _, t_loss, t_prob, other = model.forward_main(b)
+        # a smooth scalar of everything the heads produce (sum over examples -> additive over the split)
+        loss = (out ** 2).sum() + (other["temporal_scores"] ** 2).sum()
+        loss.backward()
+        grads = [p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p) for p in params]
+        return out.detach(), t_prob.detach(), other, grads
+
+    out_f, tp_f, other_f, g_f = run(batch)
+    halves = [run(parallel.shard_batch(batch, r, 2)) for r in range(2)]
+    assert rel_err(torch.cat([h[0] for h in halves]), out_f) < 1e-4
+    assert rel_err(torch.cat([h[1] for h in halves]), tp_f) < 1e-4
+    for k in ("vid_normalized_s", "sub_normalized_s", "vid_raw_s", "sub_raw_s"):
+        assert rel_err(torch.cat([h[2][k] for h in halves]), other_f[k]) < 1e-4, k
+    # attention weights: rows sum to 1 where any region is valid, exactly 0 on masked rows
+    s = other_f["vid_normalized_s"]
+    rs = s.sum(-1)
+    assert ((rs - 1).abs() < 1e-4).logical_or(rs == 0).all()
+    worst = 0.0
+    for a, b0, b1 in zip(g_f, halves[0][3], halves[1][3]):
+        worst = max(worst, rel_err(b0 + b1, a))
+    assert worst < GTOL, "summed half-batch gradients differ from the full batch: %.3e" % worst
