@@ -24,6 +24,13 @@
 #ifndef K1_ABL
 #define K1_ABL 0        // developer ablation bits (tools/ubench/k1_abl.hip): 1 no A stores, 2 no S stores, 4 no stage-2 MFMA,
 #endif                  // 8 no stage-1 MFMA -- results are wrong with any bit set, timing experiments only
+// The A tile (491 MB per launch, full 256-byte row segments, never re-read here) is stored non-temporally: -7 % kernel
+// time.  The S / S_ stores stay plain: their 80-byte rows are partial lines and measured slower with the nt hint.
+#ifndef K1_PLAIN_STORES
+#define ST4_OUT(p, v) do { float4 v__ = (v); __builtin_nontemporal_store((f32x4){v__.x, v__.y, v__.z, v__.w}, reinterpret_cast<f32x4*>(p)); } while (0)
+#else
+#define ST4_OUT(p, v) st4((p), (v))
+#endif
 #define RD 128          // row width (floats)
 #define RNCH 8          // 4-float chunks per lane group
 
@@ -281,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++)
                     if (!(K1_ABL & 1) || o[0][reg] == 1.2345e30f)
-                        st4(A + arow4[reg] + 64 * b, make_float4(o[0][reg], o[1][reg], o[2][reg], o[3][reg]));
+                        ST4_OUT(A + arow4[reg] + 64 * b, make_float4(o[0][reg], o[1][reg], o[2][reg], o[3][reg]));
             }
             if (!(K1_ABL & 32)) WAIT_CF(NST);   // only this tile's stores may still be in flight
         }
