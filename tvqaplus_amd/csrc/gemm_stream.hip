@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
             }
             if (full) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) yp[(long)((r & 3) + 8 * (r >> 2)) * N] = acc[nt][r];
+                for (int r = 0; r < 16; r++) __builtin_nontemporal_store(acc[nt][r], &yp[(long)((r & 3) + 8 * (r >> 2)) * N]);
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
