@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_sw_kernel(const float* __restr
             float4 acc = bq;
 #pragma unroll
             for (int t = 0; t < KT; t++) acc = f4add(acc, f4mul(win[t], wt[t]));
-            st4(out + ((m * L + l) * D + 4 * q), acc);
+            st4_stream(out + ((m * L + l) * D + 4 * q), acc);
         }
     }
 }
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_sw_kernel(const float* __restr
                     aw[t] = f4add(aw[t], f4mul(go, wi[t]));                 // dw[t] += dout[l] * in[l + t - pad]
                     gi = f4add(gi, f4mul(wo[KT - 1 - t], wt[t]));           // din[l] += dout[l - t + pad] * w[t]
                 }
-                st4(din + ((m * L + l) * D + 4 * q), gi);
+                st4_stream(din + ((m * L + l) * D + 4 * q), gi);
             }
         }
     }
