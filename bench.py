@@ -92,7 +92,7 @@ def k1_roofline(args, device):
     # HBM bytes per launch from the PMC passes committed under profiles/ (tools/pmc_k1.sh: WRITE_SIZE + 2 x FETCH_SIZE,
     # the x2 being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md); only valid for the default shape
     default_shape = (N, NA, Li, Lqa, Lr, D) == (16, 5, 300, 40, 20, 128) and not args.dense
-    traffic = 645.8e6 + 2 * 39.9e6 if default_shape else None
+    traffic = 646.9e6 + 2 * 36.05e6 if default_shape else None
     return {"bound": "hbm", "kernel": "str_attn_fwd_reg_kernel" if Lr <= 32 else "str_attn_fwd_d128_kernel", "achieved": round(achieved, 1), "peak": 8000.0,
             "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic, "algorithmic_bytes": alg,
             "avg_us": round(avg_ms * 1e3, 1), "min_us": round(ms[0] * 1e3, 1),
