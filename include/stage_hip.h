@@ -80,6 +80,14 @@ int stage_cat3_layernorm_bwd(const float* dy, const float* a, const float* b, co
                              const float* gamma, float* da_full, float* db, float* dgamma, float* dbeta, long long rows,
                              int D, int rep, int inner, float p_drop, unsigned long long seed, void* ws,
                              size_t ws_bytes, void* stream);
+/* Same backward with the reduction over `rep` fused in (rep > 1, D/4 a power of two in [4,64], inner <= 64): da is
+ * (rows/rep, D), already summed over the frames that share a row of `a` (the `.repeat` gradient of model/stage.py:381).
+ * ws sized by stage_cat3_layernorm_bwd_reduced_ws_bytes(rows, D, rep, inner).                                        */
+size_t stage_cat3_layernorm_bwd_reduced_ws_bytes(long long rows, int D, int rep, int inner);
+int stage_cat3_layernorm_bwd_reduced(const float* dy, const float* a, const float* b, const float* mean,
+                                     const float* rstd, const float* gamma, float* da, float* db, float* dgamma,
+                                     float* dbeta, long long rows, int D, int rep, int inner, float p_drop,
+                                     unsigned long long seed, void* ws, size_t ws_bytes, void* stream);
 /* out[g, inner_elems] = sum_{r<rep} in[g, r, inner_elems]  (gradient of a `.repeat`/broadcast, model/stage.py:381) */
 int stage_reduce_rep(const float* in, float* out, long long groups, int rep, long long inner_elems, void* stream);
 

@@ -29,6 +29,8 @@ SIGNATURES = {
     "stage_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, LL, I, F, U64, P, SZ, P]),
     "stage_cat3_layernorm_fwd": (I, [P, P, P, P, P, P, P, LL, I, I, I, F, F, U64, P]),
     "stage_cat3_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, U64, P, SZ, P]),
+    "stage_cat3_layernorm_bwd_reduced_ws_bytes": (SZ, [LL, I, I, I]),
+    "stage_cat3_layernorm_bwd_reduced": (I, [P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, U64, P, SZ, P]),
     "stage_reduce_rep": (I, [P, P, LL, I, LL, P]),
     "stage_gemm_nt": (I, [P, P, P, P, P, P, LL, I, I, I, P]),
     "stage_gemm_tn_ws_bytes": (SZ, [LL, I, I]),

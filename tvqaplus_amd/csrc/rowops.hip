@@ -438,6 +438,107 @@ __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(RowSrc src, const floa
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// cat3 LayerNorm backward with the broadcast reduction fused in (rep > 1: `a` is shared by the `rep` frames of a group).
+// A workgroup owns one (group, chunk of frames); a lane keeps the SAME positions `in` of the group for every frame, so the
+// gradient of the broadcast operand accumulates in registers in frame order (deterministic) and only one partial row per
+// (group, chunk, in) is written -- instead of a full (rows, D) tensor that stage_reduce_rep reads back (2 x 491 MB at the
+// full config).  `a` is loaded once per workgroup.  da_part: [G][CH][inner][D].
+// ------------------------------------------------------------------------------------------------
+template <bool DROP, int KI>
+__global__ __launch_bounds__(256) void cat3_ln_bwd_rep_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                              const float* __restrict__ dy, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                              float* __restrict__ da_part, float* __restrict__ db,
+                                                              float* __restrict__ part, int D, int rep, int inner, int CH,
+                                                              int fpc, uint64_t seed, uint32_t th, float inv_keep) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [RB][2][K]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int D4 = D >> 2, LPR = D4, RPW = 64 / LPR, RB = wpb * RPW;
+    const int sub = lane / LPR, sl = lane % LPR, slot = wave * RPW + sub;
+    const int K = 3 * D, K4 = 3 * D4;
+    const float invK = 1.0f / (float)K;
+    const int g = blockIdx.x / CH, chunk = blockIdx.x % CH;
+    const int f0 = chunk * fpc, f1 = min(rep, f0 + fpc);
+    float4 gm[3], ag[3], ab[3], av[KI], dacc[KI];
+#pragma unroll
+    for (int t = 0; t < 3; t++) { gm[t] = ld4(gamma + 4 * (t * D4 + sl)); ag[t] = ab[t] = f4zero(); }
+    int inx[KI];
+    bool iok[KI];
+#pragma unroll
+    for (int k = 0; k < KI; k++) {
+        const int in = slot + RB * k;
+        iok[k] = in < inner;
+        inx[k] = iok[k] ? in : inner - 1;
+        av[k] = ld4(a + ((long)g * inner + inx[k]) * D + 4 * sl);
+        dacc[k] = f4zero();
+    }
+    for (int f = f0; f < f1; f++) {
+        const long rbase = ((long)g * rep + f) * inner;
+        float4 bv[KI], d[KI][3];
+        float mu[KI], rs[KI];
+#pragma unroll
+        for (int k = 0; k < KI; k++) {
+            const long row = rbase + inx[k];
+            bv[k] = ld4(b + row * D + 4 * sl);
+#pragma unroll
+            for (int t = 0; t < 3; t++) d[k][t] = ld4(dy + row * K + 4 * (t * D4 + sl));
+            mu[k] = mean[row];
+            rs[k] = rstd[row];
+        }
+#pragma unroll
+        for (int k = 0; k < KI; k++) {
+            const long row = rbase + inx[k];
+            float4 xh[3], gq[3];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const float4 x = (t == 0) ? av[k] : ((t == 1) ? bv[k] : f4mul(av[k], bv[k]));
+                float4 dd = d[k][t];
+                if (DROP) dd = f4mul(dd, drop4(seed, (uint64_t)row * K4 + t * D4 + sl, th, inv_keep));
+                if (!iok[k]) dd = f4zero();
+                xh[t] = make_float4((x.x - mu[k]) * rs[k], (x.y - mu[k]) * rs[k], (x.z - mu[k]) * rs[k], (x.w - mu[k]) * rs[k]);
+                gq[t] = f4mul(dd, gm[t]);
+                s1 += f4hsum(gq[t]);
+                s2 += f4hsum(f4mul(gq[t], xh[t]));
+                ag[t] = f4add(ag[t], f4mul(dd, xh[t]));
+                ab[t] = f4add(ab[t], dd);
+            }
+            s1 = group_sum(s1, LPR) * invK;
+            s2 = group_sum(s2, LPR) * invK;
+            float4 dz[3];
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                dz[t].x = rs[k] * (gq[t].x - s1 - xh[t].x * s2);
+                dz[t].y = rs[k] * (gq[t].y - s1 - xh[t].y * s2);
+                dz[t].z = rs[k] * (gq[t].z - s1 - xh[t].z * s2);
+                dz[t].w = rs[k] * (gq[t].w - s1 - xh[t].w * s2);
+            }
+            // z = [a, b, a*b]:  da = dz0 + dz2*b ; db = dz1 + dz2*a
+            if (iok[k]) {
+                dacc[k] = f4add(dacc[k], f4add(dz[0], f4mul(dz[2], bv[k])));
+                st4(db + row * D + 4 * sl, f4add(dz[1], f4mul(dz[2], av[k])));
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KI; k++)
+        if (iok[k]) st4(da_part + (((long)g * CH + chunk) * inner + inx[k]) * D + 4 * sl, dacc[k]);
+    // block reduction of the per-lane column partials
+    float* sg = smem + (size_t)slot * 2 * K;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        st4(sg + 4 * (t * D4 + sl), ag[t]);
+        st4(sg + K + 4 * (t * D4 + sl), ab[t]);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * K; c += blockDim.x) {
+        float acc = 0.f;
+        for (int r = 0; r < RB; r++) acc += smem[(size_t)r * 2 * K + c];
+        part[(size_t)blockIdx.x * 2 * K + c] = acc;
+    }
+}
+
 // out[c] = sum_b part[b*stride + c]   (fixed order -> deterministic)
 __global__ void colreduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nb, long stride, int C) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -581,6 +682,67 @@ extern "C" int stage_cat3_layernorm_bwd(const float* dy, const float* a, const f
     RowSrc src{a, b, D, rep, inner, nullptr};
     return ln_bwd_launch<1>(src, dy, mean, rstd, gamma, da_full, db, dgamma, dbeta, rows, 3 * D, ln_lpr(D / 4),
                             p_drop, seed, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// frames per chunk / chunks for the fused broadcast reduction: ~1500 workgroups
+static void cat3_rep_chunks(long long groups, int rep, int* CH, int* fpc) {
+    long want = (1536 + groups - 1) / groups;
+    if (want < 1) want = 1;
+    if (want > rep) want = rep;
+    *fpc = (int)((rep + want - 1) / want);
+    *CH = (rep + *fpc - 1) / *fpc;
+}
+extern "C" size_t stage_cat3_layernorm_bwd_reduced_ws_bytes(long long rows, int D, int rep, int inner) {
+    if (rep < 1 || inner < 1 || rows <= 0) return 0;
+    const long long groups = rows / ((long long)rep * inner);
+    int CH, fpc;
+    cat3_rep_chunks(groups, rep, &CH, &fpc);
+    return ((size_t)groups * CH * 2 * 3 * D + (size_t)groups * CH * inner * D) * sizeof(float);
+}
+// da[rows/rep, D] already reduced over `rep`; requires rep > 1, D/4 a power of two in [4, 64], inner <= 64
+extern "C" int stage_cat3_layernorm_bwd_reduced(const float* dy, const float* a, const float* b, const float* mean,
+                                                const float* rstd, const float* gamma, float* da, float* db,
+                                                float* dgamma, float* dbeta, long long rows, int D, int rep, int inner,
+                                                float p_drop, unsigned long long seed, void* ws, size_t ws_bytes,
+                                                void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int D4 = D / 4;
+    if (D % 4 != 0 || D4 < 4 || D4 > 64 || (D4 & (D4 - 1)) != 0 || rep < 2 || inner < 1 || inner > 64 ||
+        rows % ((long long)rep * inner) != 0)
+        return STAGE_ERR_SHAPE;
+    if (rows <= 0) return 0;
+    if (ws_bytes < stage_cat3_layernorm_bwd_reduced_ws_bytes(rows, D, rep, inner)) return STAGE_ERR_WORKSPACE;
+    const long long groups = rows / ((long long)rep * inner);
+    int CH, fpc;
+    cat3_rep_chunks(groups, rep, &CH, &fpc);
+    const int K = 3 * D, RB = 4 * (64 / D4), KI = (inner + RB - 1) / RB;
+    float* part = (float*)ws;
+    float* da_part = part + (size_t)groups * CH * 2 * K;
+    const int grid = (int)(groups * CH);
+    const size_t lds = (size_t)RB * 2 * K * sizeof(float);
+    const bool dr = p_drop > 0.f;
+    const uint64_t sd = dr ? (uint64_t)seed : 0;
+    const uint32_t th = dr ? drop_thresh16(p_drop) : 0u;
+    const float ik = dr ? 1.0f / (1.0f - p_drop) : 1.0f;
+#define CAT3_REP(DR, KIV)                                                                                               \
+    hipLaunchKernelGGL((cat3_ln_bwd_rep_kernel<DR, KIV>), dim3(grid), dim3(256), lds, st, a, b, dy, mean, rstd, gamma,    \
+                       da_part, db, part, D, rep, inner, CH, fpc, sd, th, ik)
+    if (KI > 8) return STAGE_ERR_SHAPE;
+    switch (KI) {
+        case 1: if (dr) CAT3_REP(true, 1); else CAT3_REP(false, 1); break;
+        case 2: if (dr) CAT3_REP(true, 2); else CAT3_REP(false, 2); break;
+        case 3: if (dr) CAT3_REP(true, 3); else CAT3_REP(false, 3); break;
+        case 4: if (dr) CAT3_REP(true, 4); else CAT3_REP(false, 4); break;
+        case 5: if (dr) CAT3_REP(true, 5); else CAT3_REP(false, 5); break;
+        case 6: if (dr) CAT3_REP(true, 6); else CAT3_REP(false, 6); break;
+        case 7: if (dr) CAT3_REP(true, 7); else CAT3_REP(false, 7); break;
+        default: if (dr) CAT3_REP(true, 8); else CAT3_REP(false, 8); break;
+    }
+#undef CAT3_REP
+    STAGE_LAUNCH_CHECK();
+    stage_colreduce(part, dgamma, dbeta, grid, (long)2 * K, 2 * K, K, 1, st);
+    STAGE_LAUNCH_CHECK();
+    return stage_reduce_rep(da_part, da, groups, CH, (long long)inner * D, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

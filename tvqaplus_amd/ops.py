@@ -139,10 +139,19 @@ class _Cat3LayerNorm(torch.autograd.Function):
         D = b.shape[-1]
         rows = b.numel() // D
         dy = _chk(dy, "dy")
-        da_full = torch.empty_like(b)
         db = torch.empty_like(b)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         lib = _lib.load()
+        d4 = D // 4
+        if rep > 1 and D % 4 == 0 and 4 <= d4 <= 64 and (d4 & (d4 - 1)) == 0 and inner <= 64:
+            # broadcast reduction fused into the backward kernel: no (rows, D) intermediate
+            da = torch.empty_like(a)
+            wsb = lib.stage_cat3_layernorm_bwd_reduced_ws_bytes(rows, D, rep, inner)
+            ws = _workspace(wsb, b.device)
+            _call("stage_cat3_layernorm_bwd_reduced", _ptr(dy), _ptr(a), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(gamma),
+                  _ptr(da), _ptr(db), _ptr(dgamma), _ptr(dbeta), rows, D, rep, inner, p, seed, _ptr(ws), wsb, _stream())
+            return da, db, dgamma, dbeta, None, None, None, None
+        da_full = torch.empty_like(b)
         wsb = lib.stage_ln_bwd_ws_bytes(3 * D)
         ws = _workspace(wsb, b.device)
         _call("stage_cat3_layernorm_bwd", _ptr(dy), _ptr(a), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(gamma),
