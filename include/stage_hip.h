@@ -91,6 +91,20 @@ int stage_cat3_layernorm_bwd_reduced(const float* dy, const float* a, const floa
 /* out[g, inner_elems] = sum_{r<rep} in[g, r, inner_elems]  (gradient of a `.repeat`/broadcast, model/stage.py:381) */
 int stage_reduce_rep(const float* in, float* out, long long groups, int rep, long long inner_elems, void* stream);
 
+/* ---- fused LayerNorm (+ residual, + dropout) -> depthwise Conv1d of the encoder blocks (model/encoder.py:37-44,
+ * model/cnn.py:37-47): h = dwconv(drop(LN(x + res))); the LayerNorm output is never materialised.  x (M*L, D) rows,
+ * sequences of L rows; res / res_period / sum_out as in stage_layernorm_fwd; w (D,1,k), k odd <= 9; D/4 a power of two
+ * in [4, 64].  Backward: xin = the LayerNorm input (x or the exported sum), dx = d(xin) + dx_add, plus the parameter
+ * gradients of both layers; ws sized by stage_ln_dwconv_bwd_ws_bytes(D, k).                                          */
+int stage_ln_dwconv_fwd(const float* x, const float* res, int res_period, float* sum_out, const float* gamma,
+                        const float* beta, const float* w, const float* bias, float* h, float* mean, float* rstd,
+                        long long M, int L, int D, int k, float eps, float p_drop, unsigned long long seed, void* stream);
+size_t stage_ln_dwconv_bwd_ws_bytes(int D, int k);
+int stage_ln_dwconv_bwd(const float* dh, const float* xin, const float* mean, const float* rstd, const float* gamma,
+                        const float* beta, const float* w, float* dx, const float* dx_add, float* dgamma, float* dbeta,
+                        float* dw, float* db, long long M, int L, int D, int k, float p_drop, unsigned long long seed,
+                        void* ws, size_t ws_bytes, void* stream);
+
 /* ---- nn.Linear / 1x1 Conv1d on the matrix cores (fp32 in, fp32 accumulate, exact f32 MFMA) --------------------
  * Y[M,N] = epi((X .* [gate>0])[M,K] . W[N,K]^T + bias) ; epi: optional ReLU then optional + residual[M,N].
  * (model/stage.py:88,101,110,117,136; LinearWrapper :23; model/cnn.py:27-28,44-46; model/self_attention.py:32,46,54)

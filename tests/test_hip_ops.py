@@ -178,6 +178,42 @@ def test_dwconv(ops, M, L, D, k):
     check("db", bd.grad, bc.grad)
 
 
+@pytest.mark.parametrize("M,L,D,k,period,p", [(3, 5, 16, 7, 0, 0.0), (6, 20, 128, 7, 20, 0.0), (5, 40, 128, 5, 0, 0.0),
+                                               (2, 33, 32, 3, -1, 0.0), (7, 70, 128, 5, 0, 0.25), (4, 9, 64, 9, 9, 0.1),
+                                               (300, 40, 128, 5, 0, 0.1)])
+def test_ln_dwconv_fused_matches_unfused(ops, M, L, D, k, period, p):
+    """The fused LayerNorm -> depthwise-conv op against the composition of the two separate ops (same dropout counter):
+    outputs, exported sum and every gradient.  period: -1 no residual, 0 full residual, L position-table residual."""
+    g = torch.Generator().manual_seed(M * L + k + D)
+    x = torch.randn(M, L, D, generator=g)
+    res = None if period < 0 else (torch.randn(M, L, D, generator=g) if period == 0 else torch.randn(L, D, generator=g))
+    gam, bet = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    w, b = torch.randn(D, 1, k, generator=g), torch.randn(D, generator=g)
+    gh, gs = torch.randn(M, L, D, generator=g), torch.randn(M, L, D, generator=g)
+    outs = []
+    for fused in (False, True):
+        xd, gd, bd, wd, cd = (dev(t, True) for t in (x, gam, bet, w, b))
+        rd = None if res is None else dev(res, period == 0)
+        kw = dict(p=p, seed=1234, res=rd, res_period=max(period, 0))
+        if fused:
+            h, s_ = ops.ln_dwconv(xd, gd, bd, wd, cd, **kw)
+        else:
+            y, s_ = ops.layernorm(xd, gd, bd, **kw)
+            h = ops.dwconv(y, wd, cd)
+        loss = (h * gh.cuda()).sum()
+        if s_ is not None:
+            loss = loss + (s_ * gs.cuda()).sum()
+        loss.backward()
+        outs.append((h.detach(), None if s_ is None else s_.detach(), xd.grad, None if rd is None else rd.grad, gd.grad,
+                     bd.grad, wd.grad, cd.grad))
+    names = ("h", "sum", "dx", "dres", "dgamma", "dbeta", "dw", "db")
+    for n, a, bb in zip(names, outs[1], outs[0]):
+        if a is None or bb is None:
+            assert a is None and bb is None, n
+            continue
+        check(n, a, bb.cpu())
+
+
 def test_l2norm(ops):
     g = torch.Generator().manual_seed(3)
     x = torch.randn(37, 300, generator=g)

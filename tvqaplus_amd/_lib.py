@@ -32,6 +32,9 @@ SIGNATURES = {
     "stage_cat3_layernorm_bwd_reduced_ws_bytes": (SZ, [LL, I, I, I]),
     "stage_cat3_layernorm_bwd_reduced": (I, [P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, U64, P, SZ, P]),
     "stage_reduce_rep": (I, [P, P, LL, I, LL, P]),
+    "stage_ln_dwconv_fwd": (I, [P, P, I, P, P, P, P, P, P, P, P, LL, I, I, I, F, F, U64, P]),
+    "stage_ln_dwconv_bwd_ws_bytes": (SZ, [I, I]),
+    "stage_ln_dwconv_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, U64, P, SZ, P]),
     "stage_gemm_nt": (I, [P, P, P, P, P, P, LL, I, I, I, P]),
     "stage_gemm_tn_ws_bytes": (SZ, [LL, I, I]),
     "stage_gemm_tn": (I, [P, P, P, P, P, LL, I, I, P, SZ, P]),

@@ -1,0 +1,313 @@
+// Fused  LayerNorm (+ residual add, + inverted dropout)  ->  depthwise Conv1d  of the encoder blocks
+// (model/encoder.py:37-44: x = x + conv(drop(LN(x))) with conv = depthwise then pointwise; model/cnn.py:37-47).
+// The LayerNorm output only ever feeds the depthwise conv, so it is never written: forward reads x (+ res) and writes the
+// exported sum and the conv output; backward recomputes the normalised rows from the saved sum / mean / rstd.  Per conv
+// layer of the large (960000 x 128) tensors this removes two full passes in the forward and three in the backward.
+//
+// Work decomposition = the sliding-window conv kernels (encoder.hip): a thread owns one float4 column of one chunk of 32
+// positions of one sequence and walks it with the k taps in registers; the D/4 lanes of a row (a power of two <= 64, so a
+// row group never straddles a wave) compute the row statistics with cross-lane sums, every row exactly as the
+// LayerNorm kernels of rowops.hip do (same expressions, same summation order, same dropout counter).
+#include <stdlib.h>
+#include "common.h"
+#include "../../include/stage_hip.h"
+
+#define LDC 32          // positions per chunk
+#define LD_GRID_CAP 16384
+#define LD_PART_CAP 512
+
+template <int KT, bool DROP>
+__global__ __launch_bounds__(256) void ln_dwconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                            int res_period, float* __restrict__ sum_out,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ h, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, long M, int L, int D, float eps,
+                                                            uint64_t seed, uint32_t th, float inv_keep) {
+    constexpr int pad = KT / 2;
+    const int D4 = D >> 2, rpi = blockDim.x / D4;
+    const int q = threadIdx.x % D4, rsub = threadIdx.x / D4;
+    const float invK = 1.0f / (float)D;
+    const float4 gm = ld4(gamma + 4 * q), bt = ld4(beta + 4 * q), bq = ld4(bias + 4 * q);
+    float4 wt[KT];
+#pragma unroll
+    for (int t = 0; t < KT; t++)
+        wt[t] = make_float4(w[(4 * q + 0) * KT + t], w[(4 * q + 1) * KT + t], w[(4 * q + 2) * KT + t], w[(4 * q + 3) * KT + t]);
+    const int chunks = (L + LDC - 1) / LDC;
+    const long items = M * chunks;
+    for (long it = (long)blockIdx.x * rpi + rsub; it < items; it += (long)gridDim.x * rpi) {
+        const long m = it / chunks;
+        const int l0 = (int)(it % chunks) * LDC, l1 = min(L, l0 + LDC);
+        // normalised (and dropped) row ll of sequence m is 0 outside the sequence.  Rows of this chunk also export the
+        // sum and the statistics (every row is normalised by exactly one chunk as its own row, halo rows are recomputed).
+        // Rows enter the window in batches: all loads of a batch first (clamped addresses), then the statistics (two
+        // cross-lane reductions per row, independent chains), then the stores of the chunk's own rows -- a store or a
+        // guarded load in the middle of the chain makes the compiler wait for every load before it.
+        auto load_row = [&](int ll, float4& v) {
+            const long row = m * L + min(max(ll, 0), L - 1);
+            v = ld4(x + row * D + 4 * q);
+            if (res) v = f4add(v, ld4(res + (res_period > 0 ? (long)((unsigned long)row % (unsigned)res_period) : row) * D + 4 * q));
+        };
+        auto norm_row = [&](int ll, const float4& v, float& mu, float& rs) -> float4 {
+            const bool inside = ll >= 0 && ll < L;
+            const long row = m * L + min(max(ll, 0), L - 1);
+            mu = group_sum(f4hsum(v), D4) * invK;
+            const float4 d = make_float4(v.x - mu, v.y - mu, v.z - mu, v.w - mu);
+            rs = 1.0f / sqrtf(group_sum(f4hsum(f4mul(d, d)), D4) * invK + eps);
+            float4 o;
+            o.x = (v.x - mu) * rs * gm.x + bt.x;
+            o.y = (v.y - mu) * rs * gm.y + bt.y;
+            o.z = (v.z - mu) * rs * gm.z + bt.z;
+            o.w = (v.w - mu) * rs * gm.w + bt.w;
+            if (DROP) o = f4mul(o, drop4(seed, (uint64_t)row * D4 + q, th, inv_keep));
+            return inside ? o : f4zero();
+        };
+        auto export_row = [&](int ll, const float4& v, float mu, float rs) {   // the chunk's own rows only
+            if (ll >= l0 && ll < l1) {
+                const long row = m * L + ll;
+                if (sum_out) st4(sum_out + row * D + 4 * q, v);
+                if (q == 0) {
+                    mean[row] = mu;
+                    rstd[row] = rs;
+                }
+            }
+        };
+        float4 win[KT];   // win[t] = y[l + t - pad] for the current l
+        {
+            float4 pv[KT > 1 ? KT - 1 : 1];
+            float pm[KT > 1 ? KT - 1 : 1], pr[KT > 1 ? KT - 1 : 1];
+#pragma unroll
+            for (int t = 0; t < KT - 1; t++) load_row(l0 + t - pad, pv[t]);
+#pragma unroll
+            for (int t = 0; t < KT - 1; t++) win[t + 1] = norm_row(l0 + t - pad, pv[t], pm[t], pr[t]);
+#pragma unroll
+            for (int t = 0; t < KT - 1; t++) export_row(l0 + t - pad, pv[t], pm[t], pr[t]);
+        }
+        for (int l = l0; l < l1; l += 4) {
+            float4 nv[4], nr[4];
+            float nm[4], ns[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) load_row(l + u + pad, nv[u]);
+#pragma unroll
+            for (int u = 0; u < 4; u++) nr[u] = norm_row(l + u + pad, nv[u], nm[u], ns[u]);
+#pragma unroll
+            for (int u = 0; u < 4; u++) export_row(l + u + pad, nv[u], nm[u], ns[u]);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+#pragma unroll
+                for (int t = 0; t < KT - 1; t++) win[t] = win[t + 1];
+                win[KT - 1] = nr[u];
+                float4 acc = bq;
+#pragma unroll
+                for (int t = 0; t < KT; t++) acc = f4add(acc, f4mul(win[t], wt[t]));
+                if (l + u < l1) st4_stream(h + ((m * L + l + u) * D + 4 * q), acc);
+            }
+        }
+    }
+}
+
+// dx = LN-backward(conv-backward(dh)) + dx_add ; partials of dw/db (conv) and dgamma/dbeta (LayerNorm) per workgroup.
+template <int KT, bool DROP>
+__global__ __launch_bounds__(256) void ln_dwconv_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ xin,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ w, float* __restrict__ dx,
+                                                            const float* __restrict__ dx_add, float* __restrict__ part_conv,
+                                                            float* __restrict__ part_ln, long M, int L, int D,
+                                                            uint64_t seed, uint32_t th, float inv_keep) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // reduction scratch [rpi][KT + 1][D]
+    constexpr int pad = KT / 2;
+    const int D4 = D >> 2, rpi = blockDim.x / D4;
+    const int q = threadIdx.x % D4, rsub = threadIdx.x / D4;
+    const float invK = 1.0f / (float)D;
+    const float4 gm = ld4(gamma + 4 * q), bt = ld4(beta + 4 * q);
+    float4 wt[KT], aw[KT], abc = f4zero(), ag = f4zero(), abl = f4zero();
+#pragma unroll
+    for (int t = 0; t < KT; t++) {
+        wt[t] = make_float4(w[(4 * q + 0) * KT + t], w[(4 * q + 1) * KT + t], w[(4 * q + 2) * KT + t], w[(4 * q + 3) * KT + t]);
+        aw[t] = f4zero();
+    }
+    const int chunks = (L + LDC - 1) / LDC;
+    const long items = M * chunks;
+    for (long it = (long)blockIdx.x * rpi + rsub; it < items; it += (long)gridDim.x * rpi) {
+        const long m = it / chunks;
+        const int l0 = (int)(it % chunks) * LDC, l1 = min(L, l0 + LDC);
+        // recomputed LayerNorm output (after dropout) of row ll, 0 outside the sequence
+        auto y_row = [&](int ll) -> float4 {
+            const bool inside = ll >= 0 && ll < L;
+            const long row = m * L + min(max(ll, 0), L - 1);
+            const float4 v = ld4(xin + row * D + 4 * q);
+            const float mu = mean[row], rs = rstd[row];
+            float4 o;
+            o.x = (v.x - mu) * rs * gm.x + bt.x;
+            o.y = (v.y - mu) * rs * gm.y + bt.y;
+            o.z = (v.z - mu) * rs * gm.z + bt.z;
+            o.w = (v.w - mu) * rs * gm.w + bt.w;
+            if (DROP) o = f4mul(o, drop4(seed, (uint64_t)row * D4 + q, th, inv_keep));
+            return inside ? o : f4zero();
+        };
+        auto dh_row = [&](int ll) -> float4 {
+            const bool inside = ll >= 0 && ll < L;
+            const float4 v = ld4(dh + (m * L + min(max(ll, 0), L - 1)) * D + 4 * q);
+            return inside ? v : f4zero();
+        };
+        float4 wy[KT], wo[KT];   // wy[t] = y[l + t - pad], wo[t] = dh[l + t - pad]
+#pragma unroll
+        for (int t = 0; t < KT - 1; t++) {
+            wy[t + 1] = y_row(l0 + t - pad);
+            wo[t + 1] = dh_row(l0 + t - pad);
+        }
+        for (int l = l0; l < l1; l += 4) {
+            // four positions per iteration: all loads of the iteration (entering rows of both windows, the centre rows
+            // with their statistics and the incoming sum gradient) are issued up front
+            float4 ny[4], no[4], cv[4], ca[4];
+            float cmu[4], crs[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                ny[u] = y_row(l + u + pad);
+                no[u] = dh_row(l + u + pad);
+                const long row = m * L + min(l + u, L - 1);
+                cv[u] = ld4(xin + row * D + 4 * q);
+                cmu[u] = mean[row];
+                crs[u] = rstd[row];
+                if (dx && dx_add) ca[u] = ld4(dx_add + row * D + 4 * q);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+#pragma unroll
+                for (int t = 0; t < KT - 1; t++) { wy[t] = wy[t + 1]; wo[t] = wo[t + 1]; }
+                wy[KT - 1] = ny[u];
+                wo[KT - 1] = no[u];
+                const bool live = l + u < l1;            // positions past the chunk end contribute nothing
+                // depthwise conv backward at position l + u
+                const float4 go = live ? wo[pad] : f4zero();
+                abc = f4add(abc, go);
+                float4 din = f4zero();
+#pragma unroll
+                for (int t = 0; t < KT; t++) {
+                    aw[t] = f4add(aw[t], f4mul(go, wy[t]));                  // dw[t] += dh[l] * y[l + t - pad]
+                    din = f4add(din, f4mul(wo[KT - 1 - t], wt[t]));           // dy[l] += dh[l - t + pad] * w[t]
+                }
+                // LayerNorm backward of the row (same expressions as rowops.hip)
+                const long row = m * L + min(l + u, L - 1);
+                const float mu = cmu[u], rs = crs[u];
+                float4 dd = live ? din : f4zero();
+                if (DROP) dd = f4mul(dd, drop4(seed, (uint64_t)row * D4 + q, th, inv_keep));
+                const float4 v = cv[u];
+                const float4 xh = make_float4((v.x - mu) * rs, (v.y - mu) * rs, (v.z - mu) * rs, (v.w - mu) * rs);
+                const float4 g = f4mul(dd, gm);
+                const float s1 = group_sum(f4hsum(g), D4) * invK;
+                const float s2 = group_sum(f4hsum(f4mul(g, xh)), D4) * invK;
+                ag = f4add(ag, f4mul(dd, xh));
+                abl = f4add(abl, dd);
+                if (dx && live) {
+                    float4 o;
+                    o.x = rs * (g.x - s1 - xh.x * s2);
+                    o.y = rs * (g.y - s1 - xh.y * s2);
+                    o.z = rs * (g.z - s1 - xh.z * s2);
+                    o.w = rs * (g.w - s1 - xh.w * s2);
+                    if (dx_add) o = f4add(o, ca[u]);
+                    st4(dx + row * D + 4 * q, o);
+                }
+            }
+        }
+    }
+    // block reductions (fixed order): conv partials [KT+1][D], then LayerNorm partials [2][D]
+#pragma unroll
+    for (int t = 0; t < KT; t++) st4(&sm[((size_t)rsub * (KT + 1) + t) * D + 4 * q], aw[t]);
+    st4(&sm[((size_t)rsub * (KT + 1) + KT) * D + 4 * q], abc);
+    __syncthreads();
+    const int C = (KT + 1) * D;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int r = 0; r < rpi; r++) s += sm[(size_t)r * C + c];
+        part_conv[(size_t)blockIdx.x * C + c] = s;
+    }
+    __syncthreads();
+    st4(&sm[((size_t)rsub * 2 + 0) * D + 4 * q], ag);
+    st4(&sm[((size_t)rsub * 2 + 1) * D + 4 * q], abl);
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * D; c += blockDim.x) {
+        float s = 0.f;
+        for (int r = 0; r < rpi; r++) s += sm[(size_t)r * 2 * D + c];
+        part_ln[(size_t)blockIdx.x * 2 * D + c] = s;
+    }
+}
+
+static bool ld_shape_ok(int D, int k) {
+    const int D4 = D / 4;
+    return D % 4 == 0 && D4 >= 4 && D4 <= 64 && (D4 & (D4 - 1)) == 0 && k >= 1 && k <= 9 && (k & 1) == 1;
+}
+
+extern "C" int stage_ln_dwconv_fwd(const float* x, const float* res, int res_period, float* sum_out, const float* gamma,
+                                   const float* beta, const float* w, const float* bias, float* h, float* mean,
+                                   float* rstd, long long M, int L, int D, int k, float eps, float p_drop,
+                                   unsigned long long seed, void* stream) {
+    if (M <= 0 || L <= 0) return 0;
+    if (!ld_shape_ok(D, k)) return STAGE_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int rpi = 256 / (D / 4);
+    const long items = (long)M * ((L + LDC - 1) / LDC);
+    const int grid = stage_grid_for(items, rpi, LD_GRID_CAP);
+    const bool dr = p_drop > 0.f;
+    const uint64_t sd = dr ? (uint64_t)seed : 0;
+    const uint32_t th = dr ? drop_thresh16(p_drop) : 0u;
+    const float ik = dr ? 1.0f / (1.0f - p_drop) : 1.0f;
+#define LD_FWD(KV, DR)                                                                                                   \
+    hipLaunchKernelGGL((ln_dwconv_fwd_kernel<KV, DR>), dim3(grid), dim3(256), 0, st, x, res, res_period, sum_out, gamma,  \
+                       beta, w, bias, h, mean, rstd, (long)M, L, D, eps, sd, th, ik)
+    switch (k) {
+        case 1: if (dr) LD_FWD(1, true); else LD_FWD(1, false); break;
+        case 3: if (dr) LD_FWD(3, true); else LD_FWD(3, false); break;
+        case 5: if (dr) LD_FWD(5, true); else LD_FWD(5, false); break;
+        case 7: if (dr) LD_FWD(7, true); else LD_FWD(7, false); break;
+        default: if (dr) LD_FWD(9, true); else LD_FWD(9, false); break;
+    }
+#undef LD_FWD
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t stage_ln_dwconv_bwd_ws_bytes(int D, int k) { return (size_t)LD_PART_CAP * (k + 3) * D * sizeof(float); }
+
+extern "C" int stage_ln_dwconv_bwd(const float* dh, const float* xin, const float* mean, const float* rstd,
+                                   const float* gamma, const float* beta, const float* w, float* dx, const float* dx_add,
+                                   float* dgamma, float* dbeta, float* dw, float* db, long long M, int L, int D, int k,
+                                   float p_drop, unsigned long long seed, void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!ld_shape_ok(D, k)) return STAGE_ERR_SHAPE;
+    if (ws_bytes < stage_ln_dwconv_bwd_ws_bytes(D, k)) return STAGE_ERR_WORKSPACE;
+    if (M <= 0 || L <= 0) {
+        (void)hipMemsetAsync(dw, 0, sizeof(float) * D * k, st);
+        (void)hipMemsetAsync(db, 0, sizeof(float) * D, st);
+        (void)hipMemsetAsync(dgamma, 0, sizeof(float) * D, st);
+        (void)hipMemsetAsync(dbeta, 0, sizeof(float) * D, st);
+        return 0;
+    }
+    const int rpi = 256 / (D / 4);
+    const long items = (long)M * ((L + LDC - 1) / LDC);
+    const int grid = stage_grid_for(items, rpi, LD_PART_CAP);
+    float* part_conv = (float*)ws;
+    float* part_ln = part_conv + (size_t)LD_PART_CAP * (k + 1) * D;
+    const size_t lds = (size_t)rpi * (k + 1) * D * sizeof(float);
+    const bool dr = p_drop > 0.f;
+    const uint64_t sd = dr ? (uint64_t)seed : 0;
+    const uint32_t th = dr ? drop_thresh16(p_drop) : 0u;
+    const float ik = dr ? 1.0f / (1.0f - p_drop) : 1.0f;
+#define LD_BWD(KV, DR)                                                                                                    \
+    hipLaunchKernelGGL((ln_dwconv_bwd_kernel<KV, DR>), dim3(grid), dim3(256), lds, st, dh, xin, mean, rstd, gamma, beta, w, \
+                       dx, dx_add, part_conv, part_ln, (long)M, L, D, sd, th, ik)
+    switch (k) {
+        case 1: if (dr) LD_BWD(1, true); else LD_BWD(1, false); break;
+        case 3: if (dr) LD_BWD(3, true); else LD_BWD(3, false); break;
+        case 5: if (dr) LD_BWD(5, true); else LD_BWD(5, false); break;
+        case 7: if (dr) LD_BWD(7, true); else LD_BWD(7, false); break;
+        default: if (dr) LD_BWD(9, true); else LD_BWD(9, false); break;
+    }
+#undef LD_BWD
+    STAGE_LAUNCH_CHECK();
+    stage_colreduce(part_conv, dw, db, grid, (long)(k + 1) * D, (k + 1) * D, D, k, st);
+    stage_colreduce(part_ln, dgamma, dbeta, grid, (long)2 * D, 2 * D, D, 1, st);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}

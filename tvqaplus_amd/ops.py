@@ -252,6 +252,67 @@ def dwconv(x, w, bias):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# fused LayerNorm (+ residual, + dropout) -> depthwise Conv1d (the LayerNorm output is never materialised)
+# ---------------------------------------------------------------------------------------------------------------
+def ln_dwconv_supported(D: int, k: int) -> bool:
+    d4 = D // 4
+    return D % 4 == 0 and 4 <= d4 <= 64 and (d4 & (d4 - 1)) == 0 and 1 <= k <= 9 and k % 2 == 1
+
+
+class _LnDwConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, w, bias, res_period: int, p: float, seed: int):
+        x = _chk(x, "x")  # (M, L, D)
+        M, L, D = x.shape
+        res_c = None if res is None else _chk(res, "res")
+        gamma, beta, w, bias = _chk(gamma, "gamma"), _chk(beta, "beta"), _chk(w, "w"), _chk(bias, "bias")
+        k = w.shape[-1]
+        h = torch.empty_like(x)
+        mean = torch.empty(M * L, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        s = torch.empty_like(x) if res_c is not None else None
+        _call("stage_ln_dwconv_fwd", _ptr(x), _ptr(res_c), int(res_period), _ptr(s), _ptr(gamma), _ptr(beta), _ptr(w),
+              _ptr(bias), _ptr(h), _ptr(mean), _ptr(rstd), M, L, D, k, EPS_LN, float(p), int(seed), _stream())
+        xin = s if res_c is not None else x
+        ctx.save_for_backward(xin, mean, rstd, gamma, beta, w)
+        ctx.p, ctx.seed = float(p), int(seed)
+        ctx.has_res = res_c is not None
+        ctx.res_full = res_c is not None and res_period == 0
+        if s is None:
+            s = h.new_empty(0)
+        return h, s
+
+    @staticmethod
+    def backward(ctx, dh, dsum):
+        xin, mean, rstd, gamma, beta, w = ctx.saved_tensors
+        M, L, D = xin.shape
+        k = w.shape[-1]
+        dh = _chk(dh, "dh")
+        x_needs = ctx.needs_input_grad[0]
+        res_needs = ctx.needs_input_grad[1] and ctx.res_full
+        dx = torch.empty_like(xin) if (x_needs or res_needs) else None
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        dw = torch.empty_like(w)
+        db = torch.empty(D, dtype=torch.float32, device=xin.device)
+        lib = _lib.load()
+        wsb = lib.stage_ln_dwconv_bwd_ws_bytes(D, k)
+        ws = _workspace(wsb, xin.device)
+        dadd = None  # gradient arriving through the exported sum (next residual branch), fused into the dx store
+        if dx is not None and ctx.has_res and dsum is not None and dsum.numel() == dx.numel():
+            dadd = _chk(dsum, "dsum")
+        _call("stage_ln_dwconv_bwd", _ptr(dh), _ptr(xin), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(w),
+              _ptr(dx), _ptr(dadd), _ptr(dgamma), _ptr(dbeta), _ptr(dw), _ptr(db), M, L, D, k, ctx.p, ctx.seed,
+              _ptr(ws), wsb, _stream())
+        return (dx if x_needs else None), (dx if res_needs else None), dgamma, dbeta, dw, db, None, None, None
+
+
+def ln_dwconv(x, gamma, beta, w, bias, p: float = 0.0, seed: int = 0, res=None, res_period: int = 0):
+    """h = dwconv(drop(LN(x + res))); returns (h, x + res or None)."""
+    h, s = _LnDwConv.apply(x, res, gamma, beta, w, bias, res_period, p, seed)
+    return h, (s if res is not None else None)
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # L2 normalisation of raw features (no gradient needed: inputs are data) -- model/stage.py:256
 # ---------------------------------------------------------------------------------------------------------------
 def l2norm(x: torch.Tensor, p: float = 0.0, seed: int = 0) -> torch.Tensor:

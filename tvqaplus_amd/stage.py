@@ -12,6 +12,7 @@ Scope: the model forward/backward.  The host-side supervis
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -179,6 +180,8 @@ class STAGE(nn.Module):
         self.temporal_criterion = nn.CrossEntropyLoss(reduction="sum")
         self.classifier = _LinearWrapperParams(self.hsz * 2 if self.add_local else self.hsz, 1, self.dropout,
                                                relu=False)
+        # developer switch: False (or STAGE_NO_FUSE_LN_DWCONV=1) = separate LayerNorm and depthwise-conv kernels
+        self.fuse_ln_dwconv = os.environ.get("STAGE_NO_FUSE_LN_DWCONV") is None
         self._seed_state = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x1234567) & 0xFFFFFFFFFFFFFFFF
         self.mha_dropout_override: Optional[float] = None  # tests: the reference's fixed 0.1 can be zeroed
 
@@ -201,10 +204,17 @@ class STAGE(nn.Module):
         M, L, D = x.shape
         pending, cur, period = x, blk.position_encoding.rows(L), L  # first LN sees x + pe[:L]
         for i in range(blk.n_conv):
-            y, cur = self._ln(pending, blk.layer_norm[i], drop=(i % 2 == 0), res=cur, res_period=period)
-            period = 0
             c = blk.conv[i]
-            h = ops.dwconv(y, c.depthwise_conv.weight, c.depthwise_conv.bias)
+            ln, drop = blk.layer_norm[i], (i % 2 == 0)
+            if self.fuse_ln_dwconv and ops.ln_dwconv_supported(D, c.depthwise_conv.weight.shape[-1]):
+                # LayerNorm output only feeds the depthwise conv: one fused pass, never materialised
+                h, cur = ops.ln_dwconv(pending, ln.weight, ln.bias, c.depthwise_conv.weight, c.depthwise_conv.bias,
+                                       p=self._p() if drop else 0.0, seed=self._seed() if drop else 0, res=cur,
+                                       res_period=period)
+            else:
+                y, cur = self._ln(pending, ln, drop=drop, res=cur, res_period=period)
+                h = ops.dwconv(y, c.depthwise_conv.weight, c.depthwise_conv.bias)
+            period = 0
             pending = ops.linear(h, c.pointwise_conv.weight, c.pointwise_conv.bias, relu=True)
         if blk.num_heads != 0:
             y, cur = self._ln(pending, blk.attn_layer_norm, res=cur, res_period=period)
