@@ -115,6 +115,12 @@ static inline void stage_colreduce(const float* part, float* out, float* out2, i
     hipLaunchKernelGGL(stage_colreduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, part, out, out2, nb, stride, C, D, k);
 }
 
+// positions per work item of the sliding-window kernels: sequences up to 48 positions are one chunk (no halo rows,
+// no short tail chunk), longer ones are cut into equal chunks of at most 48
+static inline int stage_chunk_len(int L) {
+    const int n = (L + 47) / 48;
+    return (L + n - 1) / n;
+}
 static inline int stage_pow2_ceil(int v) {
     int p = 1;
     while (p < v) p <<= 1;

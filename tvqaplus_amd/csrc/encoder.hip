@@ -116,17 +116,16 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// Sliding-window versions (the ones that run): a thread owns one float4 column of one chunk of DWC positions of one
+// Sliding-window versions (the ones that run): a thread owns one float4 column of one chunk of <= 48 positions of one
 // sequence and walks it, keeping the k taps of `in` (and of `dout` in the backward) in registers: every element is
 // loaded once per chunk (+ a halo of k-1 rows) by straight-line loads from clamped addresses, instead of 2k+1 guarded
 // loads per output element.  Same arithmetic order over the taps as the kernels above.
 // ------------------------------------------------------------------------------------------------
-#define DWC 32   // positions per chunk
 
 template <int KT>
 __global__ __launch_bounds__(256) void dwconv_fwd_sw_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ out,
-                                                            long M, int L, int D) {
+                                                            long M, int L, int D, int clen) {
     constexpr int pad = KT / 2;
     const int D4 = D >> 2, rpi = blockDim.x / D4;
     const int q = threadIdx.x % D4, rsub = threadIdx.x / D4;
@@ -136,11 +135,11 @@ __global__ __launch_bounds__(256) void dwconv_fwd_sw_kernel(const float* __restr
     for (int t = 0; t < KT; t++)
         wt[t] = make_float4(w[(4 * q + 0) * KT + t], w[(4 * q + 1) * KT + t], w[(4 * q + 2) * KT + t], w[(4 * q + 3) * KT + t]);
     const float4 bq = ld4(bias + 4 * q);
-    const int chunks = (L + DWC - 1) / DWC;
+    const int chunks = (L + clen - 1) / clen;
     const long items = M * chunks;
     for (long it = (long)blockIdx.x * rpi + rsub; it < items; it += (long)gridDim.x * rpi) {
         const long m = it / chunks;
-        const int l0 = (int)(it % chunks) * DWC, l1 = min(L, l0 + DWC);
+        const int l0 = (int)(it % chunks) * clen, l1 = min(L, l0 + clen);
         const float* base = in + (m * L) * D + 4 * q;
         float4 win[KT];   // win[t] = in[l + t - pad] for the current l
 #pragma unroll
@@ -167,7 +166,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_sw_kernel(const float* __restr
 template <int KT>
 __global__ __launch_bounds__(256) void dwconv_bwd_sw_kernel(const float* __restrict__ dout, const float* __restrict__ in,
                                                             const float* __restrict__ w, float* __restrict__ din,
-                                                            float* __restrict__ part, long M, int L, int D) {
+                                                            float* __restrict__ part, long M, int L, int D, int clen) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // reduction scratch [rpi][KT + 1][D]
     constexpr int pad = KT / 2;
     const int D4 = D >> 2, rpi = blockDim.x / D4;
@@ -181,11 +180,11 @@ __global__ __launch_bounds__(256) void dwconv_bwd_sw_kernel(const float* __restr
 #pragma unroll
         for (int t = 0; t < KT; t++)
             wt[t] = make_float4(w[(4 * q + 0) * KT + t], w[(4 * q + 1) * KT + t], w[(4 * q + 2) * KT + t], w[(4 * q + 3) * KT + t]);
-        const int chunks = (L + DWC - 1) / DWC;
+        const int chunks = (L + clen - 1) / clen;
         const long items = M * chunks;
         for (long it = (long)blockIdx.x * rpi + rsub; it < items; it += (long)gridDim.x * rpi) {
             const long m = it / chunks;
-            const int l0 = (int)(it % chunks) * DWC, l1 = min(L, l0 + DWC);
+            const int l0 = (int)(it % chunks) * clen, l1 = min(L, l0 + clen);
             const float* bi = in + (m * L) * D + 4 * q;
             const float* bo = dout + (m * L) * D + 4 * q;
             float4 wi[KT], wo[KT];   // wi[t] = in[l + t - pad], wo[t] = dout[l + t - pad]
@@ -253,15 +252,16 @@ extern "C" int stage_dwconv_fwd(const float* in, const float* w, const float* bi
     if (D % 4 != 0 || k < 1 || k > KMAX || (k & 1) == 0) return STAGE_ERR_SHAPE;
     if (D / 4 <= 256 && !getenv("STAGE_DWCONV_GENERIC")) {
         const int rpi = 256 / (D / 4);
-        const long items = (long)M * ((L + DWC - 1) / DWC);
+        const int clen = stage_chunk_len(L);
+        const long items = (long)M * ((L + clen - 1) / clen);
         const int gridw = stage_grid_for(items, rpi, GRID_CAP * 4);
         hipStream_t st = (hipStream_t)stream;
         switch (k) {
-            case 1: hipLaunchKernelGGL(dwconv_fwd_sw_kernel<1>, dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D); break;
-            case 3: hipLaunchKernelGGL(dwconv_fwd_sw_kernel<3>, dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D); break;
-            case 5: hipLaunchKernelGGL(dwconv_fwd_sw_kernel<5>, dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D); break;
-            case 7: hipLaunchKernelGGL(dwconv_fwd_sw_kernel<7>, dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D); break;
-            default: hipLaunchKernelGGL(dwconv_fwd_sw_kernel<9>, dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D); break;
+            case 1: hipLaunchKernelGGL(dwconv_fwd_sw_kernel<1>, dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D, clen); break;
+            case 3: hipLaunchKernelGGL(dwconv_fwd_sw_kernel<3>, dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D, clen); break;
+            case 5: hipLaunchKernelGGL(dwconv_fwd_sw_kernel<5>, dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D, clen); break;
+            case 7: hipLaunchKernelGGL(dwconv_fwd_sw_kernel<7>, dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D, clen); break;
+            default: hipLaunchKernelGGL(dwconv_fwd_sw_kernel<9>, dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D, clen); break;
         }
         STAGE_LAUNCH_CHECK();
         return 0;
@@ -291,15 +291,16 @@ extern "C" int stage_dwconv_bwd(const float* dout, const float* in, const float*
     const size_t red = (size_t)rpi * (k + 1) * D;
     if (red > lds) lds = red;
     if (!getenv("STAGE_DWCONV_GENERIC")) {
-        const long items = (long)M * ((L + DWC - 1) / DWC);
+        const int clen = stage_chunk_len(L);
+        const long items = (long)M * ((L + clen - 1) / clen);
         grid = stage_grid_for(items, rpi, DW_PART_CAP);
         const size_t ldb = red * sizeof(float);
         switch (k) {
-            case 1: hipLaunchKernelGGL(dwconv_bwd_sw_kernel<1>, dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D); break;
-            case 3: hipLaunchKernelGGL(dwconv_bwd_sw_kernel<3>, dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D); break;
-            case 5: hipLaunchKernelGGL(dwconv_bwd_sw_kernel<5>, dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D); break;
-            case 7: hipLaunchKernelGGL(dwconv_bwd_sw_kernel<7>, dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D); break;
-            default: hipLaunchKernelGGL(dwconv_bwd_sw_kernel<9>, dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D); break;
+            case 1: hipLaunchKernelGGL(dwconv_bwd_sw_kernel<1>, dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D, clen); break;
+            case 3: hipLaunchKernelGGL(dwconv_bwd_sw_kernel<3>, dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D, clen); break;
+            case 5: hipLaunchKernelGGL(dwconv_bwd_sw_kernel<5>, dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D, clen); break;
+            case 7: hipLaunchKernelGGL(dwconv_bwd_sw_kernel<7>, dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D, clen); break;
+            default: hipLaunchKernelGGL(dwconv_bwd_sw_kernel<9>, dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D, clen); break;
         }
     } else {
         grid = stage_grid_for(M * L, rpi * 8, DW_PART_CAP);

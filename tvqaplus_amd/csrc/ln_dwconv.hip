@@ -4,7 +4,7 @@
 // exported sum and the conv output; backward recomputes the normalised rows from the saved sum / mean / rstd.  Per conv
 // layer of the large (960000 x 128) tensors this removes two full passes in the forward and three in the backward.
 //
-// Work decomposition = the sliding-window conv kernels (encoder.hip): a thread owns one float4 column of one chunk of 32
+// Work decomposition = the sliding-window conv kernels (encoder.hip): a thread owns one float4 column of one chunk of <= 48
 // positions of one sequence and walks it with the k taps in registers; the D/4 lanes of a row (a power of two <= 64, so a
 // row group never straddles a wave) compute the row statistics with cross-lane sums, every row exactly as the
 // LayerNorm kernels of rowops.hip do (same expressions, same summation order, same dropout counter).
@@ -12,7 +12,6 @@
 #include "common.h"
 #include "../../include/stage_hip.h"
 
-#define LDC 32          // positions per chunk
 #define LD_GRID_CAP 16384
 #define LD_PART_CAP 512
 
@@ -23,7 +22,7 @@ __global__ __launch_bounds__(256) void ln_dwconv_fwd_kernel(const float* __restr
                                                             const float* __restrict__ w, const float* __restrict__ bias,
                                                             float* __restrict__ h, float* __restrict__ mean,
                                                             float* __restrict__ rstd, long M, int L, int D, float eps,
-                                                            uint64_t seed, uint32_t th, float inv_keep) {
+                                                            uint64_t seed, uint32_t th, float inv_keep, int clen) {
     constexpr int pad = KT / 2;
     const int D4 = D >> 2, rpi = blockDim.x / D4;
     const int q = threadIdx.x % D4, rsub = threadIdx.x / D4;
@@ -33,11 +32,11 @@ __global__ __launch_bounds__(256) void ln_dwconv_fwd_kernel(const float* __restr
 #pragma unroll
     for (int t = 0; t < KT; t++)
         wt[t] = make_float4(w[(4 * q + 0) * KT + t], w[(4 * q + 1) * KT + t], w[(4 * q + 2) * KT + t], w[(4 * q + 3) * KT + t]);
-    const int chunks = (L + LDC - 1) / LDC;
+    const int chunks = (L + clen - 1) / clen;
     const long items = M * chunks;
     for (long it = (long)blockIdx.x * rpi + rsub; it < items; it += (long)gridDim.x * rpi) {
         const long m = it / chunks;
-        const int l0 = (int)(it % chunks) * LDC, l1 = min(L, l0 + LDC);
+        const int l0 = (int)(it % chunks) * clen, l1 = min(L, l0 + clen);
         // normalised (and dropped) row ll of sequence m is 0 outside the sequence.  Rows of this chunk also export the
         // sum and the statistics (every row is normalised by exactly one chunk as its own row, halo rows are recomputed).
         // Rows enter the window in batches: all loads of a batch first (clamped addresses), then the statistics (two
@@ -114,7 +113,7 @@ __global__ __launch_bounds__(256) void ln_dwconv_bwd_kernel(const float* __restr
                                                             const float* __restrict__ w, float* __restrict__ dx,
                                                             const float* __restrict__ dx_add, float* __restrict__ part_conv,
                                                             float* __restrict__ part_ln, long M, int L, int D,
-                                                            uint64_t seed, uint32_t th, float inv_keep) {
+                                                            uint64_t seed, uint32_t th, float inv_keep, int clen) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // reduction scratch [rpi][KT + 1][D]
     constexpr int pad = KT / 2;
     const int D4 = D >> 2, rpi = blockDim.x / D4;
@@ -127,11 +126,11 @@ __global__ __launch_bounds__(256) void ln_dwconv_bwd_kernel(const float* __restr
         wt[t] = make_float4(w[(4 * q + 0) * KT + t], w[(4 * q + 1) * KT + t], w[(4 * q + 2) * KT + t], w[(4 * q + 3) * KT + t]);
         aw[t] = f4zero();
     }
-    const int chunks = (L + LDC - 1) / LDC;
+    const int chunks = (L + clen - 1) / clen;
     const long items = M * chunks;
     for (long it = (long)blockIdx.x * rpi + rsub; it < items; it += (long)gridDim.x * rpi) {
         const long m = it / chunks;
-        const int l0 = (int)(it % chunks) * LDC, l1 = min(L, l0 + LDC);
+        const int l0 = (int)(it % chunks) * clen, l1 = min(L, l0 + clen);
         // recomputed LayerNorm output (after dropout) of row ll, 0 outside the sequence
         auto y_row = [&](int ll) -> float4 {
             const bool inside = ll >= 0 && ll < L;
@@ -247,7 +246,8 @@ extern "C" int stage_ln_dwconv_fwd(const float* x, const float* res, int res_per
     if (!ld_shape_ok(D, k)) return STAGE_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int rpi = 256 / (D / 4);
-    const long items = (long)M * ((L + LDC - 1) / LDC);
+    const int clen = stage_chunk_len(L);
+    const long items = (long)M * ((L + clen - 1) / clen);
     const int grid = stage_grid_for(items, rpi, LD_GRID_CAP);
     const bool dr = p_drop > 0.f;
     const uint64_t sd = dr ? (uint64_t)seed : 0;
@@ -255,7 +255,7 @@ extern "C" int stage_ln_dwconv_fwd(const float* x, const float* res, int res_per
     const float ik = dr ? 1.0f / (1.0f - p_drop) : 1.0f;
 #define LD_FWD(KV, DR)                                                                                                   \
     hipLaunchKernelGGL((ln_dwconv_fwd_kernel<KV, DR>), dim3(grid), dim3(256), 0, st, x, res, res_period, sum_out, gamma,  \
-                       beta, w, bias, h, mean, rstd, (long)M, L, D, eps, sd, th, ik)
+                       beta, w, bias, h, mean, rstd, (long)M, L, D, eps, sd, th, ik, clen)
     switch (k) {
         case 1: if (dr) LD_FWD(1, true); else LD_FWD(1, false); break;
         case 3: if (dr) LD_FWD(3, true); else LD_FWD(3, false); break;
@@ -285,7 +285,8 @@ extern "C" int stage_ln_dwconv_bwd(const float* dh, const float* xin, const floa
         return 0;
     }
     const int rpi = 256 / (D / 4);
-    const long items = (long)M * ((L + LDC - 1) / LDC);
+    const int clen = stage_chunk_len(L);
+    const long items = (long)M * ((L + clen - 1) / clen);
     const int grid = stage_grid_for(items, rpi, LD_PART_CAP);
     float* part_conv = (float*)ws;
     float* part_ln = part_conv + (size_t)LD_PART_CAP * (k + 1) * D;
@@ -296,7 +297,7 @@ extern "C" int stage_ln_dwconv_bwd(const float* dh, const float* xin, const floa
     const float ik = dr ? 1.0f / (1.0f - p_drop) : 1.0f;
 #define LD_BWD(KV, DR)                                                                                                    \
     hipLaunchKernelGGL((ln_dwconv_bwd_kernel<KV, DR>), dim3(grid), dim3(256), lds, st, dh, xin, mean, rstd, gamma, beta, w, \
-                       dx, dx_add, part_conv, part_ln, (long)M, L, D, sd, th, ik)
+                       dx, dx_add, part_conv, part_ln, (long)M, L, D, sd, th, ik, clen)
     switch (k) {
         case 1: if (dr) LD_BWD(1, true); else LD_BWD(1, false); break;
         case 3: if (dr) LD_BWD(3, true); else LD_BWD(3, false); break;
