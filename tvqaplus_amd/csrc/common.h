@@ -121,6 +121,40 @@ static inline int stage_chunk_len(int L) {
     const int n = (L + 47) / 48;
     return (L + n - 1) / n;
 }
+// two independent column reductions in ONE launch (weight and bias gradient partials of a GEMM): workgroups
+// [0, ceil(CA/64)) reduce segment A, the rest segment B.  Same 16-way parallel, fixed-order scheme as above.
+__global__ __launch_bounds__(1024) static void stage_colreduce2_kernel(const float* __restrict__ partA, float* __restrict__ outA,
+                                                                       long strideA, int CA, const float* __restrict__ partB,
+                                                                       float* __restrict__ outB, long strideB, int CB, int nb) {
+    __shared__ float sm[16][64];
+    const int x = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int blocksA = (CA + 63) / 64;
+    const bool isA = (int)blockIdx.x < blocksA;
+    const float* part = isA ? partA : partB;
+    float* out = isA ? outA : outB;
+    const long stride = isA ? strideA : strideB;
+    const int C = isA ? CA : CB;
+    const int c = (isA ? blockIdx.x : blockIdx.x - blocksA) * 64 + x;
+    float acc = 0.f;
+    if (c < C) {
+#pragma unroll 4
+        for (int b = r; b < nb; b += 16) acc += part[(size_t)b * stride + c];
+    }
+    sm[r][x] = acc;
+    __syncthreads();
+    if (r == 0 && c < C) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) s += sm[j][x];
+        out[c] = s;
+    }
+}
+static inline void stage_colreduce2(const float* partA, float* outA, long strideA, int CA, const float* partB, float* outB,
+                                    long strideB, int CB, int nb, hipStream_t st) {
+    hipLaunchKernelGGL(stage_colreduce2_kernel, dim3((CA + 63) / 64 + (CB + 63) / 64), dim3(1024), 0, st, partA, outA, strideA,
+                       CA, partB, outB, strideB, CB, nb);
+}
+
 static inline int stage_pow2_ceil(int v) {
     int p = 1;
     while (p < v) p <<= 1;

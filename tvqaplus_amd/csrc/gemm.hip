@@ -338,8 +338,8 @@ extern "C" int stage_gemm_tn(const float* dY, const float* gate, const float* X,
                            (long)M, N, K, rps, vecY, vecX);
     STAGE_LAUNCH_CHECK();
     const long C = (long)N * K;
-    stage_colreduce(part, dW, nullptr, S, C, (int)C, 1, 0, st);
-    if (db) stage_colreduce(part_b, db, nullptr, S, (long)N, N, 1, 0, st);
+    if (db) stage_colreduce2(part, dW, C, (int)C, part_b, db, (long)N, N, S, st);   // one launch for dW and db
+    else stage_colreduce(part, dW, nullptr, S, C, (int)C, 1, 0, st);
     STAGE_LAUNCH_CHECK();
     return 0;
 }
