@@ -358,14 +358,21 @@ static int launch_d128_t(const float* Cn, const float* Q, const float* cm, const
     const int tps = (CT + slices - 1) / slices;
     slices = (CT + tps - 1) / tps;
     const size_t wave_bytes = ((size_t)(Lr + 1) * LDQ + 2 * RT * 16 + (size_t)tps * 16) * sizeof(float);
-    int wpb = 4;
-    while (wpb > 1 && wpb * wave_bytes > 80 * 1024) wpb >>= 1;   // keep >= 2 workgroups per CU when the tile is large
+    // waves per workgroup: the grouping that lets the most waves share a CU's 160 KB of LDS (Lr = 50: 27.9 KB per wave,
+    // 5 one-wave workgroups fit where 2 two-wave ones would); ties go to the larger workgroup
+    int wpb = 1, best = 0;
+    for (int cand = 4; cand >= 1; cand >>= 1) {
+        const size_t per_wg = (cand * wave_bytes + 511) / 512 * 512;          // allocation granularity
+        int waves = (int)((160 * 1024) / per_wg) * cand;
+        if (waves > 8) waves = 8;
+        if (waves > best) { best = waves; wpb = cand; }
+    }
+    if (getenv("STAGE_K1_WPB")) wpb = atoi(getenv("STAGE_K1_WPB"));
     const size_t lds = wpb * wave_bytes;
     auto kern = str_attn_fwd_d128_kernel<RT, KL, PERM, TRAIN, VEC_S>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const long items = (long)N * Li * slices;
-    int waves_per_cu = (int)((160 * 1024) / wave_bytes);
-    if (waves_per_cu > 8) waves_per_cu = 8;
+    int waves_per_cu = best > 0 ? best : 1;
     if (getenv("STAGE_K1_WPC")) waves_per_cu = atoi(getenv("STAGE_K1_WPC"));
     if (waves_per_cu < 1) waves_per_cu = 1;
     long blocks = (256L * waves_per_cu + wpb - 1) / wpb;         // one resident round of waves; they stride the items
