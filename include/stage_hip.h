@@ -116,6 +116,17 @@ size_t stage_gemm_tn_ws_bytes(long long M, int N, int K);
 int stage_gemm_tn(const float* dY, const float* gate, const float* X, float* dW, float* db, long long M, int N, int K,
                   void* ws, size_t ws_bytes, void* stream);
 
+/* ReLU bit masks (streaming kernels; check stage_gemm_mask_supported first).  The forward GEMM of a Linear + ReLU also
+ * emits relu_mask_out[m][w] (uint32, w < ceil(N/32), bit b <=> Y[m][32w+b] > 0); the two backward GEMMs take that mask
+ * instead of the fp32 gate (nn.ReLU backward, model/stage.py:88,101; model/cnn.py:46): 1/32 of the gate bytes.
+ * stage_gemm_nt_mask: gate_mask refers to the columns of X (ceil(K/32) words per row).  Returns STAGE_ERR_SHAPE when the
+ * shape is not taken by the streaming kernel (fall back to stage_gemm_nt / stage_gemm_tn with the fp32 gate).        */
+int stage_gemm_mask_supported(long long M, int N, int K);
+int stage_gemm_nt_mask(const float* X, const unsigned* gate_mask, const float* W, const float* bias, float* Y,
+                       unsigned* relu_mask_out, long long M, int N, int K, int relu, void* stream);
+int stage_gemm_tn_mask(const float* dY, const unsigned* gate_mask, const float* X, float* dW, float* db, long long M,
+                       int N, int K, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- encoder block pieces (model/encoder.py:35-44, model/position_encoding.py:38-43, model/cnn.py:23-26,44) ---- */
 int stage_add_pe(const float* x, const float* pe /*(>=L, D)*/, float* y, long long M, int L, int D, void* stream);
 int stage_dwconv_fwd(const float* in, const float* w /*(D,1,k)*/, const float* bias, float* out, long long M, int L,

@@ -38,6 +38,9 @@ SIGNATURES = {
     "stage_gemm_nt": (I, [P, P, P, P, P, P, LL, I, I, I, P]),
     "stage_gemm_tn_ws_bytes": (SZ, [LL, I, I]),
     "stage_gemm_tn": (I, [P, P, P, P, P, LL, I, I, P, SZ, P]),
+    "stage_gemm_mask_supported": (I, [LL, I, I]),
+    "stage_gemm_nt_mask": (I, [P, P, P, P, P, P, LL, I, I, I, P]),
+    "stage_gemm_tn_mask": (I, [P, P, P, P, P, LL, I, I, P, SZ, P]),
     "stage_add_pe": (I, [P, P, P, LL, I, I, P]),
     "stage_dwconv_fwd": (I, [P, P, P, P, LL, I, I, I, P]),
     "stage_dwconv_bwd_ws_bytes": (SZ, [I, I]),
@@ -74,6 +77,10 @@ def load() -> ctypes.CDLL:
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+STAGE_ERR_SHAPE = -1      # include/stage_hip.h
+STAGE_ERR_WORKSPACE = -2
 
 
 def check(code: int, what: str) -> None:

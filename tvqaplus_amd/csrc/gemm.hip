@@ -156,10 +156,12 @@ extern "C" int stage_gemm_nt_bf16x3(const float* X, const float* gate, const flo
                                     const float* residual, float* Y, long long M, int N, int K, int relu, void* stream);
 extern "C" int stage_gemm_tn_bf16x3(const float* dY, const float* gate, const float* X, float* dW, float* db, long long M,
                                     int N, int K, void* ws, size_t ws_bytes, void* stream);
-int stage_gemm_nt_stream(const float* X, const float* gate, const float* W, const float* bias, const float* residual,
-                         float* Y, long long M, int N, int K, int relu, void* stream);   // gemm_stream.hip
-int stage_gemm_tn_stream(const float* dY, const float* gate, const float* X, float* part, float* part_b, long long M, int N,
-                         int K, int S, long rows_per_split, void* stream);   // gemm_stream.hip
+// gemm_stream.hip (gate_kind: 0 none, 1 fp32 tensor, 2 bit mask; return 1 = shape not handled there)
+int stage_gemm_nt_stream(const float* X, const void* gate, int gate_kind, const float* W, const float* bias,
+                         const float* residual, float* Y, unsigned* mask_out, long long M, int N, int K, int relu,
+                         void* stream);
+int stage_gemm_tn_stream(const float* dY, const void* gate, int gate_kind, const float* X, float* part, float* part_b,
+                         long long M, int N, int K, int S, long rows_per_split, void* stream);
 static bool gemm_exact_f32() {
     static int mode = -1;
     if (mode < 0) mode = getenv("STAGE_GEMM_F32") ? 1 : 0;
@@ -173,7 +175,7 @@ extern "C" int stage_gemm_nt(const float* X, const float* gate, const float* W, 
     if (!gemm_exact_f32()) {
         static const bool tiled_only = getenv("STAGE_GEMM_TILED") != nullptr;   // developer switch
         if (!tiled_only) {
-            const int rc = stage_gemm_nt_stream(X, gate, W, bias, residual, Y, M, N, K, relu, stream);
+            const int rc = stage_gemm_nt_stream(X, gate, gate ? 1 : 0, W, bias, residual, Y, nullptr, M, N, K, relu, stream);
             if (rc <= 0) return rc;                      // 1 = shape not handled by the streaming kernel
         }
         return stage_gemm_nt_bf16x3(X, gate, W, bias, residual, Y, M, N, K, relu, stream);
@@ -327,7 +329,7 @@ extern "C" int stage_gemm_tn(const float* dY, const float* gate, const float* X,
     static const bool tn_tiled = getenv("STAGE_GEMM_TN_TILED") != nullptr;   // developer switch
     int handled = 1;
     if (!gemm_exact_f32() && !tn_tiled)
-        handled = stage_gemm_tn_stream(dY, gate, X, part, db ? part_b : (float*)nullptr, M, N, K, S, rps, stream);
+        handled = stage_gemm_tn_stream(dY, gate, gate ? 1 : 0, X, part, db ? part_b : (float*)nullptr, M, N, K, S, rps, stream);
     if (handled < 0 || handled > 1) return handled;
     if (handled == 0) {
     } else if (vecY && vecX && N >= 4 && K >= 4)
@@ -339,6 +341,50 @@ extern "C" int stage_gemm_tn(const float* dY, const float* gate, const float* X,
     STAGE_LAUNCH_CHECK();
     const long C = (long)N * K;
     if (db) stage_colreduce2(part, dW, C, (int)C, part_b, db, (long)N, N, S, st);   // one launch for dW and db
+    else stage_colreduce(part, dW, nullptr, S, C, (int)C, 1, 0, st);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// ReLU bit-mask variants (streaming kernels only).  The forward GEMM of a Linear+ReLU also emits mask[m][w] (uint32,
+// w < ceil(N/32), bit b <=> Y[m][32w+b] > 0); both backward GEMMs take that mask in place of the fp32 gate tensor: 1/32 of
+// the gate bytes, and the 15 MB mask of a (960000, 128) layer stays cache resident.
+// ------------------------------------------------------------------------------------------------
+extern "C" int stage_gemm_mask_supported(long long M, int N, int K) {
+    if (gemm_exact_f32() || getenv("STAGE_GEMM_TILED") || getenv("STAGE_GEMM_TN_TILED") || getenv("STAGE_GEMM_NO_MASK")) return 0;
+    // forward (M,K)->(M,N), dX (M,N)->(M,K), dW: all three must be taken by the streaming kernels
+    const bool fwd = K % 4 == 0 && K >= 64 && M >= 4096 && M * (long long)K * 4 < (1ll << 31);
+    const bool dx = N % 4 == 0 && N >= 64 && M * (long long)N * 4 < (1ll << 31);
+    return fwd && dx ? 1 : 0;
+}
+
+extern "C" int stage_gemm_nt_mask(const float* X, const unsigned* gate_mask, const float* W, const float* bias, float* Y,
+                                  unsigned* relu_mask_out, long long M, int N, int K, int relu, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (K <= 0 || (relu_mask_out && !relu)) return STAGE_ERR_SHAPE;
+    const int rc = stage_gemm_nt_stream(X, gate_mask, gate_mask ? 2 : 0, W, bias, nullptr, Y, relu_mask_out, M, N, K, relu,
+                                        stream);
+    return rc == 1 ? STAGE_ERR_SHAPE : rc;
+}
+
+extern "C" int stage_gemm_tn_mask(const float* dY, const unsigned* gate_mask, const float* X, float* dW, float* db,
+                                  long long M, int N, int K, void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= 0 || K <= 0) return 0;
+    if (M <= 0) return STAGE_ERR_SHAPE;
+    if (ws_bytes < stage_gemm_tn_ws_bytes(M, N, K)) return STAGE_ERR_WORKSPACE;
+    const int S = tn_splits(M, N, K);
+    long rps = (M + S - 1) / S;
+    rps = (rps + BK - 1) / BK * BK;
+    float* part = (float*)ws;
+    float* part_b = part + (size_t)S * N * K;
+    const int rc = stage_gemm_tn_stream(dY, gate_mask, gate_mask ? 2 : 0, X, part, db ? part_b : (float*)nullptr, M, N, K, S,
+                                        rps, stream);
+    if (rc != 0) return rc == 1 ? STAGE_ERR_SHAPE : rc;
+    const long C = (long)N * K;
+    if (db) stage_colreduce2(part, dW, C, (int)C, part_b, db, (long)N, N, S, st);
     else stage_colreduce(part, dW, nullptr, S, C, (int)C, 1, 0, st);
     STAGE_LAUNCH_CHECK();
     return 0;

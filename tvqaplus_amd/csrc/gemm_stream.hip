@@ -61,13 +61,18 @@ __device__ __forceinline__ float4 s_gate4(float4 v, float4 g) {
     return make_float4(g.x > 0.f ? v.x : 0.f, g.y > 0.f ? v.y : 0.f, g.z > 0.f ? v.z : 0.f, g.w > 0.f ? v.w : 0.f);
 }
 
-template <bool HAS_GATE, bool HAS_RES, bool WPRE>
+// GATE: 0 none, 1 fp32 tensor (x kept where gate > 0), 2 bit mask (uint32 [M][ceil(K/32)], bit b of word w <=> column
+// 32w + b kept).  MASK_OUT: also emit the ReLU bit mask of Y (uint32 [M][ceil(N/32)]) for the two backward GEMMs -- they
+// then read 1/32 of the bytes the fp32 gate costs.
+template <int GATE, bool HAS_RES, bool WPRE, bool MASK_OUT>
 __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const float* __restrict__ X,
                                                                         const float* __restrict__ G,
                                                                         const float* __restrict__ W,
                                                                         const float* __restrict__ bias,
                                                                         const float* __restrict__ R, float* __restrict__ Y,
-                                                                        long M, int N, int K, int relu) {
+                                                                        unsigned* __restrict__ mask_out, long M, int N,
+                                                                        int K, int relu) {
+    constexpr bool HAS_GATE = GATE == 1;
     extern __shared__ __attribute__((aligned(16))) unsigned short Wp[];   // [3][SBN][SWS] bf16, k permuted per 16-group
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -130,8 +135,9 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
     // loop head, draining the stores), so the X/gate loads are issued as asm and awaited with hand-counted vmcnt values.
     // Rule for every count below: it must not exceed the number of VMEM instructions (of any kind) issued after the
     // awaited loads -- a smaller count only waits longer.
-    constexpr int NL = HAS_GATE ? 8 : 4;                   // loads per fetch
+    constexpr int NL = GATE == 1 ? 8 : (GATE == 2 ? 5 : 4);   // loads per fetch
     f32x4 xa[2][4], ga[2][4];
+    unsigned gw[2];                                          // GATE 2: the mask word of the line
     // buffer loads: resource + 32-bit lane offset + immediate.  A ragged last chunk (K % 128 != 0) reads past the end of
     // its row -- into the next row, or as 0 past the end of the tensor -- and is zeroed at use (mul_line).
     typedef int s_rsrc_t __attribute__((ext_vector_type(4)));
@@ -140,8 +146,14 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
         return (s_rsrc_t){(int)(unsigned)a, (int)(unsigned)((a >> 32) & 0xffffu), (int)(M * K * 4), 0x00020000};
     };
     const s_rsrc_t rsx = make_rsrc(X), rsg = make_rsrc(HAS_GATE ? G : X);
+    const int NWK = (K + 31) >> 5;                        // mask words per row (GATE 2)
     auto fetch = [&](int buf, long row, int k_line) {   // one offset per lane, immediate offsets for the 4 chunks
-        const int off = (int)(((row < M ? row : M - 1) * K + k_line + 4 * h) * 4);
+        const long rcl = row < M ? row : M - 1;
+        const int off = (int)((rcl * K + k_line + 4 * h) * 4);
+        if (GATE == 2) {
+            const unsigned* pm = reinterpret_cast<const unsigned*>(G) + rcl * NWK + min(k_line >> 5, NWK - 1);
+            asm volatile("global_load_dword %0, %1, off" : "=v"(gw[buf]) : "v"(pm) : "memory");
+        }
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3"
@@ -153,7 +165,12 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
     };
 #define WAIT_LINE(buf, n)                                                                                              \
     do {                                                                                                               \
-        if constexpr (HAS_GATE)                                                                                        \
+        if constexpr (GATE == 2)                                                                                       \
+            asm volatile("s_waitcnt vmcnt(%5)"                                                                         \
+                         : "+v"(xa[buf][0]), "+v"(xa[buf][1]), "+v"(xa[buf][2]), "+v"(xa[buf][3]), "+v"(gw[buf])       \
+                         : "n"(n)                                                                                      \
+                         : "memory");                                                                                  \
+        else if constexpr (HAS_GATE)                                                                                   \
             asm volatile("s_waitcnt vmcnt(%8)"                                                                         \
                          : "+v"(xa[buf][0]), "+v"(xa[buf][1]), "+v"(xa[buf][2]), "+v"(xa[buf][3]), "+v"(ga[buf][0]),   \
                            "+v"(ga[buf][1]), "+v"(ga[buf][2]), "+v"(ga[buf][3])                                        \
@@ -223,6 +240,17 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
                         v0 = s_gate4(v0, make_float4(g0[0], g0[1], g0[2], g0[3]));
                         v1 = s_gate4(v1, make_float4(g1[0], g1[1], g1[2], g1[3]));
                     }
+                    if (GATE == 2) {   // bit 8c + 4h + e of the line's word (c = 2up, 2up+1): 0 / -1 by v_bfe_i32, then and
+                        const int wbits = (int)gw[buf], p0b = 16 * up + 4 * h;
+                        v0.x = __int_as_float(__float_as_int(v0.x) & __builtin_amdgcn_sbfe(wbits, p0b + 0, 1));
+                        v0.y = __int_as_float(__float_as_int(v0.y) & __builtin_amdgcn_sbfe(wbits, p0b + 1, 1));
+                        v0.z = __int_as_float(__float_as_int(v0.z) & __builtin_amdgcn_sbfe(wbits, p0b + 2, 1));
+                        v0.w = __int_as_float(__float_as_int(v0.w) & __builtin_amdgcn_sbfe(wbits, p0b + 3, 1));
+                        v1.x = __int_as_float(__float_as_int(v1.x) & __builtin_amdgcn_sbfe(wbits, p0b + 8, 1));
+                        v1.y = __int_as_float(__float_as_int(v1.y) & __builtin_amdgcn_sbfe(wbits, p0b + 9, 1));
+                        v1.z = __int_as_float(__float_as_int(v1.z) & __builtin_amdgcn_sbfe(wbits, p0b + 10, 1));
+                        v1.w = __int_as_float(__float_as_int(v1.w) & __builtin_amdgcn_sbfe(wbits, p0b + 11, 1));
+                    }
                     unsigned p0[3], p1[3], p2[3], p3[3];
                     s_split3(v0.x, v0.y, p0);
                     s_split3(v0.z, v0.w, p1);
@@ -287,13 +315,14 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
         const bool full = t * 32 + 32 <= M;
 #pragma unroll
         for (int nt = 0; nt < 4; nt++) {
+            if (n0 + nt * 32 >= N) continue;              // whole column tile past N (uniform)
             const int n = n0 + nt * 32 + l31;
-            if (n >= N) continue;
+            const bool nok = n < N;
             const float bsv = bias_s[nt * 32 + l31];
-            float* yp = Y + (t * 32 + 4 * h) * N + n;
+            float* yp = Y + (t * 32 + 4 * h) * N + (nok ? n : N - 1);
             float rv[16];
             if (HAS_RES) {
-                const float* rp = R + (t * 32 + 4 * h) * N + n;
+                const float* rp = R + (t * 32 + 4 * h) * N + (nok ? n : N - 1);
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int dm = (r & 3) + 8 * (r >> 2);
@@ -307,14 +336,28 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
                 if (HAS_RES) v += rv[r];
                 acc[nt][r] = v;
             }
+            if (MASK_OUT) {
+                // ReLU bit mask: one ballot per accumulator register = the 32 columns of two rows (lane halves); lane
+                // (l31 = r, h) keeps the word of its half, so after 16 ballots lanes l31 < 16 hold one row word each
+                unsigned myw = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const unsigned long long bal = __ballot(nok && acc[nt][r] > 0.f);
+                    const unsigned wsel = h ? (unsigned)(bal >> 32) : (unsigned)bal;
+                    if (l31 == r) myw = wsel;
+                }
+                const long mrow = t * 32 + 4 * h + (l31 & 3) + 8 * ((l31 & 15) >> 2);
+                if (l31 < 16 && mrow < M) mask_out[mrow * ((N + 31) >> 5) + ((n0 >> 5) + nt)] = myw;
+            }
             if (full) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) __builtin_nontemporal_store(acc[nt][r], &yp[(long)((r & 3) + 8 * (r >> 2)) * N]);
+                for (int r = 0; r < 16; r++)
+                    if (nok) __builtin_nontemporal_store(acc[nt][r], &yp[(long)((r & 3) + 8 * (r >> 2)) * N]);
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int dm = (r & 3) + 8 * (r >> 2);
-                    if (t * 32 + 4 * h + dm < M) yp[(long)dm * N] = acc[nt][r];
+                    if (nok && t * 32 + 4 * h + dm < M) yp[(long)dm * N] = acc[nt][r];
                 }
             }
         }
@@ -322,11 +365,16 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
 }
 
 // returns 1 if the shape/alignment is not handled here (caller falls back to the tiled kernel), 0 on launch, <0 on error
-int stage_gemm_nt_stream(const float* X, const float* gate, const float* W, const float* bias, const float* residual,
-                         float* Y, long long M, int N, int K, int relu, void* stream) {
+// gate_kind: 0 none, 1 fp32 tensor, 2 bit mask; mask_out (optional, relu only): ReLU bit mask of Y
+int stage_gemm_nt_stream(const float* X, const void* gate, int gate_kind, const float* W, const float* bias,
+                         const float* residual, float* Y, unsigned* mask_out, long long M, int N, int K, int relu,
+                         void* stream) {
+    if (!gate) gate_kind = 0;
     const bool vec = (K % 4 == 0) && K >= 4 && (((uintptr_t)X & 15) == 0) && (((uintptr_t)W & 15) == 0) &&
-                     (!gate || ((uintptr_t)gate & 15) == 0);
+                     (gate_kind != 1 || ((uintptr_t)gate & 15) == 0);
     if (!vec || M < 4096 || K < 64 || M * (long long)K * 4 >= (1ll << 31)) return 1;   // buffer addressing: < 2 GiB
+    if ((gate_kind == 2 || mask_out) && residual) return 1;                              // combinations nobody needs
+    if (mask_out && gate_kind != 0) return 1;
     const int lds = 3 * SPLANE * (int)sizeof(unsigned short) + SBN * (int)sizeof(float);
     const long MT = (M + 31) / 32, n_bt = (MT + SWAVES - 1) / SWAVES;
     const int n_tiles = (N + SBN - 1) / SBN;
@@ -334,19 +382,22 @@ int stage_gemm_nt_stream(const float* X, const float* gate, const float* W, cons
     if (gx < 1) gx = 1;                                   // range run side by side (X re-reads hit L2 / MALL)
     if (gx > n_bt) gx = n_bt;
     dim3 grid((unsigned)gx, (unsigned)n_tiles), block(64 * SWAVES);
-#define LAUNCH_ST(GT, RS)                                                                                              \
+    const float* G = (const float*)gate;
+#define LAUNCH_ST(GT, RS, MO)                                                                                          \
     do {                                                                                                               \
         static bool attr_done = false;                                                                                 \
         if (!attr_done) {                                                                                              \
-            (void)hipFuncSetAttribute((const void*)gemm_nt_stream_kernel<GT, RS, !(GT && RS)>,                                      \
+            (void)hipFuncSetAttribute((const void*)gemm_nt_stream_kernel<GT, RS, !(GT == 1 && RS), MO>,                \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                \
             attr_done = true;                                                                                          \
         }                                                                                                              \
-        hipLaunchKernelGGL((gemm_nt_stream_kernel<GT, RS, !(GT && RS)>), grid, block, lds, (hipStream_t)stream, X, gate, W, bias,   \
-                           residual, Y, (long)M, N, K, relu);                                                          \
+        hipLaunchKernelGGL((gemm_nt_stream_kernel<GT, RS, !(GT == 1 && RS), MO>), grid, block, lds, (hipStream_t)stream, \
+                           X, G, W, bias, residual, Y, mask_out, (long)M, N, K, relu);                                 \
     } while (0)
-    if (gate) { if (residual) LAUNCH_ST(true, true); else LAUNCH_ST(true, false); }
-    else { if (residual) LAUNCH_ST(false, true); else LAUNCH_ST(false, false); }
+    if (mask_out) LAUNCH_ST(0, false, true);
+    else if (gate_kind == 2) LAUNCH_ST(2, false, false);
+    else if (gate_kind == 1) { if (residual) LAUNCH_ST(1, true, false); else LAUNCH_ST(1, false, false); }
+    else { if (residual) LAUNCH_ST(0, true, false); else LAUNCH_ST(0, false, false); }
 #undef LAUNCH_ST
     STAGE_LAUNCH_CHECK();
     return 0;
@@ -368,7 +419,7 @@ __device__ __forceinline__ float s_buf_load(__amdgpu_buffer_rsrc_t r, int voff_b
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff_bytes, soff_bytes, 0));
 }
 
-template <bool HAS_GATE>
+template <int GATE>   // 0 none, 1 fp32 gate (same layout as dY), 2 bit mask (uint32 [M][ceil(N/32)])
 __global__ __launch_bounds__(256, 2) void gemm_tn_stream_kernel(const float* __restrict__ dY, const float* __restrict__ G,
                                                                 const float* __restrict__ X, float* __restrict__ part,
                                                                 float* __restrict__ part_b, long M, int N, int K,
@@ -382,18 +433,24 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_stream_kernel(const float* __r
     const long mend = min(M, mbeg + rows_per_split);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)dY, 0, (int)(M * N * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)(M * K * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_GATE ? G : dY), 0, (int)(M * N * 4), 0x00020000);
+    constexpr bool HAS_GATE = GATE != 0;
+    const int NWN = (N + 31) >> 5;                        // mask words per row
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(HAS_GATE ? G : dY), 0, GATE == 2 ? (int)(M * NWN * 4) : (int)(M * N * 4), 0x00020000);
     // this lane's two dY columns and two X columns (clamped for the address, zeroed by the flag) as byte offsets inside
     // a 16-row step
-    int yoff[2], xoff[2];
+    int yoff[2], xoff[2], goff[2], gbit[2];
     bool nok[2], kok[2];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         const int n = n_base + 32 * t + l31, k = k_base + 32 * t + l31;
         nok[t] = n < N;
         kok[t] = k < K;
-        yoff[t] = (8 * h * N + (nok[t] ? n : N - 1)) * 4;
+        const int nc = nok[t] ? n : N - 1;
+        yoff[t] = (8 * h * N + nc) * 4;
         xoff[t] = (8 * h * K + (kok[t] ? k : K - 1)) * 4;
+        goff[t] = GATE == 2 ? (8 * h * NWN + (nc >> 5)) * 4 : yoff[t];   // mask: word of the column, bit nc & 31
+        gbit[t] = nc & 31;
     }
     f32x16 acc[2][2];
 #pragma unroll
@@ -409,11 +466,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_stream_kernel(const float* __r
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int sy = (int)((m0 + r) * N * 4), sx = (int)((m0 + r) * K * 4);   // wave-uniform row offsets (bytes)
+            const int sg = GATE == 2 ? (int)((m0 + r) * NWN * 4) : sy;
 #pragma unroll
             for (int t = 0; t < 2; t++) {
                 ya[buf][t][r] = s_buf_load(ry, yoff[t], sy);
                 xa[buf][t][r] = s_buf_load(rx, xoff[t], sx);
-                if (HAS_GATE) ga[buf][t][r] = s_buf_load(rg, yoff[t], sy);
+                if (HAS_GATE) ga[buf][t][r] = s_buf_load(rg, goff[t], sg);
             }
         }
     };
@@ -427,7 +485,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_stream_kernel(const float* __r
             for (int r = 0; r < 8; r++) {
                 const bool rok = full || (m0 + 8 * h + r < mend);   // rows of the next slab / past the end contribute 0
                 float y = ya[buf][t][r];
-                if (HAS_GATE) y = ga[buf][t][r] > 0.f ? y : 0.f;
+                if (GATE == 1) y = ga[buf][t][r] > 0.f ? y : 0.f;
+                if (GATE == 2) y = ((__float_as_uint(ga[buf][t][r]) >> gbit[t]) & 1u) ? y : 0.f;
                 yv[r] = (rok && nok[t]) ? y : 0.f;
                 xv[r] = (rok && kok[t]) ? xa[buf][t][r] : 0.f;
                 bsum[t] += yv[r];
@@ -493,17 +552,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_stream_kernel(const float* __r
 }
 
 // same slab rule / workspace layout as stage_gemm_tn (gemm.hip); returns 1 if not handled here
-int stage_gemm_tn_stream(const float* dY, const float* gate, const float* X, float* part, float* part_b, long long M, int N,
-                         int K, int S, long rows_per_split, void* stream) {
+int stage_gemm_tn_stream(const float* dY, const void* gate, int gate_kind, const float* X, float* part, float* part_b,
+                         long long M, int N, int K, int S, long rows_per_split, void* stream) {
     // buffer addressing: every operand must be smaller than 2 GiB
     if (M < 4096 || M * (long long)N * 4 >= (1ll << 31) || M * (long long)K * 4 >= (1ll << 31)) return 1;
+    if (!gate) gate_kind = 0;
     dim3 grid((N + 127) / 128, (K + 127) / 128, S);
-    if (gate)
-        hipLaunchKernelGGL(gemm_tn_stream_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dY, gate, X, part, part_b,
-                           (long)M, N, K, rows_per_split);
-    else
-        hipLaunchKernelGGL(gemm_tn_stream_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dY, gate, X, part, part_b,
-                           (long)M, N, K, rows_per_split);
+    const float* G = (const float*)gate;
+#define LAUNCH_TNS(GT)                                                                                                 \
+    hipLaunchKernelGGL(gemm_tn_stream_kernel<GT>, grid, dim3(256), 0, (hipStream_t)stream, dY, G, X, part, part_b, (long)M, \
+                       N, K, rows_per_split)
+    if (gate_kind == 2) LAUNCH_TNS(2);
+    else if (gate_kind == 1) LAUNCH_TNS(1);
+    else LAUNCH_TNS(0);
+#undef LAUNCH_TNS
     STAGE_LAUNCH_CHECK();
     return 0;
 }

@@ -183,8 +183,19 @@ class _Linear(torch.autograd.Function):
         M = x.numel() // K
         bias_c = None if bias is None else _chk(bias, "bias")
         y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
-        _call("stage_gemm_nt", _ptr(x), None, _ptr(w2), _ptr(bias_c), None, _ptr(y), M, N, K, int(relu), _stream())
-        ctx.save_for_backward(x, w2, y if relu else None)
+        lib = _lib.load()
+        mask = None
+        if relu and lib.stage_gemm_mask_supported(M, N, K) and x.data_ptr() % 16 == 0 and w2.data_ptr() % 16 == 0:
+            # Linear + ReLU on the streaming kernel: also emit the ReLU bit mask (1 bit per output) for the backward GEMMs
+            mask = torch.empty(M, (N + 31) // 32, dtype=torch.int32, device=x.device)
+            rc = lib.stage_gemm_nt_mask(_ptr(x), None, _ptr(w2), _ptr(bias_c), _ptr(y), _ptr(mask), M, N, K, 1, _stream())
+            if rc == _lib.STAGE_ERR_SHAPE:
+                mask = None
+            else:
+                _lib.check(rc, "stage_gemm_nt_mask")
+        if mask is None:
+            _call("stage_gemm_nt", _ptr(x), None, _ptr(w2), _ptr(bias_c), None, _ptr(y), M, N, K, int(relu), _stream())
+        ctx.save_for_backward(x, w2, y if relu else None, mask)
         ctx.relu = relu
         ctx.wshape = w.shape
         ctx.has_bias = bias is not None
@@ -192,22 +203,37 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, w2, y = ctx.saved_tensors
+        x, w2, y, mask = ctx.saved_tensors
         N, K = w2.shape
         M = x.numel() // K
         dy = _chk(dy, "dy")
         gate = y if ctx.relu else None
+        lib = _lib.load()
+        use_mask = mask is not None and dy.data_ptr() % 16 == 0
         dx = None
         if ctx.needs_input_grad[0]:
             wt = w2.t().contiguous()  # (K, N): dX = (dY .* gate) . W  ==  NT with the transposed weight
             dx = torch.empty_like(x)
-            _call("stage_gemm_nt", _ptr(dy), _ptr(gate), _ptr(wt), None, None, _ptr(dx), M, K, N, 0, _stream())
+            done = False
+            if use_mask:
+                rc = lib.stage_gemm_nt_mask(_ptr(dy), _ptr(mask), _ptr(wt), None, _ptr(dx), None, M, K, N, 0, _stream())
+                if rc != _lib.STAGE_ERR_SHAPE:
+                    _lib.check(rc, "stage_gemm_nt_mask")
+                    done = True
+            if not done:
+                _call("stage_gemm_nt", _ptr(dy), _ptr(gate), _ptr(wt), None, None, _ptr(dx), M, K, N, 0, _stream())
         dw = torch.empty_like(w2)
         db = torch.empty(N, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-        lib = _lib.load()
         wsb = lib.stage_gemm_tn_ws_bytes(M, N, K)
         ws = _workspace(wsb, x.device)
-        _call("stage_gemm_tn", _ptr(dy), _ptr(gate), _ptr(x), _ptr(dw), _ptr(db), M, N, K, _ptr(ws), wsb, _stream())
+        done = False
+        if use_mask:
+            rc = lib.stage_gemm_tn_mask(_ptr(dy), _ptr(mask), _ptr(x), _ptr(dw), _ptr(db), M, N, K, _ptr(ws), wsb, _stream())
+            if rc != _lib.STAGE_ERR_SHAPE:
+                _lib.check(rc, "stage_gemm_tn_mask")
+                done = True
+        if not done:
+            _call("stage_gemm_tn", _ptr(dy), _ptr(gate), _ptr(x), _ptr(dw), _ptr(db), M, N, K, _ptr(ws), wsb, _stream())
         return dx, dw.view(ctx.wshape), db, None
 
 
