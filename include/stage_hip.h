@@ -117,9 +117,9 @@ int stage_gemm_tn(const float* dY, const float* gate, const float* X, float* dW,
                   void* ws, size_t ws_bytes, void* stream);
 
 /* ReLU bit masks (streaming kernels; check stage_gemm_mask_supported first).  The forward GEMM of a Linear + ReLU also
- * emits relu_mask_out[m][w] (uint32, w < ceil(N/32), bit b <=> Y[m][32w+b] > 0); the two backward GEMMs take that mask
+ * emits relu_mask_out[w][m] (uint32, word-major: w < ceil(N/32) rows of M words, bit b <=> Y[m][32w+b] > 0); the two backward GEMMs take that mask
  * instead of the fp32 gate (nn.ReLU backward, model/stage.py:88,101; model/cnn.py:46): 1/32 of the gate bytes.
- * stage_gemm_nt_mask: gate_mask refers to the columns of X (ceil(K/32) words per row).  Returns STAGE_ERR_SHAPE when the
+ * stage_gemm_nt_mask: gate_mask refers to the columns of X (ceil(K/32) word rows of M words).  Returns STAGE_ERR_SHAPE when the
  * shape is not taken by the streaming kernel (fall back to stage_gemm_nt / stage_gemm_tn with the fp32 gate).        */
 int stage_gemm_mask_supported(long long M, int N, int K);
 int stage_gemm_nt_mask(const float* X, const unsigned* gate_mask, const float* W, const float* bias, float* Y,

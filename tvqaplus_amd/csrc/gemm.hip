@@ -348,7 +348,7 @@ extern "C" int stage_gemm_tn(const float* dY, const float* gate, const float* X,
 
 
 // ------------------------------------------------------------------------------------------------
-// ReLU bit-mask variants (streaming kernels only).  The forward GEMM of a Linear+ReLU also emits mask[m][w] (uint32,
+// ReLU bit-mask variants (streaming kernels only).  The forward GEMM of a Linear+ReLU also emits mask[w][m] (uint32, word-major,
 // w < ceil(N/32), bit b <=> Y[m][32w+b] > 0); both backward GEMMs take that mask in place of the fp32 gate tensor: 1/32 of
 // the gate bytes, and the 15 MB mask of a (960000, 128) layer stays cache resident.
 // ------------------------------------------------------------------------------------------------

@@ -187,7 +187,7 @@ class _Linear(torch.autograd.Function):
         mask = None
         if relu and lib.stage_gemm_mask_supported(M, N, K) and x.data_ptr() % 16 == 0 and w2.data_ptr() % 16 == 0:
             # Linear + ReLU on the streaming kernel: also emit the ReLU bit mask (1 bit per output) for the backward GEMMs
-            mask = torch.empty(M, (N + 31) // 32, dtype=torch.int32, device=x.device)
+            mask = torch.empty((N + 31) // 32, M, dtype=torch.int32, device=x.device)   # word-major [ceil(N/32)][M]
             rc = lib.stage_gemm_nt_mask(_ptr(x), None, _ptr(w2), _ptr(bias_c), _ptr(y), _ptr(mask), M, N, K, 1, _stream())
             if rc == _lib.STAGE_ERR_SHAPE:
                 mask = None
