@@ -480,21 +480,37 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_stream_kernel(const float* __r
             }
         }
     };
+    // The SIMD issues one instruction at a time and only ~5-7 of them hide behind each MFMA: at ~17 non-MFMA instructions
+    // per MFMA this kernel is issue-bound, so the steady state (full 16-row step, all four column tiles inside the matrix)
+    // drops the per-element validity selects, and only the waves that emit the bias gradient keep its running sums.
+    const bool cols_in = nok[0] && nok[1] && kok[0] && kok[1];           // lane-level, but false only in edge tiles
+    const bool want_b = part_b != nullptr && blockIdx.y == 0 && pk == 0;
     auto step = [&](int buf, long m0) {
         const bool full = m0 + 16 <= mend;
+        const bool fast = full && __all(cols_in);
         sbf16x8 a[2][3], b[2][3];
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             float yv[8], xv[8];
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const bool rok = full || (m0 + 8 * h + r < mend);   // rows of the next slab / past the end contribute 0
                 float y = ya[buf][t][r];
                 if (GATE == 1) y = ga[buf][t][r] > 0.f ? y : 0.f;
                 if (GATE == 2) y = ((__float_as_uint(ga[buf][t][r]) >> gbit[t]) & 1u) ? y : 0.f;
-                yv[r] = (rok && nok[t]) ? y : 0.f;
-                xv[r] = (rok && kok[t]) ? xa[buf][t][r] : 0.f;
-                bsum[t] += yv[r];
+                yv[r] = y;
+                xv[r] = xa[buf][t][r];
+            }
+            if (!fast) {   // one uniform branch per tile, straight-line selects inside
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const bool rok = full || (m0 + 8 * h + r < mend);   // rows of the next slab / past the end contribute 0
+                    yv[r] = (rok && nok[t]) ? yv[r] : 0.f;
+                    xv[r] = (rok && kok[t]) ? xv[r] : 0.f;
+                }
+            }
+            if (want_b) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) bsum[t] += yv[r];
             }
             unsigned p[4][3], q[4][3];
 #pragma unroll
@@ -564,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_stream_kernel(const float* __r
                 if (n < N) po[(size_t)n * K + k] = acc[i][j][r];
             }
         }
-    if (part_b && blockIdx.y == 0 && pk == 0) {
+    if (want_b) {
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             const float s = bsum[t] + __shfl_xor(bsum[t], 32);
