@@ -111,8 +111,11 @@ def cpu_baseline(args, opt):
     batch = make_batch(N=B, Li=args.frames, Lr=args.regions, Lw=args.sub_words, Lqa=args.qa_words, seed=2018,
                        ragged=not args.dense)
     torch.manual_seed(2018)
+    import contextlib
+    with contextlib.redirect_stdout(open(os.devnull, "w")):   # STAGE.__init__ prints which branches are active
+        ref_model = STAGE(opt)
     P = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(".pe"))
-         for k, v in STAGE(opt).state_dict().items()}
+         for k, v in ref_model.state_dict().items()}
     params = [v for v in P.values() if v.requires_grad]
     optim = torch.optim.Adam(params, lr=1e-3, weight_decay=3e-7)
 
