@@ -67,6 +67,10 @@ def load() -> ctypes.CDLL:
         raise StageHipError(
             "tvqaplus_amd: %s not found -- the HIP extension is required (no CPU / eager fallback exists). "
             "Build it with `make` at the repo root." % LIB_PATH)
+    # torch ships its own libamdhip64: it has to be in the process BEFORE this library so that both resolve to the same
+    # HIP runtime (loaded the other way round, the library binds /opt/rocm's copy and sees no device once torch
+    # initialises its own -- "no ROCm-capable device is detected")
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:
