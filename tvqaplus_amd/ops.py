@@ -76,6 +76,9 @@ class _LayerNorm(torch.autograd.Function):
             raise RuntimeError("internal: layernorm with residual requires want_sum=True")
         xin = s if res_c is not None else x
         ctx.save_for_backward(xin, mean, rstd, gamma)
+        # the exported sum of the LAST LayerNorm of a residual chain has no consumer: without this autograd hands the
+        # backward a materialised zero tensor for it (a full-size fill plus one more read as dx_add)
+        ctx.set_materialize_grads(False)
         ctx.p, ctx.seed = float(p), int(seed)
         ctx.has_res = res_c is not None
         ctx.res_full = res_c is not None and res_period == 0
@@ -88,6 +91,8 @@ class _LayerNorm(torch.autograd.Function):
         xin, mean, rstd, gamma = ctx.saved_tensors
         K = xin.shape[-1]
         rows = xin.numel() // K
+        if dy is None:       # only the exported sum was used downstream
+            dy = torch.zeros_like(xin)
         dy = _chk(dy, "dy")
         x_needs = ctx.needs_input_grad[0]
         res_needs = ctx.needs_input_grad[1] and ctx.res_full
@@ -301,6 +306,7 @@ class _LnDwConv(torch.autograd.Function):
               _ptr(bias), _ptr(h), _ptr(mean), _ptr(rstd), M, L, D, k, EPS_LN, float(p), int(seed), _stream())
         xin = s if res_c is not None else x
         ctx.save_for_backward(xin, mean, rstd, gamma, beta, w)
+        ctx.set_materialize_grads(False)   # see _LayerNorm
         ctx.p, ctx.seed = float(p), int(seed)
         ctx.has_res = res_c is not None
         ctx.res_full = res_c is not None and res_period == 0
@@ -313,6 +319,8 @@ class _LnDwConv(torch.autograd.Function):
         xin, mean, rstd, gamma, beta, w = ctx.saved_tensors
         M, L, D = xin.shape
         k = w.shape[-1]
+        if dh is None:
+            dh = torch.zeros_like(xin)
         dh = _chk(dh, "dh")
         x_needs = ctx.needs_input_grad[0]
         res_needs = ctx.needs_input_grad[1] and ctx.res_full
