@@ -82,21 +82,41 @@ def all_gather_outputs(local: torch.Tensor, counts: Optional[Sequence[int]] = No
 
 
 class FlatGradBucket:
-    """All parameter gradients viewed through one contiguous buffer -> ONE all-reduce per step."""
+    """All parameter gradients through one contiguous buffer -> ONE all-reduce per step.
+
+    ``zero()`` drops the gradients (``p.grad = None``, what ``optimizer.zero_grad()`` does): autograd then ASSIGNS the new
+    gradient of a parameter instead of launching one accumulate-add kernel per parameter into a zeroed view (117 small
+    kernels per step at hsz=128).  ``all_reduce()`` packs them into the flat buffer with one multi-tensor copy, reduces,
+    and points every ``p.grad`` at its slice of the buffer; with one rank it only packs (``flat`` stays inspectable)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         total = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
+        self.views: List[torch.Tensor] = []
         off = 0
-        for p in self.params:  # .grad aliases a slice of the bucket: autograd accumulates straight into it
-            p.grad = self.flat[off: off + p.numel()].view_as(p)
+        for p in self.params:
+            self.views.append(self.flat[off: off + p.numel()].view_as(p))
             off += p.numel()
 
     def zero(self) -> None:
-        self.flat.zero_()
+        for p in self.params:
+            p.grad = None
+
+    def pack(self) -> None:
+        """Copy the current gradients into the flat buffer (parameters without a gradient contribute zeros) and make
+        every ``p.grad`` a view of it."""
+        have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        missing = [v for v, p in zip(self.views, self.params) if p.grad is None]
+        if missing:
+            torch._foreach_zero_(missing)
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for v, p in zip(self.views, self.params):
+            p.grad = v
 
     def all_reduce(self) -> None:
         if dist.is_initialized() and dist.get_world_size() > 1:
+            self.pack()
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
