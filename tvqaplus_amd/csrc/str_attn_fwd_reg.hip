@@ -42,16 +42,16 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
     float inv_keep, unsigned int* __restrict__ ticket, int static_rounds) {
     constexpr int NK2 = (RT - 1) * 4 + KL;            // stage-2 k-steps (4 regions each)
     constexpr int base_last = (RT - 1) * 16;
+    // A last region tile with <= 4 regions (the headline Lr = 20) does not pay a 16-row stage-1 tile for them: its scores
+    // come from v_mfma_f32_4x4x1 (16 independent 4x4 blocks, 8 cycles instead of 32): block (c15 >> 2, g) = 4 regions x
+    // context rows 4 (c15 >> 2) .. +3 over the k values lane group g holds; the 4 partial sums per score are folded by a
+    // 3-shuffle transpose-reduce that leaves lane (c15, g) with region base + g of context row c15 -- the PERM layout.
+    constexpr bool T4 = PERM && KL == 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int c15 = lane & 15, g = lane >> 4;
     const int CR = NA * Lqa, CT = (CR + 15) >> 4;
     const float inv_lqa = 1.0f / (float)Lqa;
 
-    // region fed by this lane as stage-1 A row (i = c15), per region tile
-    int areg[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; rt++)
-        areg[rt] = (PERM && rt == RT - 1) ? base_last + (c15 >> 2) + 4 * (c15 & 3) : rt * 16 + c15;
     // region held by this lane in register k of region tile rt after stage 1 (C layout: row 4g + k); recomputed where
     // needed (8 live index registers are 8 too many here), validity kept as one bit mask
     auto Rk = [&](int rt, int k) -> int { return (PERM && rt == RT - 1) ? base_last + g + 4 * k : rt * 16 + 4 * g + k; };
@@ -93,6 +93,16 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
         const int tile1 = min(CT, tile0 + tiles_per_slice);
         const float* qf = Q + frame * Lr * RD;
 
+        // region fed by this lane as stage-1 A row (i = c15), per region tile.  Derived per item from an opaque copy of
+        // c15: hoisted out of the item loop, the 64-bit row offsets built from it stay live across the whole kernel and
+        // push the allocation over 256 VGPRs
+        int c15i = c15;
+        asm volatile("" : "+v"(c15i));
+        int areg[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+            areg[rt] = (T4 && rt == RT - 1) ? base_last + (c15i & 3)
+                       : (PERM && rt == RT - 1) ? base_last + (c15i >> 2) + 4 * (c15i & 3) : rt * 16 + c15i;
         // ---- the frame's operands (compiler-tracked loads: the one full vmcnt drain per item) ----
         float4 qa[RT][RNCH];
 #pragma unroll
@@ -186,19 +196,33 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
         WAIT_CF(0);
         for (int t = tile0; t < ((K1_ABL & 64) ? tile0 + 1 : tile1); t++) {
             // ---- stage 1 ----
+            constexpr int RF = T4 ? RT - 1 : RT;        // full 16-region tiles
             f32x4 acc[RT];
 #pragma unroll
-            for (int rt = 0; rt < RT; rt++) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int rt = 0; rt < RF; rt++) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 tl = {0.f, 0.f, 0.f, 0.f};            // T4: 4x4 blocks (one chain: a 16x16 MFMA sits between two links)
 #pragma unroll
             for (int m = 0; m < ((K1_ABL & 8) ? 1 : RNCH); m++) {
 #pragma unroll
-                for (int rt = 0; rt < RT; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[rt][m].x, cf[m][0], acc[rt], 0, 0, 0);
+                for (int rt = 0; rt < RF; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[rt][m].x, cf[m][0], acc[rt], 0, 0, 0);
+                if (T4) tl = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[RT - 1][m].x, cf[m][0], tl, 0, 0, 0);
 #pragma unroll
-                for (int rt = 0; rt < RT; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[rt][m].y, cf[m][1], acc[rt], 0, 0, 0);
+                for (int rt = 0; rt < RF; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[rt][m].y, cf[m][1], acc[rt], 0, 0, 0);
+                if (T4) tl = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[RT - 1][m].y, cf[m][1], tl, 0, 0, 0);
 #pragma unroll
-                for (int rt = 0; rt < RT; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[rt][m].z, cf[m][2], acc[rt], 0, 0, 0);
+                for (int rt = 0; rt < RF; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[rt][m].z, cf[m][2], acc[rt], 0, 0, 0);
+                if (T4) tl = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[RT - 1][m].z, cf[m][2], tl, 0, 0, 0);
 #pragma unroll
-                for (int rt = 0; rt < RT; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[rt][m].w, cf[m][3], acc[rt], 0, 0, 0);
+                for (int rt = 0; rt < RF; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[rt][m].w, cf[m][3], acc[rt], 0, 0, 0);
+                if (T4) tl = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[RT - 1][m].w, cf[m][3], tl, 0, 0, 0);
+            }
+            if (T4) {
+                // tl[i] = partial score (this lane group's k values) of region base + i, context row c15
+                const float r0 = tl[0], r1 = tl[1], r2 = tl[2], r3 = tl[3];
+                const bool b0 = g & 1, b1 = g & 2;
+                const float p0 = (b0 ? r1 : r0) + __shfl_xor(b0 ? r0 : r1, 16);     // region (g & 1), summed over g bit 0
+                const float p1 = (b0 ? r3 : r2) + __shfl_xor(b0 ? r2 : r3, 16);     // region 2 + (g & 1)
+                acc[RT - 1] = (f32x4){(b1 ? p1 : p0) + __shfl_xor(b1 ? p0 : p1, 32), 0.f, 0.f, 0.f};   // region g, all k
             }
             const float cm_cur = cmv;
             // the MFMAs above have read cf (in-order issue): request the next tile now, before this tile's stores.
