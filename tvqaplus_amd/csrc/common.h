@@ -15,25 +15,75 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+// ---- cross-lane reductions without the LDS crossbar --------------------------------------------------------------
+// __shfl_xor compiles to ds_bpermute_b32 (an LDS-pipe round trip, ~100+ cycles of dependent latency per step, plus the
+// byte-address VALU op).  Reductions only need "every lane ends up with the group's total", which DPP row operations
+// (inside 16 lanes, foldable into the consuming VALU op) and gfx950's v_permlane16_swap / v_permlane32_swap (across
+// 16-lane rows / wave halves, one VALU op each) provide directly.
+//   quad_perm [1,0,3,2] = 0xB1 (xor 1), [2,3,0,1] = 0x4E (xor 2), row_half_mirror = 0x141, row_mirror = 0x140
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+// v_permlane16_swap(a, b): odd 16-lane rows of a <-> even rows of b.  With a = b = v the two results are v and its
+// xor-16 partner (which one is which depends on the row), so any commutative op of the pair is the pair reduction.
+// Two different inputs give a transpose-reduce step: rows 0/2 get a[own] + a[row + 1], rows 1/3 get b[row - 1] + b[own].
+__device__ __forceinline__ float xsum16(float a, float b) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-// reduction inside aligned groups of `width` lanes (width = power of two <= 64)
+// v_permlane32_swap(a, b): upper half of a <-> lower half of b: lanes 0-31 get a[own] + a[lane + 32], lanes 32-63 get
+// b[lane - 32] + b[own]
+__device__ __forceinline__ float xsum32(float a, float b) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xmax16(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xmax32(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// reduction inside aligned groups of `width` lanes (width = power of two <= 64, uniform, all lanes of the group
+// active); every lane of the group returns the total.  Steps past the width are computed and discarded by a uniform
+// select rather than branched over: a runtime width keeps the code straight-line (the branches cut the unrolled row
+// loops of the LayerNorm kernels into blocks the scheduler could not interleave), a constant width folds them away.
 __device__ __forceinline__ float group_sum(float v, int width) {
-    for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    float t;
+    t = v + dpp_mov<0xB1>(v);  v = width > 1 ? t : v;
+    t = v + dpp_mov<0x4E>(v);  v = width > 2 ? t : v;
+    t = v + dpp_mov<0x141>(v); v = width > 4 ? t : v;   // quads are uniform by now: mirroring inside 8 pairs quad 0 with 1
+    t = v + dpp_mov<0x140>(v); v = width > 8 ? t : v;
+    t = xsum16(v, v);          v = width > 16 ? t : v;
+    t = xsum32(v, v);          v = width > 32 ? t : v;
     return v;
 }
 __device__ __forceinline__ float group_max(float v, int width) {
-    for (int o = width >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    float t;
+    t = fmaxf(v, dpp_mov<0xB1>(v));  v = width > 1 ? t : v;
+    t = fmaxf(v, dpp_mov<0x4E>(v));  v = width > 2 ? t : v;
+    t = fmaxf(v, dpp_mov<0x141>(v)); v = width > 4 ? t : v;
+    t = fmaxf(v, dpp_mov<0x140>(v)); v = width > 8 ? t : v;
+    t = xmax16(v);                   v = width > 16 ? t : v;
+    t = xmax32(v);                   v = width > 32 ? t : v;
     return v;
 }
+// the same through the LDS crossbar (ds_bpermute_b32): only for cat3_ln_bwd_rep_kernel, whose register allocation grows
+// from 254 to 342 VGPRs (one wave per SIMD instead of two, +14 % time) with the VALU version above
+__device__ __forceinline__ float group_sum_bperm(float v, int width) {
+    for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) { return group_sum(v, 64); }
+__device__ __forceinline__ float wave_max(float v) { return group_max(v, 64); }
+// sum / max over the 4 lanes that share (lane & 15): lanes l, l^16, l^32, l^48
+__device__ __forceinline__ float cross_row_sum(float v) {
+    v = xsum16(v, v);
+    return xsum32(v, v);
+}
+__device__ __forceinline__ float cross_row_max(float v) { return xmax32(xmax16(v)); }
 
 // Counter-based dropout: one 64-bit SplitMix hash per group of 4 consecutive elements, 16 bits per element.
 // keep(element) <=> its 16-bit field >= thresh16, thresh16 = round(p * 65536).  The same (seed, index) pair

@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_stream_kernel(const float* __r
     if (want_b) {
 #pragma unroll
         for (int t = 0; t < 2; t++) {
-            const float s = bsum[t] + __shfl_xor(bsum[t], 32);
+            const float s = xsum32(bsum[t], bsum[t]);
             const int n = n_base + 32 * t + l31;
             if (h == 0 && n < N) part_b[(size_t)split * N + n] = s;
         }

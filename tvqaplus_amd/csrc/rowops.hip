@@ -504,8 +504,8 @@ __global__ __launch_bounds__(256) void cat3_ln_bwd_rep_kernel(const float* __res
                 ag[t] = f4add(ag[t], f4mul(dd, xh[t]));
                 ab[t] = f4add(ab[t], dd);
             }
-            s1 = group_sum(s1, LPR) * invK;
-            s2 = group_sum(s2, LPR) * invK;
+            s1 = group_sum_bperm(s1, LPR) * invK;
+            s2 = group_sum_bperm(s2, LPR) * invK;
             float4 dz[3];
 #pragma unroll
             for (int t = 0; t < 3; t++) {

@@ -147,8 +147,7 @@ __global__ __launch_bounds__(512) void str_attn_fwd_kernel(
                     xs[rt][k] = raw * scale;
                     if (R < Lr) mx = fmaxf(mx, xs[rt][k]);
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = cross_row_max(mx);
             float p[RT][4], sum = 0.f;
 #pragma unroll
             for (int rt = 0; rt < RT; rt++)
@@ -158,8 +157,7 @@ __global__ __launch_bounds__(512) void str_attn_fwd_kernel(
                     p[rt][k] = (R < Lr) ? expf(xs[rt][k] - mx) : 0.f;
                     sum += p[rt][k];
                 }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
+            sum = cross_row_sum(sum);
             const long orow = orow_base[t] + (long)i * Lqa;
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
@@ -326,8 +324,7 @@ __global__ __launch_bounds__(512) void str_attn_bwd_ds_kernel(
                 p[rt][k] = (cvalid && R < Lr) ? Sn[orow * Lr + R] : 0.f;
                 dot += p[rt][k] * acc[rt][k];
             }
-        dot += __shfl_xor(dot, 16);
-        dot += __shfl_xor(dot, 32);
+        dot = cross_row_sum(dot);
         if (cvalid) {
 #pragma unroll
             for (int rt = 0; rt < RT; rt++)
@@ -410,8 +407,7 @@ __global__ __launch_bounds__(512) void str_attn_bwd_ds_d128_kernel(
 #pragma unroll
             for (int k = 0; k < 4; k++) dot += p[rt][k] * acc[rt][k];
         }
-        dot += __shfl_xor(dot, 16);
-        dot += __shfl_xor(dot, 32);
+        dot = cross_row_sum(dot);
 #pragma unroll
         for (int rt = 0; rt < RT; rt++) {
 #pragma unroll

@@ -65,6 +65,13 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
     float* cms = qm + RT * 16;
     const int CR = NA * Lqa, CT = (CR + 15) >> 4;
     constexpr int base_last = (RT - 1) * 16;
+    // a last region tile with <= 4 regions is scored by 4x4x1 MFMA blocks instead of a padded 16-row tile (see
+    // str_attn_fwd_reg.hip): lane (c15, g) feeds region base + (c15 & 3) and ends up with region base + g
+    constexpr bool T4 = PERM && KL == 1;
+    constexpr int RF = T4 ? RT - 1 : RT;            // full 16-region tiles of stage 1
+    // context tiles per step: two independent chains (MFMA, LDS reads, softmax) keep the in-order stream busy, but with
+    // 3-4 region tiles the second tile's accumulators / scores / weights no longer fit (RT = 4 spilled ~70 VGPRs)
+    constexpr int NU = RT >= 3 ? 1 : 2;
     const int sq = lane & 31, srow = lane >> 5;     // staging: 32 lanes per row, 2 rows per pass
 
     for (int i = lane; i < LDQ; i += 64) Qr[Lr * LDQ + i] = 0.f;      // shared zero row
@@ -74,7 +81,8 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
     int arow[RT], areg[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; rt++) {
-        const int r = (PERM && rt == RT - 1) ? base_last + (c15 >> 2) + 4 * (c15 & 3) : rt * 16 + c15;
+        const int r = (T4 && rt == RT - 1) ? base_last + (c15 & 3)
+                      : (PERM && rt == RT - 1) ? base_last + (c15 >> 2) + 4 * (c15 & 3) : rt * 16 + c15;
         areg[rt] = r;
         arow[rt] = r < Lr ? r : Lr;
     }
@@ -174,21 +182,24 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
         // the in-order instruction stream of the wave always has something to issue.  One Cn register set: the
         // fragments of the next pair are issued right after stage 1 has read the current ones (before this pair's
         // stores) and awaited at the top of the next step.
-        auto do_pair = [&](f32x4 (&cf)[2][NCH], int t0, int t1, bool more, int nt0, int nt1) {
-            long orow[2];
-            float cmv[2];
+        auto do_pair = [&](f32x4 (&cf)[NU][NCH], int t0, int t1, bool more, int nt0, int nt1) {
+            long orow[NU];
+            float cmv[NU];
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
+            for (int u = 0; u < NU; u++) {
                 const int tile = u ? t1 : t0;
                 const int c = min(tile * 16 + c15, CR - 1);
                 orow[u] = ((long)(n * NA + c / Lqa) * Li + i) * Lqa + c % Lqa;
                 cmv[u] = cms[(tile - tile0) * 16 + c15];
             }
-            f32x4 acc[2][RT];
+            f32x4 acc[NU][RT];
 #pragma unroll
-            for (int u = 0; u < 2; u++)
+            for (int u = 0; u < NU; u++)
 #pragma unroll
-                for (int rt = 0; rt < RT; rt++) acc[u][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int rt = 0; rt < RF; rt++) acc[u][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 tl[NU];
+#pragma unroll
+            for (int u = 0; u < NU; u++) tl[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
             // ---- stage 1 ----
 #pragma unroll
             for (int m = 0; m < NCH; m++) {
@@ -205,31 +216,32 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
                         qv[rt].w = __int_as_float(__float_as_int(qv[rt].w) & __builtin_amdgcn_sbfe(kbits, 4 * m + 3, 1));
                     }
                 }
+#define S1_STEP(E, I)                                                                                                \
+    _Pragma("unroll") for (int rt = 0; rt < RF; rt++) _Pragma("unroll") for (int u = 0; u < NU; u++)                  \
+        acc[u][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[rt].E, cf[u][m][I], acc[u][rt], 0, 0, 0);               \
+    if (T4) _Pragma("unroll") for (int u = 0; u < NU; u++)                                                            \
+        tl[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(qv[RT - 1].E, cf[u][m][I], tl[u], 0, 0, 0);
+                S1_STEP(x, 0)
+                S1_STEP(y, 1)
+                S1_STEP(z, 2)
+                S1_STEP(w, 3)
+#undef S1_STEP
+            }
+            if (T4) {
+                // tl[u][i] = partial score (this lane group's k values) of region base + i, context row c15: fold the 4
+                // lane groups so that lane (c15, g) ends up with region base + g
 #pragma unroll
-                for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-                    for (int u = 0; u < 2; u++) acc[u][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[rt].x, cf[u][m][0], acc[u][rt], 0, 0, 0);
-#pragma unroll
-                for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-                    for (int u = 0; u < 2; u++) acc[u][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[rt].y, cf[u][m][1], acc[u][rt], 0, 0, 0);
-#pragma unroll
-                for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-                    for (int u = 0; u < 2; u++) acc[u][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[rt].z, cf[u][m][2], acc[u][rt], 0, 0, 0);
-#pragma unroll
-                for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-                    for (int u = 0; u < 2; u++) acc[u][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[rt].w, cf[u][m][3], acc[u][rt], 0, 0, 0);
+                for (int u = 0; u < NU; u++)   // common.h: xsum16 / xsum32 with two inputs are transpose-reduce steps
+                    acc[u][RT - 1] = (f32x4){xsum32(xsum16(tl[u][0], tl[u][1]), xsum16(tl[u][2], tl[u][3])), 0.f, 0.f, 0.f};
             }
             TICK(2);
             if (more) {  // the MFMAs above have read cf (in-order issue): refill it for the next pair
                 issue_cf(cf[0], nt0);
-                issue_cf(cf[1], nt1);
+                if (NU == 2) issue_cf(cf[NU - 1], nt1);
             }
-            float rv[2][RT][4], pv[2][RT][4];
+            float rv[NU][RT][4], pv[NU][RT][4];
 #pragma unroll
-            for (int u = 0; u < 2; u++) {  // ---- mask + softmax over regions; pv becomes the stage-2 B operand ----
+            for (int u = 0; u < NU; u++) {  // ---- mask + softmax over regions; pv becomes the stage-2 B operand ----
 #pragma clang fp contract(off)  // scale*raw must be ONE rounded value for both the max and the exponent: a contracted
                                 // fma(raw, scale, -mx) sees -1e11 exactly vs the rounded max -> exp(-2048) = 0 -> 0/0
                 float mx = -INFINITY;
@@ -243,8 +255,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
                         xs[rt][k] = rv[u][rt][k] * scale;
                         if (Rk[rt][k] < Lr) mx = fmaxf(mx, xs[rt][k]);
                     }
-                mx = fmaxf(mx, __shfl_xor(mx, 16));
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                mx = cross_row_max(mx);
                 float sum = 0.f;
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++)
@@ -253,8 +264,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
                         pv[u][rt][k] = (Rk[rt][k] < Lr) ? __expf(xs[rt][k] - mx) : 0.f;  // v_exp_f32 path: ~1e-6 relative
                         sum += pv[u][rt][k];
                     }
-                sum += __shfl_xor(sum, 16);
-                sum += __shfl_xor(sum, 32);
+                sum = cross_row_sum(sum);
                 const float rsum = __builtin_amdgcn_rcpf(sum);  // 1 ulp
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++)
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
             }
             // ---- stores of S / S_ ----
 #pragma unroll
-            for (int u = 0; u < 2; u++)
+            for (int u = 0; u < NU; u++)
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++) {
                     if (PERM && rt == RT - 1) {
@@ -288,18 +298,19 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
             // ---- stage 2: A^T tiles: per 16-wide d tile, one accumulator chain per context tile ----
 #pragma unroll
             for (int dt = 0; dt < NCH; dt++) {
-                f32x4 o[2];
-                o[0] = o[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                f32x4 o[NU];
+#pragma unroll
+                for (int u = 0; u < NU; u++) o[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++)
 #pragma unroll
                     for (int k = 0; k < ((rt == RT - 1) ? KL : 4); k++) {
                         const float q = Qr[Rrow[rt][k] + dt * 16 + c15];
 #pragma unroll
-                        for (int u = 0; u < 2; u++) o[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(q, pv[u][rt][k], o[u], 0, 0, 0);
+                        for (int u = 0; u < NU; u++) o[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(q, pv[u][rt][k], o[u], 0, 0, 0);
                     }
 #pragma unroll
-                for (int u = 0; u < 2; u++)
+                for (int u = 0; u < NU; u++)
                     st4(A + orow[u] * DD + dt * 16 + 4 * g, make_float4(o[u][0], o[u][1], o[u][2], o[u][3]));
             }
         };
@@ -307,24 +318,31 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
         // stores every PAIR issues after the next fragments were requested -- EXACT count (an undercount makes every
         // step wait for some of its own stores to be acknowledged; the lane-predicated stores of a permuted last region
         // tile are always issued: for k < KL region base + g + 4k is valid at least for g = 0)
-        constexpr int NST_RAW = 2 * (8 + (VEC_S ? 2 : 8) * (PERM ? RT - 1 : RT) + (PERM ? 2 * KL : 0));
+        constexpr int NST_RAW = NU * (8 + (VEC_S ? 2 : 8) * (PERM ? RT - 1 : RT) + (PERM ? 2 * KL : 0));
         constexpr int NST = NST_RAW > 60 ? 60 : NST_RAW;  // vmcnt is a 6-bit field; a smaller count only waits longer
 #define WAIT_CF(n_after)                                                                                             \
-    asm volatile("s_waitcnt vmcnt(%16)"                                                                              \
-                 : "+v"(cf[0][0]), "+v"(cf[0][1]), "+v"(cf[0][2]), "+v"(cf[0][3]), "+v"(cf[0][4]), "+v"(cf[0][5]),   \
-                   "+v"(cf[0][6]), "+v"(cf[0][7]), "+v"(cf[1][0]), "+v"(cf[1][1]), "+v"(cf[1][2]), "+v"(cf[1][3]),   \
-                   "+v"(cf[1][4]), "+v"(cf[1][5]), "+v"(cf[1][6]), "+v"(cf[1][7])                                    \
-                 : "n"(n_after)                                                                                      \
-                 : "memory")
-        f32x4 cf[2][NCH];
+    do {                                                                                                             \
+        asm volatile("s_waitcnt vmcnt(%8)"                                                                           \
+                     : "+v"(cf[0][0]), "+v"(cf[0][1]), "+v"(cf[0][2]), "+v"(cf[0][3]), "+v"(cf[0][4]),               \
+                       "+v"(cf[0][5]), "+v"(cf[0][6]), "+v"(cf[0][7])                                                \
+                     : "n"(n_after)                                                                                  \
+                     : "memory");                                                                                    \
+        if (NU == 2)   /* the second set was requested after the first: same count, nothing left to wait for */     \
+            asm volatile("s_waitcnt vmcnt(%8)"                                                                       \
+                         : "+v"(cf[NU - 1][0]), "+v"(cf[NU - 1][1]), "+v"(cf[NU - 1][2]), "+v"(cf[NU - 1][3]),       \
+                           "+v"(cf[NU - 1][4]), "+v"(cf[NU - 1][5]), "+v"(cf[NU - 1][6]), "+v"(cf[NU - 1][7])        \
+                         : "n"(n_after)                                                                              \
+                         : "memory");                                                                                \
+    } while (0)
+        f32x4 cf[NU][NCH];
         issue_cf(cf[0], tile0);
-        issue_cf(cf[1], min(tile0 + 1, tile1 - 1));
+        if (NU == 2) issue_cf(cf[NU - 1], min(tile0 + 1, tile1 - 1));
         WAIT_CF(0);
         TICK(1);
-        for (int t = tile0; t < tile1; t += 2) {
-            const bool more = t + 2 < tile1;
+        for (int t = tile0; t < tile1; t += NU) {
+            const bool more = t + NU < tile1;
             // an odd tail recomputes the last tile in the second slot: identical values are stored twice
-            do_pair(cf, t, min(t + 1, tile1 - 1), more, t + 2, min(t + 3, tile1 - 1));
+            do_pair(cf, t, min(t + 1, tile1 - 1), more, t + NU, min(t + NU + 1, tile1 - 1));
             TICK(4);
             if (more) WAIT_CF(NST);  // only this pair's stores may still be in flight
             TICK(1);

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
     // A last region tile with <= 4 regions (the headline Lr = 20) does not pay a 16-row stage-1 tile for them: its scores
     // come from v_mfma_f32_4x4x1 (16 independent 4x4 blocks, 8 cycles instead of 32): block (c15 >> 2, g) = 4 regions x
     // context rows 4 (c15 >> 2) .. +3 over the k values lane group g holds; the 4 partial sums per score are folded by a
-    // 3-shuffle transpose-reduce that leaves lane (c15, g) with region base + g of context row c15 -- the PERM layout.
+    // 3-instruction transpose-reduce (v_permlane16_swap / v_permlane32_swap) that leaves lane (c15, g) with region base + g of context row c15 -- the PERM layout.
     constexpr bool T4 = PERM && KL == 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int c15 = lane & 15, g = lane >> 4;
@@ -157,8 +157,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
             float ss = 0.f;
 #pragma unroll
             for (int m = 0; m < RNCH; m++) ss += f4hsum(f4mul(qa[rt][m], qa[rt][m]));
-            ss += __shfl_xor(ss, 16);
-            ss += __shfl_xor(ss, 32);
+            ss = cross_row_sum(ss);
             const float ri = areg[rt] < Lr ? 1.0f / fmaxf(sqrtf(ss), 1e-12f) : 0.f;
 #pragma unroll
             for (int m = 0; m < RNCH; m++) {
@@ -218,11 +217,9 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
             }
             if (T4) {
                 // tl[i] = partial score (this lane group's k values) of region base + i, context row c15
-                const float r0 = tl[0], r1 = tl[1], r2 = tl[2], r3 = tl[3];
-                const bool b0 = g & 1, b1 = g & 2;
-                const float p0 = (b0 ? r1 : r0) + __shfl_xor(b0 ? r0 : r1, 16);     // region (g & 1), summed over g bit 0
-                const float p1 = (b0 ? r3 : r2) + __shfl_xor(b0 ? r2 : r3, 16);     // region 2 + (g & 1)
-                acc[RT - 1] = (f32x4){(b1 ? p1 : p0) + __shfl_xor(b1 ? p0 : p1, 32), 0.f, 0.f, 0.f};   // region g, all k
+                // fold the 4 lane groups: rows g = 0/1 keep regions 0/1, then halves keep {0,1} / {2,3} (common.h: xsum16 /
+                // xsum32 with two inputs are transpose-reduce steps) -> lane (c15, g) holds region base + g, all k
+                acc[RT - 1] = (f32x4){xsum32(xsum16(tl[0], tl[1]), xsum16(tl[2], tl[3])), 0.f, 0.f, 0.f};
             }
             const float cm_cur = cmv;
             // the MFMAs above have read cf (in-order issue): request the next tile now, before this tile's stores.
@@ -247,8 +244,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
                         xs[rt][k] = rv[rt][k] * scale;
                         if (((vmask >> (rt * 4 + k)) & 1u)) mx = fmaxf(mx, xs[rt][k]);
                     }
-                mx = fmaxf(mx, __shfl_xor(mx, 16));
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                mx = cross_row_max(mx);
                 float sum = 0.f;
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++)
@@ -257,8 +253,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
                         pv[rt][k] = (((vmask >> (rt * 4 + k)) & 1u)) ? __expf(xs[rt][k] - mx) : 0.f;  // v_exp_f32 path: ~1e-6 relative
                         sum += pv[rt][k];
                     }
-                sum += __shfl_xor(sum, 16);
-                sum += __shfl_xor(sum, 32);
+                sum = cross_row_sum(sum);
                 const float rsum = __builtin_amdgcn_rcpf(sum);  // 1 ulp
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++)
