@@ -2,6 +2,8 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tvqaplus_amd import _lib
+if os.environ.get("LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["LIB"])   # experiment builds
 lib = _lib.load()
 M, N, K = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 kind = sys.argv[4] if len(sys.argv) > 4 else "nt"

@@ -15,6 +15,9 @@
 #include "common.h"
 #include "../../include/stage_hip.h"
 
+#ifndef GEMM_ABL
+#define GEMM_ABL 0      // developer ablation bits (timing experiments only, results wrong): 1 one MFMA per column tile instead
+#endif                  // of 6, 2 no bf16 split (raw bits as operands), 4 X lines fetched once per wave, 8 no stores
 #define SBN 128                 // output columns per workgroup
 #define SKC 128                 // k per resident weight chunk
 #define SWS (SKC + 8)           // bf16 per LDS row of a plane (272 B: 16-lane ds_read_b128 groups hit distinct slots)
@@ -147,7 +150,10 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
     };
     const s_rsrc_t rsx = make_rsrc(X), rsg = make_rsrc(HAS_GATE ? G : X);
     const int NWK = (K + 31) >> 5;                        // mask words per row (GATE 2)
+    bool abl_fetched[2] = {false, false};
     auto fetch = [&](int buf, long row, int k_line) {   // one offset per lane, immediate offsets for the 4 chunks
+        if ((GEMM_ABL & 4) && abl_fetched[buf]) return;
+        abl_fetched[buf] = true;
         const long rcl = row < M ? row : M - 1;
         const int off = (int)((rcl * K + k_line + 4 * h) * 4);
         if (GATE == 2) {
@@ -252,13 +258,19 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
                         v1.w = __int_as_float(__float_as_int(v1.w) & __builtin_amdgcn_sbfe(wbits, p0b + 11, 1));
                     }
                     unsigned p0[3], p1[3], p2[3], p3[3];
-                    s_split3(v0.x, v0.y, p0);
-                    s_split3(v0.z, v0.w, p1);
-                    s_split3(v1.x, v1.y, p2);
-                    s_split3(v1.z, v1.w, p3);
                     sbf16x8 a[3];
+                    if (GEMM_ABL & 2) {
+                        a[0] = __builtin_bit_cast(sbf16x8, v0);
+                        a[1] = __builtin_bit_cast(sbf16x8, v1);
+                        a[2] = __builtin_bit_cast(sbf16x8, make_float4(v0.x, v1.y, v0.z, v1.w));
+                    } else {
+                        s_split3(v0.x, v0.y, p0);
+                        s_split3(v0.z, v0.w, p1);
+                        s_split3(v1.x, v1.y, p2);
+                        s_split3(v1.z, v1.w, p3);
 #pragma unroll
-                    for (int s = 0; s < 3; s++) a[s] = __builtin_bit_cast(sbf16x8, make_uint4(p0[s], p1[s], p2[s], p3[s]));
+                        for (int s = 0; s < 3; s++) a[s] = __builtin_bit_cast(sbf16x8, make_uint4(p0[s], p1[s], p2[s], p3[s]));
+                    }
                     const int koff = 16 * (2 * L + up) + 8 * h;
 #pragma unroll
                     for (int nt = 0; nt < 4; nt++) {
@@ -267,6 +279,12 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
                         for (int s = 0; s < 3; s++)
                             b[s] = __builtin_bit_cast(sbf16x8, *reinterpret_cast<const uint4*>(&Wp[s * SPLANE + (nt * 32 + l31) * SWS + koff]));
                         // kept cross terms, smallest first
+                        if (GEMM_ABL & 1) {
+                            const sbf16x8 am = __builtin_bit_cast(sbf16x8, __builtin_bit_cast(uint4, a[0]) ^ __builtin_bit_cast(uint4, a[1]) ^ __builtin_bit_cast(uint4, a[2]));
+                            const sbf16x8 bm = __builtin_bit_cast(sbf16x8, __builtin_bit_cast(uint4, b[0]) ^ __builtin_bit_cast(uint4, b[1]) ^ __builtin_bit_cast(uint4, b[2]));
+                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[nt], 0, 0, 0);
+                            continue;
+                        }
                         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[nt], 0, 0, 0);
                         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[nt], 0, 0, 0);
                         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[nt], 0, 0, 0);
@@ -310,6 +328,9 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
         }
         if (!live) continue;
         // epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+        // (Accumulating the tile transposed -- weight fragment as the A operand -- gives every lane 4 consecutive columns of
+        // one row and 16-byte stores, 16 per tile instead of 64; measured 25 % SLOWER at K = 128: an instruction then covers 32
+        // rows x 32 bytes instead of 2 rows x 128 bytes, and partial-line writes are what the memory system handles worst.)
         // Straight-line stores: a residual load or a per-row guard inside this loop makes the compiler put an
         // s_waitcnt vmcnt(0) in front of every store (each store then waits for the previous one to be acknowledged).
         const bool full = t * 32 + 32 <= M;
@@ -352,7 +373,8 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
             if (full) {
 #pragma unroll
                 for (int r = 0; r < 16; r++)
-                    if (nok) __builtin_nontemporal_store(acc[nt][r], &yp[(long)((r & 3) + 8 * (r >> 2)) * N]);
+                    if (nok && (!(GEMM_ABL & 8) || acc[nt][r] == 1.2345e30f))
+                        __builtin_nontemporal_store(acc[nt][r], &yp[(long)((r & 3) + 8 * (r >> 2)) * N]);
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
