@@ -326,6 +326,58 @@ def test_k1_oracle_ragged(ops, N, Li, Lr, Lqa, D):
     check("dQ", Qd.grad.view_as(Q), Qc.grad, 1e-3)
 
 
+K1_SWEEP_LR = [1, 3, 4, 8, 13, 16, 17, 19, 21, 24, 26, 28, 31, 32, 33, 36, 40, 45, 48, 49, 52, 56, 61, 64]
+
+
+@pytest.mark.parametrize("Lr", K1_SWEEP_LR)
+def test_k1_d128_region_sweep(ops, Lr):
+    """Every specialisation of the two D=128 forward kernels (register-resident: Lr <= 32, LDS-staged: Lr <= 64; full /
+    permuted / 4x4-block last region tile, vector / scalar score stores) and of the D=128 backward kernels: eval mode
+    against the oracle, training mode (dropout 0.3) against the generic kernels on the same seeds."""
+    import os
+    from tvqaplus_amd.synth import make_batch
+    N, Li, Lqa, D = 1, 3, 23, 128
+    g = torch.Generator().manual_seed(1000 + Lr)
+    b = make_batch(N=N, Li=Li, Lr=Lr, Lw=2, Lqa=Lqa, wd_size=4, vfeat_size=4, seed=Lr, empty_frames=False)
+    C = torch.randn(N, 5, 1, Lqa, D, generator=g)
+    Q = torch.randn(N, 1, Li, Lr, D, generator=g) * 2
+    cm, qm = b.qas_mask.view(N, 5, 1, Lqa), b.vid_mask.view(N, 1, Li, Lr)
+    gA = torch.randn(N, 5, Li, Lqa, D, generator=g)
+    gS = torch.randn(N, 5, Li, Lqa, Lr, generator=g) * 0.1
+    Cc, Qc = C.clone().requires_grad_(), Q.clone().requires_grad_()
+    Ao, So, _, Sno = O.structured_attention(Cc, Qc, cm, qm, 10.0)
+    ((Ao * gA).sum() + (So * gS).sum()).backward()
+    A, S, Sn, Cd, Qd = _k1_run(ops, C, Q, cm, qm, 10.0, gA, gS)
+    check("A", A, Ao)
+    check("S", S, So)
+    check("S_norm", Sn, Sno)
+    check("dC", Cd.grad.view_as(C), Cc.grad, 1e-3)
+    check("dQ", Qd.grad.view_as(Q), Qc.grad, 1e-3)
+
+    def train_run():
+        Cd, Qd = dev(C.view(N, 5, Lqa, D), True), dev(Q.view(N, Li, Lr, D), True)
+        A, S, Sn = ops.structured_attention(Cd, Qd, cm.view(N, 5, Lqa).cuda(), qm.view(N, Li, Lr).cuda(), 10.0, p=0.3,
+                                            seed_c=77, seed_q=4242)
+        ((A * gA.cuda()).sum() + (S * gS.cuda()).sum()).backward()
+        return A, S, Sn, Cd.grad, Qd.grad
+    fast = train_run()
+    switches = ("STAGE_K1_GENERIC", "STAGE_K1_BWD_SCALAR", "STAGE_K1_DS_GENERIC")
+    saved = {k: os.environ.get(k) for k in switches}
+    try:
+        for k in switches:
+            os.environ[k] = "1"
+        ref = train_run()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    for name, x, y, tol in zip(("A", "S", "S_norm", "dC", "dQ"), fast, ref, (1e-4, 1e-4, 1e-4, 1e-3, 1e-3)):
+        check("train " + name, x, y.cpu(), tol)
+    assert float((fast[0] == 0).float().mean()) < 0.9   # not a degenerate all-masked case
+
+
 def test_k1_full_size_vs_oracle(ops):
     """BASELINE.json config 2 video-stream shape (N=16, Li=300, Lr=20, Lqa=40, D=128): direct comparison plus the
     size-independent properties (valid rows of S_ sum to 1, padded rows/frames are exactly 0 / -1e10)."""
