@@ -17,7 +17,8 @@
 
 #ifndef GEMM_ABL
 #define GEMM_ABL 0      // developer ablation bits (timing experiments only, results wrong): 1 one MFMA per column tile instead
-#endif                  // of 6, 2 no bf16 split (raw bits as operands), 4 X lines fetched once per wave, 8 no stores
+#endif                  // of 6, 2 no bf16 split (raw bits as operands), 4 X lines fetched once per wave, 8 no stores,
+                        // 16 weight fragments read from LDS for one of the four column tiles only
 #define SBN 128                 // output columns per workgroup
 #define SKC 128                 // k per resident weight chunk
 #define SWS (SKC + 8)           // bf16 per LDS row of a plane (272 B: 16-lane ds_read_b128 groups hit distinct slots)
@@ -272,12 +273,13 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
                         for (int s = 0; s < 3; s++) a[s] = __builtin_bit_cast(sbf16x8, make_uint4(p0[s], p1[s], p2[s], p3[s]));
                     }
                     const int koff = 16 * (2 * L + up) + 8 * h;
+                    sbf16x8 b[3];
 #pragma unroll
                     for (int nt = 0; nt < 4; nt++) {
-                        sbf16x8 b[3];
 #pragma unroll
                         for (int s = 0; s < 3; s++)
-                            b[s] = __builtin_bit_cast(sbf16x8, *reinterpret_cast<const uint4*>(&Wp[s * SPLANE + (nt * 32 + l31) * SWS + koff]));
+                            if (!(GEMM_ABL & 16) || nt == 0)   // ablation: weight fragments read for the first column tile only
+                                b[s] = __builtin_bit_cast(sbf16x8, *reinterpret_cast<const uint4*>(&Wp[s * SPLANE + (nt * 32 + l31) * SWS + koff]));
                         // kept cross terms, smallest first
                         if (GEMM_ABL & 1) {
                             const sbf16x8 am = __builtin_bit_cast(sbf16x8, __builtin_bit_cast(uint4, a[0]) ^ __builtin_bit_cast(uint4, a[1]) ^ __builtin_bit_cast(uint4, a[2]));
