@@ -56,14 +56,15 @@ class Fixture:
                      vid=i["vid"], vid_mask=i["vid_mask"], target=i["target"],
                      ts_label=dict(st=i["ts_label_st"], ed=i["ts_label_ed"]), ts_label_mask=i["ts_label_mask"],
                      qid=list(range(N)), vid_name=["v%d" % k for k in range(N)],
-                     qas=torch.zeros(N, 5, i["qas_mask"].shape[2], dtype=torch.long, device=device), att_labels=None,
+                     qas=torch.zeros(N, 5, i["qas_mask"].shape[2], dtype=torch.long, device=device),
+                     att_labels=[[l for l in per] for per in i["att_labels"]] if "att_labels" in i else None,
                      anno_st_idx=[0] * N, q_l=[1] * N, image_indices=[list(range(Li)) for _ in range(N)],
                      boxes=[[] for _ in range(N)], use_hard_negatives=False, eval_object_word_ids=[])
 
 
 MODEL_CASES = ["tiny_eval", "tiny_inference", "tiny_train", "tiny_train_local", "small_local_eval",
                "small_local_train", "small_heads_train", "small_heads_eval", "small_subonly_train",
-               "small_vidonly_train", "mid_train", "mid_eval"]
+               "small_vidonly_train", "mid_train", "mid_eval", "small_supatt_train"]
 K1_CASES = ["k1_small", "k1_mid", "k1_sub"]
 ENC_CASES = ["enc_k7", "enc_k5_heads"]
 

@@ -59,11 +59,18 @@ def run_case(name, opt_kw, batch_kw, mode, seed):
         rec["in/" + k] = np32(batch[k])
     rec["in/ts_label_st"], rec["in/ts_label_ed"] = np32(batch.ts_label["st"]), np32(batch.ts_label["ed"])
 
+    if batch.att_labels is not None:
+        rec["in/att_labels"] = np.stack([np.stack([np32(l) for l in per]) for per in batch.att_labels])
     if mode == "train":
         model.train()
+        torch.manual_seed(seed + 7)   # the negative sampling of get_att_loss draws from the global generator
+        rec["att_seed"] = np.array(seed + 7)
         (out, targets), att_loss, _, t_loss, t_scores, other = model.forward_main(batch)
         loss = torch.nn.functional.cross_entropy(out, targets, reduction="sum") * (len(batch.qid) / len(targets)) \
             + 0.5 * t_loss
+        if opt.use_sup_att:           # main.py:57-60 with att_weight = 0.1
+            loss = loss + 0.1 * att_loss
+            rec["out/att_loss"] = np32(att_loss)
         loss.backward()
         rec["out/logits"], rec["out/targets"] = np32(out), np32(targets)
         rec["out/temporal_loss"], rec["out/t_scores"], rec["out/loss"] = np32(t_loss), np32(t_scores), np32(loss)
@@ -147,6 +154,46 @@ SMALL_T = dict(N=3, Li=7, Lr=5, Lw=9, Lqa=8)
 MID = dict(N=2, Li=6, Lr=20, Lw=50, Lqa=40)        # full per-frame shapes, D=128
 
 
+def att_case(name, seed, loss_type, hard, pool, num_hard, drop_topk, num_negatives=2, start=0):
+    """get_att_loss (model/stage.py:612-746, training mode) and get_att_prediction (:748-806) on a synthetic score
+    tensor: the host index building + negative sampling are what is pinned here (same torch seed => same draws)."""
+    from types import SimpleNamespace
+    g = torch.Generator().manual_seed(seed)
+    N, Li, Lqa, Lr, n_img = 3, 6, 7, 16, 3
+    scores = (torch.rand(N, 5, Li, Lqa, Lr, generator=g) * 2 - 1).requires_grad_()
+    target = torch.randint(0, 5, (N,), generator=g)
+    labels = []
+    for b in range(N):
+        per_img = []
+        for i in range(n_img):
+            lab = (torch.rand(Lqa, Lr, generator=g) < 0.1).float()
+            if b == 1 and i == 0:
+                lab.zero_()                                  # an annotated image without any positive
+            lab[:, 0] = 0                                    # every word keeps at least one negative region
+            per_img.append(lab)
+        labels.append(per_img)
+    words = torch.randint(0, 12, (N, 5, Lqa), generator=g)
+    boxes = [[[[int(x) for x in torch.randint(0, 100, (4,), generator=g)] for _ in range(Lr)] for _ in range(n_img)]
+             for _ in range(N)]
+    self = SimpleNamespace(negative_pool_size=pool, num_hard=num_hard, att_loss_type=loss_type, margin=0.1, alpha=20.0,
+                           training=True, vfeat_flag=True, sample_negatives=RefSTAGE.sample_negatives)
+    torch.manual_seed(seed + 1)
+    loss, _ = RefSTAGE.get_att_loss(self, scores, labels, target, words, ["v%d" % b for b in range(N)], list(range(N)),
+                                    [3] * N, [list(range(Li))] * N, boxes, [start] * N, num_negatives=num_negatives,
+                                    use_hard_negatives=hard, drop_topk=drop_topk)
+    loss.backward()
+    vocab = [1, 4, 7, 9]
+    preds = RefSTAGE.get_att_prediction(self, scores.detach(), vocab, words, ["v%d" % b for b in range(N)],
+                                        list(range(N)), [list(range(100, 100 + Li))] * N, boxes, [start] * N)
+    rec = {"scores": np32(scores), "target": np32(target), "labels": np.stack([np.stack([np32(l) for l in per]) for per in labels]),
+           "words": np32(words), "boxes": np.array(boxes), "vocab": np.array(vocab),
+           "cfg": np.array(json.dumps(dict(seed=seed + 1, loss_type=loss_type, hard=hard, pool=pool, num_hard=num_hard,
+                                           drop_topk=drop_topk, num_negatives=num_negatives, start=start, Li=Li))),
+           "loss": np32(loss), "grad": np32(scores.grad), "preds": np.array(json.dumps(preds))}
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
+    print("%-24s loss %.6f  preds %d" % (name, float(loss), sum(len(v) for q in preds for v in q.values())))
+
+
 def main():
     run_case("tiny_eval", dict(hsz=16, embedding_size=64), TINY, "eval", 11)
     run_case("tiny_inference", dict(hsz=16, embedding_size=64), TINY, "inference", 11)
@@ -171,5 +218,23 @@ def main():
     encoder_case("enc_k5_heads", M=6, L=11, D=32, k=5, n_conv=2, nh=4, seed=52)
 
 
+def att_model_main():
+    run_case("small_supatt_train", dict(hsz=32, dropout=0.0, use_sup_att=True, att_loss_type="lse", embedding_size=64, vfeat_size=48),
+             dict(N=3, Li=5, Lr=12, Lw=6, Lqa=8, att_imgs=2, ragged=False), "train", 41)   # dense masks: a masked (-1e10) positive makes lse inf
+
+
+def att_main():
+    att_case("att_lse_random", 31, "lse", False, 0, 2, 0)
+    att_case("att_hinge_hard", 32, "hinge", True, 0, 2, 1)
+    att_case("att_lse_pool_mix", 33, "lse", True, 3, 1, 0)
+    att_case("att_hinge_pool", 34, "hinge", True, 4, 2, 1, num_negatives=3)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "att":   # only the attention-loss / box-prediction fixtures
+        att_main()
+        att_model_main()
+    else:
+        main()
+        att_main()
+        att_model_main()

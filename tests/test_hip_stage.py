@@ -35,9 +35,14 @@ def test_golden_whole_model(hip_device, name):
     mode = fx.mode
     if mode == "train":
         model.train()
+        if "att_seed" in fx.z.files:   # same generator state as the reference run: identical negative samples
+            torch.manual_seed(int(fx["att_seed"]))
         (out, targets), att_loss, _, t_loss, t_scores, other = model.forward_main(batch)
         assert torch.equal(targets.cpu(), exp["targets"]), "proposal set differs"
         loss = F.cross_entropy(out, targets, reduction="sum") * (len(batch.qid) / len(targets)) + 0.5 * t_loss
+        if fx.opt.use_sup_att:
+            assert rel_err(att_loss, exp["att_loss"]) < TOL
+            loss = loss + 0.1 * att_loss
         loss.backward()
         assert rel_err(out, exp["logits"]) < TOL
         assert rel_err(t_scores, exp["t_scores"]) < TOL

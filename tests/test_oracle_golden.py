@@ -41,6 +41,16 @@ def test_whole_model(name):
             assert rel_err(out[k], exp[k]) < TOL, k
     if train:
         loss = O.training_loss(out, n_examples=batch.target.shape[0])
+        if opt.use_sup_att:   # host logic on top of the attention map (pinned on its own in test_att_host_golden.py)
+            from types import SimpleNamespace
+            from tvqaplus_amd import att_host
+            torch.manual_seed(int(fx["att_seed"]))
+            m = SimpleNamespace(num_negatives=opt.num_negatives, negative_pool_size=opt.negative_pool_size,
+                                num_hard=opt.num_hard, drop_topk=opt.drop_topk, att_loss_type=opt.att_loss_type,
+                                margin=opt.margin, alpha=opt.alpha)
+            att_loss, _ = att_host.get_att_loss(m, out["vid_raw_s"], batch)
+            assert rel_err(att_loss, exp["att_loss"]) < TOL
+            loss = loss + 0.1 * att_loss
         assert rel_err(loss, exp["loss"]) < TOL
         loss.backward()
         G = fx.group("grad")
