@@ -201,7 +201,7 @@ def main():
                                                                         "all-reduce over RCCL)" % world,
                        "final_loss": round(loss_v, 4), "peak_hbm_gib": round(peak_gb, 2)},
         }
-        if world == 1 and not args.no_roofline:
+        if not args.no_roofline:   # rank 0's GPU, after the timed region (the other ranks wait at the final barrier)
             rec["roofline"] = k1_roofline(args, device)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args, opt)
