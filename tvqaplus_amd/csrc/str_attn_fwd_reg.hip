@@ -62,9 +62,14 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
         for (int k = 0; k < 4; k++) vmask |= (Rk(rt, k) < Lr ? 1u : 0u) << (rt * 4 + k);
 
     // output row of context row c of example n, frame i:  ((n*NA + a)*Li + i)*Lqa + w ,  c = a*Lqa + w
-    auto out_row = [&](int n, int i, int c) -> long {
-        const int a = (int)(((float)c + 0.5f) * inv_lqa);      // exact for c < 2^22
-        return ((long)(n * NA + a) * Li + i) * Lqa + (c - a * Lqa);
+    //   = c + a * (Li - 1) * Lqa + (n*NA*Li + i) * Lqa :  one float reciprocal for a (exact for c < 2^22), one full-rate 24-bit
+    // multiply, two adds.  The 64-bit form of the same expression was 3 v_mul_lo_u32 + v_mad_u64_u32 per row (quarter
+    // rate), five rows per tile: ~450 VALU cycles of a 2560-cycle tile.  The launcher guarantees U < 2^24 rows.
+    const unsigned row_k1 = (unsigned)(Li - 1) * (unsigned)Lqa;
+    unsigned row_k0 = 0u;                           // per item
+    auto out_row = [&](int c) -> unsigned {
+        const int a = (int)(((float)c + 0.5f) * inv_lqa);
+        return (unsigned)c + __umul24((unsigned)a, row_k1) + row_k0;
     };
 
     const long n_items = (long)N * Li * slices;
@@ -92,6 +97,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
         const int tile0 = slice * tiles_per_slice;
         const int tile1 = min(CT, tile0 + tiles_per_slice);
         const float* qf = Q + frame * Lr * RD;
+        row_k0 = ((unsigned)n * NA * Li + i) * Lqa;
 
         // region fed by this lane as stage-1 A row (i = c15), per region tile.  Derived per item from an opaque copy of
         // c15: hoisted out of the item loop, the 64-bit row offsets built from it stay live across the whole kernel and
@@ -138,9 +144,9 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
             const int c_lo = tile0 * 16, c_hi = min(CR, tile1 * 16);
             const int sq = lane & 31;
             for (int c = c_lo + (lane >> 5); c < c_hi; c += 2) {
-                const long orow = out_row(n, i, c);
-                st4(A + orow * RD + 4 * sq, f4zero());
-                for (int r = sq; r < Lr; r += 32) { S[orow * Lr + r] = STAGE_NEG; Sn[orow * Lr + r] = 0.f; }
+                const unsigned orow = out_row(c);
+                st4(A + (size_t)orow * RD + 4 * sq, f4zero());
+                for (int r = sq; r < Lr; r += 32) { S[(size_t)orow * Lr + r] = STAGE_NEG; Sn[(size_t)orow * Lr + r] = 0.f; }
             }
             item = next_item;
             continue;
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
             if (!(K1_ABL & 32)) issue_cf(min(t + 1, tile1 - 1));
 
             const int c = min(t * 16 + c15, CR - 1);
-            const long orow = out_row(n, i, c);
+            const size_t srow = __umul24(out_row(c), (unsigned)Lr);   // element offset of the S / S_ row (< 2^29)
             float rv[RT][4], pv[RT][4];
             {   // ---- mask + softmax over regions; pv becomes the stage-2 A operand ----
 #pragma clang fp contract(off)  // scale*raw must be ONE rounded value for both the max and the exponent: a contracted
@@ -267,27 +273,27 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
 #pragma unroll
                     for (int k = 0; k < KL; k++)
                         if (((vmask >> (rt * 4 + k)) & 1u)) {
-                            S[orow * Lr + Rk(rt, k)] = rv[rt][k];
-                            Sn[orow * Lr + Rk(rt, k)] = pv[rt][k];
+                            S[srow + Rk(rt, k)] = rv[rt][k];
+                            Sn[srow + Rk(rt, k)] = pv[rt][k];
                         }
                 } else if (VEC_S) {
                     if ((K1_ABL & 2) && rv[rt][0] != 1.2345e30f) continue;
-                    st4(S + orow * Lr + rt * 16 + 4 * g, make_float4(rv[rt][0], rv[rt][1], rv[rt][2], rv[rt][3]));
-                    st4(Sn + orow * Lr + rt * 16 + 4 * g, make_float4(pv[rt][0], pv[rt][1], pv[rt][2], pv[rt][3]));
+                    st4(S + srow + rt * 16 + 4 * g, make_float4(rv[rt][0], rv[rt][1], rv[rt][2], rv[rt][3]));
+                    st4(Sn + srow + rt * 16 + 4 * g, make_float4(pv[rt][0], pv[rt][1], pv[rt][2], pv[rt][3]));
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        S[orow * Lr + Rk(rt, k)] = rv[rt][k];
-                        Sn[orow * Lr + Rk(rt, k)] = pv[rt][k];
+                        S[srow + Rk(rt, k)] = rv[rt][k];
+                        Sn[srow + Rk(rt, k)] = pv[rt][k];
                     }
                 }
             }
             // ---- stage 2: A tile (ctx x d), one 64-wide d block at a time (4 independent accumulator chains) ----
             // C layout: lane (c15, g) holds context rows 4g + reg, columns d = 64b + 4 c15 + e
-            long arow4[4];
+            size_t arow4[4];
 #pragma unroll
             for (int reg = 0; reg < 4; reg++)   // rows past the end alias the last valid row
-                arow4[reg] = out_row(n, i, min(t * 16 + 4 * g + reg, CR - 1)) * RD + 4 * c15;
+                arow4[reg] = (size_t)out_row(min(t * 16 + 4 * g + reg, CR - 1)) * RD + 4 * c15;
 #pragma unroll
             for (int b = 0; b < 2; b++) {
                 f32x4 o[4];
@@ -379,6 +385,7 @@ int stage_str_attn_fwd_reg(const float* Cn, const float* Q, const float* c_mask,
                            float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D, float scale,
                            float p_drop, unsigned long long seed, void* stream) {
     if (D != RD || Lr > 32 || (long)NA * Lqa >= (1 << 22)) return 1;
+    if ((long)N * NA * Li * Lqa >= (1l << 24) || (long)(Li - 1) * Lqa >= (1l << 24)) return 1;   // 24-bit row arithmetic
     hipStream_t st = (hipStream_t)stream;
     const bool train = p_drop > 0.f;
 #define ARGS Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st
