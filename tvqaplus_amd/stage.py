@@ -297,12 +297,14 @@ class STAGE(nn.Module):
                     wins.append((max(0, s - extra_span_length), e + extra_span_length))
             src_t = torch.tensor(src, device=x.device, dtype=torch.long)
             win_t = torch.tensor(wins, device=x.device, dtype=torch.int32)       # (N_new, 2)
-            xg = max_statement[src_t].reshape(-1, Li, D)                          # (N_new*5, Li, D)
-            mg = max_statement_mask.reshape(N, NA, Li)[src_t].reshape(-1, Li)
+            # index_select (backward: one index_add; at most two contributions per slot, so the order cannot matter)
+            # instead of advanced indexing (backward: sort-based index_put, five small kernels each)
+            xg = max_statement.index_select(0, src_t).reshape(-1, Li, D)          # (N_new*5, Li, D)
+            mg = max_statement_mask.reshape(N, NA, Li).index_select(0, src_t).reshape(-1, Li)
             wg = win_t.unsqueeze(1).expand(-1, NA, -1).reshape(-1, 2).contiguous()
             loc = ops.masked_max(xg, mg, wg).view(-1, NA, D)
-            pooled = torch.cat([loc, glob.view(N, NA, D)[src_t]], dim=-1)         # (N_new, 5, 2D)
-            return pooled, targets[src_t]
+            pooled = torch.cat([loc, glob.view(N, NA, D).index_select(0, src_t)], dim=-1)   # (N_new, 5, 2D)
+            return pooled, targets.index_select(0, src_t)
         ts = F.softmax(temporal_scores, dim=2).view(N * NA, Li, 2)
         st, ed, _ = self._best_span(ts[:, :, 0], ts[:, :, 1])
         win = torch.stack([(st - extra_span_length).clamp(min=0), ed + 1 + extra_span_length], dim=1).int().contiguous()
@@ -345,7 +347,8 @@ class STAGE(nn.Module):
     def get_ts_loss(self, temporal_scores, ts_labels, answer_indices):
         """model/stage.py:539-555."""
         bsz = len(answer_indices)
-        ca = temporal_scores[torch.arange(bsz, device=answer_indices.device), answer_indices]
+        Li = temporal_scores.shape[2]
+        ca = temporal_scores.gather(1, answer_indices.view(bsz, 1, 1, 1).expand(bsz, 1, Li, 2)).squeeze(1)   # [n, target_n]
         loss_st = self.temporal_criterion(ca[:, :, 0], ts_labels["st"])
         loss_ed = self.temporal_criterion(ca[:, :, 1], ts_labels["ed"])
         return (loss_st + loss_ed) / 2.
