@@ -122,6 +122,12 @@ __host__ __device__ __forceinline__ uint32_t drop_thresh16(float p) {
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// streaming read (a tensor this kernel reads exactly once): non-temporal hint, -2..5 % on the cat3 LayerNorm kernels and
+// the masked max (tools/bench_rowops.py); no effect on the plain LayerNorm
+__device__ __forceinline__ float4 ld4s(const float* p) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 // streaming (non-temporal) 16-byte store for large outputs that are written once
 __device__ __forceinline__ void st4_stream(float* p, float4 v) {

@@ -275,12 +275,12 @@ __global__ __launch_bounds__(256) void ln_fwd_fast_kernel(RowSrc src, const floa
                 const long rr = src.b ? (src.inner > 0 ? (long)((unsigned)rc % (unsigned)src.inner) : rc) : 0;
 #pragma unroll
                 for (int t = 0; t < NQ; t++) {
-                    v[u][t] = ld4(src.x + rc * K + 4 * jc[t]);
+                    v[u][t] = ld4s(src.x + rc * K + 4 * jc[t]);
                     if (src.b) rv[u][t] = ld4(src.b + rr * K + 4 * jc[t]);
                 }
             } else {
                 v[u][0] = ld4(src.x + a_row_fast(rc, src.rep, src.inner) * D + 4 * sl);
-                v[u][1] = ld4(src.b + rc * D + 4 * sl);
+                v[u][1] = ld4s(src.b + rc * D + 4 * sl);
             }
         }
 #pragma unroll
@@ -367,15 +367,15 @@ __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(RowSrc src, const floa
             if (MODE == 0) {
 #pragma unroll
                 for (int t = 0; t < NQ; t++) {
-                    xv[u][t] = ld4(src.x + rc * K + 4 * jc[t]);
+                    xv[u][t] = ld4s(src.x + rc * K + 4 * jc[t]);
                     if (dx && src.b) ra[u][t] = ld4(src.b + rc * K + 4 * jc[t]);
                 }
             } else {
                 xv[u][0] = ld4(src.x + a_row_fast(rc, src.rep, src.inner) * D + 4 * sl);
-                xv[u][1] = ld4(src.b + rc * D + 4 * sl);
+                xv[u][1] = ld4s(src.b + rc * D + 4 * sl);
             }
 #pragma unroll
-            for (int t = 0; t < NQ; t++) d[u][t] = ld4(dy + rc * K + 4 * jc[t]);
+            for (int t = 0; t < NQ; t++) d[u][t] = ld4s(dy + rc * K + 4 * jc[t]);
         }
 #pragma unroll
         for (int u = 0; u < LN_UR; u++) {
@@ -480,9 +480,9 @@ __global__ __launch_bounds__(256) void cat3_ln_bwd_rep_kernel(const float* __res
 #pragma unroll
         for (int k = 0; k < KI; k++) {
             const long row = rbase + inx[k];
-            bv[k] = ld4(b + row * D + 4 * sl);
+            bv[k] = ld4s(b + row * D + 4 * sl);
 #pragma unroll
-            for (int t = 0; t < 3; t++) d[k][t] = ld4(dy + row * K + 4 * (t * D4 + sl));
+            for (int t = 0; t < 3; t++) d[k][t] = ld4s(dy + row * K + 4 * (t * D4 + sl));
             mu[k] = mean[row];
             rs[k] = rstd[row];
         }
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(256) void masked_max_fwd_kernel(const float* __rest
         const float* px = x + (r * L) * (long)D4 * 4 + 4 * q;
         for (int l = st; l < ed; l++) {
             const float mk = m[r * L + l];
-            float4 v = ld4(px + (long)l * D4 * 4);
+            float4 v = ld4s(px + (long)l * D4 * 4);
             const float off = (1.0f - mk) * STAGE_NEG;
             v = make_float4(v.x * mk + off, v.y * mk + off, v.z * mk + off, v.w * mk + off);
             if (v.x > best.x) { best.x = v.x; bi.x = l; }
