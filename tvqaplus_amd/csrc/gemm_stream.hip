@@ -614,6 +614,151 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_stream_kernel(const float* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Same patch layout, but every 32-column operand tile is loaded, gated and split by ONE wave and handed to the wave that
+// shares it through LDS: wave (pn, pk) prepares dY tile pk of its row patch (shared with wave (pn, 1 - pk)) and X tile pn
+// of its column patch (shared with wave (1 - pn, pk)).  Matrix-core and VALU time of a SIMD add (DESIGN.md finding 13),
+// and this kernel spent ~480 VALU cycles per step next to 768 MFMA cycles on work that was done twice: per wave and step
+// now 16 + 8 loads (was 32 + 16), 16 operand values to gate and split (was 32), plus 6 ds_write_b128 / 12 ds_read_b128 of
+// finished fragments (identical lane mapping on both sides) and one barrier.  Two exchange buffers: a wave that runs ahead
+// writes the buffer of step i + 1 only after everyone has passed the barrier of step i, i.e. finished reading step i - 1.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int GATE>
+__global__ __launch_bounds__(256, 2) void gemm_tn_share_kernel(const float* __restrict__ dY, const float* __restrict__ G,
+                                                               const float* __restrict__ X, float* __restrict__ part,
+                                                               float* __restrict__ part_b, long M, int N, int K,
+                                                               long rows_per_split) {
+    __shared__ uint4 ex[2][4][6][64];                     // [buffer][wave][3 dY planes, 3 X planes][lane]  (48 KB)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int pn = wave >> 1, pk = wave & 1;
+    const int n_base = blockIdx.x * 128 + pn * 64, k_base = blockIdx.y * 128 + pk * 64;
+    const int split = blockIdx.z;
+    const long mbeg = (long)split * rows_per_split;
+    const long mend = min(M, mbeg + rows_per_split);
+    const int NWN = (N + 31) >> 5;                        // mask words per row
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)dY, 0, (int)(M * N * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)(M * K * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(GATE != 0 ? G : dY), 0, GATE == 2 ? (int)(M * NWN * 4) : (int)(M * N * 4), 0x00020000);
+    // the dY column (tile pk of the patch) and the X column (tile pn of the patch) this lane prepares
+    const int n_mine = n_base + 32 * pk + l31, k_mine = k_base + 32 * pn + l31;
+    const bool nok = n_mine < N, kok = k_mine < K;
+    const int nc = nok ? n_mine : N - 1;
+    const int yoff = (8 * h * N + nc) * 4, xoff = (8 * h * K + (kok ? k_mine : K - 1)) * 4, gbit = nc & 31;
+    const int moff = (int)(((long)min((n_base >> 5) + pk, NWN - 1) * M + 8 * h) * 4);   // GATE 2: [word][row] mask
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    float bsum = 0.f;
+    float ya[2][8], xa[2][8], ga[GATE != 0 ? 2 : 1][8];
+    auto fetch = [&](int buf, long m0) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int sy = (int)((m0 + r) * N * 4), sx = (int)((m0 + r) * K * 4);   // wave-uniform row offsets (bytes)
+            ya[buf][r] = s_buf_load(ry, yoff, sy);
+            xa[buf][r] = s_buf_load(rx, xoff, sx);
+            if (GATE == 1) ga[buf][r] = s_buf_load(rg, yoff, sy);
+            if (GATE == 2) ga[buf][r] = s_buf_load(rg, moff, (int)((m0 + r) * 4));   // rows past the end read 0
+        }
+    };
+    const bool cols_in = nok && kok;
+    const bool want_b = part_b != nullptr && blockIdx.y == 0;   // every wave owns the bias sums of the dY tile it prepares
+    auto step = [&](int buf, long m0, int xb) {
+        const bool full = m0 + 16 <= mend;
+        const bool fast = full && __all(cols_in);
+        float yv[8], xv[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            float y = ya[buf][r];
+            if (GATE == 1) y = ga[buf][r] > 0.f ? y : 0.f;
+            if (GATE == 2) y = ((__float_as_uint(ga[buf][r]) >> gbit) & 1u) ? y : 0.f;
+            yv[r] = y;
+            xv[r] = xa[buf][r];
+        }
+        if (!fast) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const bool rok = full || (m0 + 8 * h + r < mend);   // rows of the next slab / past the end contribute 0
+                yv[r] = (rok && nok) ? yv[r] : 0.f;
+                xv[r] = (rok && kok) ? xv[r] : 0.f;
+            }
+        }
+        if (want_b) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) bsum += yv[r];
+        }
+        unsigned p[4][3], q[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            s_split3(yv[2 * i], yv[2 * i + 1], p[i]);
+            s_split3(xv[2 * i], xv[2 * i + 1], q[i]);
+        }
+#pragma unroll
+        for (int s = 0; s < 3; s++) {
+            ex[xb][wave][s][lane] = make_uint4(p[0][s], p[1][s], p[2][s], p[3][s]);
+            ex[xb][wave][3 + s][lane] = make_uint4(q[0][s], q[1][s], q[2][s], q[3][s]);
+        }
+        __syncthreads();
+        // dY tile t of this row patch was prepared by wave (pn, t), X tile t of this column patch by wave (t, pk); the own
+        // fragments are read back as well: a register array indexed by the wave's pk / pn would live in scratch
+        sbf16x8 a[2][3], b[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int s = 0; s < 3; s++) {
+                a[t][s] = __builtin_bit_cast(sbf16x8, ex[xb][pn * 2 + t][s][lane]);
+                b[t][s] = __builtin_bit_cast(sbf16x8, ex[xb][t * 2 + pk][3 + s][lane]);
+            }
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                // kept cross terms, smallest first
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+            }
+    };
+    // the loop bounds are workgroup-uniform (every wave of a workgroup walks the same slab), so the barriers match
+    if (mbeg < mend) {
+        fetch(0, mbeg);
+        for (long m0 = mbeg; m0 < mend; m0 += 32) {
+            if (m0 + 16 < mend) fetch(1, m0 + 16);
+            step(0, m0, 0);
+            if (m0 + 16 < mend) {
+                if (m0 + 32 < mend) fetch(0, m0 + 32);
+                step(1, m0 + 16, 1);
+            }
+        }
+    }
+    // C/D layout of the 32x32 MFMA: col = lane & 31 (k), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (n)
+    float* po = part + (size_t)split * N * K;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int k = k_base + 32 * j + l31;
+            if (k >= K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int n = n_base + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (n < N) po[(size_t)n * K + k] = acc[i][j][r];
+            }
+        }
+    if (want_b) {
+        const float s = xsum32(bsum, bsum);
+        if (h == 0 && nok) part_b[(size_t)split * N + n_mine] = s;
+    }
+}
+
 // same slab rule / workspace layout as stage_gemm_tn (gemm.hip); returns 1 if not handled here
 int stage_gemm_tn_stream(const float* dY, const void* gate, int gate_kind, const float* X, float* part, float* part_b,
                          long long M, int N, int K, int S, long rows_per_split, void* stream) {
@@ -622,9 +767,16 @@ int stage_gemm_tn_stream(const float* dY, const void* gate, int gate_kind, const
     if (!gate) gate_kind = 0;
     dim3 grid((N + 127) / 128, (K + 127) / 128, S);
     const float* G = (const float*)gate;
+    static const bool no_share = getenv("STAGE_GEMM_TN_NOSHARE") != nullptr;
 #define LAUNCH_TNS(GT)                                                                                                 \
-    hipLaunchKernelGGL(gemm_tn_stream_kernel<GT>, grid, dim3(256), 0, (hipStream_t)stream, dY, G, X, part, part_b, (long)M, \
-                       N, K, rows_per_split)
+    do {                                                                                                               \
+        if (no_share)                                                                                                  \
+            hipLaunchKernelGGL(gemm_tn_stream_kernel<GT>, grid, dim3(256), 0, (hipStream_t)stream, dY, G, X, part,      \
+                               part_b, (long)M, N, K, rows_per_split);                                                 \
+        else                                                                                                           \
+            hipLaunchKernelGGL(gemm_tn_share_kernel<GT>, grid, dim3(256), 0, (hipStream_t)stream, dY, G, X, part,       \
+                               part_b, (long)M, N, K, rows_per_split);                                                 \
+    } while (0)
     if (gate_kind == 2) LAUNCH_TNS(2);
     else if (gate_kind == 1) LAUNCH_TNS(1);
     else LAUNCH_TNS(0);
