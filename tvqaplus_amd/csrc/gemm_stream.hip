@@ -18,7 +18,8 @@
 #ifndef GEMM_ABL
 #define GEMM_ABL 0      // developer ablation bits (timing experiments only, results wrong): 1 one MFMA per column tile instead
 #endif                  // of 6, 2 no bf16 split (raw bits as operands), 4 X lines fetched once per wave, 8 no stores,
-                        // 16 weight fragments read from LDS for one of the four column tiles only
+                        // 16 weight fragments read from LDS for one of the four column tiles only; TN share kernel: 1, 2, 4 alike,
+                        // 32 no barrier
 #define SBN 128                 // output columns per workgroup
 #define SKC 128                 // k per resident weight chunk
 #define SWS (SKC + 8)           // bf16 per LDS row of a plane (272 B: 16-lane ds_read_b128 groups hit distinct slots)
@@ -656,7 +657,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_share_kernel(const float* __re
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     float bsum = 0.f;
     float ya[2][8], xa[2][8], ga[GATE != 0 ? 2 : 1][8];
+    bool abl_f[2] = {false, false};
     auto fetch = [&](int buf, long m0) {
+        if ((GEMM_ABL & 4) && abl_f[buf]) return;
+        abl_f[buf] = true;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int sy = (int)((m0 + r) * N * 4), sx = (int)((m0 + r) * K * 4);   // wave-uniform row offsets (bytes)
@@ -695,6 +699,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_share_kernel(const float* __re
         unsigned p[4][3], q[4][3];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
+            if (GEMM_ABL & 2) {
+                p[i][0] = __float_as_uint(yv[2 * i]); p[i][1] = __float_as_uint(yv[2 * i + 1]); p[i][2] = p[i][0] ^ p[i][1];
+                q[i][0] = __float_as_uint(xv[2 * i]); q[i][1] = __float_as_uint(xv[2 * i + 1]); q[i][2] = q[i][0] ^ q[i][1];
+                continue;
+            }
             s_split3(yv[2 * i], yv[2 * i + 1], p[i]);
             s_split3(xv[2 * i], xv[2 * i + 1], q[i]);
         }
@@ -703,7 +712,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_share_kernel(const float* __re
             ex[xb][wave][s][lane] = make_uint4(p[0][s], p[1][s], p[2][s], p[3][s]);
             ex[xb][wave][3 + s][lane] = make_uint4(q[0][s], q[1][s], q[2][s], q[3][s]);
         }
-        __syncthreads();
+        if (!(GEMM_ABL & 32)) __syncthreads();
         // dY tile t of this row patch was prepared by wave (pn, t), X tile t of this column patch by wave (t, pk); the own
         // fragments are read back as well: a register array indexed by the wave's pk / pn would live in scratch
         sbf16x8 a[2][3], b[2][3];
@@ -718,6 +727,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_share_kernel(const float* __re
         for (int i = 0; i < 2; i++)
 #pragma unroll
             for (int j = 0; j < 2; j++) {
+                if (GEMM_ABL & 1) {
+                    const sbf16x8 am = __builtin_bit_cast(sbf16x8, __builtin_bit_cast(uint4, a[i][0]) ^ __builtin_bit_cast(uint4, a[i][1]) ^ __builtin_bit_cast(uint4, a[i][2]));
+                    const sbf16x8 bm = __builtin_bit_cast(sbf16x8, __builtin_bit_cast(uint4, b[j][0]) ^ __builtin_bit_cast(uint4, b[j][1]) ^ __builtin_bit_cast(uint4, b[j][2]));
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[i][j], 0, 0, 0);
+                    continue;
+                }
                 // kept cross terms, smallest first
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
