@@ -161,7 +161,7 @@ int stage_gemm_nt_stream(const float* X, const void* gate, int gate_kind, const 
                          const float* residual, float* Y, unsigned* mask_out, long long M, int N, int K, int relu,
                          void* stream);
 int stage_gemm_tn_stream(const float* dY, const void* gate, int gate_kind, const float* X, float* part, float* part_b,
-                         long long M, int N, int K, int S, long rows_per_split, void* stream);
+                         long long M, int N, int K, int* S_io, long* rows_per_split_io, void* stream);
 static bool gemm_exact_f32() {
     static int mode = -1;
     if (mode < 0) mode = getenv("STAGE_GEMM_F32") ? 1 : 0;
@@ -318,18 +318,18 @@ extern "C" int stage_gemm_tn(const float* dY, const float* gate, const float* X,
         return 0;
     }
     if (ws_bytes < stage_gemm_tn_ws_bytes(M, N, K)) return STAGE_ERR_WORKSPACE;
-    const int S = tn_splits(M, N, K);
+    int S = tn_splits(M, N, K);
     long rps = (M + S - 1) / S;
     rps = (rps + BK - 1) / BK * BK;
     float* part = (float*)ws;
-    float* part_b = part + (size_t)S * N * K;
+    float* part_b = part + (size_t)S * N * K;   // fixed by the workspace slab count, even if fewer slabs get used
     const int vecY = (N % 4 == 0) && (((uintptr_t)dY & 15) == 0) && (!gate || ((uintptr_t)gate & 15) == 0);
     const int vecX = (K % 4 == 0) && (((uintptr_t)X & 15) == 0);
     dim3 grid((N + BM - 1) / BM, (K + BN - 1) / BN, S);
     static const bool tn_tiled = getenv("STAGE_GEMM_TN_TILED") != nullptr;   // developer switch
     int handled = 1;
     if (!gemm_exact_f32() && !tn_tiled)
-        handled = stage_gemm_tn_stream(dY, gate, gate ? 1 : 0, X, part, db ? part_b : (float*)nullptr, M, N, K, S, rps, stream);
+        handled = stage_gemm_tn_stream(dY, gate, gate ? 1 : 0, X, part, db ? part_b : (float*)nullptr, M, N, K, &S, &rps, stream);
     if (handled < 0 || handled > 1) return handled;
     if (handled == 0) {
     } else if (vecY && vecX && N >= 4 && K >= 4)
@@ -375,13 +375,13 @@ extern "C" int stage_gemm_tn_mask(const float* dY, const unsigned* gate_mask, co
     if (N <= 0 || K <= 0) return 0;
     if (M <= 0) return STAGE_ERR_SHAPE;
     if (ws_bytes < stage_gemm_tn_ws_bytes(M, N, K)) return STAGE_ERR_WORKSPACE;
-    const int S = tn_splits(M, N, K);
+    int S = tn_splits(M, N, K);
     long rps = (M + S - 1) / S;
     rps = (rps + BK - 1) / BK * BK;
     float* part = (float*)ws;
     float* part_b = part + (size_t)S * N * K;
-    const int rc = stage_gemm_tn_stream(dY, gate_mask, gate_mask ? 2 : 0, X, part, db ? part_b : (float*)nullptr, M, N, K, S,
-                                        rps, stream);
+    const int rc = stage_gemm_tn_stream(dY, gate_mask, gate_mask ? 2 : 0, X, part, db ? part_b : (float*)nullptr, M, N, K, &S,
+                                        &rps, stream);
     if (rc != 0) return rc == 1 ? STAGE_ERR_SHAPE : rc;
     const long C = (long)N * K;
     if (db) stage_colreduce2(part, dW, C, (int)C, part_b, db, (long)N, N, S, st);

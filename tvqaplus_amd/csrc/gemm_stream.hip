@@ -774,14 +774,202 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_share_kernel(const float* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Wide variant for K > 128: a workgroup of 8 waves (2 x 4) owns a 128 x 384 output tile, wave (pn, pk) the 64 x 96 patch
+// (2 x 3 MFMA tiles, 96 accumulator registers).  The 16 operand tiles of a 16-row step (4 of dY, 12 of X) are prepared
+// by the 8 waves, two each (wave w: units w and w + 8; units 0..3 = dY tiles), and exchanged through LDS as above.  Against
+// three 128 x 128 workgroups: dY is read (and gated, split) once instead of three times, and every wave issues 36 MFMAs
+// per 16 prepared operand values instead of 24.
+// ---------------------------------------------------------------------------------------------------------------------
+#define TW_NA 4         // dY tiles per workgroup
+#define TW_NB 12        // X tiles per workgroup
+#define TW_WAVES 8
+template <int GATE>
+__global__ __launch_bounds__(64 * TW_WAVES, 2) void gemm_tn_wide_kernel(const float* __restrict__ dY, const float* __restrict__ G,
+                                                                        const float* __restrict__ X, float* __restrict__ part,
+                                                                        float* __restrict__ part_b, long M, int N, int K,
+                                                                        long rows_per_split) {
+    extern __shared__ __attribute__((aligned(16))) uint4 exw[];   // [2 buffers][16 units][3 planes][64 lanes]  (96 KB)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int pn = wave >> 2, pk = wave & 3;
+    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 384;
+    const int split = blockIdx.z;
+    const long mbeg = (long)split * rows_per_split;
+    const long mend = min(M, mbeg + rows_per_split);
+    const int NWN = (N + 31) >> 5;                        // mask words per row
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)dY, 0, (int)(M * N * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)(M * K * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(GATE != 0 ? G : dY), 0, GATE == 2 ? (int)(M * NWN * 4) : (int)(M * N * 4), 0x00020000);
+    // the two operand tiles ("units") this wave prepares: unit 0 of waves 0..3 is a dY tile, everything else an X tile
+    const bool u0_is_y = wave < TW_NA;                    // wave-uniform
+    const int y_col = n0 + 32 * wave + l31;               // only meaningful when u0_is_y
+    const bool y_ok = u0_is_y && y_col < N;
+    const int ycl = y_col < N ? y_col : N - 1;
+    const int yoff = (8 * h * N + ycl) * 4, gbit = ycl & 31;
+    const int moff = (int)(((long)min((n0 >> 5) + wave, NWN - 1) * M + 8 * h) * 4);   // GATE 2: [word][row] mask
+    int xcol[2];
+    bool x_ok[2];
+    int xoff[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int bt = wave + TW_WAVES * u - TW_NA;       // X tile index of unit u (negative: unit 0 of a dY wave)
+        xcol[u] = k0 + 32 * (bt < 0 ? 0 : bt) + l31;
+        x_ok[u] = bt >= 0 && xcol[u] < K;
+        xoff[u] = (8 * h * K + (xcol[u] < K ? xcol[u] : K - 1)) * 4;
+    }
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    float bsum = 0.f;
+    float va[2][2][8], ga[GATE != 0 ? 2 : 1][8];          // [buffer][unit][row]
+    auto fetch = [&](int buf, long m0) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int sy = (int)((m0 + r) * N * 4), sx = (int)((m0 + r) * K * 4);   // wave-uniform row offsets (bytes)
+            // unit 0: one load through a wave-uniformly selected descriptor / offset (dY for waves 0..3, X otherwise); the
+            // gate is fetched by every wave (valid clamped address, ignored by the X waves): a conditionally defined
+            // register array ends up in scratch
+            va[buf][0][r] = s_buf_load(u0_is_y ? ry : rx, u0_is_y ? yoff : xoff[0], u0_is_y ? sy : sx);
+            if (GATE == 1) ga[buf][r] = s_buf_load(rg, yoff, sy);
+            if (GATE == 2) ga[buf][r] = s_buf_load(rg, moff, (int)((m0 + r) * 4));   // rows past the end read 0
+            va[buf][1][r] = s_buf_load(rx, xoff[1], sx);
+        }
+    };
+    const bool want_b = part_b != nullptr && blockIdx.y == 0 && u0_is_y;
+    const int u_mine[2] = {wave, wave + TW_WAVES};
+    auto step = [&](int buf, long m0, int xb) {
+        const bool full = m0 + 16 <= mend;
+        uint4* exb = exw + (size_t)xb * (TW_NA + TW_NB) * 3 * 64;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                float y = va[buf][u][r];
+                if (u == 0 && u0_is_y) {
+                    if (GATE == 1) y = ga[buf][r] > 0.f ? y : 0.f;
+                    if (GATE == 2) y = ((__float_as_uint(ga[buf][r]) >> gbit) & 1u) ? y : 0.f;
+                }
+                const bool rok = full || (m0 + 8 * h + r < mend);   // rows of the next slab / past the end contribute 0
+                const bool cok = (u == 0 && u0_is_y) ? y_ok : x_ok[u];
+                v[r] = (rok && cok) ? y : 0.f;
+            }
+            if (u == 0 && want_b) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) bsum += v[r];
+            }
+            unsigned p[4][3];
+#pragma unroll
+            for (int i = 0; i < 4; i++) s_split3(v[2 * i], v[2 * i + 1], p[i]);
+#pragma unroll
+            for (int s = 0; s < 3; s++) exb[(u_mine[u] * 3 + s) * 64 + lane] = make_uint4(p[0][s], p[1][s], p[2][s], p[3][s]);
+        }
+        __syncthreads();
+        sbf16x8 a[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int s = 0; s < 3; s++) a[t][s] = __builtin_bit_cast(sbf16x8, exb[((pn * 2 + t) * 3 + s) * 64 + lane]);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            sbf16x8 b[3];
+#pragma unroll
+            for (int s = 0; s < 3; s++) b[s] = __builtin_bit_cast(sbf16x8, exb[((TW_NA + pk * 3 + j) * 3 + s) * 64 + lane]);
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                // kept cross terms, smallest first
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+    if (mbeg < mend) {   // workgroup-uniform bounds: the barriers match
+        fetch(0, mbeg);
+        for (long m0 = mbeg; m0 < mend; m0 += 32) {
+            if (m0 + 16 < mend) fetch(1, m0 + 16);
+            step(0, m0, 0);
+            if (m0 + 16 < mend) {
+                if (m0 + 32 < mend) fetch(0, m0 + 32);
+                step(1, m0 + 16, 1);
+            }
+        }
+    }
+    // C/D layout of the 32x32 MFMA: col = lane & 31 (k), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (n)
+    float* po = part + (size_t)split * N * K;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int k = k0 + 32 * (pk * 3 + j) + l31;
+            if (k >= K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int n = n0 + 32 * (pn * 2 + i) + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (n < N) po[(size_t)n * K + k] = acc[i][j][r];
+            }
+        }
+    if (want_b) {
+        const float s = xsum32(bsum, bsum);
+        if (h == 0 && y_ok) part_b[(size_t)split * N + y_col] = s;
+    }
+}
+
 // same slab rule / workspace layout as stage_gemm_tn (gemm.hip); returns 1 if not handled here
 int stage_gemm_tn_stream(const float* dY, const void* gate, int gate_kind, const float* X, float* part, float* part_b,
-                         long long M, int N, int K, int S, long rows_per_split, void* stream) {
+                         long long M, int N, int K, int* S_io, long* rows_per_split_io, void* stream) {
     // buffer addressing: every operand must be smaller than 2 GiB
     if (M < 4096 || M * (long long)N * 4 >= (1ll << 31) || M * (long long)K * 4 >= (1ll << 31)) return 1;
     if (!gate) gate_kind = 0;
-    dim3 grid((N + 127) / 128, (K + 127) / 128, S);
     const float* G = (const float*)gate;
+    int S = *S_io;
+    long rows_per_split = *rows_per_split_io;
+    static const bool no_wide = getenv("STAGE_GEMM_TN_NOWIDE") != nullptr;
+    static const bool no_share_w = getenv("STAGE_GEMM_TN_NOSHARE") != nullptr;
+    if (K > 128 && !no_wide && !no_share_w) {
+        // 128 x 384 tiles, one 8-wave workgroup per CU: as many slabs as give whole rounds of 256 workgroups (never more
+        // than the workspace was sized for)
+        const int wps = ((N + 127) / 128) * ((K + 383) / 384);
+        int sw = 256 / wps;
+        if (sw < 1) sw = 1;
+        if (2 * sw <= S) sw *= 2;
+        if (sw > S) sw = S;
+        long rps = (M + sw - 1) / sw;
+        rps = (rps + 15) / 16 * 16;
+        sw = (int)((M + rps - 1) / rps);
+        S = sw;
+        rows_per_split = rps;
+        *S_io = S;
+        *rows_per_split_io = rps;
+        const int lds = 2 * (TW_NA + TW_NB) * 3 * 64 * (int)sizeof(uint4);
+        dim3 gridw((N + 127) / 128, (K + 383) / 384, S);
+#define LAUNCH_TNW(GT)                                                                                                 \
+    do {                                                                                                               \
+        static bool attr_done = false;                                                                                 \
+        if (!attr_done) {                                                                                              \
+            (void)hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<GT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            attr_done = true;                                                                                          \
+        }                                                                                                              \
+        hipLaunchKernelGGL(gemm_tn_wide_kernel<GT>, gridw, dim3(64 * TW_WAVES), lds, (hipStream_t)stream, dY, G, X, part, \
+                           part_b, (long)M, N, K, rows_per_split);                                                     \
+    } while (0)
+        if (gate_kind == 2) LAUNCH_TNW(2);
+        else if (gate_kind == 1) LAUNCH_TNW(1);
+        else LAUNCH_TNW(0);
+#undef LAUNCH_TNW
+        STAGE_LAUNCH_CHECK();
+        return 0;
+    }
+    dim3 grid((N + 127) / 128, (K + 127) / 128, S);
     static const bool no_share = getenv("STAGE_GEMM_TN_NOSHARE") != nullptr;
 #define LAUNCH_TNS(GT)                                                                                                 \
     do {                                                                                                               \
