@@ -27,3 +27,11 @@ torch.cuda.synchronize()
 t = [s.elapsed_time(e) * 1e3 for s, e in ev]
 print(" ".join("%.0f" % x for x in t))
 print("avg %.1f min %.1f max %.1f" % (sum(t) / len(t), min(t), max(t)))
+if os.environ.get("TIM"):     # phase cycle counters of the LDS-staged kernel (STAGE_K1_TIM): sum over waves
+    tim = torch.zeros(6, dtype=torch.int64, device=dev)
+    os.environ["STAGE_K1_TIM"] = str(tim.data_ptr())
+    launch(); torch.cuda.synchronize()
+    del os.environ["STAGE_K1_TIM"]
+    v = tim.cpu().tolist(); tot = float(sum(v))
+    names = ["stage frame", "wait Cn", "stage 1", "softmax + S stores", "stage 2 + A stores", "ticket / loop"]
+    print(" | ".join("%s %.1f%%" % (n, 100 * x / tot) for n, x in zip(names, v)), "| total wave-cycles %.3g" % tot)
