@@ -46,7 +46,10 @@ __device__ __forceinline__ int dchunk(int g, int m) {
     return m + NCH * (g >> 1) + 2 * NCH * (g & 1);
 }
 
-template <int RT, int KL, bool PERM, bool TRAIN, bool VEC_S>
+// WGF = true (3-4 region tiles): ONE copy of the frame per 4-wave workgroup instead of one per wave -- the frame is staged
+// cooperatively (a quarter of the work per wave), the waves take the context tiles round-robin, and the 27 KB copy no
+// longer limits the CU to 5 waves (8 fit their registers).  Items are whole frames handed out per workgroup.
+template <int RT, int KL, bool PERM, bool TRAIN, bool VEC_S, bool WGF>
 __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
     const float* __restrict__ Cn, const float* __restrict__ Q, const float* __restrict__ cmask,
     const float* __restrict__ qmask, float* __restrict__ A, float* __restrict__ S, float* __restrict__ Sn, int N,
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
     const int WB = (Lr + 1) * LDQ + 2 * RT * 16 + tiles_per_slice * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int c15 = lane & 15, g = lane >> 4;
-    float* Qr = lds + wave * WB;
+    float* Qr = lds + (WGF ? 0 : wave * WB);        // WGF: shared by the workgroup (the host sizes it for all CT tiles)
     float* rinv = Qr + (Lr + 1) * LDQ;
     float* qm = rinv + RT * 16;
     float* cms = qm + RT * 16;
@@ -96,23 +99,36 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
             Rrow[rt][k] = (Rk[rt][k] < Lr ? Rk[rt][k] : Lr) * LDQ;
         }
 
-    const long n_items = (long)N * Li * slices;
+    const long n_items = WGF ? (long)N * Li : (long)N * Li * slices;
     const long n_waves = (long)gridDim.x * wpb;
-    // dynamic distribution: every wave starts on its own item, then draws tickets (one relaxed atomic per item), so the
-    // last items are picked up by whichever wave is free -- a static stride leaves 4800 items / 2048 waves at 78 %
-    long item = (long)blockIdx.x * wpb + wave;
-    for (; item < n_items; item = n_waves + (long)__builtin_amdgcn_readfirstlane(
-                                lane == 0 ? (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0)) {
-        const long frame = item / slices;           // n*Li + i
-        const int slice = (int)(item % slices);
+    volatile int* const wg_flag = reinterpret_cast<volatile int*>(cms + (WGF ? CT * 16 : 0));   // WGF: [any valid region, next item lo, hi]
+    // dynamic distribution: every wave (WGF: workgroup) starts on its own item, then draws tickets (one relaxed atomic per
+    // item), so the last items are picked up by whoever is free -- a static stride leaves 4800 items / 2048 waves at 78 %
+    long item = WGF ? (long)blockIdx.x : (long)blockIdx.x * wpb + wave;
+    while (item < n_items) {
+        long next_item = 0;
+        if (WGF) {
+            __syncthreads();                          // everyone is done with the previous frame's copy
+            if (threadIdx.x == 0) {
+                const unsigned drawn = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                wg_flag[0] = 0;
+                wg_flag[1] = (int)drawn;
+            }
+            __syncthreads();
+        } else {
+            next_item = n_waves + (long)__builtin_amdgcn_readfirstlane(
+                            lane == 0 ? (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0);
+        }
+        const long frame = WGF ? item : item / slices;           // n*Li + i
+        const int slice = WGF ? 0 : (int)(item % slices);
         const int n = (int)(frame / Li), i = (int)(frame % Li);
-        const int tile0 = slice * tiles_per_slice;
-        const int tile1 = min(CT, tile0 + tiles_per_slice);
+        const int tile0 = WGF ? 0 : slice * tiles_per_slice;
+        const int tile1 = WGF ? CT : min(CT, tile0 + tiles_per_slice);
 
         TICK(5);
         // ---- stage the frame: raw rows -> LDS, 1/|row| (x * (1/n) instead of x / n: 1 ulp), region mask ----
         unsigned long long anyb = 0ull;
-        for (int r0 = 0; r0 < Lr; r0 += 16) {  // 16 rows per batch: all loads of a batch are in flight together
+        for (int r0 = WGF ? 16 * wave : 0; r0 < Lr; r0 += WGF ? 16 * 4 : 16) {  // 16 rows per batch: all loads of a batch are in flight together
             float4 v[8];
             float pmv[8];
 #pragma unroll
@@ -135,15 +151,23 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
         }
         // context mask of this slice -> LDS (rows past the end alias the last valid row); keeps the tile loop free of
         // compiler-tracked global loads (each would force an s_waitcnt that also drains the stores in flight)
-        for (int j = lane; j < (tile1 - tile0) * 16; j += 64) cms[j] = cmask[(long)n * CR + min(tile0 * 16 + j, CR - 1)];
+        for (int j = WGF ? (int)threadIdx.x : lane; j < (tile1 - tile0) * 16; j += WGF ? 256 : 64)
+            cms[j] = cmask[(long)n * CR + min(tile0 * 16 + j, CR - 1)];
+        if (WGF) {
+            if (anyb != 0ull && lane == 0) wg_flag[0] = 1;
+            __syncthreads();                          // the frame copy, rinv / qm, the context mask and the flag are complete
+            anyb = wg_flag[0] ? 1ull : 0ull;
+            next_item = (long)gridDim.x + (long)(unsigned)wg_flag[1];
+        }
         if (anyb == 0ull) {
             // no valid region in this frame: S = -1e10 (cos - 1e10 rounds to -1e10), S_ = 0, A = 0 for the whole slice
             const int c_lo = tile0 * 16, c_hi = min(CR, tile1 * 16);
-            for (int c = c_lo + (lane >> 5); c < c_hi; c += 2) {
+            for (int c = c_lo + (lane >> 5) + (WGF ? 2 * wave : 0); c < c_hi; c += WGF ? 8 : 2) {
                 const long orow = ((long)(n * NA + c / Lqa) * Li + i) * Lqa + c % Lqa;
                 st4(A + orow * DD + 4 * sq, f4zero());
                 for (int r = sq; r < Lr; r += 32) { S[orow * Lr + r] = STAGE_NEG; Sn[orow * Lr + r] = 0.f; }
             }
+            item = next_item;
             continue;
         }
         TICK(0);
@@ -335,6 +359,20 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
                          : "memory");                                                                                \
     } while (0)
         f32x4 cf[NU][NCH];
+        if (WGF) {   // NU == 1: this wave's tiles are wave, wave + 4, ...
+            if (wave < tile1) {
+                issue_cf(cf[0], wave);
+                WAIT_CF(0);
+                TICK(1);
+                for (int t = wave; t < tile1; t += 4) {
+                    const bool more = t + 4 < tile1;
+                    do_pair(cf, t, t, more, t + 4, t + 4);
+                    TICK(4);
+                    if (more) WAIT_CF(NST);
+                    TICK(1);
+                }
+            }
+        } else {
         issue_cf(cf[0], tile0);
         if (NU == 2) issue_cf(cf[NU - 1], min(tile0 + 1, tile1 - 1));
         WAIT_CF(0);
@@ -347,6 +385,8 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
             if (more) WAIT_CF(NST);  // only this pair's stores may still be in flight
             TICK(1);
         }
+        }
+        item = next_item;
 #undef WAIT_CF
     }
     if (tim && lane == 0) for (int ph = 0; ph < 6; ph++) atomicAdd(tim + ph, tacc[ph]);
@@ -375,6 +415,28 @@ static int launch_d128_t(const float* Cn, const float* Q, const float* cm, const
     else while (slices < 4 && (long)N * Li * slices < 8192 && CT / (slices + 1) >= 3) slices++;
     const int tps = (CT + slices - 1) / slices;
     slices = (CT + tps - 1) / tps;
+    uint32_t th = TRAIN ? drop_thresh16(p_drop) : 0u;
+    if (TRAIN && th == 0u) th = 1u;
+    const float ik = TRAIN ? 1.0f / (1.0f - p_drop) : 1.0f;
+    unsigned int* ticket = next_ticket(st);
+    if (!ticket) return (int)hipErrorOutOfMemory;
+    unsigned long long* tim = (unsigned long long*)(getenv("STAGE_K1_TIM") ? strtoull(getenv("STAGE_K1_TIM"), 0, 0) : 0ull);
+    static const bool no_wgf = getenv("STAGE_K1_NO_WGF") != nullptr;
+    if constexpr (RT >= 3) if (!no_wgf) {
+        // one frame copy per 4-wave workgroup (kernel comment); two workgroups per CU by registers
+        const size_t lds = ((size_t)(Lr + 1) * LDQ + 2 * RT * 16 + (size_t)CT * 16 + 4) * sizeof(float);
+        auto kern = str_attn_fwd_d128_kernel<RT, KL, PERM, TRAIN, VEC_S, true>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        long wg_per_cu = (long)((160 * 1024) / ((lds + 511) / 512 * 512));
+        if (wg_per_cu > 2) wg_per_cu = 2;
+        if (wg_per_cu < 1) wg_per_cu = 1;
+        long blocks = 256 * wg_per_cu;
+        if (blocks > (long)N * Li) blocks = (long)N * Li;
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, 1,
+                           CT, (uint64_t)seed, th, ik, ticket, tim);
+        STAGE_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t wave_bytes = ((size_t)(Lr + 1) * LDQ + 2 * RT * 16 + (size_t)tps * 16) * sizeof(float);
     // waves per workgroup: the grouping that lets the most waves share a CU's 160 KB of LDS (Lr = 50: 27.9 KB per wave,
     // 5 one-wave workgroups fit where 2 two-wave ones would); ties go to the larger workgroup
@@ -387,7 +449,7 @@ static int launch_d128_t(const float* Cn, const float* Q, const float* cm, const
     }
     if (getenv("STAGE_K1_WPB")) wpb = atoi(getenv("STAGE_K1_WPB"));
     const size_t lds = wpb * wave_bytes;
-    auto kern = str_attn_fwd_d128_kernel<RT, KL, PERM, TRAIN, VEC_S>;
+    auto kern = str_attn_fwd_d128_kernel<RT, KL, PERM, TRAIN, VEC_S, false>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const long items = (long)N * Li * slices;
     int waves_per_cu = best > 0 ? best : 1;
@@ -395,13 +457,8 @@ static int launch_d128_t(const float* Cn, const float* Q, const float* cm, const
     if (waves_per_cu < 1) waves_per_cu = 1;
     long blocks = (256L * waves_per_cu + wpb - 1) / wpb;         // one resident round of waves; they stride the items
     if (blocks * wpb > items) blocks = (items + wpb - 1) / wpb;
-    uint32_t th = TRAIN ? drop_thresh16(p_drop) : 0u;
-    if (TRAIN && th == 0u) th = 1u;
-    const float ik = TRAIN ? 1.0f / (1.0f - p_drop) : 1.0f;
-    unsigned int* ticket = next_ticket(st);
-    if (!ticket) return (int)hipErrorOutOfMemory;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * wpb), lds, st, Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr,
-                       scale, slices, tps, (uint64_t)seed, th, ik, ticket, (unsigned long long*)(getenv("STAGE_K1_TIM") ? strtoull(getenv("STAGE_K1_TIM"), 0, 0) : 0ull));
+                       scale, slices, tps, (uint64_t)seed, th, ik, ticket, tim);
     STAGE_LAUNCH_CHECK();
     return 0;
 }
