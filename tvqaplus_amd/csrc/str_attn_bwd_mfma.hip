@@ -14,7 +14,10 @@
 // ---------------------------------------------------------------------------------------------------------------
 // dQraw / dQn: one wave per (frame, 64-wide d block).  RT = region tiles (Lr <= 16*RT).
 // ---------------------------------------------------------------------------------------------------------------
-template <int RT>
+// T4: the last region tile holds <= 4 regions (Lr = 20, 50): its 8 MFMAs per k-step run as v_mfma_f32_4x4x1 blocks (8 cycles
+// instead of 32; block (c15 >> 2, g) = 4 regions x 4 output columns x the context row of lane group g) and the four
+// partial sums per output are folded ONCE per item by the transpose-reduce of common.h (lane group g keeps region g).
+template <int RT, bool T4>
 __global__ __launch_bounds__(256) void str_attn_bwd_dq_mfma_kernel(const float* __restrict__ dA, const float* __restrict__ Sn,
                                                                    const float* __restrict__ dS, const float* __restrict__ Cn,
                                                                    float* __restrict__ dQraw, float* __restrict__ dQn,
@@ -39,31 +42,65 @@ __global__ __launch_bounds__(256) void str_attn_bwd_dq_mfma_kernel(const float* 
         for (int c0 = 0; c0 < CR; c0 += 4) {
             const int c = c0 + g;
             const bool ok = c < CR;
-            const long orow = ((long)(n * NA + a) * Li + i) * Lqa + w;
+            // clamped addresses, all loads issued back to back, validity applied by selects afterwards: a guarded load
+            // (`ok ? load : 0`) is an exec-masked branch with its own wait -- the loads of a k-step would serialise
+            const int cc = ok ? c : CR - 1;
+            const long orow = ok ? ((long)(n * NA + a) * Li + i) * Lqa + w : ((long)(n * NA + NA - 1) * Li + i) * Lqa + Lqa - 1;
             float p[RT], gs[RT];
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
-                const int r = rt * 16 + c15;
-                const bool rok = ok && r < Lr;
-                p[rt] = rok ? Sn[orow * Lr + r] : 0.f;
-                gs[rt] = rok ? dS[orow * Lr + r] : 0.f;
+                const int r = (T4 && rt == RT - 1) ? rt * 16 + (c15 & 3) : rt * 16 + c15;
+                const int rc = r < Lr ? r : Lr - 1;
+                p[rt] = Sn[orow * Lr + rc];
+                gs[rt] = dS[orow * Lr + rc];
             }
-            const float4 da = ok ? ld4(dA + orow * D + 64 * b + 4 * c15) : f4zero();
-            const float4 cn = ok ? ld4(Cn + ((long)n * CR + c) * D + 64 * b + 4 * c15) : f4zero();
+            float4 da = ld4(dA + orow * D + 64 * b + 4 * c15);
+            float4 cn = ld4(Cn + ((long)n * CR + cc) * D + 64 * b + 4 * c15);
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                const int r = (T4 && rt == RT - 1) ? rt * 16 + (c15 & 3) : rt * 16 + c15;
+                const bool rok = ok && r < Lr;
+                p[rt] = rok ? p[rt] : 0.f;
+                gs[rt] = rok ? gs[rt] : 0.f;
+            }
+            if (!ok) da = cn = f4zero();
             const float dav[4] = {da.x, da.y, da.z, da.w}, cnv[4] = {cn.x, cn.y, cn.z, cn.w};
 #pragma unroll
             for (int rt = 0; rt < RT; rt++)
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    ar[rt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[rt], dav[e], ar[rt][e], 0, 0, 0);
-                    an[rt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(gs[rt], cnv[e], an[rt][e], 0, 0, 0);
+                    if (T4 && rt == RT - 1) {
+                        ar[rt][e] = __builtin_amdgcn_mfma_f32_4x4x1f32(p[rt], dav[e], ar[rt][e], 0, 0, 0);
+                        an[rt][e] = __builtin_amdgcn_mfma_f32_4x4x1f32(gs[rt], cnv[e], an[rt][e], 0, 0, 0);
+                    } else {
+                        ar[rt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[rt], dav[e], ar[rt][e], 0, 0, 0);
+                        an[rt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(gs[rt], cnv[e], an[rt][e], 0, 0, 0);
+                    }
                 }
             w += 4;
             while (w >= Lqa) { w -= Lqa; a++; }
         }
+        if (T4) {
+            // register i of a 4x4 block = region base + i, summed over this lane group's context rows only: fold the four
+            // groups, lane group g keeps region base + g (column c15 as in the 16x16 layout)
+            const int r = (RT - 1) * 16 + g;
+            float4 qr, qn;
+            float* qrv = &qr.x;
+            float* qnv = &qn.x;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                qrv[e] = xsum32(xsum16(ar[RT - 1][e][0], ar[RT - 1][e][1]), xsum16(ar[RT - 1][e][2], ar[RT - 1][e][3]));
+                qnv[e] = xsum32(xsum16(an[RT - 1][e][0], an[RT - 1][e][1]), xsum16(an[RT - 1][e][2], an[RT - 1][e][3]));
+            }
+            if (r < Lr) {
+                const long off = (frame * Lr + r) * D + 64 * b + 4 * c15;
+                st4(dQraw + off, qr);
+                st4(dQn + off, qn);
+            }
+        }
         // C layout: row i = 4g + reg (region), col j = c15 (-> d = 64b + 4 c15 + e)
 #pragma unroll
-        for (int rt = 0; rt < RT; rt++)
+        for (int rt = 0; rt < (T4 ? RT - 1 : RT); rt++)
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
                 const int r = rt * 16 + 4 * g + reg;
@@ -173,12 +210,16 @@ int stage_str_attn_bwd_dq_mfma(const float* dA, const float* Sn, const float* dS
     long blocks = (items + 3) / 4;
     if (blocks > 768) blocks = 768;   // ~3 workgroups of 4 waves per CU, waves stride the items
     const dim3 grid((unsigned)blocks), block(256);
-    switch ((Lr + 15) / 16) {
-        case 1: hipLaunchKernelGGL((str_attn_bwd_dq_mfma_kernel<1>), grid, block, 0, st, dA, Sn, dS, Cn, dQraw, dQn, N, NA, Li, Lqa, Lr, D); break;
-        case 2: hipLaunchKernelGGL((str_attn_bwd_dq_mfma_kernel<2>), grid, block, 0, st, dA, Sn, dS, Cn, dQraw, dQn, N, NA, Li, Lqa, Lr, D); break;
-        case 3: hipLaunchKernelGGL((str_attn_bwd_dq_mfma_kernel<3>), grid, block, 0, st, dA, Sn, dS, Cn, dQraw, dQn, N, NA, Li, Lqa, Lr, D); break;
-        default: hipLaunchKernelGGL((str_attn_bwd_dq_mfma_kernel<4>), grid, block, 0, st, dA, Sn, dS, Cn, dQraw, dQn, N, NA, Li, Lqa, Lr, D); break;
+    const int rt = (Lr + 15) / 16;
+    const bool t4 = Lr - 16 * (rt - 1) <= 4 && !getenv("STAGE_K1_DQ_NO_T4");
+#define LAUNCH_DQ(R, T) hipLaunchKernelGGL((str_attn_bwd_dq_mfma_kernel<R, T>), grid, block, 0, st, dA, Sn, dS, Cn, dQraw, dQn, N, NA, Li, Lqa, Lr, D)
+    switch (rt) {
+        case 1: if (t4) LAUNCH_DQ(1, true); else LAUNCH_DQ(1, false); break;
+        case 2: if (t4) LAUNCH_DQ(2, true); else LAUNCH_DQ(2, false); break;
+        case 3: if (t4) LAUNCH_DQ(3, true); else LAUNCH_DQ(3, false); break;
+        default: if (t4) LAUNCH_DQ(4, true); else LAUNCH_DQ(4, false); break;
     }
+#undef LAUNCH_DQ
     STAGE_LAUNCH_CHECK();
     return 0;
 }
