@@ -910,15 +910,29 @@ __global__ __launch_bounds__(256) void masked_max_fwd_kernel(const float* __rest
         float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         int4 bi = make_int4(-1, -1, -1, -1);
         const float* px = x + (r * L) * (long)D4 * 4 + 4 * q;
-        for (int l = st; l < ed; l++) {
-            const float mk = m[r * L + l];
-            float4 v = ld4s(px + (long)l * D4 * 4);
-            const float off = (1.0f - mk) * STAGE_NEG;
-            v = make_float4(v.x * mk + off, v.y * mk + off, v.z * mk + off, v.w * mk + off);
-            if (v.x > best.x) { best.x = v.x; bi.x = l; }
-            if (v.y > best.y) { best.y = v.y; bi.y = l; }
-            if (v.z > best.z) { best.z = v.z; bi.z = l; }
-            if (v.w > best.w) { best.w = v.w; bi.w = l; }
+        // 8 positions per step, all 16 loads issued before the first compare (clamped addresses; a one-position loop keeps
+        // a single load in flight per lane); strict > in ascending order keeps the first maximum, as torch.max does
+        for (int l0 = st; l0 < ed; l0 += 8) {
+            float4 v[8];
+            float mk[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int l = min(l0 + u, ed - 1);
+                v[u] = ld4s(px + (long)l * D4 * 4);
+                mk[u] = m[r * L + l];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int l = l0 + u;
+                if (l < ed) {
+                    const float off = (1.0f - mk[u]) * STAGE_NEG;
+                    const float4 w = make_float4(v[u].x * mk[u] + off, v[u].y * mk[u] + off, v[u].z * mk[u] + off, v[u].w * mk[u] + off);
+                    if (w.x > best.x) { best.x = w.x; bi.x = l; }
+                    if (w.y > best.y) { best.y = w.y; bi.y = l; }
+                    if (w.z > best.z) { best.z = w.z; bi.z = l; }
+                    if (w.w > best.w) { best.w = w.w; bi.w = l; }
+                }
+            }
         }
         st4(out + e * 4, best);
         *reinterpret_cast<int4*>(idx + e * 4) = bi;
