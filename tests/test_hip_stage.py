@@ -207,3 +207,48 @@ def test_full_size_batch_split_invariance(hip_device):
     for a, b0, b1 in zip(g_f, halves[0][3], halves[1][3]):
         worst = max(worst, rel_err(b0 + b1, a))
     assert worst < GTOL, "summed half-batch gradients differ from the full batch: %.3e" % worst
+
+
+def test_full_length_example_vs_oracle(hip_device):
+    """One example at BASELINE.json's full sequence shapes (300 frames x 20 regions / 50 subtitle words, 40 QA words,
+    hsz=128, add_local, default 768 / 300 feature widths) against the CPU oracle (fp64) with the same parameters: logits,
+    temporal scores, loss, the four attention maps, and every parameter gradient of the training loss (dropout 0).
+    This is the direct comparison at the sizes the production kernels were specialised for (streaming / wide GEMMs with
+    M = 60000, register-resident and workgroup-staged K1, fused LayerNorm->dwconv, broadcast-reduced cat3 LayerNorm)."""
+    from tvqaplus_amd.stage import STAGE
+    from tvqaplus_amd.synth import make_batch, make_opt
+    torch.manual_seed(2018)
+    opt = make_opt(hsz=128, add_local=True, dropout=0.0)
+    model = STAGE(opt)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    batch = make_batch(N=1, Li=300, Lr=20, Lw=50, Lqa=40, seed=4)
+    # fp64 oracle: fp32 gradients of this graph are ill-conditioned (DESIGN.md section 2), fp64 is the yardstick
+    P = {k: (v.double().requires_grad_(not k.endswith(".pe")) if v.is_floating_point() else v.clone())
+         for k, v in model.state_dict().items()}
+    b64 = type(batch)({k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in batch.items()})
+    ref = O.stage_forward(P, opt, b64, training=True)
+    ref_loss = O.training_loss(ref, n_examples=1)
+    ref_loss.backward()
+    model = model.to(hip_device).train()
+    (out, targets), _, _, t_loss, t_scores, other = model.forward_main(batch.to(hip_device))
+    assert torch.equal(targets.cpu(), ref["targets"])
+    loss = F.cross_entropy(out, targets, reduction="sum") * (1 / len(targets)) + 0.5 * t_loss
+    loss.backward()
+    assert rel_err(out, ref["logits"]) < 1e-3
+    assert rel_err(t_scores, ref["t_scores"]) < 1e-3
+    assert rel_err(loss, ref_loss) < 1e-3
+    for k in ("sub_raw_s", "sub_normalized_s", "vid_raw_s", "vid_normalized_s"):
+        assert rel_err(other[k], ref[k]) < 1e-3, k
+    worst = ("", 0.0)
+    for k, p in model.named_parameters():
+        g = P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        e = rel_err(got, g)
+        if e > worst[1]:
+            worst = (k, e)
+    # 1e-2: with 300 frames the masked maxima see near-ties, and ONE arg-max that flips under a 1e-6 perturbation reroutes a
+    # whole gradient row (seeds 1..4 give 2e-4 .. 7e-3 for this build AND for its tiled-GEMM variant, in no fixed order;
+    # every GEMM product of this step is within 3e-7 of fp64 given its inputs: tools/debug_linear_bwd.py)
+    assert worst[1] < 1e-2, "grad %s rel err %.3e" % worst

@@ -395,6 +395,15 @@ int stage_gemm_nt_stream(const float* X, const void* gate, int gate_kind, const 
                          const float* residual, float* Y, unsigned* mask_out, long long M, int N, int K, int relu,
                          void* stream) {
     if (!gate) gate_kind = 0;
+    {   // developer bisect switch: STAGE_GEMM_STREAM_SKIP="n384" / "k300" / "g2" (gate kind) / "r" (residual) / "m" (mask out)
+        static const char* skip = getenv("STAGE_GEMM_STREAM_SKIP");
+        if (skip) {
+            const int v = atoi(skip + 1);
+            if ((skip[0] == 'n' && v == N) || (skip[0] == 'k' && v == K) || (skip[0] == 'g' && v == gate_kind) ||
+                (skip[0] == 'r' && residual) || (skip[0] == 'm' && mask_out))
+                return 1;
+        }
+    }
     const bool vec = (K % 4 == 0) && K >= 4 && (((uintptr_t)X & 15) == 0) && (((uintptr_t)W & 15) == 0) &&
                      (gate_kind != 1 || ((uintptr_t)gate & 15) == 0);
     if (!vec || M < 4096 || K < 64 || M * (long long)K * 4 >= (1ll << 31)) return 1;   // buffer addressing: < 2 GiB
