@@ -85,6 +85,28 @@ __device__ __forceinline__ float cross_row_sum(float v) {
 }
 __device__ __forceinline__ float cross_row_max(float v) { return xmax32(xmax16(v)); }
 
+// Ticket counters for dynamically distributed kernels WITHOUT a per-launch reset: a device-resident ring of 64 words that
+// only ever count up.  The host knows exactly how many tickets a launch draws (every processed item past the static rounds
+// draws one), so it hands the kernel the value its word will have when the launch starts (`base`, kernels use drawn - base in
+// unsigned arithmetic) and adds the draw count afterwards.  A stream-ordered 4-byte memset per launch cost ~9 us of the K1
+// forward's event-timed duration (launch gap + a second tiny kernel).  Launches are issued by one host thread; the ring only
+// guards against a handful of launches being in flight on different streams.
+struct StageTicket { unsigned int* word; unsigned int base; };
+static inline StageTicket stage_next_ticket(unsigned int draws) {
+    static unsigned int* ring = nullptr;
+    static unsigned int bases[64];
+    static unsigned int slot = 0;
+    if (!ring) {
+        if (hipMalloc((void**)&ring, 64 * sizeof(unsigned int)) != hipSuccess) return {nullptr, 0u};
+        if (hipMemset(ring, 0, 64 * sizeof(unsigned int)) != hipSuccess) return {nullptr, 0u};
+        for (int i = 0; i < 64; i++) bases[i] = 0u;
+    }
+    const unsigned int sl = slot++ & 63u;
+    StageTicket t = {ring + sl, bases[sl]};
+    bases[sl] += draws;
+    return t;
+}
+
 // Counter-based dropout: one 64-bit SplitMix hash per group of 4 consecutive elements, 16 bits per element.
 // keep(element) <=> its 16-bit field >= thresh16, thresh16 = round(p * 65536).  The same (seed, index) pair
 // regenerates the identical mask in the backward kernels, so no mask tensor is ever stored.

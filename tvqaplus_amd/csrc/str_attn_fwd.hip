@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
     const float* __restrict__ Cn, const float* __restrict__ Q, const float* __restrict__ cmask,
     const float* __restrict__ qmask, float* __restrict__ A, float* __restrict__ S, float* __restrict__ Sn, int N,
     int NA, int Li, int Lqa, int Lr, float scale, int slices, int tiles_per_slice, uint64_t seed, uint32_t th,
-    float inv_keep, unsigned int* __restrict__ ticket, unsigned long long* __restrict__ tim) {
+    float inv_keep, unsigned int* __restrict__ ticket, unsigned int ticket_base, unsigned long long* __restrict__ tim) {
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = tim ? __builtin_readcyclecounter() : 0;
 #define TICK(ph) do { if (tim) { unsigned long long tn = __builtin_readcyclecounter(); tacc[ph] += tn - tlast; tlast = tn; } } while (0)
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -110,14 +110,14 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
         if (WGF) {
             __syncthreads();                          // everyone is done with the previous frame's copy
             if (threadIdx.x == 0) {
-                const unsigned drawn = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned drawn = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_base;
                 wg_flag[0] = 0;
                 wg_flag[1] = (int)drawn;
             }
             __syncthreads();
         } else {
-            next_item = n_waves + (long)__builtin_amdgcn_readfirstlane(
-                            lane == 0 ? (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0);
+            next_item = n_waves + (long)(unsigned)__builtin_amdgcn_readfirstlane(
+                            lane == 0 ? (int)(__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_base) : 0);
         }
         const long frame = WGF ? item : item / slices;           // n*Li + i
         const int slice = WGF ? 0 : (int)(item % slices);
@@ -393,17 +393,6 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
 #undef TICK
 }
 
-// One zeroed ticket word per launch out of a small device-resident ring (stream-ordered memset; launches of one process
-// run on one stream, the ring only guards against a handful of launches being in flight on different streams).
-static unsigned int* next_ticket(hipStream_t st) {
-    static unsigned int* ring = nullptr;
-    static unsigned int slot = 0;
-    if (!ring && hipMalloc((void**)&ring, 64 * sizeof(unsigned int)) != hipSuccess) return nullptr;
-    unsigned int* t = ring + (slot++ & 63u);
-    if (hipMemsetAsync(t, 0, sizeof(unsigned int), st) != hipSuccess) return nullptr;
-    return t;
-}
-
 template <int RT, int KL, bool PERM, bool TRAIN, bool VEC_S>
 static int launch_d128_t(const float* Cn, const float* Q, const float* cm, const float* qm, float* A, float* S, float* Sn,
                          int N, int NA, int Li, int Lqa, int Lr, float scale, float p_drop, unsigned long long seed,
@@ -418,8 +407,6 @@ static int launch_d128_t(const float* Cn, const float* Q, const float* cm, const
     uint32_t th = TRAIN ? drop_thresh16(p_drop) : 0u;
     if (TRAIN && th == 0u) th = 1u;
     const float ik = TRAIN ? 1.0f / (1.0f - p_drop) : 1.0f;
-    unsigned int* ticket = next_ticket(st);
-    if (!ticket) return (int)hipErrorOutOfMemory;
     unsigned long long* tim = (unsigned long long*)(getenv("STAGE_K1_TIM") ? strtoull(getenv("STAGE_K1_TIM"), 0, 0) : 0ull);
     static const bool no_wgf = getenv("STAGE_K1_NO_WGF") != nullptr;
     if constexpr (RT >= 3) if (!no_wgf) {
@@ -432,8 +419,11 @@ static int launch_d128_t(const float* Cn, const float* Q, const float* cm, const
         if (wg_per_cu < 1) wg_per_cu = 1;
         long blocks = 256 * wg_per_cu;
         if (blocks > (long)N * Li) blocks = (long)N * Li;
+        // every processed frame draws one ticket (common.h)
+        const StageTicket tk = stage_next_ticket((unsigned int)((long)N * Li));
+        if (!tk.word) return (int)hipErrorOutOfMemory;
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, 1,
-                           CT, (uint64_t)seed, th, ik, ticket, tim);
+                           CT, (uint64_t)seed, th, ik, tk.word, tk.base, tim);
         STAGE_LAUNCH_CHECK();
         return 0;
     }
@@ -457,8 +447,10 @@ static int launch_d128_t(const float* Cn, const float* Q, const float* cm, const
     if (waves_per_cu < 1) waves_per_cu = 1;
     long blocks = (256L * waves_per_cu + wpb - 1) / wpb;         // one resident round of waves; they stride the items
     if (blocks * wpb > items) blocks = (items + wpb - 1) / wpb;
+    const StageTicket tk = stage_next_ticket((unsigned int)items);   // every processed item draws one ticket (common.h)
+    if (!tk.word) return (int)hipErrorOutOfMemory;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * wpb), lds, st, Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr,
-                       scale, slices, tps, (uint64_t)seed, th, ik, ticket, tim);
+                       scale, slices, tps, (uint64_t)seed, th, ik, tk.word, tk.base, tim);
     STAGE_LAUNCH_CHECK();
     return 0;
 }

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
     const float* __restrict__ Cn, const float* __restrict__ Q, const float* __restrict__ cmask,
     const float* __restrict__ qmask, float* __restrict__ A, float* __restrict__ S, float* __restrict__ Sn, int N,
     int NA, int Li, int Lqa, int Lr, float scale, int slices, int tiles_per_slice, uint64_t seed, uint32_t th,
-    float inv_keep, unsigned int* __restrict__ ticket, int static_rounds) {
+    float inv_keep, unsigned int* __restrict__ ticket, unsigned int ticket_base, int static_rounds) {
     constexpr int NK2 = (RT - 1) * 4 + KL;            // stage-2 k-steps (4 regions each)
     constexpr int base_last = (RT - 1) * 16;
     // A last region tile with <= 4 regions (the headline Lr = 20) does not pay a 16-row stage-1 tile for them: its scores
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
             next_item = item + n_waves;
         } else {
             const unsigned drawn = lane == 0 ? __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            next_item = (long)static_rounds * n_waves + (long)__builtin_amdgcn_readfirstlane((int)drawn);
+            next_item = (long)static_rounds * n_waves + (long)(unsigned)__builtin_amdgcn_readfirstlane((int)(drawn - ticket_base));
         }
         const long frame = item / slices;           // n*Li + i
         const int slice = (int)(item % slices);
@@ -322,17 +322,6 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
     }
 }
 
-// One zeroed ticket word per launch out of a small device-resident ring (stream-ordered memset; the ring only guards
-// against a handful of launches being in flight on different streams).
-static unsigned int* reg_next_ticket(hipStream_t st) {
-    static unsigned int* ring = nullptr;
-    static unsigned int slot = 0;
-    if (!ring && hipMalloc((void**)&ring, 64 * sizeof(unsigned int)) != hipSuccess) return nullptr;
-    unsigned int* t = ring + (slot++ & 63u);
-    if (hipMemsetAsync(t, 0, sizeof(unsigned int), st) != hipSuccess) return nullptr;
-    return t;
-}
-
 template <int RT, int KL, bool PERM, bool TRAIN, bool VEC_S>
 static int launch_reg_t(const float* Cn, const float* Q, const float* cm, const float* qm, float* A, float* S, float* Sn,
                         int N, int NA, int Li, int Lqa, int Lr, float scale, float p_drop, unsigned long long seed,
@@ -351,14 +340,22 @@ static int launch_reg_t(const float* Cn, const float* Q, const float* cm, const 
     uint32_t th = TRAIN ? drop_thresh16(p_drop) : 0u;
     if (TRAIN && th == 0u) th = 1u;
     const float ik = TRAIN ? 1.0f / (1.0f - p_drop) : 1.0f;
-    unsigned int* ticket = reg_next_ticket(st);
-    if (!ticket) return (int)hipErrorOutOfMemory;
     // ~70 % of the items by static stride, the tail by tickets (at least one dynamic round)
     int static_rounds = (int)((items * 7) / (blocks * 4 * 10));
     if (getenv("STAGE_K1_STATIC")) static_rounds = atoi(getenv("STAGE_K1_STATIC"));
     if (static_rounds < 1) static_rounds = 1;
+    const long n_waves = blocks * 4;
+    while (static_rounds > 1 && (long)static_rounds * n_waves > items) static_rounds--;
+    // tickets drawn by this launch (common.h): one per item processed in a round >= static_rounds.  Every wave that has a
+    // first item reaches that round (static_rounds * n_waves <= items, or static_rounds == 1), the rounds before it take
+    // (static_rounds - 1) items per wave
+    const long entering = n_waves < items ? n_waves : items;
+    const long draws = items - (long)(static_rounds - 1) * entering;
+    const StageTicket tk = stage_next_ticket((unsigned int)draws);
+    if (!tk.word) return (int)hipErrorOutOfMemory;
     hipLaunchKernelGGL((str_attn_fwd_reg_kernel<RT, KL, PERM, TRAIN, VEC_S>), dim3((unsigned)blocks), dim3(256), 0, st, Cn, Q,
-                       cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, slices, tps, (uint64_t)seed, th, ik, ticket, static_rounds);
+                       cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, slices, tps, (uint64_t)seed, th, ik, tk.word, tk.base,
+                       static_rounds);
     STAGE_LAUNCH_CHECK();
     return 0;
 }
