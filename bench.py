@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--only_roofline", action="store_true")
     ap.add_argument("--cpu_seconds", type=float, default=20.0, help="CPU-baseline time budget")
+    ap.add_argument("--h2d", action="store_true", help="developer mode: every step takes its batch from pinned host memory "
+                    "through tvqaplus_amd.prefetch.BatchPrefetcher (PCIe-inclusive rate for DESIGN.md; never the headline value)")
     return ap.parse_args()
 
 
@@ -169,12 +171,24 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    if args.h2d:
+        # PCIe-inclusive variant: the same host batch (pinned once) is re-sent every step, overlapped with the previous step
+        from tvqaplus_amd.prefetch import BatchPrefetcher
+        host = make_batch(N=args.bsz, Li=args.frames, Lr=args.regions, Lw=args.sub_words, Lqa=args.qa_words,
+                          seed=2018 + rank, ragged=not args.dense)
+        for k, v in host.items():
+            if torch.is_tensor(v):
+                host[k] = v.pin_memory()
+        feed = BatchPrefetcher((host for _ in range(args.warmup + args.steps)), device)
+        nxt = lambda: next(feed)
+    else:
+        nxt = lambda: batch
     for _ in range(args.warmup):
-        train_step(model, batch, bucket, params, optimizer, args.bsz)
+        train_step(model, nxt(), bucket, params, optimizer, args.bsz)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = train_step(model, batch, bucket, params, optimizer, args.bsz)
+        loss = train_step(model, nxt(), bucket, params, optimizer, args.bsz)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -192,7 +206,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic" + (" (re-sent from pinned host memory every step)" if args.h2d else ""),
             "config": {"workload": "STAGE full training step (fwd + loss + bwd + clip + Adam), hsz=128, add_local, "
                                    "dropout 0.1; per GPU B=%d x 5 candidates x %d frames x %d regions x %d sub words x "
                                    "%d QA words; %s masks" % (args.bsz, args.frames, args.regions, args.sub_words,

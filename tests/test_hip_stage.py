@@ -252,3 +252,25 @@ def test_full_length_example_vs_oracle(hip_device):
     # whole gradient row (seeds 1..4 give 2e-4 .. 7e-3 for this build AND for its tiled-GEMM variant, in no fixed order;
     # every GEMM product of this step is within 3e-7 of fp64 given its inputs: tools/debug_linear_bwd.py)
     assert worst[1] < 1e-2, "grad %s rel err %.3e" % worst
+
+
+def test_batch_prefetcher_delivers_identical_batches(hip_device):
+    """the pinned / side-stream input pipeline hands over bit-identical batches, in order, and the model
+    output through it equals the output of a plain ``.to(device)`` batch."""
+    from tvqaplus_amd.prefetch import BatchPrefetcher
+    from tvqaplus_amd.stage import STAGE
+    from tvqaplus_amd.synth import make_batch, make_opt
+    host = [make_batch(N=2, Li=5, Lr=6, Lw=7, Lqa=8, wd_size=64, vfeat_size=32, seed=s) for s in range(5)]
+    got = list(BatchPrefetcher(host, hip_device))
+    assert len(got) == len(host)
+    for h, d in zip(host, got):
+        assert d["qid"] == h["qid"]
+        for k in ("qas_bert", "sub_bert", "vid", "vid_mask", "target"):
+            assert d[k].is_cuda and torch.equal(d[k].cpu(), h[k]), k
+        assert torch.equal(d["ts_label"]["st"].cpu(), h["ts_label"]["st"])
+    torch.manual_seed(3)
+    model = STAGE(make_opt(hsz=32, embedding_size=64, vfeat_size=32, add_local=True)).to(hip_device).eval()
+    with torch.no_grad():
+        a = model.forward_main(next(iter(BatchPrefetcher(host[:1], hip_device))))[0]
+        b = model.forward_main(host[0].to(hip_device))[0]
+    assert torch.equal(a, b)

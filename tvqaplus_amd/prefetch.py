@@ -1,0 +1,93 @@
+"""Host -> device input pipeline for ``prepare_inputs``-style batches (tvqa_dataset.py:631-688).
+
+One training step consumes 862 MB of fp32 features at the full configuration (``sub_bert`` alone is 737 MB), i.e. >= 13.7 ms
+over PCIe Gen5 x16 -- more than half of the 24 ms step.  ``BatchPrefetcher`` moves batch i+1 while step i computes:
+
+* every tensor is staged through a reusable PINNED host buffer (two sets, ping-pong) so the copy is a true async DMA,
+* the copies are enqueued on a side stream, an event marks the batch complete, the consumer's stream waits on the event
+  (no host synchronisation anywhere),
+* ``record_stream`` tells the caching allocator that the device tensors are used on the consumer's stream.
+
+Non-tensor fields (qid lists, att_labels, boxes, ...) pass through untouched.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, Iterator, Optional
+
+import torch
+
+
+class BatchPrefetcher:
+    def __init__(self, batches: Iterable, device, depth: int = 2):
+        if not torch.cuda.is_available():
+            raise RuntimeError("BatchPrefetcher needs a GPU (the HIP path has no CPU fallback)")
+        self.src = iter(batches)
+        self.device = torch.device(device)
+        self.side = torch.cuda.Stream(device=self.device)
+        self.depth = max(2, int(depth))
+        self._pinned: list = [dict() for _ in range(self.depth)]   # per slot: key -> pinned staging tensor
+        self._free_evt: list = [None] * self.depth                  # per slot: event after which the staging set is reusable
+        self._slot = 0
+        self._queue: list = []
+        for _ in range(self.depth - 1):
+            self._enqueue()
+
+    # -- staging ------------------------------------------------------------------------------------------------------
+    def _stage(self, slot: int, key: str, t: torch.Tensor) -> torch.Tensor:
+        if t.is_cuda:
+            return t
+        if t.is_pinned():
+            return t
+        buf: Dict[str, torch.Tensor] = self._pinned[slot]
+        p = buf.get(key)
+        if p is None or p.shape != t.shape or p.dtype != t.dtype:
+            p = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            buf[key] = p
+        p.copy_(t)
+        return p
+
+    def _enqueue(self) -> bool:
+        try:
+            host = next(self.src)
+        except StopIteration:
+            return False
+        slot = self._slot
+        self._slot = (self._slot + 1) % self.depth
+        if self._free_evt[slot] is not None:
+            self._free_evt[slot].synchronize()       # the DMA that last read this staging set has finished
+        out = type(host)()
+        with torch.cuda.stream(self.side):
+            for k, v in host.items():
+                if torch.is_tensor(v):
+                    out[k] = self._stage(slot, k, v).to(self.device, non_blocking=True)
+                elif isinstance(v, dict):
+                    out[k] = {kk: (self._stage(slot, k + "." + kk, vv).to(self.device, non_blocking=True)
+                                   if torch.is_tensor(vv) else vv) for kk, vv in v.items()}
+                else:
+                    out[k] = v
+            done = torch.cuda.Event()
+            done.record(self.side)
+        self._free_evt[slot] = done
+        self._queue.append((out, done))
+        return True
+
+    # -- iteration ----------------------------------------------------------------------------------------------------
+    def __iter__(self) -> Iterator:
+        return self
+
+    def __next__(self):
+        if not self._queue:
+            if not self._enqueue():
+                raise StopIteration
+        batch, done = self._queue.pop(0)
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(done)
+        for v in batch.values():
+            if torch.is_tensor(v):
+                v.record_stream(cur)
+            elif isinstance(v, dict):
+                for vv in v.values():
+                    if torch.is_tensor(vv):
+                        vv.record_stream(cur)
+        self._enqueue()                              # start the next transfer now: it overlaps the caller's step
+        return batch
