@@ -182,6 +182,7 @@ class STAGE(nn.Module):
                                                relu=False)
         # developer switch: False (or STAGE_NO_FUSE_LN_DWCONV=1) = separate LayerNorm and depthwise-conv kernels
         self.fuse_ln_dwconv = os.environ.get("STAGE_NO_FUSE_LN_DWCONV") is None
+        self._span_host = None      # pinned landing buffer of the per-step proposal spans (get_proposals)
         self._seed_state = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x1234567) & 0xFFFFFFFFFFFFFFFF
         self.mha_dropout_override: Optional[float] = None  # tests: the reference's fixed 0.1 can be zeroed
 
@@ -276,12 +277,25 @@ class STAGE(nn.Module):
         N, NA, Li, D = max_statement.shape
         x = max_statement.reshape(N * NA, Li, D)
         m = max_statement_mask.reshape(N * NA, Li)
-        glob = ops.masked_max(x, m)                                               # (N*5, D)
         if self.training:
             ca = F.softmax(temporal_scores[torch.arange(N, device=targets.device), targets].detach(), dim=1)
             st, ed, conf = self._best_span(ca[:, :, 0], ca[:, :, 1])
-            # one small D2H copy per step: the number of proposals (N_new) is data dependent by construction
-            host = torch.stack([st.float(), ed.float(), conf, ts_labels["st"].float(), ts_labels["ed"].float()]).tolist()
+            # one small D2H copy per step: the number of proposals (N_new) is data dependent by construction.  It is
+            # requested BEFORE the global masked max is queued and awaited through an event: the host resumes as soon as the
+            # 5 x N floats have arrived and issues the proposal kernels while that 0.1 ms kernel still runs.
+            dev_spans = torch.stack([st.float(), ed.float(), conf, ts_labels["st"].float(), ts_labels["ed"].float()])
+            if dev_spans.is_cuda:
+                if self._span_host is None or self._span_host.shape != dev_spans.shape:
+                    self._span_host = torch.empty(dev_spans.shape, dtype=torch.float32, pin_memory=True)
+                self._span_host.copy_(dev_spans, non_blocking=True)
+                arrived = torch.cuda.Event()
+                arrived.record()
+                glob = ops.masked_max(x, m)                                       # (N*5, D)
+                arrived.synchronize()
+                host = self._span_host.tolist()
+            else:   # CPU tensors only reach this point in host-logic tests
+                glob = ops.masked_max(x, m)
+                host = dev_spans.tolist()
             src, wins = [], []
             for n in range(N):
                 gs, ge = int(host[3][n]), int(host[4][n]) + 1
@@ -305,6 +319,7 @@ class STAGE(nn.Module):
             loc = ops.masked_max(xg, mg, wg).view(-1, NA, D)
             pooled = torch.cat([loc, glob.view(N, NA, D).index_select(0, src_t)], dim=-1)   # (N_new, 5, 2D)
             return pooled, targets.index_select(0, src_t)
+        glob = ops.masked_max(x, m)                                               # (N*5, D)
         ts = F.softmax(temporal_scores, dim=2).view(N * NA, Li, 2)
         st, ed, _ = self._best_span(ts[:, :, 0], ts[:, :, 1])
         win = torch.stack([(st - extra_span_length).clamp(min=0), ed + 1 + extra_span_length], dim=1).int().contiguous()
