@@ -139,6 +139,16 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
                 if (!((vmask >> (rt * 4 + k)) & 1u)) qmk[rt][k] = 0.f;
                 anyb |= __ballot(qmk[rt][k] != 0.f);
             }
+        // T4: are any of the (<= 4) regions of the last region tile valid in THIS frame?  If not, their scores are exactly
+        // -1e10 / 0 whatever the operands are, so the 4x4 blocks of stage 1 and the last k-step of stage 2 are skipped
+        // (ragged frames: 8..20 valid regions -> the tail is empty in ~2/3 of the frames)
+        bool tail_any = true;
+        if (T4) {
+            unsigned long long tb = 0ull;
+#pragma unroll
+            for (int k = 0; k < 4; k++) tb |= __ballot(qmk[RT - 1][k] != 0.f);
+            tail_any = tb != 0ull;
+        }
         if (anyb == 0ull) {
             // no valid region in this frame: S = -1e10 (cos - 1e10 rounds to -1e10), S_ = 0, A = 0 for the whole slice
             const int c_lo = tile0 * 16, c_hi = min(CR, tile1 * 16);
@@ -206,21 +216,19 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
 #pragma unroll
             for (int rt = 0; rt < RF; rt++) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             f32x4 tl = {0.f, 0.f, 0.f, 0.f};            // T4: 4x4 blocks (one chain: a 16x16 MFMA sits between two links)
-#pragma unroll
-            for (int m = 0; m < ((K1_ABL & 8) ? 1 : RNCH); m++) {
-#pragma unroll
-                for (int rt = 0; rt < RF; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[rt][m].x, cf[m][0], acc[rt], 0, 0, 0);
-                if (T4) tl = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[RT - 1][m].x, cf[m][0], tl, 0, 0, 0);
-#pragma unroll
-                for (int rt = 0; rt < RF; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[rt][m].y, cf[m][1], acc[rt], 0, 0, 0);
-                if (T4) tl = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[RT - 1][m].y, cf[m][1], tl, 0, 0, 0);
-#pragma unroll
-                for (int rt = 0; rt < RF; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[rt][m].z, cf[m][2], acc[rt], 0, 0, 0);
-                if (T4) tl = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[RT - 1][m].z, cf[m][2], tl, 0, 0, 0);
-#pragma unroll
-                for (int rt = 0; rt < RF; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[rt][m].w, cf[m][3], acc[rt], 0, 0, 0);
-                if (T4) tl = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[RT - 1][m].w, cf[m][3], tl, 0, 0, 0);
-            }
+#define S1_BODY(TAIL)                                                                                                 \
+    _Pragma("unroll") for (int m = 0; m < ((K1_ABL & 8) ? 1 : RNCH); m++) {                                           \
+        _Pragma("unroll") for (int rt = 0; rt < RF; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[rt][m].x, cf[m][0], acc[rt], 0, 0, 0); \
+        if (TAIL) tl = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[RT - 1][m].x, cf[m][0], tl, 0, 0, 0);                    \
+        _Pragma("unroll") for (int rt = 0; rt < RF; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[rt][m].y, cf[m][1], acc[rt], 0, 0, 0); \
+        if (TAIL) tl = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[RT - 1][m].y, cf[m][1], tl, 0, 0, 0);                    \
+        _Pragma("unroll") for (int rt = 0; rt < RF; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[rt][m].z, cf[m][2], acc[rt], 0, 0, 0); \
+        if (TAIL) tl = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[RT - 1][m].z, cf[m][2], tl, 0, 0, 0);                    \
+        _Pragma("unroll") for (int rt = 0; rt < RF; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[rt][m].w, cf[m][3], acc[rt], 0, 0, 0); \
+        if (TAIL) tl = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[RT - 1][m].w, cf[m][3], tl, 0, 0, 0);                    \
+    }
+            if (T4 && tail_any) { S1_BODY(true) } else { S1_BODY(false) }   // one uniform branch per tile
+#undef S1_BODY
             if (T4) {
                 // tl[i] = partial score (this lane group's k values) of region base + i, context row c15
                 // fold the 4 lane groups: rows g = 0/1 keep regions 0/1, then halves keep {0,1} / {2,3} (common.h: xsum16 /
@@ -303,6 +311,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
                 for (int rt = 0; rt < RT; rt++)
 #pragma unroll
                     for (int k = 0; k < ((K1_ABL & 4) ? (rt == 0 ? 1 : 0) : ((rt == RT - 1) ? KL : 4)); k++) {
+                        if (T4 && rt == RT - 1 && !tail_any) continue;   // all weights of this k-step are exactly 0
                         const float4 q = q2[rt * 4 + k][b];
                         const float p = pv[rt][k];
                         o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, q.x, o[0], 0, 0, 0);
