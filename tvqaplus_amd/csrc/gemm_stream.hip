@@ -76,12 +76,24 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
                                                                         const float* __restrict__ bias,
                                                                         const float* __restrict__ R, float* __restrict__ Y,
                                                                         unsigned* __restrict__ mask_out, long M, int N,
-                                                                        int K, int relu) {
+                                                                        int K, int relu, int xcd_gx) {
     constexpr bool HAS_GATE = GATE == 1;
     extern __shared__ __attribute__((aligned(16))) unsigned short Wp[];   // [3][SBN][SWS] bf16, k permuted per 16-group
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.y * SBN;
+    // Workgroup -> (row group bx, column tile by).  Workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own
+    // L2: with a plain 2-D grid the column tiles of one row range land on different XCDs and every one of them pulls the X
+    // rows from HBM again (N = 384: 3 x 491 MB instead of 1 x).  xcd_gx > 0 (a multiple of 8 row groups): 1-D grid,
+    // id = 8 * (n_tiles * q + by) + r with bx = 8 q + r -- all column tiles of a row group share id % 8, the re-reads hit L2.
+    int bx = blockIdx.x, by = blockIdx.y, gx = gridDim.x;
+    if (xcd_gx > 0) {
+        const int n_tiles_g = (N + SBN - 1) / SBN;
+        const int r = blockIdx.x & 7, tq = blockIdx.x >> 3;
+        by = tq % n_tiles_g;
+        bx = (tq / n_tiles_g) * 8 + r;
+        gx = xcd_gx;
+    }
+    const int n0 = by * SBN;
     const int nkc = (K + SKC - 1) / SKC;
     const long MT = (M + 31) >> 5;                       // 32-row wave tiles
     const long n_bt = (MT + SWAVES - 1) / SWAVES;        // workgroup iterations
@@ -201,9 +213,9 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
     const bool full_cols = n0 + SBN <= N;                 // this workgroup stores all 4 column tiles: 64 stores per tile
     bool w_loaded = false, first = true, after_stores = false;
     if (multi) w_issue(0);
-    fetch(0, ((long)blockIdx.x * SWAVES + wave) * 32 + l31, 0);
-    fetch(1, ((long)blockIdx.x * SWAVES + wave) * 32 + l31, 32);
-    for (long bt = blockIdx.x; bt < n_bt; bt += gridDim.x) {
+    fetch(0, ((long)bx * SWAVES + wave) * 32 + l31, 0);
+    fetch(1, ((long)bx * SWAVES + wave) * 32 + l31, 32);
+    for (long bt = bx; bt < n_bt; bt += gx) {
         const long t = bt * SWAVES + wave;               // this wave's tile (may be past the end: then it only syncs)
         const bool live = t < MT;
         const long row = t * 32 + l31;
@@ -322,7 +334,7 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
             mul_line(1, 3);
             // lines 0, 1 of the next unit (same tile / next chunk, or next tile / chunk 0; clamped past the end)
             const bool last_chunk = kc + 1 == nkc;
-            const long nrow = last_chunk ? ((bt + gridDim.x) * SWAVES + wave) * 32 + l31 : row;
+            const long nrow = last_chunk ? ((bt + gx) * SWAVES + wave) * 32 + l31 : row;
             const int nk = last_chunk ? 0 : kb + SKC;
             fetch(0, nrow, nk);
             fetch(1, nrow, nk + 32);
@@ -413,9 +425,16 @@ int stage_gemm_nt_stream(const float* X, const void* gate, int gate_kind, const 
     const long MT = (M + 31) / 32, n_bt = (MT + SWAVES - 1) / SWAVES;
     const int n_tiles = (N + SBN - 1) / SBN;
     long gx = 256 / n_tiles;                              // one resident workgroup per CU; the column tiles of a row
-    if (gx < 1) gx = 1;                                   // range run side by side (X re-reads hit L2 / MALL)
+    if (gx < 1) gx = 1;                                   // range run side by side
     if (gx > n_bt) gx = n_bt;
-    dim3 grid((unsigned)gx, (unsigned)n_tiles), block(64 * SWAVES);
+    // several column tiles and at least 8 row groups: XCD-aware 1-D grid (kernel comment), gx rounded down to a multiple of 8
+    static const bool no_xcd = getenv("STAGE_GEMM_NO_XCD") != nullptr;
+    int xcd_gx = 0;
+    if (n_tiles > 1 && gx >= 8 && !no_xcd) {
+        gx = gx / 8 * 8;
+        xcd_gx = (int)gx;
+    }
+    dim3 grid(xcd_gx ? (unsigned)(gx * n_tiles) : (unsigned)gx, xcd_gx ? 1u : (unsigned)n_tiles), block(64 * SWAVES);
     const float* G = (const float*)gate;
 #define LAUNCH_ST(GT, RS, MO)                                                                                          \
     do {                                                                                                               \
@@ -426,7 +445,7 @@ int stage_gemm_nt_stream(const float* X, const void* gate, int gate_kind, const 
             attr_done = true;                                                                                          \
         }                                                                                                              \
         hipLaunchKernelGGL((gemm_nt_stream_kernel<GT, RS, !(GT == 1 && RS), MO>), grid, block, lds, (hipStream_t)stream, \
-                           X, G, W, bias, residual, Y, mask_out, (long)M, N, K, relu);                                 \
+                           X, G, W, bias, residual, Y, mask_out, (long)M, N, K, relu, xcd_gx);                         \
     } while (0)
     if (mask_out) LAUNCH_ST(0, false, true);
     else if (gate_kind == 2) LAUNCH_ST(2, false, false);
