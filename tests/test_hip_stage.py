@@ -104,6 +104,7 @@ def test_golden_encoder(hip_device, name):
 @pytest.mark.parametrize("kw", [
     dict(hsz=64, add_local=True, input_encoder_n_heads=0),
     dict(hsz=32, add_local=False, input_encoder_n_heads=4, cls_encoder_n_heads=2),
+    dict(hsz=256, add_local=True, input_encoder_n_heads=0),     # BASELINE config 4's width (fp32 here): generic K1 / 256-wide rows
 ])
 def test_oracle_fresh_batch(hip_device, kw):
     """Fresh seeded ragged batch (not a stored fixture): HIP model vs the CPU oracle with the same parameters."""
