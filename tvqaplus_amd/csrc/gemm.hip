@@ -295,7 +295,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const float* __restrict
 
 static int tn_splits(long long M, int N, int K) {
     const long tiles = (long)((N + BM - 1) / BM) * ((K + BN - 1) / BN);
-    long s = (1024 + tiles - 1) / tiles;
+    // workgroups per launch: ~4 per CU; a single 128 x 128 tile runs best as ONE resident round (2 per CU): half the slab
+    // partials to write and reduce, -6 % (M = 960000) ... -16 % (M = 240000)
+    const long target = tiles == 1 ? 512 : 1024;
+    long s = (target + tiles - 1) / tiles;
     const long max_by_rows = (M + 8 * BK - 1) / (8 * BK);
     if (s > max_by_rows) s = max_by_rows;
     if (s > TN_MAX_SPLIT) s = TN_MAX_SPLIT;
