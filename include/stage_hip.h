@@ -48,6 +48,16 @@ int stage_str_attn_bwd(const float* dA, const float* dS_raw_ext, const float* Cn
                        const float* S_norm, float* dS_out, float* dQraw, float* dQn, float* dCn, int N, int NA, int Li,
                        int Lqa, int Lr, int D, float scale, void* ws, size_t ws_bytes, void* stream);
 
+/* Fused single-pass backward (D == 128, Lr even <= 64, Lqa >= 4, NA*Lqa <= 256; otherwise STAGE_ERR_SHAPE -> use
+ * stage_str_attn_bwd): same mathematics (model/context_query_attention.py:58-61, 81, 95-101), but dA is read from HBM
+ * once and dS never leaves the compute unit.  q_mask (N, Li, Lr) lets region tiles / frames without a valid region be
+ * skipped (their gradient is exactly zero when dS_raw_ext is NULL).  ws sized by stage_str_attn_bwd_fused_ws_bytes.   */
+size_t stage_str_attn_bwd_fused_ws_bytes(int N, int NA, int Lqa, int D);
+int stage_str_attn_bwd_fused(const float* dA, const float* dS_raw_ext, const float* Cn, const float* Q, const float* Qn,
+                             const float* S_norm, const float* q_mask, float* dQraw, float* dQn, float* dCn, int N,
+                             int NA, int Li, int Lqa, int Lr, int D, float scale, void* ws, size_t ws_bytes,
+                             void* stream);
+
 /* ---- F.normalize(p=2, eps) (+dropout)  (model/stage.py:256, model/context_query_attention.py:95-96) ----------- */
 int stage_l2norm_fwd(const float* x, float* y, float* norm_out /*may be NULL*/, long long rows, int K, float eps,
                      float p_drop, unsigned long long seed, void* stream);

@@ -1,0 +1,459 @@
+// K1 backward, ONE pass over dA for D = 128 -- StructuredAttention (model/context_query_attention.py:58-61, 81, 95-101).
+//
+// With P = S_ (saved by the forward), dP = dA . Q^T, G = dS = scale * P * (dP - <P, dP>) (+ the gradient arriving on
+// raw_s), the four products of the backward are
+//     dP   [c, r] = sum_d dA[c, d] Q [r, d]            dQraw[r, d] = sum_c P[c, r] dA[c, d]
+//     dCn  [c, d] = sum_{i, r} G[(c, i), r] Qn[i, r, d] dQn  [r, d] = sum_c G[c, r] Cn[c, d]        (c = NA*Lqa context rows)
+// The three-kernel version (str_attn.hip: ds -> dq -> dc) reads dA from HBM twice and writes dS (77 / 192 MB) to read it back
+// twice.  Here a workgroup owns (example n, a strided set of frames) and never lets G leave the CU:
+//
+//   phase 1 (waves split the 16-row context tiles, as in the forward)       for each of the wave's <= 2 tiles:
+//       dP^T tile (regions x ctx) = Qraw . dA^T     A operand = Qraw rows from LDS, B operand = dA fragments from global
+//       -> lane (c15, g) owns context row c15 and regions rt*16 + 4g + k: softmax backward in registers, G^T is ALREADY
+//          the B operand (k = regions) of
+//       dCn^T tile (d x ctx) += Qn^T . G^T          A operand = Qn^T from LDS (stored transposed: one ds_read_b128 = 4 k-steps)
+//          accumulated in registers over ALL frames of the workgroup (64 accumulator registers per wave), written once as
+//          a slab [chunk][n*CR + c][d]; a fixed-order slab sum finishes dCn (deterministic)
+//       G tile -> LDS (row c, region columns; xor swizzle so that phase 2 reads it conflict-free)
+//   phase 2 (waves split the OUTPUT: wave = (raw | normalised path, 32-wide d block), contraction over all context rows)
+//       dQraw[r, d] = sum_c P[c, r] dA[c, d]        A operand = S_ from global (64-byte row pieces, L2-hot from phase 1),
+//                                                   B operand = dA re-read in k = c layout (L2 / infinity-cache hot)
+//       dQn  [r, d] = sum_c G[c, r] Cn[c, d]        A operand = G from LDS, B operand = Cn (100 KB per example, L2 resident)
+//
+// Region tiles without a valid region contribute exact zeros (P = 0 => G = 0) and are skipped per frame (ragged frames:
+// two thirds of the video frames need one tile of two, fully padded frames cost two zero stores); with an external
+// gradient on raw_s nothing is skipped (it may touch padded regions).  Every inner loop has compile-time trip counts
+// (NRT = region tiles actually computed is a template parameter of the frame body).
+#include <stdlib.h>
+#include "common.h"
+#include "../../include/stage_hip.h"
+
+#define FD 128          // row width (floats)
+#define FLDQ 132        // padded LDS row of the raw region tile
+#define FUS_MAX_CHUNKS 32
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int fchunk(int g, int m) { return m + 8 * (g >> 1) + 16 * (g & 1); }   // as dchunk(g, m, 8)
+__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ void st2(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
+
+template <int RT> struct FusLay {
+    static constexpr int LT = RT * 16 + 4;            // Qn^T row stride: 4 * odd -> the 16 d-rows of a ds_read_b128 group hit 64 banks
+    static constexpr int LG = RT * 16;                // G row stride
+    static constexpr bool SWZ = (RT % 2) == 0;        // LG % 32 == 0: rows c, c+1 would share banks -> xor 16 on odd rows
+    static constexpr int QR_FLOATS = RT * 16 * FLDQ;
+    static constexpr int QT_FLOATS = FD * LT;
+};
+template <int RT> __device__ __forceinline__ int gcol(int c, int col) { return FusLay<RT>::SWZ ? (col ^ ((c & 1) << 4)) : col; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// phase 1, one 16-row context tile: operands are fetched one tile ahead (fus_p1_fetch of tile s+1 is issued before the
+// MFMAs of tile s)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NRT, bool HAS_EXT> struct FusTile {
+    float4 gv[8];            // dA fragments: context row c15, floats 4*fchunk(g, m) .. +3
+    float2 pq[NRT][2];       // S_ pieces: regions rt*16 + 4g + {0,1}, {2,3}
+    float2 eq[HAS_EXT ? NRT : 1][2];
+};
+
+template <int NRT, bool HAS_EXT>
+__device__ __forceinline__ void fus_p1_fetch(FusTile<NRT, HAS_EXT>& T, const float* __restrict__ dA, const float* __restrict__ Sn,
+                                             const float* __restrict__ ext, long orow, int Lr, int g) {
+    const float* da = dA + orow * FD;
+#pragma unroll
+    for (int m = 0; m < 8; m++) T.gv[m] = ld4(da + 4 * fchunk(g, m));
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++)
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            const int r0 = min(rt * 16 + 4 * g + 2 * hh, Lr - 2);
+            T.pq[rt][hh] = ld2(Sn + orow * Lr + r0);
+            if (HAS_EXT) T.eq[rt][hh] = ld2(ext + orow * Lr + r0);
+        }
+}
+
+template <int RT, int NRT, bool HAS_EXT>
+__device__ __forceinline__ void fus_p1_tile(const FusTile<NRT, HAS_EXT>& T, const float* Qr, const float* QnT, float* Gs, int c,
+                                            bool cvalid, int Lr, float scale, f32x4 (&dcn)[8], int c15, int g) {
+    constexpr int LT = FusLay<RT>::LT, LG = FusLay<RT>::LG;
+    constexpr int NCHAIN = NRT == 1 ? 2 : 1;   // a single accumulator would be one dependent chain (40 instead of 32 cycles per MFMA)
+    f32x4 acc[NRT][NCHAIN];
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++)
+#pragma unroll
+        for (int h = 0; h < NCHAIN; h++) acc[rt][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int qrow[NRT];
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++) qrow[rt] = min(rt * 16 + c15, Lr - 1) * FLDQ;   // pad rows alias the last region (P = 0 there)
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        const float gj[4] = {T.gv[m].x, T.gv[m].y, T.gv[m].z, T.gv[m].w};
+        float4 qv[NRT];
+#pragma unroll
+        for (int rt = 0; rt < NRT; rt++) qv[rt] = ld4(&Qr[qrow[rt] + 4 * fchunk(g, m)]);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int rt = 0; rt < NRT; rt++) {
+                const float qa = j == 0 ? qv[rt].x : (j == 1 ? qv[rt].y : (j == 2 ? qv[rt].z : qv[rt].w));
+                acc[rt][j % NCHAIN] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa, gj[j], acc[rt][j % NCHAIN], 0, 0, 0);
+            }
+    }
+    // dP[c][r = rt*16 + 4g + k] = sum of the chains
+    float p[NRT][4], dp[NRT][4], dot = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++) {
+        const bool rok0 = rt * 16 + 4 * g < Lr, rok1 = rt * 16 + 4 * g + 2 < Lr;
+        p[rt][0] = rok0 ? T.pq[rt][0].x : 0.f;
+        p[rt][1] = rok0 ? T.pq[rt][0].y : 0.f;
+        p[rt][2] = rok1 ? T.pq[rt][1].x : 0.f;
+        p[rt][3] = rok1 ? T.pq[rt][1].y : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            dp[rt][k] = NCHAIN == 2 ? acc[rt][0][k] + acc[rt][NCHAIN - 1][k] : acc[rt][0][k];
+            dot += p[rt][k] * dp[rt][k];
+        }
+    }
+    dot = cross_row_sum(dot);
+    f32x4 G[NRT];
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++) {
+        const bool rok0 = rt * 16 + 4 * g < Lr, rok1 = rt * 16 + 4 * g + 2 < Lr;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float v = scale * p[rt][k] * (dp[rt][k] - dot);
+            if (HAS_EXT) {
+                const float e = k == 0 ? T.eq[rt][0].x : (k == 1 ? T.eq[rt][0].y : (k == 2 ? T.eq[rt][1].x : T.eq[rt][1].y));
+                v += (k < 2 ? rok0 : rok1) ? e : 0.f;
+            }
+            G[rt][k] = v;
+        }
+        if (cvalid) *reinterpret_cast<f32x4*>(&Gs[c * LG + gcol<RT>(c, rt * 16 + 4 * g)]) = G[rt];
+    }
+    // dCn^T (d x ctx) += Qn^T . G^T ; k outer so that consecutive MFMAs hit different accumulators; columns of padded
+    // context rows are never stored
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++)
+#pragma unroll
+        for (int dh = 0; dh < 8; dh += 4) {
+            float4 a4[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) a4[dt] = ld4(&QnT[((dh + dt) * 16 + c15) * LT + rt * 16 + 4 * g]);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int dt = 0; dt < 4; dt++) {
+                    const float a = k == 0 ? a4[dt].x : (k == 1 ? a4[dt].y : (k == 2 ? a4[dt].z : a4[dt].w));
+                    dcn[dh + dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, G[rt][k], dcn[dh + dt], 0, 0, 0);
+                }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// phase 2: this wave's d block (E floats per lane: 64-wide for 4-wave workgroups, 32-wide for 8-wave ones) of dQraw (RAW)
+// or dQn, contraction over the CR context rows in k-steps of 4
+// ---------------------------------------------------------------------------------------------------------------------
+#define FUS_U 5   // k-steps per fetch group (CR = 200 -> 50 steps = 10 groups)
+
+template <int E> struct FusVec;
+template <> struct FusVec<4> { typedef float4 T; };
+template <> struct FusVec<2> { typedef float2 T; };
+template <int E> __device__ __forceinline__ typename FusVec<E>::T fus_ldv(const float* p) { return *reinterpret_cast<const typename FusVec<E>::T*>(p); }
+__device__ __forceinline__ float fus_elt(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
+__device__ __forceinline__ float fus_elt(const float2& v, int e) { return e == 0 ? v.x : v.y; }
+
+template <int RT, int NRT, int E, bool RAW, bool PIPE>
+__device__ __forceinline__ void fus_p2(const float* __restrict__ dA, const float* __restrict__ Sn, const float* __restrict__ Cn,
+                                       const float* Gs, float* __restrict__ out, long frame, int n, int i, int NA, int Li,
+                                       int Lqa, int Lr, int d0, int c15, int g) {
+    typedef typename FusVec<E>::T vec_t;
+    constexpr int LG = FusLay<RT>::LG;
+    const int CR = NA * Lqa;
+    const int nsteps = (CR + 3) >> 2;
+    const int ngroups = (nsteps + FUS_U - 1) / FUS_U;
+    f32x4 acc[NRT][E];
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++)
+#pragma unroll
+        for (int e = 0; e < E; e++) acc[rt][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // this lane's context row c = 4*step + g, walked as (rel = a*Li*Lqa + w, w); output row = nbase + rel
+    const long nbase = ((long)n * NA * Li + i) * Lqa;
+    const int jump = (Li - 1) * Lqa;                      // extra row offset when w wraps into the next answer
+    const int rel_last = (NA - 1) * Li * Lqa + Lqa - 1;   // clamp target for c >= CR
+    int c = g, w = g, rel = g;                            // Lqa >= 4 > g
+    int rcl[NRT];
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++) rcl[rt] = min(rt * 16 + c15, Lr - 1);
+
+    auto fetch = [&](vec_t (&bv)[FUS_U], float (&av)[FUS_U][NRT], bool (&okv)[FUS_U]) {
+#pragma unroll
+        for (int u = 0; u < FUS_U; u++) {
+            const bool ok = c < CR;
+            okv[u] = ok;
+            const int cc = ok ? c : CR - 1;
+            const long orow = nbase + (ok ? rel : rel_last);
+            if (RAW) {
+                bv[u] = fus_ldv<E>(dA + orow * FD + d0);
+#pragma unroll
+                for (int rt = 0; rt < NRT; rt++) av[u][rt] = Sn[orow * Lr + rcl[rt]];
+            } else {
+                bv[u] = fus_ldv<E>(Cn + ((long)n * CR + cc) * FD + d0);
+#pragma unroll
+                for (int rt = 0; rt < NRT; rt++) av[u][rt] = Gs[cc * LG + gcol<RT>(cc, rt * 16 + c15)];
+            }
+            c += 4; w += 4; rel += 4;
+            const bool wrap = w >= Lqa;      // Lqa >= 4: at most one wrap per step; selects, not a divergent loop
+            w -= wrap ? Lqa : 0;
+            rel += wrap ? jump : 0;
+        }
+    };
+    auto mul = [&](const vec_t (&bv)[FUS_U], const float (&av)[FUS_U][NRT], const bool (&okv)[FUS_U]) {
+#pragma unroll
+        for (int u = 0; u < FUS_U; u++) {
+            float b[E];
+#pragma unroll
+            for (int e = 0; e < E; e++) b[e] = okv[u] ? fus_elt(bv[u], e) : 0.f;
+#pragma unroll
+            for (int rt = 0; rt < NRT; rt++) {
+                const float a = (okv[u] && rt * 16 + c15 < Lr) ? av[u][rt] : 0.f;
+#pragma unroll
+                for (int e = 0; e < E; e++) acc[rt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[e], acc[rt][e], 0, 0, 0);
+            }
+        }
+    };
+    if (PIPE) {   // 2 waves per SIMD: groups double-buffered in registers
+        vec_t b0[FUS_U], b1[FUS_U];
+        float a0[FUS_U][NRT], a1[FUS_U][NRT];
+        bool k0[FUS_U], k1[FUS_U];
+        fetch(b0, a0, k0);
+        for (int gi = 0; gi < ngroups; gi += 2) {
+            fetch(b1, a1, k1);          // group gi + 1 (clamped + zeroed past the end)
+            mul(b0, a0, k0);
+            fetch(b0, a0, k0);          // group gi + 2
+            if (gi + 1 < ngroups) mul(b1, a1, k1);
+        }
+    } else {      // 4 waves per SIMD cover the latency of a group, the registers go to the dCn accumulators instead
+        for (int gi = 0; gi < ngroups; gi++) {
+            vec_t b0[FUS_U];
+            float a0[FUS_U][NRT];
+            bool k0[FUS_U];
+            fetch(b0, a0, k0);
+            mul(b0, a0, k0);
+        }
+    }
+    // C layout: row 4g + reg = region inside the tile, column c15 -> d = d0 + e
+    float* o = out + frame * Lr * FD + d0;
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int r = rt * 16 + 4 * g + reg;
+            if (r < Lr) {
+                constexpr int Z = 0;
+                const int ra = rt < NRT ? rt : Z;
+                if (E == 4) {
+                    st4(o + r * FD, rt < NRT ? make_float4(acc[ra][0][reg], acc[ra][1][reg], acc[ra][E - 2][reg], acc[ra][E - 1][reg]) : f4zero());
+                } else {
+                    st2(o + r * FD, rt < NRT ? make_float2(acc[ra][0][reg], acc[ra][1][reg]) : make_float2(0.f, 0.f));
+                }
+            }
+        }
+}
+
+// one frame: phase 1 over the wave's tiles (slot s -> tile wave + NW*s), barrier, phase 2
+template <int RT, int NRT, int NW, bool HAS_EXT, bool PIPE>
+__device__ __forceinline__ void fus_frame(const float* __restrict__ dA, const float* __restrict__ ext,
+                                          const float* __restrict__ Cn, const float* __restrict__ Sn, const float* Qr,
+                                          const float* QnT, float* Gs, float* __restrict__ dQraw, float* __restrict__ dQn,
+                                          long frame, int n, int i, int NA, int Li, int Lqa, int Lr, float scale,
+                                          const long (&obase)[16 / NW], int ntiles, f32x4 (&dcn)[16 / NW][8], int wave, int lane) {
+    constexpr int TPW = 16 / NW, E = NW == 4 ? 4 : 2;
+    const int CR = NA * Lqa;
+    // c15 / g re-derived from an opaque copy of the lane id per frame: hoisted out of the frame loop, the address
+    // arithmetic built on them stays live across the kernel and is spilled to scratch
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    const int c15 = l & 15, g = l >> 4;
+    const long fr = (long)i * Lqa;
+    if (PIPE) {
+        FusTile<NRT, HAS_EXT> Ta, Tb;
+        if (ntiles > 0) fus_p1_fetch<NRT, HAS_EXT>(Ta, dA, Sn, ext, obase[0] + fr, Lr, g);
+#pragma unroll
+        for (int s = 0; s < TPW; s++) {
+            if (s < ntiles) {
+                const int c = (wave + NW * s) * 16 + c15;
+                if (s & 1) {
+                    if (s + 1 < TPW && s + 1 < ntiles) fus_p1_fetch<NRT, HAS_EXT>(Ta, dA, Sn, ext, obase[s + 1 < TPW ? s + 1 : 0] + fr, Lr, g);
+                    fus_p1_tile<RT, NRT, HAS_EXT>(Tb, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g);
+                } else {
+                    if (s + 1 < TPW && s + 1 < ntiles) fus_p1_fetch<NRT, HAS_EXT>(Tb, dA, Sn, ext, obase[s + 1 < TPW ? s + 1 : 0] + fr, Lr, g);
+                    fus_p1_tile<RT, NRT, HAS_EXT>(Ta, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < TPW; s++) {
+            if (s < ntiles) {
+                const int c = (wave + NW * s) * 16 + c15;
+                FusTile<NRT, HAS_EXT> T;
+                fus_p1_fetch<NRT, HAS_EXT>(T, dA, Sn, ext, obase[s] + fr, Lr, g);
+                fus_p1_tile<RT, NRT, HAS_EXT>(T, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g);
+            }
+        }
+    }
+    __syncthreads();   // G of the whole frame is in LDS
+    const int d0 = (16 * E) * (wave % (NW / 2)) + E * c15;
+    if (wave < NW / 2) fus_p2<RT, NRT, E, true, PIPE>(dA, Sn, Cn, Gs, dQraw, frame, n, i, NA, Li, Lqa, Lr, d0, c15, g);
+    else fus_p2<RT, NRT, E, false, PIPE>(dA, Sn, Cn, Gs, dQn, frame, n, i, NA, Li, Lqa, Lr, d0, c15, g);
+}
+
+template <int RT, int NW, bool HAS_EXT>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void str_attn_bwd_fused_kernel(
+    const float* __restrict__ dA, const float* __restrict__ ext, const float* __restrict__ Cn, const float* __restrict__ Q,
+    const float* __restrict__ Qn, const float* __restrict__ Sn, const float* __restrict__ qmask, float* __restrict__ dQraw,
+    float* __restrict__ dQn, float* __restrict__ part, int N, int NA, int Li, int Lqa, int Lr, float scale, int nchunks) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int LT = FusLay<RT>::LT, TPW = 16 / NW, NT = 64 * NW;
+    float* Qr = lds;                                  // [RT*16][FLDQ]  raw regions (rows >= Lr never read)
+    float* QnT = Qr + FusLay<RT>::QR_FLOATS;          // [128][LT]      normalised regions, transposed, pad columns zero
+    float* Gs = QnT + FusLay<RT>::QT_FLOATS;          // [CT*16][LG]    dS of the frame
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int CR = NA * Lqa, CT = (CR + 15) >> 4;
+    const int n = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
+
+    for (int e = tid; e < FusLay<RT>::QR_FLOATS + FusLay<RT>::QT_FLOATS; e += NT) lds[e] = 0.f;
+
+    // this wave's context tiles (phase 1): slot s -> tile wave + NW*s
+    long obase[TPW];
+    const int ntiles = wave < CT ? (CT - 1 - wave) / NW + 1 : 0;
+#pragma unroll
+    for (int s = 0; s < TPW; s++) {
+        const int c = (wave + NW * s) * 16 + (lane & 15);
+        const int cc = c < CR ? c : CR - 1;
+        obase[s] = ((long)(n * NA + cc / Lqa) * Li) * Lqa + cc % Lqa;
+    }
+    f32x4 dcn[TPW][8];
+#pragma unroll
+    for (int s = 0; s < TPW; s++)
+#pragma unroll
+        for (int dt = 0; dt < 8; dt++) dcn[s][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    // staging map: a wave-step covers 8 region rows x 8 sixteen-byte pieces (128 contiguous bytes per row); 8 rows per
+    // 32-lane half keep the transposed ds_write_b32 of Qn^T at 2-way bank conflicts (free) instead of 16-way
+    constexpr int UNITS = RT * 2 * 4, NST = (UNITS + NW - 1) / NW;
+    for (int i = chunk; i < Li; i += nchunks) {
+        const long frame = (long)n * Li + i;
+        const float mv = lane < Lr ? qmask[frame * Lr + lane] : 0.f;
+        const unsigned long long bal = __ballot(mv != 0.f);
+        const int nvalid = HAS_EXT ? Lr : (bal ? 64 - __builtin_clzll(bal) : 0);
+        if (nvalid == 0) {   // uniform over the workgroup: no region contributes, both gradients of the frame are zero
+            for (int e = tid; e < Lr * 32; e += NT) {
+                st4(dQraw + frame * Lr * FD + 4 * e, f4zero());
+                st4(dQn + frame * Lr * FD + 4 * e, f4zero());
+            }
+            continue;
+        }
+        // ---- stage the frame's regions ----
+#pragma unroll
+        for (int s = 0; s < NST; s++) {
+            const int u = wave + NW * s;
+            const int r = 8 * (u >> 2) + (lane & 7), q = 8 * (u & 3) + (lane >> 3);
+            if (u < UNITS && r < Lr) {
+                const float4 vq = ld4(Q + (frame * Lr + r) * FD + 4 * q);
+                const float4 vn = ld4(Qn + (frame * Lr + r) * FD + 4 * q);
+                st4(&Qr[r * FLDQ + 4 * q], vq);
+                QnT[(4 * q + 0) * LT + r] = vn.x;
+                QnT[(4 * q + 1) * LT + r] = vn.y;
+                QnT[(4 * q + 2) * LT + r] = vn.z;
+                QnT[(4 * q + 3) * LT + r] = vn.w;
+            }
+        }
+        __syncthreads();
+        const int nrt = (nvalid + 15) >> 4;
+#define FUS_FRAME(NRTV)                                                                                                  \
+    fus_frame<RT, (NRTV) <= RT ? (NRTV) : RT, NW, HAS_EXT, true>(dA, ext, Cn, Sn, Qr, QnT, Gs, dQraw, dQn, frame, n, i, NA, Li, \
+                                                         Lqa, Lr, scale, obase, ntiles, dcn, wave, lane)
+        if (RT == 1 || nrt == 1) FUS_FRAME(1);
+        else if (RT == 2 || nrt == 2) FUS_FRAME(2);
+        else if (RT == 3 || nrt == 3) FUS_FRAME(3);
+        else FUS_FRAME(4);
+#undef FUS_FRAME
+        // no barrier here: the next frame's staging writes Qr / Qn^T (last read before the phase barrier above), G is only
+        // overwritten after the next staging barrier
+    }
+    // dCn slab of this workgroup: [chunk][n*CR + c][d], lane (c15, g) holds d = dt*16 + 4g .. +3 of context row c15
+#pragma unroll
+    for (int s = 0; s < TPW; s++) {
+        const int c = (wave + NW * s) * 16 + (lane & 15);
+        if (s < ntiles && c < CR) {
+            float* dst = part + (((size_t)chunk * N + n) * CR + c) * FD + 4 * (lane >> 4);
+#pragma unroll
+            for (int dt = 0; dt < 8; dt++)
+                st4(dst + dt * 16, make_float4(dcn[s][dt][0], dcn[s][dt][1], dcn[s][dt][2], dcn[s][dt][3]));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void fus_slab_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int nb, long C4) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= C4) return;
+    float4 acc = f4zero();
+    for (int b = 0; b < nb; b++) acc = f4add(acc, ld4s(part + ((size_t)b * C4 + e) * 4));
+    st4(out + e * 4, acc);
+}
+
+template <int RT, int NW>
+static int fus_launch(const float* dA, const float* ext, const float* Cn, const float* Q, const float* Qn, const float* Sn,
+                      const float* qmask, float* dQraw, float* dQn, float* dCn, int N, int NA, int Li, int Lqa, int Lr,
+                      float scale, float* part, int nchunks, hipStream_t st) {
+    const int CR = NA * Lqa, CT = (CR + 15) / 16;
+    const size_t lds = ((size_t)FusLay<RT>::QR_FLOATS + FusLay<RT>::QT_FLOATS + (size_t)CT * 16 * FusLay<RT>::LG) * sizeof(float);
+    const dim3 grid(N * nchunks), block(64 * NW);
+    if (ext) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)str_attn_bwd_fused_kernel<RT, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((str_attn_bwd_fused_kernel<RT, NW, true>), grid, block, lds, st, dA, ext, Cn, Q, Qn, Sn, qmask, dQraw, dQn,
+                           part, N, NA, Li, Lqa, Lr, scale, nchunks);
+    } else {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)str_attn_bwd_fused_kernel<RT, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((str_attn_bwd_fused_kernel<RT, NW, false>), grid, block, lds, st, dA, ext, Cn, Q, Qn, Sn, qmask, dQraw, dQn,
+                           part, N, NA, Li, Lqa, Lr, scale, nchunks);
+    }
+    STAGE_LAUNCH_CHECK();
+    const long total = (long)N * CR * (FD / 4);
+    hipLaunchKernelGGL(fus_slab_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)part, dCn,
+                       nchunks, total);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t stage_str_attn_bwd_fused_ws_bytes(int N, int NA, int Lqa, int D) {
+    return (size_t)FUS_MAX_CHUNKS * N * NA * Lqa * D * sizeof(float);
+}
+
+extern "C" int stage_str_attn_bwd_fused(const float* dA, const float* dS_raw_ext, const float* Cn, const float* Q,
+                                        const float* Qn, const float* S_norm, const float* q_mask, float* dQraw,
+                                        float* dQn, float* dCn, int N, int NA, int Li, int Lqa, int Lr, int D, float scale,
+                                        void* ws, size_t ws_bytes, void* stream) {
+    if (N <= 0 || Li <= 0) return 0;
+    if (D != FD || Lr < 2 || Lr > 64 || (Lr & 1) || Lqa < 4 || NA < 1 || NA * Lqa > 256) return STAGE_ERR_SHAPE;
+    if (ws_bytes < stage_str_attn_bwd_fused_ws_bytes(N, NA, Lqa, D)) return STAGE_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    // frame chunks per example: ~2 resident workgroups per CU, every workgroup accumulates dCn over its frames in registers
+    static const int env_chunks = getenv("STAGE_K1_BWD_CHUNKS") ? atoi(getenv("STAGE_K1_BWD_CHUNKS")) : 0;
+    int nchunks = env_chunks > 0 ? env_chunks : (512 + N - 1) / N;
+    if (nchunks > FUS_MAX_CHUNKS) nchunks = FUS_MAX_CHUNKS;
+    if (nchunks > Li) nchunks = Li;
+    if (nchunks < 1) nchunks = 1;
+    const int RT = (Lr + 15) / 16;
+    switch (RT) {
+        case 1: return fus_launch<1, 8>(dA, dS_raw_ext, Cn, Q, Qn, S_norm, q_mask, dQraw, dQn, dCn, N, NA, Li, Lqa, Lr, scale, (float*)ws, nchunks, st);
+        case 2: return fus_launch<2, 8>(dA, dS_raw_ext, Cn, Q, Qn, S_norm, q_mask, dQraw, dQn, dCn, N, NA, Li, Lqa, Lr, scale, (float*)ws, nchunks, st);
+        case 3: return fus_launch<3, 8>(dA, dS_raw_ext, Cn, Q, Qn, S_norm, q_mask, dQraw, dQn, dCn, N, NA, Li, Lqa, Lr, scale, (float*)ws, nchunks, st);
+        default: return fus_launch<4, 8>(dA, dS_raw_ext, Cn, Q, Qn, S_norm, q_mask, dQraw, dQn, dCn, N, NA, Li, Lqa, Lr, scale, (float*)ws, nchunks, st);
+    }
+}

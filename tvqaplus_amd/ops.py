@@ -374,6 +374,11 @@ def l2norm(x: torch.Tensor, p: float = 0.0, seed: int = 0) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------------------------
 # K1: StructuredAttention
 # ---------------------------------------------------------------------------------------------------------------
+import os as _os
+
+_K1_BWD_UNFUSED = _os.environ.get("STAGE_K1_BWD_UNFUSED") is not None   # developer switch (cross-check in the tests)
+
+
 class _StrAttn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, C, Q, c_mask, q_mask, scale: float, p: float, seed_c: int, seed_q: int):
@@ -388,7 +393,7 @@ class _StrAttn(torch.autograd.Function):
         Sn = torch.empty_like(S)
         _call("stage_str_attn_fwd", _ptr(Cn), _ptr(Q), _ptr(c_mask), _ptr(q_mask), _ptr(A), _ptr(S), _ptr(Sn), N, NA, Li,
               Lqa, Lr, D, float(scale), float(p), int(seed_q), _stream())
-        ctx.save_for_backward(C, Q, Cn, Sn)
+        ctx.save_for_backward(C, Q, Cn, Sn, q_mask)
         ctx.cfg = (float(scale), float(p), int(seed_c), int(seed_q))
         ctx.mark_non_differentiable(Sn)
         # raw S only receives a gradient when the supervised attention loss is on: without this autograd hands the
@@ -398,7 +403,7 @@ class _StrAttn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dA, dS, _dSn):
-        C, Q, Cn, Sn = ctx.saved_tensors
+        C, Q, Cn, Sn, q_mask = ctx.saved_tensors
         scale, p, seed_c, seed_q = ctx.cfg
         N, NA, Lqa, D = C.shape
         _, Li, Lr, _ = Q.shape
@@ -406,15 +411,26 @@ class _StrAttn(torch.autograd.Function):
         dS_ext = _chk(dS, "dS") if dS is not None else None
         Qn = torch.empty_like(Q)
         _call("stage_l2norm_fwd", _ptr(Q), _ptr(Qn), None, N * Li * Lr, D, EPS_L2, p, seed_q, _stream())
-        dS_out = torch.empty_like(Sn)
         dQ = torch.empty_like(Q)       # receives the value-path gradient, then the normalised-path one on top
         dQn = torch.empty_like(Q)
         dCn = torch.empty_like(C)
         lib = _lib.load()
-        wsb = lib.stage_str_attn_bwd_ws_bytes(N, NA, Lqa, D)
-        ws = _workspace(wsb, C.device)
-        _call("stage_str_attn_bwd", _ptr(dA), _ptr(dS_ext), _ptr(Cn), _ptr(Q), _ptr(Qn), _ptr(Sn), _ptr(dS_out),
-              _ptr(dQ), _ptr(dQn), _ptr(dCn), N, NA, Li, Lqa, Lr, D, scale, _ptr(ws), wsb, _stream())
+        rc = _lib.STAGE_ERR_SHAPE
+        if not _K1_BWD_UNFUSED:
+            # one pass over dA, dS stays on chip (D = 128, even Lr); other shapes take the three-kernel path below
+            wsb = lib.stage_str_attn_bwd_fused_ws_bytes(N, NA, Lqa, D)
+            ws = _workspace(wsb, C.device)
+            rc = lib.stage_str_attn_bwd_fused(_ptr(dA), _ptr(dS_ext), _ptr(Cn), _ptr(Q), _ptr(Qn), _ptr(Sn), _ptr(q_mask),
+                                              _ptr(dQ), _ptr(dQn), _ptr(dCn), N, NA, Li, Lqa, Lr, D, scale, _ptr(ws), wsb,
+                                              _stream())
+            if rc != _lib.STAGE_ERR_SHAPE:
+                _lib.check(rc, "stage_str_attn_bwd_fused")
+        if rc == _lib.STAGE_ERR_SHAPE:
+            dS_out = torch.empty_like(Sn)
+            wsb = lib.stage_str_attn_bwd_ws_bytes(N, NA, Lqa, D)
+            ws = _workspace(wsb, C.device)
+            _call("stage_str_attn_bwd", _ptr(dA), _ptr(dS_ext), _ptr(Cn), _ptr(Q), _ptr(Qn), _ptr(Sn), _ptr(dS_out),
+                  _ptr(dQ), _ptr(dQn), _ptr(dCn), N, NA, Li, Lqa, Lr, D, scale, _ptr(ws), wsb, _stream())
         _call("stage_l2norm_bwd", _ptr(dQn), _ptr(Q), _ptr(dQ), N * Li * Lr, D, EPS_L2, p, seed_q, 1, _stream())
         dC = torch.empty_like(C)
         _call("stage_l2norm_bwd", _ptr(dCn), _ptr(C), _ptr(dC), N * NA * Lqa, D, EPS_L2, p, seed_c, 0, _stream())
