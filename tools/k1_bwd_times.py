@@ -54,3 +54,11 @@ def timeit(fn, name, reps=20):
     t = [s.elapsed_time(e) * 1e3 for s, e in ev]
     print("%s: avg %.1f min %.1f max %.1f us" % (name, sum(t) / len(t), min(t), max(t)))
 timeit(old, "three-kernel"); timeit(new, "fused")
+if os.environ.get("TIM"):     # phase cycle counters (STAGE_K1_BWD_TIM): sum over waves
+    tim = torch.zeros(6, dtype=torch.int64, device=dev)
+    os.environ["STAGE_K1_BWD_TIM"] = str(tim.data_ptr())
+    new(); torch.cuda.synchronize()
+    del os.environ["STAGE_K1_BWD_TIM"]
+    v = tim.cpu().tolist(); tot = float(sum(v))
+    names = ["stage/skip", "wait S1", "phase 1", "wait S2", "phase 2", "slab"]
+    print(" | ".join("%s %.1f%%" % (n, 100 * x / tot) for n, x in zip(names, v)), "| total wave-cycles %.3g" % tot)

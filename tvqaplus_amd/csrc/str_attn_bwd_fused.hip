@@ -31,6 +31,8 @@
 #define FD 128          // row width (floats)
 #define FLDQ 132        // padded LDS row of the raw region tile
 #define FUS_MAX_CHUNKS 32
+// developer phase timers (STAGE_K1_BWD_TIM = device pointer to 6 uint64): wave cycles per phase, summed over waves
+#define TICK(ph) do { if (tim) { unsigned long long tn = __builtin_readcyclecounter(); tacc[ph] += tn - tlast; tlast = tn; } } while (0)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -51,32 +53,43 @@ template <int RT> __device__ __forceinline__ int gcol(int c, int col) { return F
 // phase 1, one 16-row context tile: operands are fetched one tile ahead (fus_p1_fetch of tile s+1 is issued before the
 // MFMAs of tile s)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NRT, bool HAS_EXT> struct FusTile {
+template <int PT, bool HAS_EXT> struct FusTile {   // PT = region tiles fetched (>= the NRT a frame body uses)
     float4 gv[8];            // dA fragments: context row c15, floats 4*fchunk(g, m) .. +3
-    float2 pq[NRT][2];       // S_ pieces: regions rt*16 + 4g + {0,1}, {2,3}
-    float2 eq[HAS_EXT ? NRT : 1][2];
+    float2 pq[PT][2];        // S_ pieces: regions rt*16 + 4g + {0,1}, {2,3}
+    float2 eq[HAS_EXT ? PT : 1][2];
 };
+// column swizzle of the LDS copy of dA (pipelined kernel): phase 2 reads rows 4k+g (two rows per 32-lane half) as 8-byte
+// pieces of one 128-byte segment -> odd rows move to the other bank half, rows 2,3 mod 4 by 8 floats
+__device__ __forceinline__ int fswz(int c) { return ((c & 1) << 5) | ((c & 2) << 2); }
 
-template <int NRT, bool HAS_EXT>
-__device__ __forceinline__ void fus_p1_fetch(FusTile<NRT, HAS_EXT>& T, const float* __restrict__ dA, const float* __restrict__ Sn,
-                                             const float* __restrict__ ext, long orow, int Lr, int g) {
-    const float* da = dA + orow * FD;
+// dAf / Snf / extf: row 0 = output row ((n*NA)*Li + i)*Lqa of the frame (uniform -> scalar base registers); rel = this lane's
+// row offset a*Li*Lqa + w (32 bits)
+template <int NRT, bool HAS_EXT>   // NRT = pieces fetched
+__device__ __forceinline__ void fus_p1_fetch(FusTile<NRT, HAS_EXT>& T, const float* __restrict__ dAf, const float* __restrict__ Snf,
+                                             const float* __restrict__ extf, unsigned rel, int Lr, int g) {
+    const unsigned offa = rel * FD + 4u * fchunk(g, 0);
 #pragma unroll
-    for (int m = 0; m < 8; m++) T.gv[m] = ld4(da + 4 * fchunk(g, m));
+    for (int m = 0; m < 8; m++) T.gv[m] = ld4(dAf + (offa + 4u * m));
+    const unsigned offs = rel * (unsigned)Lr;
 #pragma unroll
     for (int rt = 0; rt < NRT; rt++)
 #pragma unroll
         for (int hh = 0; hh < 2; hh++) {
-            const int r0 = min(rt * 16 + 4 * g + 2 * hh, Lr - 2);
-            T.pq[rt][hh] = ld2(Sn + orow * Lr + r0);
-            if (HAS_EXT) T.eq[rt][hh] = ld2(ext + orow * Lr + r0);
+            const unsigned r0 = (unsigned)min(rt * 16 + 4 * g + 2 * hh, Lr - 2);
+            T.pq[rt][hh] = ld2(Snf + (offs + r0));
+            if (HAS_EXT) T.eq[rt][hh] = ld2(extf + (offs + r0));
         }
 }
 
-template <int RT, int NRT, bool HAS_EXT>
-__device__ __forceinline__ void fus_p1_tile(const FusTile<NRT, HAS_EXT>& T, const float* Qr, const float* QnT, float* Gs, int c,
-                                            bool cvalid, int Lr, float scale, f32x4 (&dcn)[8], int c15, int g) {
+template <int RT, int NRT, bool HAS_EXT, int PT = NRT, bool LDSA = false>
+__device__ __forceinline__ void fus_p1_tile(const FusTile<PT, HAS_EXT>& T, const float* Qr, const float* QnT, float* Gs, int c,
+                                            bool cvalid, int Lr, float scale, f32x4 (&dcn)[8], int c15, int g,
+                                            float* dAs = nullptr) {
     constexpr int LT = FusLay<RT>::LT, LG = FusLay<RT>::LG;
+    if (LDSA && cvalid) {   // the tile's dA rows for phase 2 (k = context row layout is read back from LDS, not from L2 / HBM)
+#pragma unroll
+        for (int m = 0; m < 8; m++) st4(&dAs[c * FD + ((4 * fchunk(g, m)) ^ fswz(c))], T.gv[m]);
+    }
     constexpr int NCHAIN = NRT == 1 ? 2 : 1;   // a single accumulator would be one dependent chain (40 instead of 32 cycles per MFMA)
     f32x4 acc[NRT][NCHAIN];
 #pragma unroll
@@ -261,13 +274,103 @@ __device__ __forceinline__ void fus_p2(const float* __restrict__ dA, const float
         }
 }
 
+// The same with a UNIFORM row walk (Lqa % 4 == 0 and CR/4 a multiple of FUS_U: the published shapes): the four lane groups
+// of a k-step sit in the same answer block, so the row pointer advances in scalar registers and every load is
+// (scalar base) + (constant lane offset) -- no vector address arithmetic, no validity selects between the MFMAs.
+// dAf / Snf / outf are the frame bases of fus_p1_fetch, Cnn = Cn + n*CR*128.
+template <int RT, int NRT, int E, bool RAW, bool PIPE, bool LDSA = false, int UG = FUS_U>
+__device__ __forceinline__ void fus_p2_unif(const float* __restrict__ dAf, const float* __restrict__ Snf,
+                                            const float* __restrict__ Cnn, const float* Gs, float* __restrict__ outf, int NA,
+                                            int Li, int Lqa, int Lr, int d0, int c15, int g, const float* dAs = nullptr) {
+    typedef typename FusVec<E>::T vec_t;
+    constexpr int LG = FusLay<RT>::LG;
+    const int ngroups = (NA * Lqa) / (4 * UG);
+    f32x4 acc[NRT][E];
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++)
+#pragma unroll
+        for (int e = 0; e < E; e++) acc[rt][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned offB = (RAW && LDSA) ? (unsigned)(g * FD + (d0 ^ fswz(g))) : (unsigned)(g * FD + d0);
+    unsigned offA[NRT];
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++)
+        offA[rt] = RAW ? (unsigned)(g * Lr + min(rt * 16 + c15, Lr - 1)) : (unsigned)(g * LG + gcol<RT>(g, rt * 16 + c15));
+    const float* pB = RAW ? dAf : Cnn;                    // row 4*step of the B operand (uniform)
+    const float* pA = Snf;
+    const long jumpB = (long)(Li - 1) * Lqa * FD, jumpA = (long)(Li - 1) * Lqa * Lr;
+    const int wq_n = Lqa >> 2;
+    int wq = 0, gs = 0, bs = 0;
+
+    auto fetch = [&](vec_t (&bv)[UG], float (&av)[UG][NRT]) {
+#pragma unroll
+        for (int u = 0; u < UG; u++) {
+            bv[u] = (RAW && LDSA) ? fus_ldv<E>(dAs + bs + offB) : fus_ldv<E>(pB + offB);
+#pragma unroll
+            for (int rt = 0; rt < NRT; rt++) av[u][rt] = RAW ? pA[offA[rt]] : Gs[gs + offA[rt]];
+            pB += 4 * FD;
+            gs += 4 * LG;
+            bs += 4 * FD;
+            if (RAW) {
+                pA += 4 * Lr;
+                const bool wrap = ++wq == wq_n;       // uniform
+                wq = wrap ? 0 : wq;
+                pB += wrap ? jumpB : 0;
+                pA += wrap ? jumpA : 0;
+            }
+        }
+    };
+    auto mul = [&](const vec_t (&bv)[UG], const float (&av)[UG][NRT]) {
+#pragma unroll
+        for (int u = 0; u < UG; u++)
+#pragma unroll
+            for (int rt = 0; rt < NRT; rt++)
+#pragma unroll
+                for (int e = 0; e < E; e++)   // A rows >= Lr only feed output rows that are never stored
+                    acc[rt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][rt], fus_elt(bv[u], e), acc[rt][e], 0, 0, 0);
+    };
+    if (PIPE) {
+        vec_t b0[UG], b1[UG];
+        float a0[UG][NRT], a1[UG][NRT];
+        fetch(b0, a0);
+        for (int gi = 0; gi < ngroups; gi += 2) {
+            if (gi + 1 < ngroups) fetch(b1, a1);
+            mul(b0, a0);
+            if (gi + 2 < ngroups) fetch(b0, a0);
+            if (gi + 1 < ngroups) mul(b1, a1);
+        }
+    } else {
+        for (int gi = 0; gi < ngroups; gi++) {
+            vec_t b0[UG];
+            float a0[UG][NRT];
+            fetch(b0, a0);
+            mul(b0, a0);
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int r = rt * 16 + 4 * g + reg;
+            if (r < Lr) {
+                constexpr int Z = 0;
+                const int ra = rt < NRT ? rt : Z;
+                if (E == 4) {
+                    st4(outf + r * FD + d0, rt < NRT ? make_float4(acc[ra][0][reg], acc[ra][1][reg], acc[ra][E - 2][reg], acc[ra][E - 1][reg]) : f4zero());
+                } else {
+                    st2(outf + r * FD + d0, rt < NRT ? make_float2(acc[ra][0][reg], acc[ra][1][reg]) : make_float2(0.f, 0.f));
+                }
+            }
+        }
+}
+
 // one frame: phase 1 over the wave's tiles (slot s -> tile wave + NW*s), barrier, phase 2
-template <int RT, int NRT, int NW, bool HAS_EXT, bool PIPE>
+template <int RT, int NRT, int NW, bool HAS_EXT, bool PIPE, bool LDSA>
 __device__ __forceinline__ void fus_frame(const float* __restrict__ dA, const float* __restrict__ ext,
                                           const float* __restrict__ Cn, const float* __restrict__ Sn, const float* Qr,
-                                          const float* QnT, float* Gs, float* __restrict__ dQraw, float* __restrict__ dQn,
+                                          const float* QnT, float* Gs, float* dAs, float* __restrict__ dQraw, float* __restrict__ dQn,
                                           long frame, int n, int i, int NA, int Li, int Lqa, int Lr, float scale,
-                                          const long (&obase)[16 / NW], int ntiles, f32x4 (&dcn)[16 / NW][8], int wave, int lane) {
+                                          const unsigned (&orel)[16 / NW], int ntiles, f32x4 (&dcn)[16 / NW][8], int wave, int lane,
+                                          unsigned long long* tim, unsigned long long (&tacc)[6], unsigned long long& tlast) {
     constexpr int TPW = 16 / NW, E = NW == 4 ? 4 : 2;
     const int CR = NA * Lqa;
     // c15 / g re-derived from an opaque copy of the lane id per frame: hoisted out of the frame loop, the address
@@ -275,20 +378,23 @@ __device__ __forceinline__ void fus_frame(const float* __restrict__ dA, const fl
     int l = lane;
     asm volatile("" : "+v"(l));
     const int c15 = l & 15, g = l >> 4;
-    const long fr = (long)i * Lqa;
+    const long rowbase = ((long)n * NA * Li + i) * Lqa;     // uniform
+    const float* dAf = dA + rowbase * FD;
+    const float* Snf = Sn + rowbase * Lr;
+    const float* extf = HAS_EXT ? ext + rowbase * Lr : nullptr;
     if (PIPE) {
         FusTile<NRT, HAS_EXT> Ta, Tb;
-        if (ntiles > 0) fus_p1_fetch<NRT, HAS_EXT>(Ta, dA, Sn, ext, obase[0] + fr, Lr, g);
+        if (ntiles > 0) fus_p1_fetch<NRT, HAS_EXT>(Ta, dAf, Snf, extf, orel[0], Lr, g);
 #pragma unroll
         for (int s = 0; s < TPW; s++) {
             if (s < ntiles) {
                 const int c = (wave + NW * s) * 16 + c15;
                 if (s & 1) {
-                    if (s + 1 < TPW && s + 1 < ntiles) fus_p1_fetch<NRT, HAS_EXT>(Ta, dA, Sn, ext, obase[s + 1 < TPW ? s + 1 : 0] + fr, Lr, g);
-                    fus_p1_tile<RT, NRT, HAS_EXT>(Tb, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g);
+                    if (s + 1 < TPW && s + 1 < ntiles) fus_p1_fetch<NRT, HAS_EXT>(Ta, dAf, Snf, extf, orel[s + 1 < TPW ? s + 1 : 0], Lr, g);
+                    fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(Tb, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, dAs);
                 } else {
-                    if (s + 1 < TPW && s + 1 < ntiles) fus_p1_fetch<NRT, HAS_EXT>(Tb, dA, Sn, ext, obase[s + 1 < TPW ? s + 1 : 0] + fr, Lr, g);
-                    fus_p1_tile<RT, NRT, HAS_EXT>(Ta, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g);
+                    if (s + 1 < TPW && s + 1 < ntiles) fus_p1_fetch<NRT, HAS_EXT>(Tb, dAf, Snf, extf, orel[s + 1 < TPW ? s + 1 : 0], Lr, g);
+                    fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(Ta, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, dAs);
                 }
             }
         }
@@ -298,41 +404,54 @@ __device__ __forceinline__ void fus_frame(const float* __restrict__ dA, const fl
             if (s < ntiles) {
                 const int c = (wave + NW * s) * 16 + c15;
                 FusTile<NRT, HAS_EXT> T;
-                fus_p1_fetch<NRT, HAS_EXT>(T, dA, Sn, ext, obase[s] + fr, Lr, g);
-                fus_p1_tile<RT, NRT, HAS_EXT>(T, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g);
+                fus_p1_fetch<NRT, HAS_EXT>(T, dAf, Snf, extf, orel[s], Lr, g);
+                fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(T, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, dAs);
             }
         }
     }
+    TICK(2);
     __syncthreads();   // G of the whole frame is in LDS
+    TICK(3);
     const int d0 = (16 * E) * (wave % (NW / 2)) + E * c15;
-    if (wave < NW / 2) fus_p2<RT, NRT, E, true, PIPE>(dA, Sn, Cn, Gs, dQraw, frame, n, i, NA, Li, Lqa, Lr, d0, c15, g);
-    else fus_p2<RT, NRT, E, false, PIPE>(dA, Sn, Cn, Gs, dQn, frame, n, i, NA, Li, Lqa, Lr, d0, c15, g);
+    // one region tile: 2 MFMAs per k-step -- the L2 latency of the S_ / Cn operands needs 10 k-steps per group in flight
+    constexpr int UG = (PIPE && NRT == 1) ? 10 : FUS_U;
+    const bool unif = (Lqa & 3) == 0 && ((CR >> 2) % UG) == 0;
+    if (unif) {
+        if (wave < NW / 2) fus_p2_unif<RT, NRT, E, true, PIPE, LDSA, UG>(dAf, Snf, nullptr, Gs, dQraw + frame * Lr * FD, NA, Li, Lqa, Lr, d0, c15, g, dAs);
+        else fus_p2_unif<RT, NRT, E, false, PIPE, false, UG>(dAf, Snf, Cn + (long)n * CR * FD, Gs, dQn + frame * Lr * FD, NA, Li, Lqa, Lr, d0, c15, g);
+    } else {
+        if (wave < NW / 2) fus_p2<RT, NRT, E, true, PIPE>(dA, Sn, Cn, Gs, dQraw, frame, n, i, NA, Li, Lqa, Lr, d0, c15, g);
+        else fus_p2<RT, NRT, E, false, PIPE>(dA, Sn, Cn, Gs, dQn, frame, n, i, NA, Li, Lqa, Lr, d0, c15, g);
+    }
 }
 
-template <int RT, int NW, bool HAS_EXT>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void str_attn_bwd_fused_kernel(
+template <int RT, int NW, bool HAS_EXT, int OCC, bool LDSA>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void str_attn_bwd_fused_kernel(
     const float* __restrict__ dA, const float* __restrict__ ext, const float* __restrict__ Cn, const float* __restrict__ Q,
     const float* __restrict__ Qn, const float* __restrict__ Sn, const float* __restrict__ qmask, float* __restrict__ dQraw,
-    float* __restrict__ dQn, float* __restrict__ part, int N, int NA, int Li, int Lqa, int Lr, float scale, int nchunks) {
+    float* __restrict__ dQn, float* __restrict__ part, int N, int NA, int Li, int Lqa, int Lr, float scale, int nchunks,
+    unsigned long long* __restrict__ tim) {
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = tim ? __builtin_readcyclecounter() : 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int LT = FusLay<RT>::LT, TPW = 16 / NW, NT = 64 * NW;
-    float* Qr = lds;                                  // [RT*16][FLDQ]  raw regions (rows >= Lr never read)
-    float* QnT = Qr + FusLay<RT>::QR_FLOATS;          // [128][LT]      normalised regions, transposed, pad columns zero
-    float* Gs = QnT + FusLay<RT>::QT_FLOATS;          // [CT*16][LG]    dS of the frame
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int CR = NA * Lqa, CT = (CR + 15) >> 4;
+    float* Qr = lds;                                  // [Lr][FLDQ]     raw regions (reads of pad rows are clamped to the last region)
+    float* QnT = Qr + Lr * FLDQ;                      // [128][LT]      normalised regions, transposed, pad columns zero
+    float* Gs = QnT + FusLay<RT>::QT_FLOATS;          // [CR][LG]       dS of the frame
+    float* dAs = Gs + CR * FusLay<RT>::LG;            // [CR][128]      dA of the frame (LDSA: phase 2 re-reads it from here)
     const int n = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
 
-    for (int e = tid; e < FusLay<RT>::QR_FLOATS + FusLay<RT>::QT_FLOATS; e += NT) lds[e] = 0.f;
+    for (int e = tid; e < FusLay<RT>::QT_FLOATS; e += NT) QnT[e] = 0.f;
 
     // this wave's context tiles (phase 1): slot s -> tile wave + NW*s
-    long obase[TPW];
+    unsigned orel[TPW];   // row offset of context row c inside a frame's row block: a*Li*Lqa + w
     const int ntiles = wave < CT ? (CT - 1 - wave) / NW + 1 : 0;
 #pragma unroll
     for (int s = 0; s < TPW; s++) {
         const int c = (wave + NW * s) * 16 + (lane & 15);
         const int cc = c < CR ? c : CR - 1;
-        obase[s] = ((long)(n * NA + cc / Lqa) * Li) * Lqa + cc % Lqa;
+        orel[s] = (unsigned)((cc / Lqa) * Li * Lqa + cc % Lqa);
     }
     f32x4 dcn[TPW][8];
 #pragma unroll
@@ -371,19 +490,23 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 QnT[(4 * q + 3) * LT + r] = vn.w;
             }
         }
+        TICK(0);
         __syncthreads();
+        TICK(1);
         const int nrt = (nvalid + 15) >> 4;
 #define FUS_FRAME(NRTV)                                                                                                  \
-    fus_frame<RT, (NRTV) <= RT ? (NRTV) : RT, NW, HAS_EXT, true>(dA, ext, Cn, Sn, Qr, QnT, Gs, dQraw, dQn, frame, n, i, NA, Li, \
-                                                         Lqa, Lr, scale, obase, ntiles, dcn, wave, lane)
+    fus_frame<RT, (NRTV) <= RT ? (NRTV) : RT, NW, HAS_EXT, (OCC == 2 && NW == 8), LDSA>(dA, ext, Cn, Sn, Qr, QnT, Gs, dAs, dQraw, dQn, frame, n, i, NA, Li, \
+                                                         Lqa, Lr, scale, orel, ntiles, dcn, wave, lane, tim, tacc, tlast)
         if (RT == 1 || nrt == 1) FUS_FRAME(1);
         else if (RT == 2 || nrt == 2) FUS_FRAME(2);
         else if (RT == 3 || nrt == 3) FUS_FRAME(3);
         else FUS_FRAME(4);
 #undef FUS_FRAME
+        TICK(4);
         // no barrier here: the next frame's staging writes Qr / Qn^T (last read before the phase barrier above), G is only
         // overwritten after the next staging barrier
     }
+    TICK(0);
     // dCn slab of this workgroup: [chunk][n*CR + c][d], lane (c15, g) holds d = dt*16 + 4g .. +3 of context row c15
 #pragma unroll
     for (int s = 0; s < TPW; s++) {
@@ -395,6 +518,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 st4(dst + dt * 16, make_float4(dcn[s][dt][0], dcn[s][dt][1], dcn[s][dt][2], dcn[s][dt][3]));
         }
     }
+    TICK(5);
+    if (tim && lane == 0) for (int ph = 0; ph < 6; ph++) atomicAdd(tim + ph, tacc[ph]);
 }
 
 __global__ __launch_bounds__(256) void fus_slab_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int nb, long C4) {
@@ -405,24 +530,30 @@ __global__ __launch_bounds__(256) void fus_slab_sum_kernel(const float* __restri
     st4(out + e * 4, acc);
 }
 
-template <int RT, int NW>
+template <int RT, int NW, int OCC>
 static int fus_launch(const float* dA, const float* ext, const float* Cn, const float* Q, const float* Qn, const float* Sn,
                       const float* qmask, float* dQraw, float* dQn, float* dCn, int N, int NA, int Li, int Lqa, int Lr,
                       float scale, float* part, int nchunks, hipStream_t st) {
-    const int CR = NA * Lqa, CT = (CR + 15) / 16;
-    const size_t lds = ((size_t)FusLay<RT>::QR_FLOATS + FusLay<RT>::QT_FLOATS + (size_t)CT * 16 * FusLay<RT>::LG) * sizeof(float);
+    const int CR = NA * Lqa;
+    const size_t base = ((size_t)Lr * FLDQ + FusLay<RT>::QT_FLOATS + (size_t)CR * FusLay<RT>::LG) * sizeof(float);
+    const size_t with_da = base + (size_t)CR * FD * sizeof(float);
+    // dA of a frame stays in LDS between the phases when it fits (the video shape) and the uniform phase 2 applies
+    static const bool no_ldsa = getenv("STAGE_K1_BWD_NOLDSA") != nullptr;   // developer switch
+    const bool unif = (Lqa & 3) == 0 && ((CR >> 2) % 10) == 0;
+    const bool ldsa = !no_ldsa && unif && NW == 8 && OCC == 2 && with_da <= 160 * 1024;
+    const size_t lds = ldsa ? with_da : base;
     const dim3 grid(N * nchunks), block(64 * NW);
-    if (ext) {
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)str_attn_bwd_fused_kernel<RT, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((str_attn_bwd_fused_kernel<RT, NW, true>), grid, block, lds, st, dA, ext, Cn, Q, Qn, Sn, qmask, dQraw, dQn,
-                           part, N, NA, Li, Lqa, Lr, scale, nchunks);
-    } else {
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)str_attn_bwd_fused_kernel<RT, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((str_attn_bwd_fused_kernel<RT, NW, false>), grid, block, lds, st, dA, ext, Cn, Q, Qn, Sn, qmask, dQraw, dQn,
-                           part, N, NA, Li, Lqa, Lr, scale, nchunks);
-    }
+    unsigned long long* tim = (unsigned long long*)(getenv("STAGE_K1_BWD_TIM") ? strtoull(getenv("STAGE_K1_BWD_TIM"), 0, 0) : 0ull);
+#define FUS_GO(EXTV, LDSAV)                                                                                                     \
+    do {                                                                                                                        \
+        if (lds > 64 * 1024)                                                                                                    \
+            (void)hipFuncSetAttribute((const void*)str_attn_bwd_fused_kernel<RT, NW, EXTV, OCC, LDSAV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((str_attn_bwd_fused_kernel<RT, NW, EXTV, OCC, LDSAV>), grid, block, lds, st, dA, ext, Cn, Q, Qn, Sn, qmask, \
+                           dQraw, dQn, part, N, NA, Li, Lqa, Lr, scale, nchunks, tim);                                          \
+    } while (0)
+    if (ext) { if (ldsa) FUS_GO(true, (NW == 8 && OCC == 2)); else FUS_GO(true, false); }
+    else { if (ldsa) FUS_GO(false, (NW == 8 && OCC == 2)); else FUS_GO(false, false); }
+#undef FUS_GO
     STAGE_LAUNCH_CHECK();
     const long total = (long)N * CR * (FD / 4);
     hipLaunchKernelGGL(fus_slab_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)part, dCn,
@@ -440,20 +571,23 @@ extern "C" int stage_str_attn_bwd_fused(const float* dA, const float* dS_raw_ext
                                         float* dQn, float* dCn, int N, int NA, int Li, int Lqa, int Lr, int D, float scale,
                                         void* ws, size_t ws_bytes, void* stream) {
     if (N <= 0 || Li <= 0) return 0;
-    if (D != FD || Lr < 2 || Lr > 64 || (Lr & 1) || Lqa < 4 || NA < 1 || NA * Lqa > 256) return STAGE_ERR_SHAPE;
+    if (D != FD || Lr < 2 || Lr > 64 || (Lr & 1) || Lqa < 4 || NA < 1 || NA * Lqa > 256 ||
+        (long)NA * Li * Lqa * FD >= (1l << 29)) return STAGE_ERR_SHAPE;   // 32-bit element offsets inside an example
     if (ws_bytes < stage_str_attn_bwd_fused_ws_bytes(N, NA, Lqa, D)) return STAGE_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     // frame chunks per example: ~2 resident workgroups per CU, every workgroup accumulates dCn over its frames in registers
     static const int env_chunks = getenv("STAGE_K1_BWD_CHUNKS") ? atoi(getenv("STAGE_K1_BWD_CHUNKS")) : 0;
-    int nchunks = env_chunks > 0 ? env_chunks : (512 + N - 1) / N;
+    int nchunks = env_chunks > 0 ? env_chunks : (256 + N - 1) / N;   // one workgroup per CU (256 registers, up to 157 KB of LDS)
     if (nchunks > FUS_MAX_CHUNKS) nchunks = FUS_MAX_CHUNKS;
     if (nchunks > Li) nchunks = Li;
     if (nchunks < 1) nchunks = 1;
     const int RT = (Lr + 15) / 16;
+#define FUS_ARGS dA, dS_raw_ext, Cn, Q, Qn, S_norm, q_mask, dQraw, dQn, dCn, N, NA, Li, Lqa, Lr, scale, (float*)ws, nchunks, st
     switch (RT) {
-        case 1: return fus_launch<1, 8>(dA, dS_raw_ext, Cn, Q, Qn, S_norm, q_mask, dQraw, dQn, dCn, N, NA, Li, Lqa, Lr, scale, (float*)ws, nchunks, st);
-        case 2: return fus_launch<2, 8>(dA, dS_raw_ext, Cn, Q, Qn, S_norm, q_mask, dQraw, dQn, dCn, N, NA, Li, Lqa, Lr, scale, (float*)ws, nchunks, st);
-        case 3: return fus_launch<3, 8>(dA, dS_raw_ext, Cn, Q, Qn, S_norm, q_mask, dQraw, dQn, dCn, N, NA, Li, Lqa, Lr, scale, (float*)ws, nchunks, st);
-        default: return fus_launch<4, 8>(dA, dS_raw_ext, Cn, Q, Qn, S_norm, q_mask, dQraw, dQn, dCn, N, NA, Li, Lqa, Lr, scale, (float*)ws, nchunks, st);
+        case 1: return fus_launch<1, 8, 2>(FUS_ARGS);
+        case 2: return fus_launch<2, 8, 2>(FUS_ARGS);
+        case 3: return fus_launch<3, 8, 2>(FUS_ARGS);
+        default: return fus_launch<4, 8, 2>(FUS_ARGS);
     }
+#undef FUS_ARGS
 }
