@@ -4,6 +4,8 @@ import os, sys, torch, torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tvqaplus_amd import _lib
 from tvqaplus_amd.synth import make_batch
+if os.environ.get("LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["LIB"])   # experiment builds (tools/build_variant.sh)
 lib = _lib.load()
 dev = "cuda"
 N, NA, Li, Lqa, Lr, D = int(os.environ.get("NB", 16)), 5, int(os.environ.get("LI", 300)), 40, int(os.environ.get("LR", 20)), 128

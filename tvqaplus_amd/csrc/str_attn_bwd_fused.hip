@@ -31,6 +31,9 @@
 #define FD 128          // row width (floats)
 #define FLDQ 132        // padded LDS row of the raw region tile
 #define FUS_MAX_CHUNKS 32
+#ifndef FUS_ABL
+#define FUS_ABL 0   // developer ablation bits (tools/build_variant.sh; results are wrong with any bit set): 1 no phase 2, 2 no dP MFMAs,
+#endif              // 4 no dCn MFMAs, 8 no LDS copy of dA, 16 no G store, 32 no phase-2 MFMAs, 64 no dQ stores
 // developer phase timers (STAGE_K1_BWD_TIM = device pointer to 6 uint64): wave cycles per phase, summed over waves
 #define TICK(ph) do { if (tim) { unsigned long long tn = __builtin_readcyclecounter(); tacc[ph] += tn - tlast; tlast = tn; } } while (0)
 
@@ -86,7 +89,7 @@ __device__ __forceinline__ void fus_p1_tile(const FusTile<PT, HAS_EXT>& T, const
                                             bool cvalid, int Lr, float scale, f32x4 (&dcn)[8], int c15, int g,
                                             float* dAs = nullptr) {
     constexpr int LT = FusLay<RT>::LT, LG = FusLay<RT>::LG;
-    if (LDSA && cvalid) {   // the tile's dA rows for phase 2 (k = context row layout is read back from LDS, not from L2 / HBM)
+    if (LDSA && cvalid && !(FUS_ABL & 8)) {   // the tile's dA rows for phase 2 (k = context row layout is read back from LDS, not from L2 / HBM)
 #pragma unroll
         for (int m = 0; m < 8; m++) st4(&dAs[c * FD + ((4 * fchunk(g, m)) ^ fswz(c))], T.gv[m]);
     }
@@ -110,7 +113,8 @@ __device__ __forceinline__ void fus_p1_tile(const FusTile<PT, HAS_EXT>& T, const
 #pragma unroll
             for (int rt = 0; rt < NRT; rt++) {
                 const float qa = j == 0 ? qv[rt].x : (j == 1 ? qv[rt].y : (j == 2 ? qv[rt].z : qv[rt].w));
-                acc[rt][j % NCHAIN] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa, gj[j], acc[rt][j % NCHAIN], 0, 0, 0);
+                if (!(FUS_ABL & 2)) acc[rt][j % NCHAIN] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa, gj[j], acc[rt][j % NCHAIN], 0, 0, 0);
+                else acc[rt][j % NCHAIN][j] += qa * gj[j];
             }
     }
     // dP[c][r = rt*16 + 4g + k] = sum of the chains
@@ -142,7 +146,7 @@ __device__ __forceinline__ void fus_p1_tile(const FusTile<PT, HAS_EXT>& T, const
             }
             G[rt][k] = v;
         }
-        if (cvalid) *reinterpret_cast<f32x4*>(&Gs[c * LG + gcol<RT>(c, rt * 16 + 4 * g)]) = G[rt];
+        if (cvalid && !(FUS_ABL & 16)) *reinterpret_cast<f32x4*>(&Gs[c * LG + gcol<RT>(c, rt * 16 + 4 * g)]) = G[rt];
     }
     // dCn^T (d x ctx) += Qn^T . G^T ; k outer so that consecutive MFMAs hit different accumulators; columns of padded
     // context rows are never stored
@@ -158,7 +162,8 @@ __device__ __forceinline__ void fus_p1_tile(const FusTile<PT, HAS_EXT>& T, const
 #pragma unroll
                 for (int dt = 0; dt < 4; dt++) {
                     const float a = k == 0 ? a4[dt].x : (k == 1 ? a4[dt].y : (k == 2 ? a4[dt].z : a4[dt].w));
-                    dcn[dh + dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, G[rt][k], dcn[dh + dt], 0, 0, 0);
+                    if (!(FUS_ABL & 4)) dcn[dh + dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, G[rt][k], dcn[dh + dt], 0, 0, 0);
+                    else dcn[dh + dt][k] += a * G[rt][k];
                 }
         }
 }
@@ -326,7 +331,8 @@ __device__ __forceinline__ void fus_p2_unif(const float* __restrict__ dAf, const
             for (int rt = 0; rt < NRT; rt++)
 #pragma unroll
                 for (int e = 0; e < E; e++)   // A rows >= Lr only feed output rows that are never stored
-                    acc[rt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][rt], fus_elt(bv[u], e), acc[rt][e], 0, 0, 0);
+                    if (!(FUS_ABL & 32)) acc[rt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][rt], fus_elt(bv[u], e), acc[rt][e], 0, 0, 0);
+                    else acc[rt][e][u & 3] += av[u][rt] * fus_elt(bv[u], e);
     };
     if (PIPE) {
         vec_t b0[UG], b1[UG];
@@ -416,6 +422,7 @@ __device__ __forceinline__ void fus_frame(const float* __restrict__ dA, const fl
     // one region tile: 2 MFMAs per k-step -- the L2 latency of the S_ / Cn operands needs 10 k-steps per group in flight
     constexpr int UG = (PIPE && NRT == 1) ? 10 : FUS_U;
     const bool unif = (Lqa & 3) == 0 && ((CR >> 2) % UG) == 0;
+    if (FUS_ABL & 1) return;
     if (unif) {
         if (wave < NW / 2) fus_p2_unif<RT, NRT, E, true, PIPE, LDSA, UG>(dAf, Snf, nullptr, Gs, dQraw + frame * Lr * FD, NA, Li, Lqa, Lr, d0, c15, g, dAs);
         else fus_p2_unif<RT, NRT, E, false, PIPE, false, UG>(dAf, Snf, Cn + (long)n * CR * FD, Gs, dQn + frame * Lr * FD, NA, Li, Lqa, Lr, d0, c15, g);
