@@ -30,7 +30,8 @@
 
 #define FD 128          // row width (floats)
 #define FLDQ 132        // padded LDS row of the raw region tile
-#define FUS_MAX_CHUNKS 32
+#define FUS_MAX_WGS 1024
+#define FUS_TABLE_BYTES(G, N) ((((size_t)(G) * sizeof(int4) + (size_t)(N) * sizeof(int2)) + 255) & ~(size_t)255)
 #ifndef FUS_ABL
 #define FUS_ABL 0   // developer ablation bits (tools/build_variant.sh; results are wrong with any bit set): 1 no phase 2, 2 no dP MFMAs,
 #endif              // 4 no dCn MFMAs, 8 no LDS copy of dA, 16 no G store, 32 no phase-2 MFMAs, 64 no dQ stores
@@ -63,16 +64,41 @@ template <int PT, bool HAS_EXT> struct FusTile {   // PT = region tiles fetched 
 };
 // column swizzle of the LDS copy of dA (pipelined kernel): phase 2 reads rows 4k+g (two rows per 32-lane half) as 8-byte
 // pieces of one 128-byte segment -> odd rows move to the other bank half, rows 2,3 mod 4 by 8 floats
-__device__ __forceinline__ int fswz(int c) { return ((c & 1) << 5) | ((c & 2) << 2); }
+// column swizzle (floats) of the LDS copy of dA; three access patterns, all conflict free: coalesced row writes (8 lanes = 128
+// contiguous bytes), phase-1 MFMA layout (16 lanes = 16 rows at one column -> 16 distinct 16-byte bank groups), phase-2 rows
+// 4k+g as 8-byte pieces (two rows per 32-lane half -> odd rows on the other bank half)
+__device__ __forceinline__ int fswz(int c) { return ((c & 1) << 5) | (((c >> 1) & 7) << 2); }
 
 // dAf / Snf / extf: row 0 = output row ((n*NA)*Li + i)*Lqa of the frame (uniform -> scalar base registers); rel = this lane's
 // row offset a*Li*Lqa + w (32 bits)
-template <int NRT, bool HAS_EXT>   // NRT = pieces fetched
+// COAL (with the LDS copy of dA): gv[i] = row 2i + (lane >> 5) of the tile, floats 4*(lane & 31) .. +3 -- every load covers
+// two full rows (1 KB contiguous).  In the MFMA layout (lane = row c15, eight 16-byte pieces of one 128-byte line) every
+// instruction touches 64 different lines and the eight instructions of a tile re-touch them; with 100+ KB of tiles in flight
+// per CU the 32 KB vector L1 evicts them in between and refills them up to eight times (measured ~9 GB/s per CU instead of
+// ~25).  The tile is transposed through the LDS copy that phase 2 needs anyway.
+template <int NRT, bool HAS_EXT, bool COAL = false>   // NRT = pieces fetched
 __device__ __forceinline__ void fus_p1_fetch(FusTile<NRT, HAS_EXT>& T, const float* __restrict__ dAf, const float* __restrict__ Snf,
-                                             const float* __restrict__ extf, unsigned rel, int Lr, int g) {
-    const unsigned offa = rel * FD + 4u * fchunk(g, 0);
+                                             const float* __restrict__ extf, unsigned rel, int Lr, int g, int tile = 0, int lane = 0,
+                                             int NA = 0, int Li = 0, int Lqa = 1) {
+    if (COAL) {
+        const int CR = NA * Lqa;
+        int c = tile * 16 + (lane >> 5);
+        int a = c / Lqa, w = c - a * Lqa;
 #pragma unroll
-    for (int m = 0; m < 8; m++) T.gv[m] = ld4(dAf + (offa + 4u * m));
+        for (int i = 0; i < 8; i++) {
+            const bool ok = c < CR;
+            const unsigned r = ok ? (unsigned)(a * Li * Lqa + w) : (unsigned)((NA - 1) * Li * Lqa + Lqa - 1);
+            T.gv[i] = ld4(dAf + (r * FD + 4u * (lane & 31)));
+            c += 2; w += 2;
+            const bool wrap = w >= Lqa;        // Lqa >= 4: at most one wrap per step
+            w -= wrap ? Lqa : 0;
+            a += wrap ? 1 : 0;
+        }
+    } else {
+        const unsigned offa = rel * FD + 4u * fchunk(g, 0);
+#pragma unroll
+        for (int m = 0; m < 8; m++) T.gv[m] = ld4(dAf + (offa + 4u * m));
+    }
     const unsigned offs = rel * (unsigned)Lr;
 #pragma unroll
     for (int rt = 0; rt < NRT; rt++)
@@ -87,11 +113,22 @@ __device__ __forceinline__ void fus_p1_fetch(FusTile<NRT, HAS_EXT>& T, const flo
 template <int RT, int NRT, bool HAS_EXT, int PT = NRT, bool LDSA = false>
 __device__ __forceinline__ void fus_p1_tile(const FusTile<PT, HAS_EXT>& T, const float* Qr, const float* QnT, float* Gs, int c,
                                             bool cvalid, int Lr, float scale, f32x4 (&dcn)[8], int c15, int g,
-                                            float* dAs = nullptr) {
+                                            float* dAs = nullptr, int CRr = 0) {
     constexpr int LT = FusLay<RT>::LT, LG = FusLay<RT>::LG;
-    if (LDSA && cvalid && !(FUS_ABL & 8)) {   // the tile's dA rows for phase 2 (k = context row layout is read back from LDS, not from L2 / HBM)
+    float4 gl[8];      // dA fragments in MFMA layout: context row c15, floats 4*fchunk(g, m) .. +3
+    if (LDSA) {        // coalesced rows -> LDS copy (kept for phase 2) -> this wave's MFMA fragments; no barrier: its own rows
+        const int lane = c15 + 16 * g, tile0 = c - c15;
 #pragma unroll
-        for (int m = 0; m < 8; m++) st4(&dAs[c * FD + ((4 * fchunk(g, m)) ^ fswz(c))], T.gv[m]);
+        for (int i = 0; i < 8; i++) {
+            const int row = tile0 + 2 * i + (lane >> 5);
+            if (row < CRr) st4(&dAs[row * FD + ((4 * (lane & 31)) ^ fswz(row))], T.gv[i]);
+        }
+        const int rr = min(c, CRr - 1);           // padded context rows alias the last one (their columns are discarded)
+#pragma unroll
+        for (int m = 0; m < 8; m++) gl[m] = ld4(&dAs[rr * FD + ((4 * fchunk(g, m)) ^ fswz(rr))]);
+    } else {
+#pragma unroll
+        for (int m = 0; m < 8; m++) gl[m] = T.gv[m];
     }
     constexpr int NCHAIN = NRT == 1 ? 2 : 1;   // a single accumulator would be one dependent chain (40 instead of 32 cycles per MFMA)
     f32x4 acc[NRT][NCHAIN];
@@ -104,7 +141,7 @@ __device__ __forceinline__ void fus_p1_tile(const FusTile<PT, HAS_EXT>& T, const
     for (int rt = 0; rt < NRT; rt++) qrow[rt] = min(rt * 16 + c15, Lr - 1) * FLDQ;   // pad rows alias the last region (P = 0 there)
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-        const float gj[4] = {T.gv[m].x, T.gv[m].y, T.gv[m].z, T.gv[m].w};
+        const float gj[4] = {gl[m].x, gl[m].y, gl[m].z, gl[m].w};
         float4 qv[NRT];
 #pragma unroll
         for (int rt = 0; rt < NRT; rt++) qv[rt] = ld4(&Qr[qrow[rt] + 4 * fchunk(g, m)]);
@@ -309,7 +346,8 @@ __device__ __forceinline__ void fus_p2_unif(const float* __restrict__ dAf, const
     auto fetch = [&](vec_t (&bv)[UG], float (&av)[UG][NRT]) {
 #pragma unroll
         for (int u = 0; u < UG; u++) {
-            bv[u] = (RAW && LDSA) ? fus_ldv<E>(dAs + bs + offB) : fus_ldv<E>(pB + offB);
+            // fswz(4k + g) = fswz(g) ^ (((2k) & 7) << 2) (g < 4 sets disjoint bits); bs = 4k * FD
+            bv[u] = (RAW && LDSA) ? fus_ldv<E>(dAs + bs + (offB ^ (unsigned)(((bs >> 8) & 7) << 2))) : fus_ldv<E>(pB + offB);
 #pragma unroll
             for (int rt = 0; rt < NRT; rt++) av[u][rt] = RAW ? pA[offA[rt]] : Gs[gs + offA[rt]];
             pB += 4 * FD;
@@ -390,17 +428,17 @@ __device__ __forceinline__ void fus_frame(const float* __restrict__ dA, const fl
     const float* extf = HAS_EXT ? ext + rowbase * Lr : nullptr;
     if (PIPE) {
         FusTile<NRT, HAS_EXT> Ta, Tb;
-        if (ntiles > 0) fus_p1_fetch<NRT, HAS_EXT>(Ta, dAf, Snf, extf, orel[0], Lr, g);
+        if (ntiles > 0) fus_p1_fetch<NRT, HAS_EXT, LDSA>(Ta, dAf, Snf, extf, orel[0], Lr, g, wave, l, NA, Li, Lqa);
 #pragma unroll
         for (int s = 0; s < TPW; s++) {
             if (s < ntiles) {
                 const int c = (wave + NW * s) * 16 + c15;
                 if (s & 1) {
-                    if (s + 1 < TPW && s + 1 < ntiles) fus_p1_fetch<NRT, HAS_EXT>(Ta, dAf, Snf, extf, orel[s + 1 < TPW ? s + 1 : 0], Lr, g);
-                    fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(Tb, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, dAs);
+                    if (s + 1 < TPW && s + 1 < ntiles) fus_p1_fetch<NRT, HAS_EXT, LDSA>(Ta, dAf, Snf, extf, orel[s + 1 < TPW ? s + 1 : 0], Lr, g, wave + NW * (s + 1), l, NA, Li, Lqa);
+                    fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(Tb, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, dAs, CR);
                 } else {
-                    if (s + 1 < TPW && s + 1 < ntiles) fus_p1_fetch<NRT, HAS_EXT>(Tb, dAf, Snf, extf, orel[s + 1 < TPW ? s + 1 : 0], Lr, g);
-                    fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(Ta, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, dAs);
+                    if (s + 1 < TPW && s + 1 < ntiles) fus_p1_fetch<NRT, HAS_EXT, LDSA>(Tb, dAf, Snf, extf, orel[s + 1 < TPW ? s + 1 : 0], Lr, g, wave + NW * (s + 1), l, NA, Li, Lqa);
+                    fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(Ta, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, dAs, CR);
                 }
             }
         }
@@ -410,8 +448,8 @@ __device__ __forceinline__ void fus_frame(const float* __restrict__ dA, const fl
             if (s < ntiles) {
                 const int c = (wave + NW * s) * 16 + c15;
                 FusTile<NRT, HAS_EXT> T;
-                fus_p1_fetch<NRT, HAS_EXT>(T, dAf, Snf, extf, orel[s], Lr, g);
-                fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(T, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, dAs);
+                fus_p1_fetch<NRT, HAS_EXT, LDSA>(T, dAf, Snf, extf, orel[s], Lr, g, wave + NW * s, l, NA, Li, Lqa);
+                fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(T, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, dAs, CR);
             }
         }
     }
@@ -436,8 +474,8 @@ template <int RT, int NW, bool HAS_EXT, int OCC, bool LDSA>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void str_attn_bwd_fused_kernel(
     const float* __restrict__ dA, const float* __restrict__ ext, const float* __restrict__ Cn, const float* __restrict__ Q,
     const float* __restrict__ Qn, const float* __restrict__ Sn, const float* __restrict__ qmask, float* __restrict__ dQraw,
-    float* __restrict__ dQn, float* __restrict__ part, int N, int NA, int Li, int Lqa, int Lr, float scale, int nchunks,
-    unsigned long long* __restrict__ tim) {
+    float* __restrict__ dQn, float* __restrict__ part, int N, int NA, int Li, int Lqa, int Lr, float scale,
+    const int4* __restrict__ sched, unsigned long long* __restrict__ tim) {
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = tim ? __builtin_readcyclecounter() : 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int LT = FusLay<RT>::LT, TPW = 16 / NW, NT = 64 * NW;
@@ -447,7 +485,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OC
     float* QnT = Qr + Lr * FLDQ;                      // [128][LT]      normalised regions, transposed, pad columns zero
     float* Gs = QnT + FusLay<RT>::QT_FLOATS;          // [CR][LG]       dS of the frame
     float* dAs = Gs + CR * FusLay<RT>::LG;            // [CR][128]      dA of the frame (LDSA: phase 2 re-reads it from here)
-    const int n = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
+    // work assignment from the schedule kernel: example n, frames chunk, chunk + nchunks, ... (workgroups are dealt to the
+    // examples in proportion to their non-empty frames)
+    const int4 job = sched[blockIdx.x];
+    const int n = job.x, chunk = job.y, nchunks = job.z;
+    if (n < 0) return;
 
     for (int e = tid; e < FusLay<RT>::QT_FLOATS; e += NT) QnT[e] = 0.f;
 
@@ -514,12 +556,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OC
         // overwritten after the next staging barrier
     }
     TICK(0);
-    // dCn slab of this workgroup: [chunk][n*CR + c][d], lane (c15, g) holds d = dt*16 + 4g .. +3 of context row c15
+    // dCn slab of this workgroup: [workgroup][c][d] (the slabs of one example are consecutive), lane (c15, g) holds d = dt*16 + 4g .. +3 of context row c15
 #pragma unroll
     for (int s = 0; s < TPW; s++) {
         const int c = (wave + NW * s) * 16 + (lane & 15);
         if (s < ntiles && c < CR) {
-            float* dst = part + (((size_t)chunk * N + n) * CR + c) * FD + 4 * (lane >> 4);
+            float* dst = part + ((size_t)blockIdx.x * CR + c) * FD + 4 * (lane >> 4);
 #pragma unroll
             for (int dt = 0; dt < 8; dt++)
                 st4(dst + dt * 16, make_float4(dcn[s][dt][0], dcn[s][dt][1], dcn[s][dt][2], dcn[s][dt][3]));
@@ -529,19 +571,98 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OC
     if (tim && lane == 0) for (int ph = 0; ph < 6; ph++) atomicAdd(tim + ph, tacc[ph]);
 }
 
-__global__ __launch_bounds__(256) void fus_slab_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int nb, long C4) {
+// dCn[n][c][:] = sum over the slabs of example n (workgroups first .. first + count - 1, fixed order: deterministic)
+__global__ __launch_bounds__(256) void fus_slab_sum_kernel(const float* __restrict__ part, const int2* __restrict__ per_n,
+                                                           float* __restrict__ out, int N, long C4n) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= C4) return;
+    if (e >= (long)N * C4n) return;
+    const int n = (int)(e / C4n);
+    const long ce = e - (long)n * C4n;
+    const int2 fc = per_n[n];
     float4 acc = f4zero();
-    for (int b = 0; b < nb; b++) acc = f4add(acc, ld4s(part + ((size_t)b * C4 + e) * 4));
+    for (int b = 0; b < fc.y; b++) acc = f4add(acc, ld4s(part + ((size_t)(fc.x + b) * C4n + ce) * 4));
     st4(out + e * 4, acc);
+}
+
+// Schedule (one workgroup, runs in front of the main kernel): example n gets W_n of the G workgroups, W_n ~ G * V_n / sum V
+// (V_n = frames of n with a valid region; every frame when a gradient arrives on raw_s), at least one.  With one workgroup
+// per CU and equal shares an example with 300 valid frames ran 1.5x longer than one with 200 and the CUs of the short ones
+// idled (~17 % of the kernel at the synthetic TVQA+ length distribution).  Output: sched[b] = (n, chunk, W_n, 0) for
+// workgroup b (n = -1: unused), per_n[n] = (first workgroup, W_n).  Depends on the masks only: run-to-run deterministic.
+__global__ __launch_bounds__(256) void fus_schedule_kernel(const float* __restrict__ qmask, int N, int Li, int Lr, int G, int count_all,
+                                                           int4* __restrict__ sched, int2* __restrict__ per_n) {
+    extern __shared__ int sh[];        // V[N], W[N]
+    int* V = sh;
+    int* W = sh + N;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) V[n] = 0;
+    __syncthreads();
+    for (long f = threadIdx.x; f < (long)N * Li; f += blockDim.x) {
+        // all Lr mask values of the frame requested at once (Lr is even: 8-byte loads), no early exit: a chain of dependent
+        // loads per frame made this kernel cost ~25 us
+        float nz = count_all != 0 ? 1.f : 0.f;
+        const float2* qm = reinterpret_cast<const float2*>(qmask + f * Lr);
+#pragma unroll 8
+        for (int r = 0; r < (Lr >> 1); r++) { const float2 v = qm[r]; nz += fabsf(v.x) + fabsf(v.y); }
+        if (nz != 0.f) atomicAdd(&V[f / Li], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long total = 0;
+        for (int n = 0; n < N; n++) total += V[n];
+        const int R = G - N;            // one workgroup each, the rest in proportion (G >= N by construction)
+        int given = 0;
+        for (int n = 0; n < N; n++) {
+            const int q = total > 0 ? (int)(((long)R * V[n]) / total) : 0;
+            W[n] = 1 + q;
+            given += q;
+        }
+        // remainders: one more to the examples with the most frames per workgroup until the budget is used
+        for (int left = R - given; left > 0 && total > 0; left--) {
+            int best = 0;
+            float load = -1.f;
+            for (int n = 0; n < N; n++) {
+                const float l = (float)V[n] / (float)W[n];
+                if (l > load) { load = l; best = n; }
+            }
+            W[best]++;
+        }
+        int first = 0;
+        for (int n = 0; n < N; n++) {
+            if (W[n] > Li) W[n] = Li;
+            per_n[n] = make_int2(first, W[n]);
+            for (int b = 0; b < W[n]; b++) sched[first + b] = make_int4(n, b, W[n], 0);
+            first += W[n];
+        }
+        for (int b = first; b < G; b++) sched[b] = make_int4(-1, 0, 1, 0);
+    }
+}
+
+static int fus_num_wgs(int N, int Li = 1 << 20) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus = v;
+    }
+    static const int env_wgs = getenv("STAGE_K1_BWD_WGS") ? atoi(getenv("STAGE_K1_BWD_WGS")) : 0;   // developer switch
+    int G = env_wgs > 0 ? env_wgs : cus;      // one workgroup per CU (256 registers, up to 157 KB of LDS)
+    if (G > FUS_MAX_WGS) G = FUS_MAX_WGS;
+    const long few = ((long)N * Li + 3) / 4;          // small problems: at least ~4 frames per workgroup (per-workgroup slab + set-up)
+    if (G > few) G = (int)few;
+    return G > N ? G : N;
 }
 
 template <int RT, int NW, int OCC>
 static int fus_launch(const float* dA, const float* ext, const float* Cn, const float* Q, const float* Qn, const float* Sn,
                       const float* qmask, float* dQraw, float* dQn, float* dCn, int N, int NA, int Li, int Lqa, int Lr,
-                      float scale, float* part, int nchunks, hipStream_t st) {
+                      float scale, void* ws, hipStream_t st) {
     const int CR = NA * Lqa;
+    const int G = fus_num_wgs(N, Li);
+    int4* sched = (int4*)ws;
+    int2* per_n = (int2*)(sched + G);
+    float* part = (float*)((char*)ws + FUS_TABLE_BYTES(G, N));
+    hipLaunchKernelGGL(fus_schedule_kernel, dim3(1), dim3(256), 2 * N * sizeof(int), st, qmask, N, Li, Lr, G, ext ? 1 : 0, sched, per_n);
+    STAGE_LAUNCH_CHECK();
     const size_t base = ((size_t)Lr * FLDQ + FusLay<RT>::QT_FLOATS + (size_t)CR * FusLay<RT>::LG) * sizeof(float);
     const size_t with_da = base + (size_t)CR * FD * sizeof(float);
     // dA of a frame stays in LDS between the phases when it fits (the video shape) and the uniform phase 2 applies
@@ -549,28 +670,29 @@ static int fus_launch(const float* dA, const float* ext, const float* Cn, const 
     const bool unif = (Lqa & 3) == 0 && ((CR >> 2) % 10) == 0;
     const bool ldsa = !no_ldsa && unif && NW == 8 && OCC == 2 && with_da <= 160 * 1024;
     const size_t lds = ldsa ? with_da : base;
-    const dim3 grid(N * nchunks), block(64 * NW);
+    const dim3 grid(G), block(64 * NW);
     unsigned long long* tim = (unsigned long long*)(getenv("STAGE_K1_BWD_TIM") ? strtoull(getenv("STAGE_K1_BWD_TIM"), 0, 0) : 0ull);
 #define FUS_GO(EXTV, LDSAV)                                                                                                     \
     do {                                                                                                                        \
         if (lds > 64 * 1024)                                                                                                    \
             (void)hipFuncSetAttribute((const void*)str_attn_bwd_fused_kernel<RT, NW, EXTV, OCC, LDSAV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((str_attn_bwd_fused_kernel<RT, NW, EXTV, OCC, LDSAV>), grid, block, lds, st, dA, ext, Cn, Q, Qn, Sn, qmask, \
-                           dQraw, dQn, part, N, NA, Li, Lqa, Lr, scale, nchunks, tim);                                          \
+                           dQraw, dQn, part, N, NA, Li, Lqa, Lr, scale, (const int4*)sched, tim);                               \
     } while (0)
     if (ext) { if (ldsa) FUS_GO(true, (NW == 8 && OCC == 2)); else FUS_GO(true, false); }
     else { if (ldsa) FUS_GO(false, (NW == 8 && OCC == 2)); else FUS_GO(false, false); }
 #undef FUS_GO
     STAGE_LAUNCH_CHECK();
-    const long total = (long)N * CR * (FD / 4);
-    hipLaunchKernelGGL(fus_slab_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)part, dCn,
-                       nchunks, total);
+    const long C4n = (long)CR * (FD / 4);
+    hipLaunchKernelGGL(fus_slab_sum_kernel, dim3((unsigned)(((long)N * C4n + 255) / 256)), dim3(256), 0, st, (const float*)part,
+                       (const int2*)per_n, dCn, N, C4n);
     STAGE_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" size_t stage_str_attn_bwd_fused_ws_bytes(int N, int NA, int Lqa, int D) {
-    return (size_t)FUS_MAX_CHUNKS * N * NA * Lqa * D * sizeof(float);
+    const int G = fus_num_wgs(N);     // schedule tables + one dCn slab per workgroup
+    return FUS_TABLE_BYTES(G, N) + (size_t)G * NA * Lqa * D * sizeof(float);
 }
 
 extern "C" int stage_str_attn_bwd_fused(const float* dA, const float* dS_raw_ext, const float* Cn, const float* Q,
@@ -582,14 +704,8 @@ extern "C" int stage_str_attn_bwd_fused(const float* dA, const float* dS_raw_ext
         (long)NA * Li * Lqa * FD >= (1l << 29)) return STAGE_ERR_SHAPE;   // 32-bit element offsets inside an example
     if (ws_bytes < stage_str_attn_bwd_fused_ws_bytes(N, NA, Lqa, D)) return STAGE_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    // frame chunks per example: ~2 resident workgroups per CU, every workgroup accumulates dCn over its frames in registers
-    static const int env_chunks = getenv("STAGE_K1_BWD_CHUNKS") ? atoi(getenv("STAGE_K1_BWD_CHUNKS")) : 0;
-    int nchunks = env_chunks > 0 ? env_chunks : (256 + N - 1) / N;   // one workgroup per CU (256 registers, up to 157 KB of LDS)
-    if (nchunks > FUS_MAX_CHUNKS) nchunks = FUS_MAX_CHUNKS;
-    if (nchunks > Li) nchunks = Li;
-    if (nchunks < 1) nchunks = 1;
     const int RT = (Lr + 15) / 16;
-#define FUS_ARGS dA, dS_raw_ext, Cn, Q, Qn, S_norm, q_mask, dQraw, dQn, dCn, N, NA, Li, Lqa, Lr, scale, (float*)ws, nchunks, st
+#define FUS_ARGS dA, dS_raw_ext, Cn, Q, Qn, S_norm, q_mask, dQraw, dQn, dCn, N, NA, Li, Lqa, Lr, scale, ws, st
     switch (RT) {
         case 1: return fus_launch<1, 8, 2>(FUS_ARGS);
         case 2: return fus_launch<2, 8, 2>(FUS_ARGS);
