@@ -7,8 +7,10 @@ plus the K1 (StructuredAttention forward) roofline line and a CPU baseline of th
         bench.py --gpus N --steps K --warmup W                # N>1: one rank per GPU over RCCL (driver does this)
 
 Workload (BASELINE.json configs[1]): full STAGE, hsz=128, 300 frames x 20 regions, 50 subtitle
-words/frame, 40 QA words, 5 candidates, B=16 per GPU (weak scaling), --add_local, dropout 0.1, fp32, synthetic ragged
-features seeded 2018.  One step = forward + loss (main.py:55-60 w/o att term) + backward + grad all-reduce (N>1) +
+words/frame, 40 QA words, 5 candidates, B=16 per GPU (weak scaling; --scaling strong: global B=16 split over the GPUs),
+--add_local --use_sup_att (run_main.sh:45 always passes it), dropout 0.1, fp32, synthetic ragged features seeded 2018.
+One step = forward + loss (main.py:55-60: CE_sum * len(qids)/len(targets) + 0.1 * att_loss + 0.5 * temporal_loss, the ratio
+taken over the GATHERED batch as the reference's DataParallel does) + backward + grad all-reduce (N>1) +
 clip_grad_norm_(10) + Adam step, i.e. everything main.py:53-66 does per batch.  Inputs are resident in HBM.
 """
 import argparse
@@ -36,6 +38,11 @@ def parse():
     ap.add_argument("--qa_words", type=int, default=40)
     ap.add_argument("--hsz", type=int, default=128)
     ap.add_argument("--dense", action="store_true", help="all-ones masks instead of ragged lengths")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --bsz examples per GPU; strong: --bsz examples in total, sharded over the GPUs (SURVEY 8d)")
+    ap.add_argument("--no_sup_att", action="store_true", help="drop the supervised attention loss term (round-1 workload)")
+    ap.add_argument("--att_imgs", type=int, default=4, help="annotated frames per question (synthetic att_labels)")
+    ap.add_argument("--att_words", type=int, default=3, help="labelled object words per annotated frame")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--only_roofline", action="store_true")
@@ -45,15 +52,35 @@ def parse():
     return ap.parse_args()
 
 
-def train_step(model, batch, bucket, params, optimizer, n_examples):
+def train_step(model, batch, bucket, params, optimizer, n_examples, world=1):
+    from tvqaplus_amd import parallel
     bucket.zero()
     (out, targets), att_loss, _, t_loss, _ = model(batch)
-    loss = F.cross_entropy(out, targets, reduction="sum") * (1.0 * n_examples / len(targets)) + 0.5 * t_loss
+    # main.py:59 -- len(qids) / len(targets) of the gathered batch (N_new is data dependent with add_local)
+    scale = (1.0 * n_examples / len(targets)) if world == 1 else parallel.global_loss_scale(n_examples, len(targets), out.device)
+    loss = F.cross_entropy(out, targets, reduction="sum") * scale + 0.1 * att_loss + 0.5 * t_loss   # att_weight 0.1, ts_weight 0.5 (config.py)
     loss.backward()
     bucket.all_reduce()
     torch.nn.utils.clip_grad_norm_(params, 10.0)
     optimizer.step()
     return loss
+
+
+def _profile_traffic(name):
+    """WRITE_SIZE + 2 * FETCH_SIZE (KiB -> bytes) of the K1 forward from a committed rocprofv3 PMC summary, or None."""
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        vals = {}
+        with open(path) as f:
+            for line in f:
+                if "str_attn_fwd" in line and ("FETCH_SIZE" in line or "WRITE_SIZE" in line):
+                    key = "FETCH_SIZE" if "FETCH_SIZE" in line else "WRITE_SIZE"
+                    vals[key] = float(line.rsplit("avg=", 1)[1])
+        if len(vals) == 2:
+            return round((vals["WRITE_SIZE"] + 2.0 * vals["FETCH_SIZE"]) * 1024.0)
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
 
 
 def k1_roofline(args, device):
@@ -91,10 +118,11 @@ def k1_roofline(args, device):
     # algorithmic bytes: inputs once + A + S + S_ written once, fp32
     alg = 4 * (N * NA * Lqa * D + N * Li * Lr * D + N * NA * Lqa + N * Li * Lr + U * D + 2 * U * Lr)
     achieved = alg / (avg_ms * 1e-3) / 1e9
-    # HBM bytes per launch from the PMC passes committed under profiles/ (tools/pmc_k1.sh: WRITE_SIZE + 2 x FETCH_SIZE,
-    # the x2 being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md); only valid for the default shape
-    default_shape = (N, NA, Li, Lqa, Lr, D) == (16, 5, 300, 40, 20, 128) and not args.dense
-    traffic = 646.9e6 + 2 * 36.05e6 if default_shape else None
+    # HBM bytes per launch from the PMC passes committed under profiles/ (tools/pmc_run.sh: WRITE_SIZE + 2 x FETCH_SIZE in
+    # KiB, the x2 being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md); only valid for the default shapes
+    traffic = None
+    if (N, NA, Li, Lqa, D) == (16, 5, 300, 40, 128) and not args.dense and Lr in (20, 50):
+        traffic = _profile_traffic("r02_k1_fwd_pmc_%s.txt" % ("vid" if Lr == 20 else "sub"))
     return {"bound": "hbm", "kernel": "str_attn_fwd_reg_kernel" if Lr <= 32 else "str_attn_fwd_d128_kernel", "achieved": round(achieved, 1), "peak": 8000.0,
             "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic, "algorithmic_bytes": alg,
             "avg_us": round(avg_ms * 1e3, 1), "min_us": round(ms[0] * 1e3, 1),
@@ -109,9 +137,19 @@ def cpu_baseline(args, opt):
     # torch's CPU kernels stop scaling (and thrash) far below a 256-thread host: 32 threads is what is used and reported
     cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
+    cpu_model = "?"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     B = 1
+    sup = not args.no_sup_att
     batch = make_batch(N=B, Li=args.frames, Lr=args.regions, Lw=args.sub_words, Lqa=args.qa_words, seed=2018,
-                       ragged=not args.dense)
+                       ragged=not args.dense, att_imgs=args.att_imgs if sup else 0, att_words=args.att_words)
     torch.manual_seed(2018)
     import contextlib
     with contextlib.redirect_stdout(open(os.devnull, "w")):   # STAGE.__init__ prints which branches are active
@@ -124,7 +162,11 @@ def cpu_baseline(args, opt):
     def step():
         optim.zero_grad(set_to_none=True)
         out = O.stage_forward(P, opt, batch, training=True)
-        O.training_loss(out, n_examples=B).backward()
+        loss = O.training_loss(out, n_examples=B)
+        if sup:   # the supervised attention term on the oracle's own attention map (host index building is shared code)
+            from tvqaplus_amd import att_host
+            loss = loss + 0.1 * att_host.get_att_loss(opt, out["vid_raw_s"].squeeze(2) if out["vid_raw_s"].dim() == 6 else out["vid_raw_s"], batch)[0]
+        loss.backward()
         torch.nn.utils.clip_grad_norm_(params, 10.0)
         optim.step()
 
@@ -135,7 +177,8 @@ def cpu_baseline(args, opt):
         step()
         n += 1
     dt = time.time() - t0
-    return {"value": round(B * n / dt, 4), "unit": "QA-examples/s", "cores": cores, "kind": "port",
+    return {"value": round(B * n / dt, 4), "unit": "QA-examples/s", "cores": cores, "host_cores": os.cpu_count(),
+            "cpu_model": cpu_model, "kind": "port",
             "sample": "%d full training steps of B=%d x %d frames (same per-example shapes, dropout 0.1) in %.1f s"
                       % (n, B, args.frames, dt)}
 
@@ -155,7 +198,8 @@ def main():
         print(json.dumps({"sub": k1_roofline(args, device)}))
         return
     torch.manual_seed(2018)
-    opt = make_opt(hsz=args.hsz, add_local=True, dropout=0.1)
+    sup = not args.no_sup_att
+    opt = make_opt(hsz=args.hsz, add_local=True, dropout=0.1, use_sup_att=sup)
     import contextlib
     with contextlib.redirect_stdout(open(os.devnull, "w")):
         model = STAGE(opt)
@@ -163,8 +207,18 @@ def main():
     params = [p for p in model.parameters() if p.requires_grad]
     bucket = parallel.FlatGradBucket(params)
     optimizer = torch.optim.Adam(params, lr=1e-3, weight_decay=3e-7)
-    batch = make_batch(N=args.bsz, Li=args.frames, Lr=args.regions, Lw=args.sub_words, Lqa=args.qa_words,
-                       seed=2018 + rank, ragged=not args.dense).to(device)
+    if args.scaling == "strong":      # global batch of --bsz examples, example-major shards
+        full = make_batch(N=args.bsz, Li=args.frames, Lr=args.regions, Lw=args.sub_words, Lqa=args.qa_words, seed=2018,
+                          ragged=not args.dense, att_imgs=args.att_imgs if sup else 0, att_words=args.att_words)
+        batch = parallel.shard_batch(full, rank, world).to(device)
+        n_local = len(batch.qid)
+        assert n_local > 0, "strong scaling needs at least one example per GPU (use parallel.CandidateLayout beyond that)"
+    else:
+        batch = make_batch(N=args.bsz, Li=args.frames, Lr=args.regions, Lw=args.sub_words, Lqa=args.qa_words,
+                           seed=2018 + rank, ragged=not args.dense, att_imgs=args.att_imgs if sup else 0,
+                           att_words=args.att_words).to(device)
+        n_local = args.bsz
+    n_global = args.bsz if args.scaling == "strong" else world * args.bsz
 
     def sync():
         if world > 1:
@@ -175,7 +229,8 @@ def main():
         # PCIe-inclusive variant: the same host batch (pinned once) is re-sent every step, overlapped with the previous step
         from tvqaplus_amd.prefetch import BatchPrefetcher
         host = make_batch(N=args.bsz, Li=args.frames, Lr=args.regions, Lw=args.sub_words, Lqa=args.qa_words,
-                          seed=2018 + rank, ragged=not args.dense)
+                          seed=2018 + rank, ragged=not args.dense, att_imgs=args.att_imgs if sup else 0,
+                          att_words=args.att_words)
         for k, v in host.items():
             if torch.is_tensor(v):
                 host[k] = v.pin_memory()
@@ -184,11 +239,11 @@ def main():
     else:
         nxt = lambda: batch
     for _ in range(args.warmup):
-        train_step(model, nxt(), bucket, params, optimizer, args.bsz)
+        train_step(model, nxt(), bucket, params, optimizer, n_local, world)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = train_step(model, nxt(), bucket, params, optimizer, args.bsz)
+        loss = train_step(model, nxt(), bucket, params, optimizer, n_local, world)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -201,22 +256,26 @@ def main():
     if rank == 0:
         rec = {
             "metric": "QA-examples/sec (5-candidate fwd+bwd) at B=16",
-            "value": round(world * args.bsz * args.steps / dt, 3),
+            "value": round(n_global * args.steps / dt, 3),
             "unit": "QA-examples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" + (" (re-sent from pinned host memory every step)" if args.h2d else ""),
-            "config": {"workload": "STAGE full training step (fwd + loss + bwd + clip + Adam), hsz=128, add_local, "
-                                   "dropout 0.1; per GPU B=%d x 5 candidates x %d frames x %d regions x %d sub words x "
-                                   "%d QA words; %s masks" % (args.bsz, args.frames, args.regions, args.sub_words,
-                                                              args.qa_words, "all-ones" if args.dense else "ragged"),
-                       "global_batch": world * args.bsz, "parallelism": "dp%d (example-sharded, flat 2.2MB grad "
-                                                                        "all-reduce over RCCL)" % world,
+            "config": {"workload": "STAGE train step B=%d/GPU x5 cand x%d frames x%d regions x%d sub x%d QA words, hsz=%d, "
+                                   "add_local%s, dropout 0.1, %s masks; fp32 via exact 3-way bf16-split MFMA GEMMs"
+                                   % (n_local, args.frames, args.regions, args.sub_words, args.qa_words, args.hsz,
+                                      " + supervised attention loss" if sup else "", "all-ones" if args.dense else "ragged"),
+                       "step": "fwd + loss (main.py:55-60) + bwd + grad all-reduce + clip_grad_norm_ + Adam",
+                       "global_batch": n_global, "parallelism": "dp%d (example-sharded, flat 2.2MB grad "
+                                                                  "all-reduce over RCCL)" % world,
                        "final_loss": round(loss_v, 4), "peak_hbm_gib": round(peak_gb, 2)},
         }
         if not args.no_roofline:   # rank 0's GPU, after the timed region (the other ranks wait at the final barrier)
             rec["roofline"] = k1_roofline(args, device)
+            sub_args = argparse.Namespace(**vars(args))
+            sub_args.regions = args.sub_words          # the same kernel family on the subtitle stream (50 words per frame)
+            rec["roofline_sub"] = k1_roofline(sub_args, device)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args, opt)
         print(json.dumps(rec))

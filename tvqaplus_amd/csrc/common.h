@@ -89,23 +89,57 @@ __device__ __forceinline__ float cross_row_max(float v) { return xmax32(xmax16(v
 // only ever count up.  The host knows exactly how many tickets a launch draws (every processed item past the static rounds
 // draws one), so it hands the kernel the value its word will have when the launch starts (`base`, kernels use drawn - base in
 // unsigned arithmetic) and adds the draw count afterwards.  A stream-ordered 4-byte memset per launch cost ~9 us of the K1
-// forward's event-timed duration (launch gap + a second tiny kernel).  Launches are issued by one host thread; the ring only
-// guards against a handful of launches being in flight on different streams.
-struct StageTicket { unsigned int* word; unsigned int base; };
+// forward's event-timed duration (launch gap + a second tiny kernel).  The 64 slots of a ring guard against a handful of
+// launches being in flight on different streams.
+struct StageTicket { unsigned int* word; unsigned int base; int dev; int slot; };
+#include <mutex>
+#define STAGE_MAX_DEVICES 16
+struct StageTicketRing {
+    unsigned int* ring = nullptr;     // device resident, 64 words
+    unsigned int bases[64];
+    unsigned int next = 0;
+};
+static inline StageTicketRing* stage_ticket_rings() { static StageTicketRing rings[STAGE_MAX_DEVICES]; return rings; }
+static inline std::mutex& stage_ticket_mutex() { static std::mutex m; return m; }
+// One ring per device (launches may come from several host threads / devices: nn.DataParallel replicas, autograd's backward
+// threads).  The ring is zeroed with a host-synchronous memset at first use on a device, so every later launch -- on any
+// stream -- is ordered after it.  Call stage_ticket_abort() when the launch that was to draw the tickets failed.
 static inline StageTicket stage_next_ticket(unsigned int draws) {
-    static unsigned int* ring = nullptr;
-    static unsigned int bases[64];
-    static unsigned int slot = 0;
-    if (!ring) {
-        if (hipMalloc((void**)&ring, 64 * sizeof(unsigned int)) != hipSuccess) return {nullptr, 0u};
-        if (hipMemset(ring, 0, 64 * sizeof(unsigned int)) != hipSuccess) return {nullptr, 0u};
-        for (int i = 0; i < 64; i++) bases[i] = 0u;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= STAGE_MAX_DEVICES) return {nullptr, 0u, -1, 0};
+    std::lock_guard<std::mutex> lock(stage_ticket_mutex());
+    StageTicketRing& r = stage_ticket_rings()[dev];
+    if (!r.ring) {
+        unsigned int* p = nullptr;
+        if (hipMalloc((void**)&p, 64 * sizeof(unsigned int)) != hipSuccess) return {nullptr, 0u, -1, 0};
+        if (hipMemset(p, 0, 64 * sizeof(unsigned int)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            (void)hipFree(p);
+            return {nullptr, 0u, -1, 0};
+        }
+        for (int i = 0; i < 64; i++) r.bases[i] = 0u;
+        r.ring = p;
     }
-    const unsigned int sl = slot++ & 63u;
-    StageTicket t = {ring + sl, bases[sl]};
-    bases[sl] += draws;
+    const int sl = (int)(r.next++ & 63u);
+    StageTicket t = {r.ring + sl, r.bases[sl], dev, sl};
+    r.bases[sl] += draws;
     return t;
 }
+// the launch failed: its tickets were never drawn -- put the slot back into a known state (word = base = 0)
+static inline void stage_ticket_abort(const StageTicket& t) {
+    if (!t.word || t.dev < 0) return;
+    std::lock_guard<std::mutex> lock(stage_ticket_mutex());
+    (void)hipMemset(t.word, 0, sizeof(unsigned int));
+    (void)hipDeviceSynchronize();
+    stage_ticket_rings()[t.dev].bases[t.slot] = 0u;
+}
+#define STAGE_LAUNCH_CHECK_TICKET(tk)              \
+    do {                                           \
+        hipError_t e__ = hipGetLastError();        \
+        if (e__ != hipSuccess) {                   \
+            stage_ticket_abort(tk);                \
+            return (int)e__;                       \
+        }                                          \
+    } while (0)
 
 // Counter-based dropout: one 64-bit SplitMix hash per group of 4 consecutive elements, 16 bits per element.
 // keep(element) <=> its 16-bit field >= thresh16, thresh16 = round(p * 65536).  The same (seed, index) pair

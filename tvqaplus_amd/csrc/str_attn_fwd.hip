@@ -424,7 +424,7 @@ static int launch_d128_t(const float* Cn, const float* Q, const float* cm, const
         if (!tk.word) return (int)hipErrorOutOfMemory;
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, 1,
                            CT, (uint64_t)seed, th, ik, tk.word, tk.base, tim);
-        STAGE_LAUNCH_CHECK();
+        STAGE_LAUNCH_CHECK_TICKET(tk);
         return 0;
     }
     const size_t wave_bytes = ((size_t)(Lr + 1) * LDQ + 2 * RT * 16 + (size_t)tps * 16) * sizeof(float);
@@ -451,7 +451,7 @@ static int launch_d128_t(const float* Cn, const float* Q, const float* cm, const
     if (!tk.word) return (int)hipErrorOutOfMemory;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * wpb), lds, st, Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr,
                        scale, slices, tps, (uint64_t)seed, th, ik, tk.word, tk.base, tim);
-    STAGE_LAUNCH_CHECK();
+    STAGE_LAUNCH_CHECK_TICKET(tk);
     return 0;
 }
 

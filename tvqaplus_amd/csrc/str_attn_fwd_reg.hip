@@ -365,7 +365,7 @@ static int launch_reg_t(const float* Cn, const float* Q, const float* cm, const 
     hipLaunchKernelGGL((str_attn_fwd_reg_kernel<RT, KL, PERM, TRAIN, VEC_S>), dim3((unsigned)blocks), dim3(256), 0, st, Cn, Q,
                        cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, slices, tps, (uint64_t)seed, th, ik, tk.word, tk.base,
                        static_rounds);
-    STAGE_LAUNCH_CHECK();
+    STAGE_LAUNCH_CHECK_TICKET(tk);
     return 0;
 }
 

@@ -43,6 +43,29 @@ def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _on_device(fn):
+    """Run an autograd forward / backward on the device of its tensors.  The reference driver moves the model with
+    ``model.to(cuda:N)`` without ``torch.cuda.set_device`` (``--device_ids 1``): buffers then live on cuda:N while the
+    current device is 0, and a launch on device 0's stream would be cross-device and unordered against torch's own work
+    on cuda:N.  All tensor operands must share one device."""
+    def wrapped(ctx, *args):
+        dev = None
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if dev is None:
+                    dev = a.device.index
+                elif a.device.index != dev:
+                    raise _lib.StageHipError("tvqaplus_amd.ops: operands on different devices (cuda:%d and cuda:%d)"
+                                             % (dev, a.device.index))
+        if dev is None or dev == torch.cuda.current_device():
+            return fn(ctx, *args)
+        with torch.cuda.device(dev):
+            return fn(ctx, *args)
+    wrapped.__name__ = fn.__name__
+    wrapped.__doc__ = fn.__doc__
+    return staticmethod(wrapped)
+
+
 _WS = {}
 
 
@@ -72,7 +95,7 @@ def _call(name: str, *args):
 # LayerNorm (+ fused residual add / position table, + fused dropout)
 # ---------------------------------------------------------------------------------------------------------------
 class _LayerNorm(torch.autograd.Function):
-    @staticmethod
+    @_on_device
     def forward(ctx, x, res, gamma, beta, res_period: int, want_sum: bool, p: float, seed: int):
         x = _chk(x, "x")
         K = x.shape[-1]
@@ -100,7 +123,7 @@ class _LayerNorm(torch.autograd.Function):
             s = y.new_empty(0)
         return y, s
 
-    @staticmethod
+    @_on_device
     def backward(ctx, dy, dsum):
         xin, mean, rstd, gamma = ctx.saved_tensors
         K = xin.shape[-1]
@@ -135,7 +158,7 @@ def layernorm(x, gamma, beta, p: float = 0.0, seed: int = 0, res=None, res_perio
 # LayerNorm over cat([a, b, a*b])
 # ---------------------------------------------------------------------------------------------------------------
 class _Cat3LayerNorm(torch.autograd.Function):
-    @staticmethod
+    @_on_device
     def forward(ctx, a, b, gamma, beta, rep: int, inner: int, p: float, seed: int):
         a, b = _chk(a, "a"), _chk(b, "b")
         D = b.shape[-1]
@@ -151,7 +174,7 @@ class _Cat3LayerNorm(torch.autograd.Function):
         ctx.cfg = (int(rep), int(inner), float(p), int(seed))
         return y
 
-    @staticmethod
+    @_on_device
     def backward(ctx, dy):
         a, b, mean, rstd, gamma = ctx.saved_tensors
         rep, inner, p, seed = ctx.cfg
@@ -193,7 +216,7 @@ def cat3_layernorm(a, b, gamma, beta, rep: int = 1, inner: int = 1, p: float = 0
 # Linear (+bias, +ReLU) on the matrix cores
 # ---------------------------------------------------------------------------------------------------------------
 class _Linear(torch.autograd.Function):
-    @staticmethod
+    @_on_device
     def forward(ctx, x, w, bias, relu: bool):
         x = _chk(x, "x")
         w2 = _chk(w, "w").reshape(w.shape[0], -1)  # (N, K) ; pointwise Conv1d weights are (N, K, 1)
@@ -220,7 +243,7 @@ class _Linear(torch.autograd.Function):
         ctx.has_bias = bias is not None
         return y
 
-    @staticmethod
+    @_on_device
     def backward(ctx, dy):
         x, w2, y, mask = ctx.saved_tensors
         N, K = w2.shape
@@ -264,7 +287,7 @@ def linear(x, w, bias=None, relu: bool = False):
 # depthwise Conv1d along L
 # ---------------------------------------------------------------------------------------------------------------
 class _DWConv(torch.autograd.Function):
-    @staticmethod
+    @_on_device
     def forward(ctx, x, w, bias):
         x = _chk(x, "x")  # (M, L, D)
         M, L, D = x.shape
@@ -275,7 +298,7 @@ class _DWConv(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         return y
 
-    @staticmethod
+    @_on_device
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         M, L, D = x.shape
@@ -305,7 +328,7 @@ def ln_dwconv_supported(D: int, k: int) -> bool:
 
 
 class _LnDwConv(torch.autograd.Function):
-    @staticmethod
+    @_on_device
     def forward(ctx, x, res, gamma, beta, w, bias, res_period: int, p: float, seed: int):
         x = _chk(x, "x")  # (M, L, D)
         M, L, D = x.shape
@@ -328,7 +351,7 @@ class _LnDwConv(torch.autograd.Function):
             s = h.new_empty(0)
         return h, s
 
-    @staticmethod
+    @_on_device
     def backward(ctx, dh, dsum):
         xin, mean, rstd, gamma, beta, w = ctx.saved_tensors
         M, L, D = xin.shape
@@ -367,7 +390,8 @@ def l2norm(x: torch.Tensor, p: float = 0.0, seed: int = 0) -> torch.Tensor:
     x = _chk(x, "x")
     K = x.shape[-1]
     y = torch.empty_like(x)
-    _call("stage_l2norm_fwd", _ptr(x), _ptr(y), None, x.numel() // K, K, EPS_L2, float(p), int(seed), _stream())
+    with torch.cuda.device(x.device):
+        _call("stage_l2norm_fwd", _ptr(x), _ptr(y), None, x.numel() // K, K, EPS_L2, float(p), int(seed), _stream())
     return y
 
 
@@ -380,7 +404,7 @@ _K1_BWD_UNFUSED = _os.environ.get("STAGE_K1_BWD_UNFUSED") is not None   # develo
 
 
 class _StrAttn(torch.autograd.Function):
-    @staticmethod
+    @_on_device
     def forward(ctx, C, Q, c_mask, q_mask, scale: float, p: float, seed_c: int, seed_q: int):
         C, Q = _chk(C, "C"), _chk(Q, "Q")                    # (N, NA, Lqa, D), (N, Li, Lr, D)
         c_mask, q_mask = _chk(c_mask, "c_mask"), _chk(q_mask, "q_mask")
@@ -401,7 +425,7 @@ class _StrAttn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         return A, S, Sn
 
-    @staticmethod
+    @_on_device
     def backward(ctx, dA, dS, _dSn):
         C, Q, Cn, Sn, q_mask = ctx.saved_tensors
         scale, p, seed_c, seed_q = ctx.cfg
@@ -446,7 +470,7 @@ def structured_attention(C, Q, c_mask, q_mask, scale: float, p: float = 0.0, see
 # masked max over a sequence axis (optionally windowed)
 # ---------------------------------------------------------------------------------------------------------------
 class _MaskedMax(torch.autograd.Function):
-    @staticmethod
+    @_on_device
     def forward(ctx, x, mask, window):
         x, mask = _chk(x, "x"), _chk(mask, "mask")  # (R, L, D), (R, L)
         R, L, D = x.shape
@@ -458,7 +482,7 @@ class _MaskedMax(torch.autograd.Function):
         ctx.shape = (R, L, D)
         return out
 
-    @staticmethod
+    @_on_device
     def backward(ctx, dout):
         idx, mask = ctx.saved_tensors
         R, L, D = ctx.shape
@@ -476,7 +500,7 @@ def masked_max(x, mask, window=None):
 # multi-head attention core
 # ---------------------------------------------------------------------------------------------------------------
 class _MHACore(torch.autograd.Function):
-    @staticmethod
+    @_on_device
     def forward(ctx, q, k, v, mask, nh: int, p: float, seed: int):
         q, k, v, mask = _chk(q, "q"), _chk(k, "k"), _chk(v, "v"), _chk(mask, "mask")
         M, L, D = q.shape
@@ -488,7 +512,7 @@ class _MHACore(torch.autograd.Function):
         ctx.cfg = (nh, float(p), int(seed))
         return out
 
-    @staticmethod
+    @_on_device
     def backward(ctx, dout):
         q, k, v, probs, mask = ctx.saved_tensors
         nh, p, seed = ctx.cfg

@@ -3,9 +3,19 @@
 is sharded example-major and exactly two collectives exist:
 
 * ``all_gather_outputs``  -- logits (N_loc, 5) [+ t_scores] of every rank -> all ranks (forward, 320 B .. 192 KB)
-* ``all_reduce_grads``    -- ONE flat bucket with every parameter gradient (552 947 fp32 = 2.2 MB at D=128), summed;
-                             the losses are CE(sum), so sum-reduction reproduces the single-GPU gradient of the
-                             concatenated batch (main.py:57-60, 208).
+* ``all_reduce_grads``    -- ONE flat bucket with every parameter gradient (552 947 fp32 = 2.2 MB at D=128), summed.
+                             The losses are sums over examples (CE(sum), main.py:57-60, 208), so the sum over ranks is
+                             the single-GPU gradient of the concatenated batch PROVIDED the classification term is
+                             scaled by the GLOBAL len(qids) / len(targets) (main.py:59 normalises on the gathered
+                             DataParallel outputs; with add_local the number of proposals N_new is data dependent, so
+                             a per-rank N_r / N_new_r is a different loss) -- ``global_loss_scale`` below.
+
+When there are more GPUs than examples (inference at small B; BASELINE config 4 names a candidate x batch split) the
+five answer candidates of an example are split over the ranks of a ``CandidateLayout`` group as well: every operator between
+the QA embedding and ``answer_scores[n, a]`` is independent per (n, a); the context encoders are
+replicated inside the group, the classification loss needs the five logits of an example (one all-gather inside the
+group, autograd-aware), and add_local training derives its proposal spans from the ground-truth candidate's temporal
+scores (model/stage.py:408-418) -- broadcast inside the group by ``CandidateLayout.gt_scores``.
 
 Both are latency-bound at these sizes (2.2 MB over a 153 GB/s xGMI link is ~15 us/hop), so no bucketing / overlap
 machinery is warranted; the flat bucket exists to pay the collective latency once instead of ~80 times.
@@ -87,7 +97,7 @@ class FlatGradBucket:
     ``zero()`` drops the gradients (``p.grad = None``, what ``optimizer.zero_grad()`` does): autograd then ASSIGNS the new
     gradient of a parameter instead of launching one accumulate-add kernel per parameter into a zeroed view (117 small
     kernels per step at hsz=128).  ``all_reduce()`` packs them into the flat buffer with one multi-tensor copy, reduces,
-    and points every ``p.grad`` at its slice of the buffer; with one rank it only packs (``flat`` stays inspectable)."""
+    and points every ``p.grad`` at its slice of the buffer (with one rank it only packs)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
@@ -105,18 +115,173 @@ class FlatGradBucket:
             p.grad = None
 
     def pack(self) -> None:
-        """Copy the current gradients into the flat buffer (parameters without a gradient contribute zeros) and make
-        every ``p.grad`` a view of it."""
+        """Copy the current gradients into the flat buffer and make every ``p.grad`` a view of it.  Parameters without a
+        gradient contribute zeros to the buffer; whether such a parameter receives ``p.grad`` afterwards is decided by
+        ``_absent_everywhere`` (the reference leaves the never-used t_iter > 0 layers at ``grad = None``, so Adam with
+        weight decay does not touch them -- zero gradients would decay them, only when world > 1)."""
         have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         missing = [v for v, p in zip(self.views, self.params) if p.grad is None]
         if missing:
             torch._foreach_zero_(missing)
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        self._present_local = [p.grad is not None for p in self.params]
         for v, p in zip(self.views, self.params):
             p.grad = v
 
+    def _drop_absent(self) -> None:
+        """Parameters that have no gradient on ANY rank keep ``grad = None``.  Which ones is a property of the model
+        structure, so it is agreed once (one small all-reduce + host read at the first step) and cached."""
+        if getattr(self, "_absent", None) is None:
+            flags = torch.tensor([1.0 if f else 0.0 for f in self._present_local], device=self.flat.device)
+            if dist.is_initialized() and dist.get_world_size() > 1:
+                dist.all_reduce(flags, op=dist.ReduceOp.SUM)
+            self._absent = [f == 0.0 for f in flags.tolist()]
+        for absent, p in zip(self._absent, self.params):
+            if absent:
+                p.grad = None
+
     def all_reduce(self) -> None:
+        """Pack (always: ``flat`` is valid with one rank too), sum over ranks, drop the structurally absent gradients."""
+        self.pack()
         if dist.is_initialized() and dist.get_world_size() > 1:
-            self.pack()
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self._drop_absent()
+
+# ---------------------------------------------------------------------------------------------------------------
+# reference-faithful loss normalisation across ranks (main.py:57-60)
+# ---------------------------------------------------------------------------------------------------------------
+def global_loss_scale(n_examples_local: int, n_targets_local: int, device=None, count_this_rank: bool = True) -> float:
+    """len(qids) / len(targets) of the GATHERED batch: one 2-element all-reduce.  ``count_this_rank=False`` for the ranks of
+    a candidate group that replicate the examples of the group's first rank."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(n_examples_local) / float(n_targets_local)
+    if device is None:
+        device = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    v = torch.tensor([float(n_examples_local), float(n_targets_local)], dtype=torch.float64, device=device)
+    if not count_this_rank:
+        v.zero_()
+    dist.all_reduce(v, op=dist.ReduceOp.SUM)
+    return float(v[0].item() / v[1].item())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# candidate x batch layout (more ranks than examples)
+# ---------------------------------------------------------------------------------------------------------------
+NUM_CANDIDATES = 5   # model/stage.py:79
+
+
+class _GroupCE(torch.autograd.Function):
+    """Sum cross-entropy over examples whose five logits are spread over the ranks of a candidate group.
+    forward: all-gather the local columns -> full rows -> CE(sum) (the same value on every rank of the group);
+    backward: (softmax - onehot) restricted to the local columns.  Each rank back-propagates only through its own
+    candidates, so the flat sum all-reduce of the parameter gradients counts every path once."""
+
+    @staticmethod
+    def forward(ctx, local_logits, targets, layout):
+        full = layout.gather_candidates(local_logits.detach())                 # (M, 5)
+        logp = torch.log_softmax(full.double(), dim=1)
+        ctx.save_for_backward(logp, targets)
+        ctx.cols = layout.cand_range
+        return -(logp.gather(1, targets.view(-1, 1)).sum()).to(local_logits.dtype)
+
+    @staticmethod
+    def backward(ctx, gout):
+        logp, targets = ctx.saved_tensors
+        g = torch.exp(logp)
+        g.scatter_add_(1, targets.view(-1, 1), -torch.ones_like(g[:, :1]))
+        k0, k1 = ctx.cols
+        return (g[:, k0:k1] * gout).to(gout.dtype), None, None
+
+
+class CandidateLayout:
+    """world = E x C: E example blocks (example-major, as ``shard_range``), C <= 5 ranks per block splitting the five
+    candidates contiguously.  rank r -> block r // C, candidate part r % C; ranks >= E*C idle (``active`` False).
+
+    ``shard(batch)`` returns the local batch: the example slice, ``qas_bert`` / ``qas_mask`` / ``qas`` restricted to the
+    local candidates, ``target`` kept GLOBAL, plus ``cand_offset`` (global index of local candidate 0) and ``gt_scores_fn``
+    which the model calls in add_local training to obtain the ground-truth candidate's temporal scores
+    (tvqaplus_amd.stage.STAGE.get_proposals)."""
+
+    def __init__(self, n_examples: int, rank: Optional[int] = None, world: Optional[int] = None):
+        if rank is None:
+            rank = dist.get_rank() if dist.is_initialized() else 0
+        if world is None:
+            world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank, self.world, self.n_examples = rank, world, n_examples
+        self.E = min(n_examples, world)
+        self.C = max(1, min(NUM_CANDIDATES, world // self.E))
+        self.active = rank < self.E * self.C
+        self.block = rank // self.C if self.active else -1
+        self.part = rank % self.C if self.active else -1
+        self.example_range = shard_range(n_examples, self.block, self.E) if self.active else (0, 0)
+        self.cand_range = shard_range(NUM_CANDIDATES, self.part, self.C) if self.active else (0, 0)
+        self.group = None
+        self.group_ranks = list(range(self.block * self.C, (self.block + 1) * self.C)) if self.active else []
+        if dist.is_initialized() and world > 1 and self.C > 1:
+            # new_group is collective over the world: every rank creates every block's group
+            for b in range(self.E):
+                g = dist.new_group(ranks=list(range(b * self.C, (b + 1) * self.C)))
+                if b == self.block:
+                    self.group = g
+
+    # ---- data --------------------------------------------------------------------------------------------------
+    def shard(self, batch):
+        lo, hi = self.example_range
+        k0, k1 = self.cand_range
+        out = type(batch)()
+        for k, v in batch.items():
+            if k in ("qas_bert", "qas_mask", "qas") and torch.is_tensor(v):
+                out[k] = v[lo:hi, k0:k1].contiguous()
+            elif k in _TENSOR_KEYS and torch.is_tensor(v):
+                out[k] = v[lo:hi]
+            elif k == "ts_label" and isinstance(v, dict):
+                out[k] = {kk: vv[lo:hi] for kk, vv in v.items()}
+            elif k in _LIST_KEYS and isinstance(v, list):
+                out[k] = v[lo:hi]
+            else:
+                out[k] = v
+        out["cand_offset"] = k0
+        out["gt_scores_fn"] = self.gt_scores
+        return out
+
+    # ---- collectives inside the group ----------------------------------------------------------------------------
+    def gather_candidates(self, local: torch.Tensor) -> torch.Tensor:
+        """local (M, k_local, ...) -> (M, 5, ...) on every rank of the group (candidate parts differ by at most one)."""
+        if self.C == 1 or self.group is None:
+            return local
+        kmax = max(shard_range(NUM_CANDIDATES, p, self.C)[1] - shard_range(NUM_CANDIDATES, p, self.C)[0] for p in range(self.C))
+        pad = local.new_zeros((local.shape[0], kmax) + tuple(local.shape[2:]))
+        pad[:, : local.shape[1]] = local
+        parts = [torch.empty_like(pad) for _ in range(self.C)]
+        dist.all_gather(parts, pad.contiguous(), group=self.group)
+        cols = []
+        for p, t in enumerate(parts):
+            a, b = shard_range(NUM_CANDIDATES, p, self.C)
+            cols.append(t[:, : b - a])
+        return torch.cat(cols, dim=1)
+
+    def gt_scores(self, t_scores_local: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+        """(N, k_local, Li, 2) masked temporal scores of the local candidates + global targets (N,) -> (N, Li, 2) of the
+        ground-truth candidate (model/stage.py:408-409), identical on every rank of the group."""
+        full = self.gather_candidates(t_scores_local.detach())
+        return full[torch.arange(full.shape[0], device=full.device), targets]
+
+    def cross_entropy_sum(self, local_logits: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+        if self.C == 1:
+            return torch.nn.functional.cross_entropy(local_logits, targets, reduction="sum")
+        return _GroupCE.apply(local_logits, targets, self)
+
+    def gather_logits_world(self, local_logits: torch.Tensor) -> torch.Tensor:
+        """(N_loc, k_local) -> (N, 5) on every rank of the world: candidates inside the group, then the blocks (taken from
+        each block's first rank)."""
+        full = self.gather_candidates(local_logits.detach()) if self.active else local_logits.new_zeros((0, NUM_CANDIDATES))
+        if not dist.is_initialized() or self.world == 1:
+            return full
+        counts = [shard_range(self.n_examples, b, self.E)[1] - shard_range(self.n_examples, b, self.E)[0] for b in range(self.E)]
+        mx = max(counts)
+        pad = full.new_zeros((mx, NUM_CANDIDATES))
+        pad[: full.shape[0]] = full
+        out = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(out, pad)
+        return torch.cat([out[b * self.C][: counts[b]] for b in range(self.E)], dim=0)

@@ -11,6 +11,8 @@ Scope: the model forward/backward.  The host-side supervis
 """
 from __future__ import annotations
 
+import copy
+
 import math
 import os
 from typing import Dict, List, Optional, Tuple
@@ -22,6 +24,13 @@ import torch.nn.functional as F
 from . import ops
 
 NEG = -1e10
+
+
+def _opt(batch, key, default=None):
+    """Optional batch field (candidate-sharded batches of tvqaplus_amd.parallel.CandidateLayout carry extra ones)."""
+    if isinstance(batch, dict):
+        return batch.get(key, default)
+    return getattr(batch, key, default)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -70,7 +79,10 @@ class _MHAParams(nn.Module):
         super().__init__()
         assert d_model % nh == 0
         self.nh = nh
-        self.linears = nn.ModuleList([nn.Linear(d_model, d_model) for _ in range(4)])
+        # model/self_attention.py:26 `clones(nn.Linear(d_model, d_model), 4)` deep-copies ONE initialised layer: the four
+        # projections start identical and consume a single draw of the generator
+        first = nn.Linear(d_model, d_model)
+        self.linears = nn.ModuleList([first] + [copy.deepcopy(first) for _ in range(3)])
         self.p_attn_drop = 0.1
 
 
@@ -183,7 +195,11 @@ class STAGE(nn.Module):
         # developer switch: False (or STAGE_NO_FUSE_LN_DWCONV=1) = separate LayerNorm and depthwise-conv kernels
         self.fuse_ln_dwconv = os.environ.get("STAGE_NO_FUSE_LN_DWCONV") is None
         self._span_host = None      # pinned landing buffer of the per-step proposal spans (get_proposals)
-        self._seed_state = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x1234567) & 0xFFFFFFFFFFFFFFFF
+        # counter-based dropout stream (csrc/common.h): seeded lazily from the seed of torch's default generator at the first
+        # use (so torch.manual_seed() before training takes effect, as for the reference's nn.Dropout) and mixed with the
+        # process rank (identical seeds on every data-parallel rank would drop the same units everywhere).  The stream
+        # position is not part of state_dict(): like the reference, a resumed run does not replay the masks.
+        self._seed_state: Optional[int] = None
         self.mha_dropout_override: Optional[float] = None  # tests: the reference's fixed 0.1 can be zeroed
 
     # ---- dropout bookkeeping ---------------------------------------------------------------------------------
@@ -191,7 +207,12 @@ class STAGE(nn.Module):
         return float(self.dropout) if self.training else 0.0
 
     def _seed(self) -> int:
-        """A fresh 63-bit stream id per dropout site per forward (host-side LCG: no device sync)."""
+        if self._seed_state is None:
+            # the seed of torch's default generator as of NOW (the latest torch.manual_seed), read without consuming a draw:
+            # the reference's negative sampling (get_att_loss) draws from that generator and must see the same sequence
+            draw = int(torch.initial_seed())
+            rank = int(os.environ.get("RANK", "0"))
+            self._seed_state = (draw * 0x9E3779B97F4A7C15 + 0x1234567 + rank * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
         self._seed_state = (self._seed_state * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
         return self._seed_state >> 1
 
@@ -273,12 +294,16 @@ class STAGE(nn.Module):
         return flat // Li, flat % Li, conf
 
     def get_proposals(self, max_statement, max_statement_mask, temporal_scores, targets, ts_labels,
-                      iou_thd=0.5, ce_prob_thd=0.01, extra_span_length=3):
+                      iou_thd=0.5, ce_prob_thd=0.01, extra_span_length=3, gt_scores_fn=None):
         N, NA, Li, D = max_statement.shape
         x = max_statement.reshape(N * NA, Li, D)
         m = max_statement_mask.reshape(N * NA, Li)
         if self.training:
-            ca = F.softmax(temporal_scores[torch.arange(N, device=targets.device), targets].detach(), dim=1)
+            # ground-truth candidate's scores (:408-409); with the candidates of an example spread over a rank group they
+            # come from the rank that holds it (parallel.CandidateLayout.gt_scores)
+            gt = (gt_scores_fn(temporal_scores, targets) if gt_scores_fn is not None
+                  else temporal_scores[torch.arange(N, device=targets.device), targets])
+            ca = F.softmax(gt.detach(), dim=1)
             st, ed, conf = self._best_span(ca[:, :, 0], ca[:, :, 1])
             # one small D2H copy per step: the number of proposals (N_new) is data dependent by construction.  It is
             # requested BEFORE the global masked max is queued and awaited through an event: the host resumes as soon as the
@@ -287,11 +312,12 @@ class STAGE(nn.Module):
             if dev_spans.is_cuda:
                 if self._span_host is None or self._span_host.shape != dev_spans.shape:
                     self._span_host = torch.empty(dev_spans.shape, dtype=torch.float32, pin_memory=True)
-                self._span_host.copy_(dev_spans, non_blocking=True)
-                arrived = torch.cuda.Event()
-                arrived.record()
-                glob = ops.masked_max(x, m)                                       # (N*5, D)
-                arrived.synchronize()
+                with torch.cuda.device(dev_spans.device):    # the model may live on a device that is not the current one
+                    self._span_host.copy_(dev_spans, non_blocking=True)
+                    arrived = torch.cuda.Event()
+                    arrived.record(torch.cuda.current_stream(dev_spans.device))
+                    glob = ops.masked_max(x, m)                                   # (N*5, D)
+                    arrived.synchronize()
                 host = self._span_host.tolist()
             else:   # CPU tensors only reach this point in host-logic tests
                 glob = ops.masked_max(x, m)
@@ -331,7 +357,7 @@ class STAGE(nn.Module):
         return ops.linear(y, lw.conv[2].weight, lw.conv[2].bias, relu=lw.relu), s
 
     def classfier_head_multi_proposal(self, statement, statement_mask, targets, ts_labels, ts_labels_mask,
-                                      extra_span_length=3):
+                                      extra_span_length=3, gt_scores_fn=None):
         """model/stage.py:484-537."""
         N, NA, Li, Lqa = statement_mask.shape
         D = statement.shape[-1]
@@ -353,23 +379,38 @@ class STAGE(nn.Module):
         first = first.view(N, NA, Li, D)
         if self.add_local:
             pooled, targets = self.get_proposals(first, mx_mask, t_scores, targets, ts_labels,
-                                                 extra_span_length=extra_span_length)
+                                                 extra_span_length=extra_span_length, gt_scores_fn=gt_scores_fn)
         else:
             pooled = ops.masked_max(first.view(N * NA, Li, D), mx_mask.view(N * NA, Li)).view(N, NA, D)
         logits, _ = self._linear_wrapper(pooled.reshape(-1, pooled.shape[-1]), self.classifier)
         return logits.view(-1, NA), targets, t_scores
 
-    def get_ts_loss(self, temporal_scores, ts_labels, answer_indices):
-        """model/stage.py:539-555."""
+    def get_ts_loss(self, temporal_scores, ts_labels, answer_indices, cand_offset: int = 0):
+        """model/stage.py:539-555.  ``cand_offset``: global index of local candidate 0 when the candidates of an example
+        are spread over ranks -- only examples whose ground-truth candidate is local contribute here (the sum over the
+        ranks of the group is the full loss)."""
         bsz = len(answer_indices)
-        Li = temporal_scores.shape[2]
-        ca = temporal_scores.gather(1, answer_indices.view(bsz, 1, 1, 1).expand(bsz, 1, Li, 2)).squeeze(1)   # [n, target_n]
-        loss_st = self.temporal_criterion(ca[:, :, 0], ts_labels["st"])
-        loss_ed = self.temporal_criterion(ca[:, :, 1], ts_labels["ed"])
-        return (loss_st + loss_ed) / 2.
+        NA_loc, Li = temporal_scores.shape[1:3]
+        local = answer_indices - cand_offset
+        if cand_offset == 0 and NA_loc == self.num_a:
+            ca = temporal_scores.gather(1, local.view(bsz, 1, 1, 1).expand(bsz, 1, Li, 2)).squeeze(1)   # [n, target_n]
+            loss_st = self.temporal_criterion(ca[:, :, 0], ts_labels["st"])
+            loss_ed = self.temporal_criterion(ca[:, :, 1], ts_labels["ed"])
+            return (loss_st + loss_ed) / 2.
+        here = ((local >= 0) & (local < NA_loc))
+        idx = local.clamp(0, NA_loc - 1)
+        ca = temporal_scores.gather(1, idx.view(bsz, 1, 1, 1).expand(bsz, 1, Li, 2)).squeeze(1)
+        per = (F.cross_entropy(ca[:, :, 0], ts_labels["st"], reduction="none")
+               + F.cross_entropy(ca[:, :, 1], ts_labels["ed"], reduction="none"))
+        return (per * here.to(per.dtype)).sum() / 2.
 
     # ---- forward ----------------------------------------------------------------------------------------------
     def forward(self, batch):
+        if getattr(self, "_is_replica", False):
+            # nn.DataParallel (main.py:204-206) replicates the module into THREADS of one process; the HIP path keeps per-process
+            # launch state (scratch buffers, ticket rings) and is built for one process per GPU over RCCL instead
+            raise RuntimeError("tvqaplus_amd.STAGE does not run under nn.DataParallel: launch one process per GPU "
+                               "(python -m torch.distributed.run ...) and use tvqaplus_amd.parallel (INTEGRATION.md section 4)")
         if self.inference_mode:
             return self.forward_main(batch)
         out, att_loss, att_predictions, temporal_loss, temporal_predictions, _ = self.forward_main(batch)
@@ -378,7 +419,10 @@ class STAGE(nn.Module):
     def forward_main(self, batch):
         """model/stage.py:199-348."""
         self.bsz = len(batch.qid)
-        N, NA, D = self.bsz, self.num_a, self.hsz
+        N, D = self.bsz, self.hsz
+        NA = batch.qas_bert.shape[1]          # 5 (self.num_a), or the local candidates of a candidate-sharded batch
+        cand_offset = int(_opt(batch, "cand_offset", 0) or 0)
+        gt_scores_fn = _opt(batch, "gt_scores_fn", None)
         qas_mask = batch.qas_mask.view(N, NA, -1).float()
         a_embed = self.base_encoder(batch.qas_bert.view(N * NA, -1, self.wd_size), qas_mask.view(N * NA, -1),
                                     self.bert_word_encoding_fc, self.input_embedding, self.input_encoder)
@@ -416,7 +460,7 @@ class STAGE(nn.Module):
             raise NotImplementedError
         out, target, t_scores = self.classfier_head_multi_proposal(
             statement, statement_mask, batch.target, batch.ts_label, batch.ts_label_mask.float(),
-            extra_span_length=self.extra_span_length)
+            extra_span_length=self.extra_span_length, gt_scores_fn=gt_scores_fn)
         assert len(out) == len(target)
         other_outputs["temporal_scores"] = t_scores
 
@@ -436,7 +480,7 @@ class STAGE(nn.Module):
         if self.use_sup_att and self.training and self.vfeat_flag:
             from .att_host import get_att_loss
             att_loss, att_predictions = get_att_loss(self, other_outputs["vid_raw_s"], batch)
-        temporal_loss = self.get_ts_loss(t_scores, batch.ts_label, batch.target)
+        temporal_loss = self.get_ts_loss(t_scores, batch.ts_label, batch.target, cand_offset)
         if self.training:
             return [out, target], att_loss, att_predictions, temporal_loss, t_scores, other_outputs
         return out, att_loss, att_predictions, temporal_loss, F.softmax(t_scores, dim=2), other_outputs

@@ -60,13 +60,15 @@ def _len_mask(lengths: torch.Tensor, L: int) -> torch.Tensor:
 
 def make_batch(N: int = 16, Li: int = 300, Lr: int = 20, Lw: int = 50, Lqa: int = 40, wd_size: int = 768,
                vfeat_size: int = 300, seed: int = 2018, ragged: bool = True, device: Optional[str] = None,
-               empty_frames: bool = False, att_imgs: int = 0) -> Batch:
+               empty_frames: bool = False, att_imgs: int = 0, att_words: int = 0) -> Batch:
     """ragged=True: Lqa_{n,a}~U[0.3Lqa,Lqa], Lw_{n,i}~U[0.1Lw,Lw], Lr_{n,i}~U[0.4Lr,Lr], frames
     Li_n~U[2Li/3,Li] with trailing frames fully masked (ts_label_mask = frame mask); item 0 keeps full
     lengths so padded shapes equal the requested ones.  ragged=False: all-ones masks (dense upper bound).
     empty_frames=True additionally blanks the regions of one *valid* frame per item (edge case).
     att_imgs > 0: region-level attention labels for the first att_imgs frames of every item (tvqa_dataset.py's
-    att_labels: per item a list of (Lqa, Lr) 0/1 tensors, ~10 % positives, region 0 always negative)."""
+    att_labels: per item a list of (Lqa, Lr) 0/1 tensors, ~10 % positives, region 0 always negative).
+    att_words > 0 (the bench): TVQA+-like sparsity instead -- per annotated frame `att_words` object words of the
+    ground-truth answer, each with one or two positive regions, all inside the valid words / regions of the item."""
     gen = torch.Generator().manual_seed(seed)
     f32 = dict(generator=gen, dtype=torch.float32)
     qas_bert = torch.randn(N, 5, Lqa, wd_size, **f32)
@@ -111,8 +113,17 @@ def make_batch(N: int = 16, Li: int = 300, Lr: int = 20, Lw: int = 50, Lqa: int 
         for n in range(N):
             per = []
             for i in range(att_imgs):
-                lab = (torch.rand(Lqa, Lr, generator=gen) < 0.1).float()
-                lab[:, 0] = 0
+                if att_words > 0:
+                    lab = torch.zeros(Lqa, Lr)
+                    nw, nr = int(qa_len[n, int(target[n])]), int(r_len[n, i])
+                    words = torch.randperm(nw, generator=gen)[:min(att_words, nw)]
+                    for w in words.tolist():
+                        k = 1 + int(torch.randint(0, 2, (1,), generator=gen))
+                        regs = 1 + torch.randperm(max(nr - 1, 1), generator=gen)[:k]      # region 0 stays negative
+                        lab[w, regs.clamp(max=nr - 1)] = 1.0
+                else:
+                    lab = (torch.rand(Lqa, Lr, generator=gen) < 0.1).float()
+                    lab[:, 0] = 0
                 per.append(lab)
             b.att_labels.append(per)
     return b.to(device) if device is not None else b
