@@ -1,0 +1,49 @@
+"""Host-side timeline of the bench step: time the host spends in forward / backward / optimizer calls (no sync) and the
+synchronised step time.  python tools/step_host_timeline.py [--no_sup_att]"""
+import os, sys, time, contextlib, torch, torch.nn.functional as F
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tvqaplus_amd import parallel
+from tvqaplus_amd.stage import STAGE
+from tvqaplus_amd.synth import make_batch, make_opt
+sup = "--no_sup_att" not in sys.argv
+torch.manual_seed(2018)
+opt = make_opt(hsz=128, add_local=True, dropout=0.1, use_sup_att=sup)
+with contextlib.redirect_stdout(open(os.devnull, "w")):
+    model = STAGE(opt).cuda().train()
+params = [p for p in model.parameters() if p.requires_grad]
+bucket = parallel.FlatGradBucket(params)
+optim = torch.optim.Adam(params, lr=1e-3, weight_decay=3e-7)
+batch = make_batch(N=16, seed=2018, att_imgs=4 if sup else 0, att_words=3).to("cuda")
+acc = [0.0] * 4
+def step(record):
+    t0 = time.perf_counter()
+    bucket.zero()
+    (out, targets), att_loss, _, t_loss, _ = model(batch)
+    loss = F.cross_entropy(out, targets, reduction="sum") * (16.0 / len(targets)) + 0.1 * att_loss + 0.5 * t_loss
+    t1 = time.perf_counter()
+    loss.backward()
+    t2 = time.perf_counter()
+    bucket.all_reduce(); torch.nn.utils.clip_grad_norm_(params, 10.0); optim.step()
+    t3 = time.perf_counter()
+    if record:
+        for i, v in enumerate((t1 - t0, t2 - t1, t3 - t2)): acc[i] += v
+for _ in range(3): step(False)
+torch.cuda.synchronize(); T0 = time.perf_counter()
+n = 10
+for _ in range(n): step(True)
+torch.cuda.synchronize(); T = time.perf_counter() - T0
+print("sup_att", sup, "step %.2f ms | host: forward %.2f backward %.2f optimizer %.2f ms" % (1e3 * T / n, 1e3 * acc[0] / n, 1e3 * acc[1] / n, 1e3 * acc[2] / n))
+# finer: time spent in selected host functions (monkeypatched timers), per step
+import tvqaplus_amd.att_host as AH
+tm = {}
+def wrap(obj, name, key):
+    f = getattr(obj, name)
+    def g(*a, **k):
+        t = time.perf_counter(); r = f(*a, **k); tm[key] = tm.get(key, 0.0) + time.perf_counter() - t; return r
+    setattr(obj, name, g)
+wrap(AH, "build_att_pairs", "build_att_pairs"); wrap(AH, "get_att_loss", "get_att_loss")
+wrap(torch.cuda.Event, "synchronize", "event.synchronize")
+torch.cuda.synchronize()
+for _ in range(n): step(False)
+torch.cuda.synchronize()
+print({k: round(1e3 * v / n, 3) for k, v in tm.items()})

@@ -26,9 +26,9 @@ def _sample_negatives_np(row: Optional[np.ndarray], pr: np.ndarray, nr: np.ndarr
     """model/stage.py:557-611 for ONE (image, word) pair.  pr / nr: positive / negative region indices; ``row``: the
     predicted scores of the word's regions (hard mode only).  Returns the region indices of (P*num_negatives) pairs."""
     n_pos = pr.shape[0]
-    pos_rep = np.tile(pr, num_negatives)
+    pos_rep = pr if num_negatives == 1 else np.concatenate((pr,) * num_negatives)      # == pos.repeat(num_negatives, 1)
     if not hard:
-        return pos_rep, nr[_draw(nr.shape[0], pos_rep.shape[0])]
+        return pos_rep, nr[torch.randint(0, nr.shape[0], (pos_rep.shape[0],)).numpy()]
     # descending by predicted score (torch.sort(descending=True) at :577; scores are distinct floats in practice)
     order = nr[np.argsort(-row[nr], kind="stable")]
     if pool > num_negatives:
@@ -61,11 +61,16 @@ def build_att_pairs(model, batch, scores: Optional[torch.Tensor] = None, n_local
     random draws.  Random-negative mode needs no scores (it can run ahead of the device, e.g. in the data loader);
     hard-negative mode reads the predicted scores of the labelled words -- ONE gather + ONE device-to-host copy per
     batch instead of the reference's sort + ``.cpu()`` per word."""
-    targets = batch.target.tolist()
+    # host copy of the answer indices when the input pipeline kept one (`.tolist()` of a device tensor waits for the whole
+    # queue: measured 11-16 ms inside the step -- a full host/device serialisation per batch, which the reference also pays)
+    targets = getattr(batch, "target_list", None)
+    if targets is None:
+        targets = batch.target.tolist()
+    targets = list(targets)
     hard = bool(getattr(batch, "use_hard_negatives", False))
     k0 = int(getattr(batch, "cand_offset", 0) or 0)      # candidate-sharded batches: only locally held ground truths contribute
     labels = _labels_to_host(batch.att_labels)
-    entries = []                                           # (b, ca_local, img, word, pr, nr)
+    heads, prs, nrs = [], [], []                           # per (image, word) entry: (b, ca_local, img, word), pos / neg regions
     for b, ca in enumerate(targets):
         ca -= k0
         if n_local_candidates is not None and (ca < 0 or ca >= n_local_candidates):
@@ -74,48 +79,79 @@ def build_att_pairs(model, batch, scores: Optional[torch.Tensor] = None, n_local
         for local, lab in enumerate(labels[b]):
             nz = lab != 0
             rows = np.flatnonzero(nz.any(axis=1))
-            for w in rows.tolist():
-                entries.append((b, ca, start + local, w, np.flatnonzero(nz[w]), np.flatnonzero(~nz[w])))
-    if not entries:
+            if rows.size == 0:
+                continue
+            sub = nz[rows]                                  # (#labelled words, Lr): one nonzero each way for the image
+            pw, pr_all = np.nonzero(sub)
+            nw, nr_all = np.nonzero(~sub)
+            pcut = np.searchsorted(pw, np.arange(rows.size + 1)).tolist()
+            ncut = np.searchsorted(nw, np.arange(rows.size + 1)).tolist()
+            img = start + local
+            for j, w in enumerate(rows.tolist()):
+                prs.append(pr_all[pcut[j]:pcut[j + 1]])
+                nrs.append(nr_all[ncut[j]:ncut[j + 1]])
+                heads.append((b, ca, img, w))
+    if not heads:
         return None, None
     pred_rows = None
     if hard:
         if scores is None:
             raise ValueError("hard-negative sampling ranks the negatives by their predicted scores: pass `scores`")
-        idx = torch.tensor([e[:4] for e in entries], dtype=torch.long)
-        idx = idx.to(scores.device, non_blocking=True)
+        idx = torch.tensor(heads, dtype=torch.long).to(scores.device, non_blocking=True)
         pred_rows = scores.detach()[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]].cpu().numpy()    # (K, Lr): the one sync
-    pos_chunks, neg_chunks = [], []
-    for k, (b, ca, img, w, pr, nr) in enumerate(entries):
-        sp, sn = _sample_negatives_np(None if pred_rows is None else pred_rows[k], pr, nr, model.num_negatives, hard,
-                                      model.negative_pool_size, model.num_hard, model.drop_topk)
-        head = np.empty((sp.shape[0], 4), dtype=np.int64)
-        head[:] = (b, ca, img, w)
-        pos_chunks.append(np.concatenate([head, sp[:, None].astype(np.int64)], axis=1))
-        neg_chunks.append(np.concatenate([head, sn[:, None].astype(np.int64)], axis=1))
-    return np.concatenate(pos_chunks, axis=0), np.concatenate(neg_chunks, axis=0)
+    sps, sns = [], []
+    for k in range(len(heads)):
+        sp, sn = _sample_negatives_np(None if pred_rows is None else pred_rows[k], prs[k], nrs[k], model.num_negatives,
+                                      hard, model.negative_pool_size, model.num_hard, model.drop_topk)
+        sps.append(sp)
+        sns.append(sn)
+    counts = np.fromiter((a.shape[0] for a in sps), dtype=np.int64, count=len(sps))
+    head_rows = np.repeat(np.asarray(heads, dtype=np.int64), counts, axis=0)
+    pos = np.concatenate([head_rows, np.concatenate(sps).astype(np.int64)[:, None]], axis=1)
+    neg = np.concatenate([head_rows, np.concatenate(sns).astype(np.int64)[:, None]], axis=1)
+    return pos, neg
 
 
-def get_att_loss(model, scores: torch.Tensor, batch):
+class AttPairs:
+    """Flat indices into a contiguous (N, NA, Li, Lqa, Lr) score tensor for the M positive rows followed by the M negative
+    rows, resident on the device.  ``stage`` = pinned host buffer reused across steps (``pin_memory()`` per call registers
+    a fresh page-locked allocation every time: ~0.5 ms of host time on the launch path)."""
+
+    def __init__(self, pos: np.ndarray, neg: np.ndarray, shape, device, stage: Optional[torch.Tensor] = None):
+        both = np.concatenate([pos, neg], axis=0)
+        _, NA, Li, Lqa, Lr = shape
+        flat = (((both[:, 0] * NA + both[:, 1]) * Li + both[:, 2]) * Lqa + both[:, 3]) * Lr + both[:, 4]
+        self.m = pos.shape[0]
+        self.shape = tuple(shape)
+        t = torch.from_numpy(flat)
+        if torch.device(device).type == "cuda":
+            if stage is None or stage.numel() < t.numel():
+                stage = torch.empty(max(2 * t.numel(), 4096), dtype=torch.int64, pin_memory=True)
+            stage[: t.numel()].copy_(t)
+            self.flat = stage[: t.numel()].to(device, non_blocking=True)
+        else:
+            self.flat = t
+        self.stage = stage
+
+
+def get_att_loss(model, scores: torch.Tensor, batch, pairs=None):
     """scores (N,5,Li,Lqa,Lr) raw cosine scores; batch.att_labels: per item a list (per annotated image) of
     (num_words, num_regions) 0/1 tensors; batch.anno_st_idx: index of the first annotated image.
-    ``batch.att_pairs`` (a ``build_att_pairs`` result prepared ahead, random-negative mode) is used when present."""
-    pairs = getattr(batch, "att_pairs", None)
+    ``pairs``: an ``AttPairs`` prepared ahead (random-negative mode: STAGE.forward_main builds it before the first launch of
+    the step) or a ``build_att_pairs`` result; built here otherwise (hard negatives rank by the scores)."""
+    if pairs is None:
+        pairs = getattr(batch, "att_pairs", None)
     if pairs is None:
         pairs = build_att_pairs(model, batch, scores, n_local_candidates=scores.shape[1])
-    pos, neg = pairs
-    if pos is None:
-        return scores.sum() * 0.0, None
-    # one host->device copy for both index sets, then ONE flat gather: the gradient reaches raw_s as a sparse scatter
-    both = torch.from_numpy(np.concatenate([pos, neg], axis=0))
-    if scores.is_cuda:
-        both = both.pin_memory().to(scores.device, non_blocking=True)
-    st = scores.stride()
-    flat_idx = both[:, 0] * st[0] + both[:, 1] * st[1] + both[:, 2] * st[2] + both[:, 3] * st[3] + both[:, 4] * st[4]
-    vals = scores.reshape(-1).index_select(0, flat_idx) if scores.is_contiguous() else \
-        scores[both[:, 0], both[:, 1], both[:, 2], both[:, 3], both[:, 4]]
-    m = pos.shape[0]
-    s_pos, s_neg = vals[:m], vals[m:]
+    if not isinstance(pairs, AttPairs):
+        pos, neg = pairs
+        if pos is None:
+            return scores.sum() * 0.0, None
+        pairs = AttPairs(pos, neg, scores.shape, scores.device)
+    assert pairs.shape == tuple(scores.shape), (pairs.shape, tuple(scores.shape))
+    # ONE flat gather: the gradient reaches raw_s as a sparse scatter
+    vals = scores.contiguous().reshape(-1).index_select(0, pairs.flat)
+    s_pos, s_neg = vals[: pairs.m], vals[pairs.m:]
     if model.att_loss_type == "hinge":
         loss = torch.clamp(model.margin + s_neg - s_pos, min=0).sum()
     elif model.att_loss_type == "lse":

@@ -54,7 +54,7 @@ def shard_range(n_examples: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 _TENSOR_KEYS = ("qas_bert", "qas_mask", "sub_bert", "sub_mask", "vid", "vid_mask", "target", "ts_label_mask", "qas")
-_LIST_KEYS = ("qid", "vid_name", "anno_st_idx", "q_l", "image_indices", "boxes", "att_labels")
+_LIST_KEYS = ("qid", "vid_name", "anno_st_idx", "q_l", "image_indices", "boxes", "att_labels", "target_list")
 
 
 def shard_batch(batch, rank: int, world: int):

@@ -67,6 +67,11 @@ class BatchPrefetcher:
                     out[k] = v
             done = torch.cuda.Event()
             done.record(self.side)
+        # host copy of the answer indices for the supervised-attention index building (att_host.build_att_pairs): reading
+        # them back from the device tensor inside the step would drain the whole launch queue
+        tgt = host.get("target") if hasattr(host, "get") else None
+        if torch.is_tensor(tgt) and not tgt.is_cuda and "target_list" not in out:
+            out["target_list"] = tgt.tolist()
         self._free_evt[slot] = done
         self._queue.append((out, done))
         return True

@@ -458,6 +458,21 @@ class STAGE(nn.Module):
             statement, statement_mask = attended_vid, attended_vid_mask
         else:
             raise NotImplementedError
+        # supervised attention loss, random-negative mode: the (positive, negative) index pairs need no scores.  They are
+        # built HERE -- the encoders, both attentions and the fusion (most of the forward's device time) are queued, and
+        # the host is about to wait for the device at the proposal read-back anyway: ~10 ms of slack, the 3-11 ms of index
+        # building hide completely.  Built at the top of the step they left the device idle for ~2 ms (the previous
+        # step's queue drained first); the reference builds them after the forward, on the critical path.
+        att_pairs = None
+        if (self.use_sup_att and self.training and self.vfeat_flag and not self.inference_mode
+                and not bool(_opt(batch, "use_hard_negatives", False)) and _opt(batch, "att_pairs", None) is None):
+            from .att_host import AttPairs, build_att_pairs
+            pos, neg = build_att_pairs(self, batch, None, n_local_candidates=NA)
+            if pos is not None:
+                Li_v, Lr_v = batch.vid.shape[1:3]
+                att_pairs = AttPairs(pos, neg, (N, NA, Li_v, batch.qas_mask.shape[-1], Lr_v), batch.vid.device,
+                                     getattr(self, "_att_stage", None))
+                self._att_stage = att_pairs.stage
         out, target, t_scores = self.classfier_head_multi_proposal(
             statement, statement_mask, batch.target, batch.ts_label, batch.ts_label_mask.float(),
             extra_span_length=self.extra_span_length, gt_scores_fn=gt_scores_fn)
@@ -479,7 +494,7 @@ class STAGE(nn.Module):
         att_predictions = None
         if self.use_sup_att and self.training and self.vfeat_flag:
             from .att_host import get_att_loss
-            att_loss, att_predictions = get_att_loss(self, other_outputs["vid_raw_s"], batch)
+            att_loss, att_predictions = get_att_loss(self, other_outputs["vid_raw_s"], batch, pairs=att_pairs)
         temporal_loss = self.get_ts_loss(t_scores, batch.ts_label, batch.target, cand_offset)
         if self.training:
             return [out, target], att_loss, att_predictions, temporal_loss, t_scores, other_outputs

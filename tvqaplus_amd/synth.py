@@ -104,6 +104,7 @@ def make_batch(N: int = 16, Li: int = 300, Lr: int = 20, Lw: int = 50, Lqa: int 
     ed = torch.minimum(ed, n_frames - 1)
     b = Batch(qas_bert=qas_bert, qas_mask=qas_mask, sub_bert=sub_bert, sub_mask=sub_mask, vid=vid, vid_mask=vid_mask,
               target=target, ts_label=dict(st=st, ed=ed), ts_label_mask=frame_mask,
+              target_list=target.tolist(),     # host copy kept by the input pipeline (att_host.build_att_pairs)
               qid=list(range(N)), vid_name=["synthetic_%d" % i for i in range(N)],
               qas=torch.zeros(N, 5, Lqa, dtype=torch.long), att_labels=None, anno_st_idx=[0] * N, q_l=[1] * N,
               image_indices=[list(range(Li)) for _ in range(N)], boxes=[[] for _ in range(N)],
