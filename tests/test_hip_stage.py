@@ -275,3 +275,34 @@ def test_batch_prefetcher_delivers_identical_batches(hip_device):
         a = model.forward_main(next(iter(BatchPrefetcher(host[:1], hip_device))))[0]
         b = model.forward_main(host[0].to(hip_device))[0]
     assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_inference_outputs_feed_the_prediction_writer(hip_device):
+    """inference.py:49-72 end to end on the device: inference_mode outputs -> arg-max answer, span of the predicted answer
+    decoded by the batched device decoder (evaluation.find_max_pair_batch) -> the prediction dictionary; checked against the
+    host decoder (the reference's algorithm, pinned in tests/test_evaluation.py) on the same probabilities."""
+    from tvqaplus_amd import evaluation as E
+    fx = Fixture("tiny_inference")
+    model = _model_from(fx, hip_device).eval()
+    model.inference_mode = True
+    batch = fx.batch().to(hip_device)
+    with torch.no_grad():
+        out = model(batch)
+    w = E.PredictionWriter()
+    w.add_batch(out, batch.qid, batch.image_indices)
+    ans, t = out["answer"].cpu(), out["t_scores"].cpu()
+    assert len(w.predictions["ts_answer"]) == len(batch.qid)
+    for n, qid in enumerate(batch.qid):
+        a = int(ans[n].argmax())
+        (st, ed), _ = E.find_max_pair(t[n, a, :, 0].tolist(), t[n, a, :, 1].tolist())
+        off = (batch.image_indices[n][0] % 6) / 3
+        assert w.predictions["ts_answer"][str(qid)] == [[st * 2 + off, (ed + 1) * 2 + off], a]
+    # the decoder itself on device tensors, long rows with ties
+    g = torch.Generator().manual_seed(5)
+    p1 = torch.round(torch.rand(64, 300, generator=g) * 20) / 20
+    p2 = torch.round(torch.rand(64, 300, generator=g) * 20) / 20
+    st, ed, val = E.find_max_pair_batch(p1.to(hip_device), p2.to(hip_device))
+    for r in range(64):
+        (s, e), v = E.find_max_pair(p1[r].tolist(), p2[r].tolist())
+        assert (int(st[r]), int(ed[r])) == (s, e) and abs(float(val[r]) - v) < 1e-6
