@@ -64,7 +64,18 @@ class Fixture:
 
 MODEL_CASES = ["tiny_eval", "tiny_inference", "tiny_train", "tiny_train_local", "small_local_eval",
                "small_local_train", "small_heads_train", "small_heads_eval", "small_subonly_train",
-               "small_vidonly_train", "mid_train", "mid_eval", "small_supatt_train"]
+               "small_vidonly_train", "mid_train", "mid_eval", "small_supatt_train", "small_emptyframe_train"]
+# Gradients the reference itself cannot define, per fixture.  A valid frame whose regions are all masked pools to a CONSTANT
+# -1e10 row (model/stage.py:503), which then passes LayerNorm(enc) -> Linear -> (+ enc) -> LayerNorm -> st / ed scorers
+# (:469-482).  Forward: xhat = 0 exactly, every output is the LayerNorm bias -- well defined, and compared.  Backward: the
+# derivative of LayerNorm at a constant row is rstd * (centred dy * gamma) with rstd = eps^-1/2 = 316; torch's CPU kernel
+# evaluates it with |x| = 1e10 operands and returns rounding noise (0 for dx, ~1e5 for d gamma) that depends on its
+# summation order.  The noise stays inside the temporal head (mask_logits' backward zeroes it before the encoders): it
+# reaches exactly the five parameters below.  Every other gradient of the fixture is compared as usual, and the product's
+# values for these five must be finite.
+UNDEFINED_GRADS = {"small_emptyframe_train": (
+    "cls_projection_layers.0.conv.0.bias", "cls_projection_layers.0.conv.2.weight", "cls_projection_layers.0.conv.2.bias",
+    "temporal_scoring_st_layers.0.conv.0.weight", "temporal_scoring_ed_layers.0.conv.0.weight")}
 K1_CASES = ["k1_small", "k1_mid", "k1_sub"]
 ENC_CASES = ["enc_k7", "enc_k5_heads"]
 

@@ -218,6 +218,15 @@ def main():
     encoder_case("enc_k5_heads", M=6, L=11, D=32, k=5, n_conv=2, nh=4, seed=52)
 
 
+def emptyframe_main():
+    """A VALID frame whose regions are all masked, in TRAINING mode (the other train fixtures avoid it).  The forward of
+    that frame is well defined (eval fixtures hold it); its backward sends a constant -1e10 row through three LayerNorms,
+    where the reference's own CPU kernel returns rounding noise for the affine weight gradients (xhat = 0 exactly;
+    tests/test_oracle_golden.py lists the three parameters that are therefore not compared)."""
+    run_case("small_emptyframe_train", dict(hsz=32, embedding_size=48, vfeat_size=40, add_local=True, dropout=0.0),
+             dict(N=3, Li=7, Lr=5, Lw=9, Lqa=8, empty_frames=True), "train", 27)
+
+
 def att_model_main():
     run_case("small_supatt_train", dict(hsz=32, dropout=0.0, use_sup_att=True, att_loss_type="lse", embedding_size=64, vfeat_size=48),
              dict(N=3, Li=5, Lr=12, Lw=6, Lqa=8, att_imgs=2, ragged=False), "train", 41)   # dense masks: a masked (-1e10) positive makes lse inf
@@ -234,7 +243,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "att":   # only the attention-loss / box-prediction fixtures
         att_main()
         att_model_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "emptyframe":
+        emptyframe_main()
     else:
         main()
         att_main()
         att_model_main()
+        emptyframe_main()

@@ -150,6 +150,30 @@ def test_gemm_nt_gate_residual_c_abi(ops, M, N, K):
     check("y", y, ref.float())
 
 
+@pytest.mark.parametrize("scale_x,scale_w", [(1e-30, 1.0), (1e-20, 1e-18), (1e18, 1e-18), (3e4, 3e4), (1.0, 1e-35)])
+def test_linear_dynamic_range(ops, scale_x, scale_w):
+    """The GEMMs compute fp32 products as an exact 3-way bf16 split (hi + mid + lo, six cross terms kept).  bf16 has fp32's
+    exponent range, but the residual terms sit 8 / 16 binades below the value: operands near the bottom of the fp32
+    range lose their mid / lo terms to flush-to-zero earlier than an fp32 FMA chain would.  Held to: tiny-but-normal and
+    huge operands reproduce torch's fp32 matmul to the usual tolerance relative to the result's scale; operands whose
+    products underflow fp32 entirely give (near-)zeros, never NaN / Inf."""
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 4200, 128, 384
+    x = torch.randn(M, K, generator=g) * scale_x
+    w = torch.randn(N, K, generator=g) * scale_w
+    y = ops.linear(x.cuda(), w.cuda())
+    ref = (x.double() @ w.double().t())
+    assert bool(torch.isfinite(y).all())
+    mag = float(ref.abs().max())
+    if mag < 1e-37:                                   # the products underflow fp32: nothing but (denormal) zeros is expected
+        assert float(y.abs().max()) <= 1e-36
+    else:
+        err = float((y.double().cpu() - ref).abs().max()) / mag
+        # residual terms below 2^-126 flush: with operands at 1e-30 only the hi x hi term survives (bf16-level, 2^-8)
+        tol = 2e-5 if min(scale_x, scale_w) > 1e-25 and scale_x * scale_w > 1e-30 else 1e-2
+        assert err < tol, (err, tol)
+
+
 def test_linear_is_transpose_safe(ops):
     """A = I with an asymmetric weight: catches swapped MFMA output rows/cols."""
     K = 64
