@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--dense", action="store_true", help="all-ones masks instead of ragged lengths")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --bsz examples per GPU; strong: --bsz examples in total, sharded over the GPUs (SURVEY 8d)")
+    ap.add_argument("--gemm_terms", type=int, choices=(2, 3), default=3, help="bf16 terms per fp32 GEMM operand: 3 = exact split "
+                    "(default, fp32-faithful); 2 = hi + mid only (opt-in fast mode, products accurate to ~2^-17; DESIGN.md)")
     ap.add_argument("--no_sup_att", action="store_true", help="drop the supervised attention loss term (round-1 workload)")
     ap.add_argument("--att_imgs", type=int, default=4, help="annotated frames per question (synthetic att_labels)")
     ap.add_argument("--att_words", type=int, default=3, help="labelled object words per annotated frame")
@@ -185,6 +187,8 @@ def cpu_baseline(args, opt):
 
 def main():
     args = parse()
+    if args.gemm_terms == 2:
+        os.environ["STAGE_GEMM_TERMS"] = "2"       # read by tvqaplus_amd._lib at import
     from tvqaplus_amd import parallel
     from tvqaplus_amd.stage import STAGE
     from tvqaplus_amd.synth import make_batch, make_opt
@@ -263,9 +267,10 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" + (" (re-sent from pinned host memory every step)" if args.h2d else ""),
             "config": {"workload": "STAGE train step B=%d/GPU x5 cand x%d frames x%d regions x%d sub x%d QA words, hsz=%d, "
-                                   "add_local%s, dropout 0.1, %s masks; fp32 via exact 3-way bf16-split MFMA GEMMs"
+                                   "add_local%s, dropout 0.1, %s masks; fp32 via %s bf16-split MFMA GEMMs"
                                    % (n_local, args.frames, args.regions, args.sub_words, args.qa_words, args.hsz,
-                                      " + supervised attention loss" if sup else "", "all-ones" if args.dense else "ragged"),
+                                      " + supervised attention loss" if sup else "", "all-ones" if args.dense else "ragged",
+                                      "exact 3-term" if args.gemm_terms == 3 else "2-term (hi+mid, ~2^-17 products)"),
                        "step": "fwd + loss (main.py:55-60) + bwd + grad all-reduce + clip_grad_norm_ + Adam",
                        "global_batch": n_global, "parallelism": "dp%d (example-sharded, flat 2.2MB grad "
                                                                   "all-reduce over RCCL)" % world,

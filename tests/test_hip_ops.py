@@ -4,6 +4,7 @@ Tolerance: the north star asks for 1e-3 fp32 on outputs; the kernels use exact-f
 tests hold them to 2e-4 relative-to-(1+|x|) (summation-order noise only), gradients included."""
 import json
 import math
+import os
 
 import pytest
 import torch
@@ -172,6 +173,32 @@ def test_linear_dynamic_range(ops, scale_x, scale_w):
         # residual terms below 2^-126 flush: with operands at 1e-30 only the hi x hi term survives (bf16-level, 2^-8)
         tol = 2e-5 if min(scale_x, scale_w) > 1e-25 and scale_x * scale_w > 1e-30 else 1e-2
         assert err < tol, (err, tol)
+
+
+def test_two_term_gemm_library_accuracy():
+    """The opt-in fast GEMM mode (STAGE_GEMM_TERMS=2 -> libstage_hip_t2.so: hi + mid bf16 terms, three products instead of
+    six): same C ABI; against an fp64 product its error is ~1e-5 of the result's scale -- an order of magnitude above the
+    default library's (fp32-faithful, ~3e-7) and two below the 1e-3 parity bar.  Both loaded side by side."""
+    import ctypes
+    from tvqaplus_amd import _lib
+    here = os.path.dirname(_lib.__file__)
+    fast = ctypes.CDLL(os.path.join(here, "libstage_hip_t2.so"))
+    exact = ctypes.CDLL(os.path.join(here, "libstage_hip.so"))
+    for lib in (fast, exact):
+        res, args = _lib.SIGNATURES["stage_gemm_nt"]
+        lib.stage_gemm_nt.restype, lib.stage_gemm_nt.argtypes = res, args
+    g = torch.Generator().manual_seed(5)
+    st = torch.cuda.current_stream().cuda_stream
+    for (M, N, K) in ((60000, 128, 384), (8192, 384, 128), (5000, 300, 768)):
+        x = torch.randn(M, K, generator=g).cuda()
+        w = (torch.randn(N, K, generator=g) * 0.1).cuda()
+        ref = x.double() @ w.double().t()
+        errs = []
+        for lib in (fast, exact):
+            y = torch.empty(M, N, device="cuda")
+            assert lib.stage_gemm_nt(x.data_ptr(), None, w.data_ptr(), None, None, y.data_ptr(), M, N, K, 0, st) == 0
+            errs.append(float((y.double() - ref).abs().max() / ref.abs().max()))
+        assert errs[1] < 2e-6 and errs[1] < errs[0] < 5e-5, (M, N, K, errs)
 
 
 def test_linear_is_transpose_safe(ops):

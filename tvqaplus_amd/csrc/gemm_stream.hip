@@ -20,6 +20,10 @@
 #endif                  // of 6, 2 no bf16 split (raw bits as operands), 4 X lines fetched once per wave, 8 no stores,
                         // 16 weight fragments read from LDS for one of the four column tiles only; TN share kernel: 1, 2, 4 alike,
                         // 32 no barrier
+#ifndef STAGE_GEMM_TERMS
+#define STAGE_GEMM_TERMS 3      // bf16 terms per fp32 operand: 3 = exact split (six products kept, 3e-7 vs fp64);
+#endif                          // 2 = hi + mid only (three products kept: every product carries a relative error <= ~2^-17,
+                                // measured ~1e-5 of the result's scale; half the matrix-core work) -- `make TERMS=2`
 #define SBN 128                 // output columns per workgroup
 #define SKC 128                 // k per resident weight chunk
 #define SWS (SKC + 8)           // bf16 per LDS row of a plane (272 B: 16-lane ds_read_b128 groups hit distinct slots)
@@ -37,10 +41,26 @@ __device__ __forceinline__ unsigned s_cvt_pk_bf16(float lo, float hi) {
 __device__ __forceinline__ void s_split3(float a, float b, unsigned (&out)[3]) {
 #pragma unroll
     for (int s = 0; s < 3; s++) {
-        out[s] = s_cvt_pk_bf16(a, b);
-        a -= __uint_as_float(out[s] << 16);
-        b -= __uint_as_float(out[s] & 0xFFFF0000u);
+        if (s < STAGE_GEMM_TERMS) {
+            out[s] = s_cvt_pk_bf16(a, b);
+            if (s + 1 < STAGE_GEMM_TERMS) {
+                a -= __uint_as_float(out[s] << 16);
+                b -= __uint_as_float(out[s] & 0xFFFF0000u);
+            }
+        } else out[s] = 0u;
     }
+}
+// acc += sum of the kept cross terms of (a0 + a1 + a2) x (b0 + b1 + b2), smallest first
+__device__ __forceinline__ f32x16 s_mfma_terms(const sbf16x8 (&a)[3], const sbf16x8 (&b)[3], f32x16 acc) {
+    if (STAGE_GEMM_TERMS == 3) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+    return acc;
 }
 __device__ __forceinline__ float4 s_load4(const float* __restrict__ base, long row, long ld, int col, long nrows, int ncols) {
     const long r = row < nrows ? row : nrows - 1;
@@ -109,7 +129,7 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
             s_split3(v.z, v.w, s23);
             const int pos = 16 * (q >> 2) + 8 * (q & 1) + 4 * ((q >> 1) & 1);
 #pragma unroll
-            for (int s = 0; s < 3; s++) *reinterpret_cast<uint2*>(&Wp[s * SPLANE + n * SWS + pos]) = make_uint2(s01[s], s23[s]);
+            for (int s = 0; s < STAGE_GEMM_TERMS; s++) *reinterpret_cast<uint2*>(&Wp[s * SPLANE + n * SWS + pos]) = make_uint2(s01[s], s23[s]);
         }
     };
 
@@ -136,7 +156,7 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
             s_split3(ok ? wr[j][2] : 0.f, ok ? wr[j][3] : 0.f, s23);
             const int pos = 16 * (q >> 2) + 8 * (q & 1) + 4 * ((q >> 1) & 1);
 #pragma unroll
-            for (int s = 0; s < 3; s++) *reinterpret_cast<uint2*>(&Wp[s * SPLANE + n * SWS + pos]) = make_uint2(s01[s], s23[s]);
+            for (int s = 0; s < STAGE_GEMM_TERMS; s++) *reinterpret_cast<uint2*>(&Wp[s * SPLANE + n * SWS + pos]) = make_uint2(s01[s], s23[s]);
         }
     };
 #define WAIT_W(n)                                                                                                      \
@@ -283,14 +303,14 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
                         s_split3(v1.x, v1.y, p2);
                         s_split3(v1.z, v1.w, p3);
 #pragma unroll
-                        for (int s = 0; s < 3; s++) a[s] = __builtin_bit_cast(sbf16x8, make_uint4(p0[s], p1[s], p2[s], p3[s]));
+                        for (int s = 0; s < STAGE_GEMM_TERMS; s++) a[s] = __builtin_bit_cast(sbf16x8, make_uint4(p0[s], p1[s], p2[s], p3[s]));
                     }
                     const int koff = 16 * (2 * L + up) + 8 * h;
                     sbf16x8 b[3];
 #pragma unroll
                     for (int nt = 0; nt < 4; nt++) {
 #pragma unroll
-                        for (int s = 0; s < 3; s++)
+                        for (int s = 0; s < STAGE_GEMM_TERMS; s++)
                             if (!(GEMM_ABL & 16) || nt == 0)   // ablation: weight fragments read for the first column tile only
                                 b[s] = __builtin_bit_cast(sbf16x8, *reinterpret_cast<const uint4*>(&Wp[s * SPLANE + (nt * 32 + l31) * SWS + koff]));
                         // kept cross terms, smallest first
@@ -300,12 +320,7 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
                             acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[nt], 0, 0, 0);
                             continue;
                         }
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[nt], 0, 0, 0);
+                        acc[nt] = s_mfma_terms(a, b, acc[nt]);
                     }
                 }
             };
@@ -572,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_stream_kernel(const float* __r
                 s_split3(xv[2 * i], xv[2 * i + 1], q[i]);
             }
 #pragma unroll
-            for (int s = 0; s < 3; s++) {
+            for (int s = 0; s < STAGE_GEMM_TERMS; s++) {
                 a[t][s] = __builtin_bit_cast(sbf16x8, make_uint4(p[0][s], p[1][s], p[2][s], p[3][s]));
                 b[t][s] = __builtin_bit_cast(sbf16x8, make_uint4(q[0][s], q[1][s], q[2][s], q[3][s]));
             }
@@ -582,12 +597,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_stream_kernel(const float* __r
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 // kept cross terms, smallest first
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = s_mfma_terms(a[i], b[j], acc[i][j]);
             }
     };
     if (mbeg < mend) {
@@ -736,7 +746,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_share_kernel(const float* __re
             s_split3(xv[2 * i], xv[2 * i + 1], q[i]);
         }
 #pragma unroll
-        for (int s = 0; s < 3; s++) {
+        for (int s = 0; s < STAGE_GEMM_TERMS; s++) {
             ex[xb][wave][s][lane] = make_uint4(p[0][s], p[1][s], p[2][s], p[3][s]);
             ex[xb][wave][3 + s][lane] = make_uint4(q[0][s], q[1][s], q[2][s], q[3][s]);
         }
@@ -747,7 +757,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_share_kernel(const float* __re
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
-            for (int s = 0; s < 3; s++) {
+            for (int s = 0; s < STAGE_GEMM_TERMS; s++) {
                 a[t][s] = __builtin_bit_cast(sbf16x8, ex[xb][pn * 2 + t][s][lane]);
                 b[t][s] = __builtin_bit_cast(sbf16x8, ex[xb][t * 2 + pk][3 + s][lane]);
             }
@@ -762,12 +772,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_share_kernel(const float* __re
                     continue;
                 }
                 // kept cross terms, smallest first
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = s_mfma_terms(a[i], b[j], acc[i][j]);
             }
     };
     // the loop bounds are workgroup-uniform (every wave of a workgroup walks the same slab), so the barriers match
@@ -896,28 +901,23 @@ __global__ __launch_bounds__(64 * TW_WAVES, 2) void gemm_tn_wide_kernel(const fl
 #pragma unroll
             for (int i = 0; i < 4; i++) s_split3(v[2 * i], v[2 * i + 1], p[i]);
 #pragma unroll
-            for (int s = 0; s < 3; s++) exb[(u_mine[u] * 3 + s) * 64 + lane] = make_uint4(p[0][s], p[1][s], p[2][s], p[3][s]);
+            for (int s = 0; s < STAGE_GEMM_TERMS; s++) exb[(u_mine[u] * 3 + s) * 64 + lane] = make_uint4(p[0][s], p[1][s], p[2][s], p[3][s]);
         }
         __syncthreads();
         sbf16x8 a[2][3];
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
-            for (int s = 0; s < 3; s++) a[t][s] = __builtin_bit_cast(sbf16x8, exb[((pn * 2 + t) * 3 + s) * 64 + lane]);
+            for (int s = 0; s < STAGE_GEMM_TERMS; s++) a[t][s] = __builtin_bit_cast(sbf16x8, exb[((pn * 2 + t) * 3 + s) * 64 + lane]);
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             sbf16x8 b[3];
 #pragma unroll
-            for (int s = 0; s < 3; s++) b[s] = __builtin_bit_cast(sbf16x8, exb[((TW_NA + pk * 3 + j) * 3 + s) * 64 + lane]);
+            for (int s = 0; s < STAGE_GEMM_TERMS; s++) b[s] = __builtin_bit_cast(sbf16x8, exb[((TW_NA + pk * 3 + j) * 3 + s) * 64 + lane]);
 #pragma unroll
             for (int i = 0; i < 2; i++) {
                 // kept cross terms, smallest first
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0], acc[i][j], 0, 0, 0);
+                acc[i][j] = s_mfma_terms(a[i], b, acc[i][j]);
             }
         }
     };
