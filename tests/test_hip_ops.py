@@ -524,3 +524,26 @@ def test_dropout_statistics_and_backward_mask(ops):
     c = (~kept).float()
     (y * c).sum().backward()
     assert float(x.grad.abs().max()) == 0.0
+
+
+def test_torch_ops_namespace_runs_the_hip_kernels(ops):
+    """torch.ops.stage_hip.structured_attention / .linear / .layernorm: same results and gradients as the wrappers (they ARE
+    the wrappers behind the dispatcher), autograd included."""
+    g = torch.Generator().manual_seed(2)
+    N, Li, Lr, Lqa, D = 2, 3, 20, 40, 128
+    C = torch.randn(N, 5, Lqa, D, generator=g).cuda().requires_grad_()
+    Q = torch.randn(N, Li, Lr, D, generator=g).cuda().requires_grad_()
+    cm, qm = torch.ones(N, 5, Lqa).cuda(), torch.ones(N, Li, Lr).cuda()
+    A1, S1, Sn1 = torch.ops.stage_hip.structured_attention(C, Q, cm, qm, 10.0)
+    A1.sum().backward()
+    gC, gQ = C.grad.clone(), Q.grad.clone()
+    C.grad = Q.grad = None
+    A2, S2, Sn2 = ops.structured_attention(C, Q, cm, qm, 10.0)
+    A2.sum().backward()
+    assert torch.equal(A1, A2) and torch.equal(S1, S2) and torch.equal(Sn1, Sn2)
+    assert torch.equal(gC, C.grad) and torch.equal(gQ, Q.grad)
+    x = torch.randn(300, 128, generator=g).cuda()
+    w, b = torch.randn(64, 128, generator=g).cuda(), torch.randn(64, generator=g).cuda()
+    assert torch.equal(torch.ops.stage_hip.linear(x, w, b, True), ops.linear(x, w, b, True))
+    y, s = torch.ops.stage_hip.layernorm(x, torch.ones(128).cuda(), torch.zeros(128).cuda())
+    assert s is None and torch.equal(y, ops.layernorm(x, torch.ones(128).cuda(), torch.zeros(128).cuda())[0])
