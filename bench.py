@@ -42,6 +42,7 @@ def parse():
                     help="weak: --bsz examples per GPU; strong: --bsz examples in total, sharded over the GPUs (SURVEY 8d)")
     ap.add_argument("--gemm_terms", type=int, choices=(2, 3), default=3, help="bf16 terms per fp32 GEMM operand: 3 = exact split "
                     "(default, fp32-faithful); 2 = hi + mid only (opt-in fast mode, products accurate to ~2^-17; DESIGN.md)")
+    ap.add_argument("--heads", type=int, default=0, help="self-attention heads in both encoders (BASELINE config 3: 4)")
     ap.add_argument("--no_sup_att", action="store_true", help="drop the supervised attention loss term (round-1 workload)")
     ap.add_argument("--att_imgs", type=int, default=4, help="annotated frames per question (synthetic att_labels)")
     ap.add_argument("--att_words", type=int, default=3, help="labelled object words per annotated frame")
@@ -203,7 +204,8 @@ def main():
         return
     torch.manual_seed(2018)
     sup = not args.no_sup_att
-    opt = make_opt(hsz=args.hsz, add_local=True, dropout=0.1, use_sup_att=sup)
+    opt = make_opt(hsz=args.hsz, add_local=True, dropout=0.1, use_sup_att=sup, input_encoder_n_heads=args.heads,
+                   cls_encoder_n_heads=args.heads)
     import contextlib
     with contextlib.redirect_stdout(open(os.devnull, "w")):
         model = STAGE(opt)
@@ -267,9 +269,11 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" + (" (re-sent from pinned host memory every step)" if args.h2d else ""),
             "config": {"workload": "STAGE train step B=%d/GPU x5 cand x%d frames x%d regions x%d sub x%d QA words, hsz=%d, "
-                                   "add_local%s, dropout 0.1, %s masks; fp32 via %s bf16-split MFMA GEMMs"
+                                   "add_local%s%s, dropout 0.1, %s masks; fp32 via %s bf16-split MFMA GEMMs"
                                    % (n_local, args.frames, args.regions, args.sub_words, args.qa_words, args.hsz,
-                                      " + supervised attention loss" if sup else "", "all-ones" if args.dense else "ragged",
+                                      " + supervised attention loss" if sup else "",
+                                      (" + %d-head self-attention" % args.heads) if args.heads else "",
+                                      "all-ones" if args.dense else "ragged",
                                       "exact 3-term" if args.gemm_terms == 3 else "2-term (hi+mid, ~2^-17 products)"),
                        "step": "fwd + loss (main.py:55-60) + bwd + grad all-reduce + clip_grad_norm_ + Adam",
                        "global_batch": n_global, "parallelism": "dp%d (example-sharded, flat 2.2MB grad "

@@ -147,7 +147,10 @@ int stage_dwconv_bwd(const float* dout, const float* in, const float* w, float* 
 
 /* ---- multi-head self-attention core (model/self_attention.py:56-71) with the query-row mask quirk --------------
  * q,k,v,out: (M, L, D) with heads interleaved along D (head h = columns [h*dk, (h+1)*dk)); mask (M, L);
- * probs (M, nh, L, L) saved for the backward (post-softmax, pre-dropout).  L <= 64.                              */
+ * probs (M, nh, L, L) saved for the backward (post-softmax, pre-dropout).  L <= 64.
+ * stage_mha_core_recomputes(L, D, nh) == 1 (head width D/nh in {8, 16, 32, 64}): the matrix-core kernels run, which
+ * recompute the probabilities in the backward -- `probs` is then neither written nor read and may be NULL.            */
+int stage_mha_core_recomputes(int L, int D, int nh);
 int stage_mha_core_fwd(const float* q, const float* k, const float* v, const float* mask, float* out, float* probs,
                        long long M, int L, int D, int nh, float p_drop, unsigned long long seed, void* stream);
 int stage_mha_core_bwd(const float* dout, const float* q, const float* k, const float* v, const float* probs,

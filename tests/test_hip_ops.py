@@ -324,6 +324,40 @@ def test_mha_core(ops, M, L, D, nh):
     check("dv", vd.grad, vc.grad)
 
 
+@pytest.mark.parametrize("M,L,D,nh,p", [(5, 20, 128, 4, 0.0), (3, 50, 128, 4, 0.1), (4, 40, 128, 4, 0.1), (2, 64, 64, 1, 0.1),
+                                        (6, 13, 32, 4, 0.3), (3, 33, 32, 2, 0.1)])
+def test_mha_matrix_core_kernels_match_scalar(ops, M, L, D, nh, p):
+    """csrc/mha_mfma.hip (one wave per sequence and head on v_mfma_f32_16x16x4_f32, probabilities recomputed in the
+    backward) against the scalar kernels of csrc/mha.hip on the same inputs AND the same dropout seed: the two generate
+    the identical (seed, element) mask, so outputs and all three gradients agree to rounding -- with ragged masks (padded
+    QUERY rows attend uniformly, padded keys are not masked: the reference's quirk) and every tile count T = 1..4."""
+    import os
+    g = torch.Generator().manual_seed(M * 100 + L)
+    q, k, v = (torch.randn(M, L, D, generator=g) for _ in range(3))
+    lens = torch.randint(1, L + 1, (M,), generator=g)
+    lens[0] = L
+    m = (torch.arange(L).unsqueeze(0) < lens.unsqueeze(1)).float().cuda()
+    go = torch.randn(M, L, D, generator=g).cuda()
+    assert ops._lib.load().stage_mha_core_recomputes(L, D, nh) == 1
+
+    def run():
+        qd, kd, vd = dev(q, True), dev(k, True), dev(v, True)
+        o = ops.mha_core(qd, kd, vd, m, nh, p=p, seed=991)
+        o.backward(go)
+        return o.detach(), qd.grad, kd.grad, vd.grad
+
+    fast = run()
+    os.environ["STAGE_MHA_SCALAR"] = "1"
+    try:
+        slow = run()
+    finally:
+        del os.environ["STAGE_MHA_SCALAR"]
+    for name, a, b in zip(("out", "dq", "dk", "dv"), fast, slow):
+        check(name, a, b.cpu(), 2e-5)
+    if p > 0:
+        assert float((fast[0] - run()[0]).abs().max()) == 0.0      # same seed -> same mask, bit for bit
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # K1 against the golden fixtures of the reference and against the oracle on ragged random inputs
 # ---------------------------------------------------------------------------------------------------------------

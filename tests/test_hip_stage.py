@@ -172,8 +172,11 @@ def test_train_step_with_dropout_runs(hip_device):
             assert torch.isfinite(p.grad).all(), k
 
 
-def test_full_size_batch_split_invariance(hip_device):
-    """BASELINE.json's full configuration (B=16, 300 frames x 20 regions, 50 subtitle words, 40 QA words, hsz=128):
+@pytest.mark.parametrize("heads", [0, 4])
+def test_full_size_batch_split_invariance(hip_device, heads):
+    """heads = 4: BASELINE config 3 -- region / word self-attention on in both encoders (the matrix-core MHA kernels at
+    M = 4800 x 20 / 50 and 24000 x 40 tokens, four heads of 32).
+    BASELINE.json's full configuration (B=16, 300 frames x 20 regions, 50 subtitle words, 40 QA words, hsz=128):
     examples are independent, so the outputs of the full batch must equal the outputs of its two halves and the summed
     loss gradients must add up -- a size-independent property that runs every production kernel (streaming GEMMs,
     register-resident K1, sliding-window convs, fast LayerNorms) at the sizes the bench measures.  Eval mode (no dropout:
@@ -182,7 +185,7 @@ def test_full_size_batch_split_invariance(hip_device):
     from tvqaplus_amd.stage import STAGE
     from tvqaplus_amd.synth import make_batch, make_opt
     torch.manual_seed(3)
-    opt = make_opt(hsz=128, add_local=True, dropout=0.0)
+    opt = make_opt(hsz=128, add_local=True, dropout=0.0, input_encoder_n_heads=heads, cls_encoder_n_heads=heads)
     model = STAGE(opt).to(hip_device).eval()
     model.mha_dropout_override = 0.0
     batch = make_batch(N=16, Li=300, Lr=20, Lw=50, Lqa=40, seed=2018).to(hip_device)

@@ -50,6 +50,7 @@ SIGNATURES = {
     "stage_dwconv_fwd": (I, [P, P, P, P, LL, I, I, I, P]),
     "stage_dwconv_bwd_ws_bytes": (SZ, [I, I]),
     "stage_dwconv_bwd": (I, [P, P, P, P, P, P, LL, I, I, I, P, SZ, P]),
+    "stage_mha_core_recomputes": (I, [I, I, I]),
     "stage_mha_core_fwd": (I, [P, P, P, P, P, P, LL, I, I, I, F, U64, P]),
     "stage_mha_core_bwd": (I, [P, P, P, P, P, P, P, P, P, LL, I, I, I, F, U64, P]),
     "stage_masked_max_fwd": (I, [P, P, P, P, P, LL, I, I, P]),

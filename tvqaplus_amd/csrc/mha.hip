@@ -4,6 +4,7 @@
 // (uniform attention over all keys, padded keys included); keys are never masked.
 // One workgroup per (sequence m, head h); L <= 64, so the whole L x L score tile lives in LDS and a softmax row is
 // one wave64 shuffle reduction.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/stage_hip.h"
 
@@ -124,11 +125,24 @@ __global__ __launch_bounds__(256) void mha_core_bwd_kernel(const float* __restri
     }
 }
 
+// matrix-core kernels (mha_mfma.hip): dk in {8, 16, 32, 64}; they recompute the probabilities in the backward
+extern "C" int stage_mha_core_recomputes(int L, int D, int nh);
+int stage_mha_fwd_mfma(const float* q, const float* k, const float* v, const float* mask, float* out, long long M, int L, int D,
+                       int nh, float p_drop, unsigned long long seed, void* stream);
+int stage_mha_bwd_mfma(const float* dout, const float* q, const float* k, const float* v, const float* mask, float* dq, float* dk_out,
+                       float* dv, long long M, int L, int D, int nh, float p_drop, unsigned long long seed, void* stream);
+static bool mha_use_mfma(int L, int D, int nh) {
+    const bool scalar = getenv("STAGE_MHA_SCALAR") != nullptr;   // developer switch, read per call (cross-check in the tests)
+    return !scalar && stage_mha_core_recomputes(L, D, nh) != 0;
+}
+
 extern "C" int stage_mha_core_fwd(const float* q, const float* k, const float* v, const float* mask, float* out,
                                   float* probs, long long M, int L, int D, int nh, float p_drop,
                                   unsigned long long seed, void* stream) {
     if (M <= 0) return 0;
     if (L < 1 || L > 64 || nh < 1 || D % nh != 0) return STAGE_ERR_SHAPE;
+    if (mha_use_mfma(L, D, nh)) return stage_mha_fwd_mfma(q, k, v, mask, out, M, L, D, nh, p_drop, seed, stream);
+    if (!probs) return STAGE_ERR_SHAPE;     // the scalar kernels keep the probabilities for the backward
     const int dk = D / nh;
     const size_t lds = ((size_t)3 * L * (dk + 1) + (size_t)L * (L + 1)) * sizeof(float);
     uint32_t th = p_drop > 0.f ? drop_thresh16(p_drop) : 0u;
@@ -146,6 +160,8 @@ extern "C" int stage_mha_core_bwd(const float* dout, const float* q, const float
                                   int nh, float p_drop, unsigned long long seed, void* stream) {
     if (M <= 0) return 0;
     if (L < 1 || L > 64 || nh < 1 || D % nh != 0) return STAGE_ERR_SHAPE;
+    if (mha_use_mfma(L, D, nh)) return stage_mha_bwd_mfma(dout, q, k, v, mask, dq, dk_out, dv, M, L, D, nh, p_drop, seed, stream);
+    if (!probs) return STAGE_ERR_SHAPE;
     const int dk = D / nh;
     const size_t lds = ((size_t)4 * L * (dk + 1) + (size_t)2 * L * (L + 1)) * sizeof(float);
     uint32_t th = p_drop > 0.f ? drop_thresh16(p_drop) : 0u;

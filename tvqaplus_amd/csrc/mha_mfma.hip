@@ -1,0 +1,353 @@
+// K5 on the matrix cores -- the scaled-dot-product core of MultiHeadedAttention (model/self_attention.py:56-71) for head
+// widths dk = D/nh that are a multiple of 8 (<= 64) and L <= 64; other shapes run the scalar kernels of mha.hip.
+// Same contract and quirks as mha.hip: `mask.view(M,1,L,1) == 0` fills whole QUERY rows with -1e9 (uniform attention over
+// all L keys, padded keys included), keys are never masked; dropout on the probabilities regenerated from (seed, index).
+//
+// One wave per (sequence m, head h); nothing goes through LDS and NO probability tensor is stored: the backward recomputes
+// S, softmax and the dropout multipliers from q, k (the (M, nh, L, L) tensor was 614 MB for the classifier encoder of the
+// full config, written once and read once -- more bytes than q, k, v together).
+//   forward   S^T tile (keys x queries) = K . Q^T  on v_mfma_f32_16x16x4_f32 -> lane (c15, g) owns query c15 and keys
+//             jt*16 + 4g + reg: softmax over the keys is a per-lane loop + one cross-lane-group reduction, and P^T is
+//             already the B operand (k = keys) of  O^T (d x queries) = V^T . P^T  -> 16-byte stores of 4 consecutive d.
+//   backward  in the same "transposed" layout: dP^T = V . dout^T, dS^T, dQ^T = K^T . dS^T;
+//             in the "normal" layout (lane owns a KEY, S = Q . K^T recomputed, row statistics by DPP reductions over the
+//             16 lanes of a row): dV^T = dout^T . P', dK^T = Q^T . dS.  Both layouts loop over 16-query tiles, the
+//             dV / dK accumulators stay in registers across them.
+// The k index of every product is permuted freely (both operands agree): a lane's operand elements are contiguous in
+// memory (dk/4 floats of its row), loaded as float4 / float2.
+#include "common.h"
+#include "../../include/stage_hip.h"
+
+// row fragment: lane (c15, g) <- X[row][g*KS .. g*KS + KS - 1] of the head slice (row clamped by the caller)
+template <int KS>
+__device__ __forceinline__ void mha_row_frag(float (&f)[KS], const float* __restrict__ p, int g) {
+    const float* s = p + g * KS;
+    if (KS == 2) { const float2 v = *reinterpret_cast<const float2*>(s); f[0] = v.x; f[1] = v.y; }
+    else {
+#pragma unroll
+        for (int c = 0; c < KS / 4; c++) { const float4 v = ld4(s + 4 * c); f[4 * c] = v.x; f[4 * c + 1] = v.y; f[4 * c + 2] = v.z; f[4 * c + 3] = v.w; }
+    }
+}
+template <int KS>
+__device__ __forceinline__ f32x4 mha_dot(const float (&a)[KS], const float (&b)[KS]) {
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------------------
+template <int T, int KS>
+__global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                           const float* __restrict__ v, const float* __restrict__ mask,
+                                                           float* __restrict__ out, long items, int L, int D, int nh,
+                                                           uint64_t seed, uint32_t th, float inv_keep) {
+    constexpr int DK = 4 * KS, DT = (DK + 15) / 16;
+    const int lane = threadIdx.x & 63, c15 = lane & 15, g = lane >> 4;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= items) return;
+    const long m = item / nh;
+    const int h = (int)(item % nh);
+    const long base = m * L * (long)D + (long)h * DK, pbase = (m * nh + h) * (long)L;
+    const float rs = sqrtf((float)DK);
+    float kf[T][KS];
+#pragma unroll
+    for (int jt = 0; jt < T; jt++) mha_row_frag<KS>(kf[jt], k + base + (long)min(jt * 16 + c15, L - 1) * D, g);
+#pragma unroll
+    for (int it = 0; it < T; it++) {
+        if (it * 16 >= L) break;
+        const int qi = it * 16 + c15, qc = min(qi, L - 1);
+        float qf[KS];
+        mha_row_frag<KS>(qf, q + base + (long)qc * D, g);
+        const bool dead = mask[m * L + qc] == 0.f;
+        f32x4 p[T];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < T; jt++) {
+            p[jt] = mha_dot<KS>(kf[jt], qf);                 // S^T[j = jt*16 + 4g + reg][i = qi]
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float s = dead ? -1e9f : p[jt][r] / rs;
+                p[jt][r] = s;
+                if (jt * 16 + 4 * g + r < L) mx = fmaxf(mx, s);
+            }
+        }
+        mx = cross_row_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < T; jt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float e = (jt * 16 + 4 * g + r < L) ? expf(p[jt][r] - mx) : 0.f;
+                p[jt][r] = e;
+                sum += e;
+            }
+        sum = cross_row_sum(sum);
+#pragma unroll
+        for (int jt = 0; jt < T; jt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float pr = p[jt][r] / sum;
+                const int j = jt * 16 + 4 * g + r;
+                if (th && j < L) pr *= drop1(seed, (uint64_t)((pbase + qc) * L + j), th, inv_keep);
+                p[jt][r] = pr;
+            }
+        // O^T (d x queries) = V^T . P^T
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++) {
+            f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int dcol = min(dt * 16 + c15, DK - 1);
+#pragma unroll
+            for (int jt = 0; jt < T; jt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float a = v[base + (long)min(jt * 16 + 4 * g + r, L - 1) * D + dcol];   // P = 0 for keys >= L
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p[jt][r], o, 0, 0, 0);
+                }
+            const int d0 = dt * 16 + 4 * g;
+            if (qi < L && d0 < DK) st4(out + base + (long)qi * D + d0, make_float4(o[0], o[1], o[2], o[3]));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------------------------------
+template <int T, int KS>
+__global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(const float* __restrict__ dout, const float* __restrict__ q,
+                                                           const float* __restrict__ k, const float* __restrict__ v,
+                                                           const float* __restrict__ mask, float* __restrict__ dq,
+                                                           float* __restrict__ dkk, float* __restrict__ dv, long items, int L,
+                                                           int D, int nh, uint64_t seed, uint32_t th, float inv_keep) {
+    constexpr int DK = 4 * KS, DT = (DK + 15) / 16;
+    const int lane = threadIdx.x & 63, c15 = lane & 15, g = lane >> 4;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= items) return;
+    const long m = item / nh;
+    const int h = (int)(item % nh);
+    const long base = m * L * (long)D + (long)h * DK, pbase = (m * nh + h) * (long)L;
+    const float rs = sqrtf((float)DK);
+    float kf[T][KS], vf[T][KS];                      // row fragments of K and V (rows jt*16 + c15)
+#pragma unroll
+    for (int jt = 0; jt < T; jt++) {
+        const long ro = (long)min(jt * 16 + c15, L - 1) * D;
+        mha_row_frag<KS>(kf[jt], k + base + ro, g);
+        mha_row_frag<KS>(vf[jt], v + base + ro, g);
+    }
+    f32x4 adv[DT][T], adk[DT][T];                    // dV^T, dK^T (d x keys), accumulated over the query tiles
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+        for (int jt = 0; jt < T; jt++) adv[dt][jt] = adk[dt][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int it = 0; it < T; it++) {
+        if (it * 16 >= L) break;
+        float qf[KS], gf[KS];                        // row fragments of Q and dout (rows it*16 + c15)
+        {
+            const long ro = (long)min(it * 16 + c15, L - 1) * D;
+            mha_row_frag<KS>(qf, q + base + ro, g);
+            mha_row_frag<KS>(gf, dout + base + ro, g);
+        }
+        // ---------------- transposed layout: lane = query it*16 + c15, registers = keys -> dQ ----------------
+        {
+            const int qi = it * 16 + c15, qc = min(qi, L - 1);
+            const bool dead = mask[m * L + qc] == 0.f;
+            f32x4 p[T], dp[T];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int jt = 0; jt < T; jt++) {
+                p[jt] = mha_dot<KS>(kf[jt], qf);
+                dp[jt] = mha_dot<KS>(vf[jt], gf);          // dP'^T[j][i] = <v_j, dout_i>
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float s = dead ? -1e9f : p[jt][r] / rs;
+                    p[jt][r] = s;
+                    if (jt * 16 + 4 * g + r < L) mx = fmaxf(mx, s);
+                }
+            }
+            mx = cross_row_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < T; jt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float e = (jt * 16 + 4 * g + r < L) ? expf(p[jt][r] - mx) : 0.f;
+                    p[jt][r] = e;
+                    sum += e;
+                }
+            sum = cross_row_sum(sum);
+            float dot = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < T; jt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int j = jt * 16 + 4 * g + r;
+                    const float pr = p[jt][r] / sum;
+                    const float mult = (th && j < L) ? drop1(seed, (uint64_t)((pbase + qc) * L + j), th, inv_keep) : 1.0f;
+                    p[jt][r] = pr;
+                    dp[jt][r] *= mult;                      // dP = dP' * mult
+                    dot += pr * dp[jt][r];
+                }
+            dot = cross_row_sum(dot);
+#pragma unroll
+            for (int jt = 0; jt < T; jt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) p[jt][r] = dead ? 0.f : p[jt][r] * (dp[jt][r] - dot);   // dS^T
+#pragma unroll
+            for (int dt = 0; dt < DT; dt++) {
+                f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const int dcol = min(dt * 16 + c15, DK - 1);
+#pragma unroll
+                for (int jt = 0; jt < T; jt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float a = k[base + (long)min(jt * 16 + 4 * g + r, L - 1) * D + dcol];   // dS = 0 for keys >= L
+                        o = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p[jt][r], o, 0, 0, 0);
+                    }
+                const int d0 = dt * 16 + 4 * g;
+                if (qi < L && d0 < DK) st4(dq + base + (long)qi * D + d0, make_float4(o[0] / rs, o[1] / rs, o[2] / rs, o[3] / rs));
+            }
+        }
+        // ---------------- normal layout: lane = key jt*16 + c15, registers = queries it*16 + 4g + reg -> dV, dK ----------------
+        {
+            f32x4 p[T], dp[T];
+            float mx[4], sum[4], dot[4];
+            bool dead[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                mx[r] = -INFINITY;
+                dead[r] = mask[m * L + min(it * 16 + 4 * g + r, L - 1)] == 0.f;
+            }
+#pragma unroll
+            for (int jt = 0; jt < T; jt++) {
+                p[jt] = mha_dot<KS>(qf, kf[jt]);           // S[i = it*16 + 4g + reg][j = jt*16 + c15]
+                dp[jt] = mha_dot<KS>(gf, vf[jt]);
+                const bool jok = jt * 16 + c15 < L;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float s = dead[r] ? -1e9f : p[jt][r] / rs;
+                    p[jt][r] = s;
+                    if (jok) mx[r] = fmaxf(mx[r], s);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) { mx[r] = group_max(mx[r], 16); sum[r] = 0.f; dot[r] = 0.f; }
+#pragma unroll
+            for (int jt = 0; jt < T; jt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float e = (jt * 16 + c15 < L) ? expf(p[jt][r] - mx[r]) : 0.f;
+                    p[jt][r] = e;
+                    sum[r] += e;
+                }
+#pragma unroll
+            for (int r = 0; r < 4; r++) sum[r] = group_sum(sum[r], 16);
+            f32x4 pd[T];                                   // P' = P * mult (B operand of dV)
+#pragma unroll
+            for (int jt = 0; jt < T; jt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int i = min(it * 16 + 4 * g + r, L - 1), j = jt * 16 + c15;
+                    const float pr = p[jt][r] / sum[r];
+                    const float mult = (th && j < L) ? drop1(seed, (uint64_t)((pbase + i) * L + j), th, inv_keep) : 1.0f;
+                    const bool iok = it * 16 + 4 * g + r < L;
+                    p[jt][r] = pr;
+                    pd[jt][r] = iok ? pr * mult : 0.f;     // query rows >= L contribute nothing
+                    dp[jt][r] *= mult;
+                    dot[r] += pr * dp[jt][r];
+                }
+#pragma unroll
+            for (int r = 0; r < 4; r++) dot[r] = group_sum(dot[r], 16);
+#pragma unroll
+            for (int jt = 0; jt < T; jt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    p[jt][r] = (dead[r] || it * 16 + 4 * g + r >= L) ? 0.f : p[jt][r] * (dp[jt][r] - dot[r]);   // dS
+#pragma unroll
+            for (int dt = 0; dt < DT; dt++) {
+                const int dcol = min(dt * 16 + c15, DK - 1);
+                float ga[4], qa[4];                        // dout^T / Q^T operands: rows d = dt*16 + c15, k = queries 4g + r
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const long ro = (long)min(it * 16 + 4 * g + r, L - 1) * D + dcol;
+                    ga[r] = dout[base + ro];
+                    qa[r] = q[base + ro];
+                }
+#pragma unroll
+                for (int jt = 0; jt < T; jt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        adv[dt][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[r], pd[jt][r], adv[dt][jt], 0, 0, 0);
+                        adk[dt][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[r], p[jt][r], adk[dt][jt], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    // dV^T / dK^T: lane (c15 = key, g) holds d = dt*16 + 4g .. +3
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+        for (int jt = 0; jt < T; jt++) {
+            const int j = jt * 16 + c15, d0 = dt * 16 + 4 * g;
+            if (j < L && d0 < DK) {
+                st4(dv + base + (long)j * D + d0, make_float4(adv[dt][jt][0], adv[dt][jt][1], adv[dt][jt][2], adv[dt][jt][3]));
+                st4(dkk + base + (long)j * D + d0,
+                    make_float4(adk[dt][jt][0] / rs, adk[dt][jt][1] / rs, adk[dt][jt][2] / rs, adk[dt][jt][3] / rs));
+            }
+        }
+}
+
+// 1 if the matrix-core kernels take this shape (then `probs` is neither written nor read)
+extern "C" int stage_mha_core_recomputes(int L, int D, int nh) {
+    if (L < 1 || L > 64 || nh < 1 || D % nh != 0) return 0;
+    const int dk = D / nh;
+    return (dk == 8 || dk == 16 || dk == 32 || dk == 64) ? 1 : 0;
+}
+
+#define MHA_DISPATCH(KERNEL, ...)                                                                                        \
+    do {                                                                                                                 \
+        const int T = (L + 15) / 16;                                                                                     \
+        const dim3 grid((unsigned)((items + 3) / 4)), block(256);                                                        \
+        switch (dk) {                                                                                                    \
+            case 8:  MHA_T(KERNEL, 2, __VA_ARGS__); break;                                                               \
+            case 16: MHA_T(KERNEL, 4, __VA_ARGS__); break;                                                               \
+            case 32: MHA_T(KERNEL, 8, __VA_ARGS__); break;                                                               \
+            default: MHA_T(KERNEL, 16, __VA_ARGS__); break;                                                              \
+        }                                                                                                                \
+    } while (0)
+#define MHA_T(KERNEL, KSV, ...)                                                                                          \
+    switch (T) {                                                                                                         \
+        case 1: hipLaunchKernelGGL((KERNEL<1, KSV>), grid, block, 0, st, __VA_ARGS__); break;                            \
+        case 2: hipLaunchKernelGGL((KERNEL<2, KSV>), grid, block, 0, st, __VA_ARGS__); break;                            \
+        case 3: hipLaunchKernelGGL((KERNEL<3, KSV>), grid, block, 0, st, __VA_ARGS__); break;                            \
+        default: hipLaunchKernelGGL((KERNEL<4, KSV>), grid, block, 0, st, __VA_ARGS__); break;                           \
+    }
+
+int stage_mha_fwd_mfma(const float* q, const float* k, const float* v, const float* mask, float* out, long long M, int L, int D,
+                       int nh, float p_drop, unsigned long long seed, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int dk = D / nh;
+    const long items = (long)M * nh;
+    uint32_t th = p_drop > 0.f ? drop_thresh16(p_drop) : 0u;
+    if (p_drop > 0.f && th == 0u) th = 1u;
+    const float ik = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    MHA_DISPATCH(mha_fwd_mfma_kernel, q, k, v, mask, out, items, L, D, nh, (uint64_t)seed, th, ik);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+int stage_mha_bwd_mfma(const float* dout, const float* q, const float* k, const float* v, const float* mask, float* dq, float* dk_out,
+                       float* dv, long long M, int L, int D, int nh, float p_drop, unsigned long long seed, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int dk = D / nh;
+    const long items = (long)M * nh;
+    uint32_t th = p_drop > 0.f ? drop_thresh16(p_drop) : 0u;
+    if (p_drop > 0.f && th == 0u) th = 1u;
+    const float ik = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    MHA_DISPATCH(mha_bwd_mfma_kernel, dout, q, k, v, mask, dq, dk_out, dv, items, L, D, nh, (uint64_t)seed, th, ik);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}

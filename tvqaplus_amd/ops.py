@@ -505,7 +505,11 @@ class _MHACore(torch.autograd.Function):
         q, k, v, mask = _chk(q, "q"), _chk(k, "k"), _chk(v, "v"), _chk(mask, "mask")
         M, L, D = q.shape
         out = torch.empty_like(q)
-        probs = torch.empty(M, nh, L, L, dtype=torch.float32, device=q.device)
+        # the matrix-core kernels recompute the probabilities in the backward: no (M, nh, L, L) tensor (614 MB for the
+        # classifier encoder of the full config); only the scalar fallback shapes keep it
+        probs = None
+        if _os.environ.get("STAGE_MHA_SCALAR") is not None or not _lib.load().stage_mha_core_recomputes(L, D, nh):
+            probs = torch.empty(M, nh, L, L, dtype=torch.float32, device=q.device)
         _call("stage_mha_core_fwd", _ptr(q), _ptr(k), _ptr(v), _ptr(mask), _ptr(out), _ptr(probs), M, L, D, nh, float(p),
               int(seed), _stream())
         ctx.save_for_backward(q, k, v, probs, mask)
