@@ -58,6 +58,21 @@ int stage_str_attn_bwd_fused(const float* dA, const float* dS_raw_ext, const flo
                              int NA, int Li, int Lqa, int Lr, int D, float scale, void* ws, size_t ws_bytes,
                              void* stream);
 
+/* Long region rows / bf16 storage (BASELINE.json configs[4]: bf16 weights and activations with fp32 softmax accumulation,
+ * D = 256, 512 subtitle words per frame): the same StructuredAttention for ANY Lr (16-region blocks, two-pass softmax) and
+ * D in {16, 32, 64, 128, 256}.  storage_bf16 != 0: Cn, Q, Qn, A, dA are bf16 (masks, scores, S maps and the gradients
+ * dQraw / dQn / dCn stay fp32; every product accumulates in fp32).  Qn = normalised (+dropped) Q in storage precision.
+ * Backward: A is the forward output (the softmax backward's row term <P, dP> equals <dA, A>); dS_ws is an (N,NA,Li,Lqa,Lr)
+ * fp32 scratch that receives the gradient wrt the raw scores; ws from stage_str_attn_long_bwd_ws_bytes.              */
+int stage_str_attn_long_fwd(const void* Cn, const void* Q, const void* Qn, const float* c_mask, const float* q_mask, void* A,
+                            float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D, float scale,
+                            int storage_bf16, void* stream);
+size_t stage_str_attn_long_bwd_ws_bytes(int N, int NA, int Lqa, int D);
+int stage_str_attn_long_bwd(const void* dA, const void* A, const float* dS_raw_ext, const void* Cn, const void* Q,
+                            const void* Qn, const float* S_norm, float* dS_ws, float* dQraw, float* dQn, float* dCn, int N,
+                            int NA, int Li, int Lqa, int Lr, int D, float scale, int storage_bf16, void* ws, size_t ws_bytes,
+                            void* stream);
+
 /* ---- F.normalize(p=2, eps) (+dropout)  (model/stage.py:256, model/context_query_attention.py:95-96) ----------- */
 int stage_l2norm_fwd(const float* x, float* y, float* norm_out /*may be NULL*/, long long rows, int K, float eps,
                      float p_drop, unsigned long long seed, void* stream);

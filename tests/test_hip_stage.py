@@ -389,3 +389,42 @@ def test_best_span_ties_are_maximal_pairs():
         a = torch.triu(ps[r].unsqueeze(1) * pe[r].unsqueeze(0)).numpy()
         rr, cc = np.unravel_index(np.argsort(a, axis=None), a.shape)
         assert (int(st[r]), int(ed[r])) == (int(rr[-1]), int(cc[-1]))
+
+
+@pytest.mark.gpu
+def test_stress_config_long_subtitles_d256(hip_device):
+    """BASELINE.json configs[4] shapes through the WHOLE model in fp32: hsz = 256 and 512 subtitle words per frame (the
+    reference crashes at 512: its position table has 500 rows, SURVEY.md note 3; the oracle and the product continue the
+    same closed form).  The subtitle stream's attention runs on the long-row kernels (csrc/str_attn_long.hip: 16-region
+    blocks, two-pass softmax), the encoders on 512-position sequences.  Forward outputs, attention maps and every
+    parameter gradient against the fp64 oracle."""
+    from tvqaplus_amd.stage import STAGE
+    from tvqaplus_amd.synth import make_batch, make_opt
+    torch.manual_seed(512)
+    opt = make_opt(hsz=256, embedding_size=64, vfeat_size=48, dropout=0.0, add_local=True)
+    model = STAGE(opt)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    batch = make_batch(N=2, Li=3, Lr=20, Lw=512, Lqa=40, wd_size=64, vfeat_size=48, seed=6)
+    P = {k: (v.double().requires_grad_(not k.endswith(".pe")) if v.is_floating_point() else v.clone())
+         for k, v in model.state_dict().items()}
+    b64 = type(batch)({k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in batch.items()})
+    ref = O.stage_forward(P, opt, b64, training=True)
+    ref_loss = O.training_loss(ref, n_examples=2)
+    ref_loss.backward()
+    model = model.to(hip_device).train()
+    (out, targets), _, _, t_loss, t_scores, other = model.forward_main(batch.to(hip_device))
+    assert other["sub_raw_s"].shape[-1] == 512
+    assert torch.equal(targets.cpu(), ref["targets"])
+    loss = F.cross_entropy(out, targets, reduction="sum") * (2 / len(targets)) + 0.5 * t_loss
+    loss.backward()
+    assert rel_err(out, ref["logits"]) < TOL
+    assert rel_err(t_scores, ref["t_scores"]) < TOL
+    assert rel_err(loss, ref_loss) < TOL
+    for k in ("sub_raw_s", "sub_normalized_s", "vid_raw_s", "vid_normalized_s"):
+        assert rel_err(other[k], ref[k]) < TOL, k
+    for k, p in model.named_parameters():
+        g = P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert rel_err(got, g) < 4e-3, k

@@ -190,9 +190,12 @@ class _Cat3LayerNorm(torch.autograd.Function):
             da = torch.empty_like(a)
             wsb = lib.stage_cat3_layernorm_bwd_reduced_ws_bytes(rows, D, rep, inner)
             ws = _workspace(wsb, b.device)
-            _call("stage_cat3_layernorm_bwd_reduced", _ptr(dy), _ptr(a), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(gamma),
-                  _ptr(da), _ptr(db), _ptr(dgamma), _ptr(dbeta), rows, D, rep, inner, p, seed, _ptr(ws), wsb, _stream())
-            return da, db, dgamma, dbeta, None, None, None, None
+            rc = lib.stage_cat3_layernorm_bwd_reduced(_ptr(dy), _ptr(a), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(da),
+                                                      _ptr(db), _ptr(dgamma), _ptr(dbeta), rows, D, rep, inner, p, seed,
+                                                      _ptr(ws), wsb, _stream())
+            if rc != _lib.STAGE_ERR_SHAPE:      # e.g. D = 256 with 40 inner rows: the generic path below
+                _lib.check(rc, "stage_cat3_layernorm_bwd_reduced")
+                return da, db, dgamma, dbeta, None, None, None, None
         da_full = torch.empty_like(b)
         wsb = lib.stage_ln_bwd_ws_bytes(3 * D)
         ws = _workspace(wsb, b.device)
@@ -461,8 +464,70 @@ class _StrAttn(torch.autograd.Function):
         return dC, dQ, None, None, None, None, None, None
 
 
+class _StrAttnLong(torch.autograd.Function):
+    """StructuredAttention for long region rows (any Lr) and / or bf16 storage (csrc/str_attn_long.hip).  C and Q are fp32 or
+    bf16 (both the same); A comes back in that type, the score maps in fp32.  The L2 normalisation (+ dropout) of both
+    sides runs in the fp32 kernels on an fp32 view (dtype casts are plumbing); the normalised operands are rounded to the
+    storage type before the attention, like every other activation of a bf16 pipeline."""
+
+    @_on_device
+    def forward(ctx, C, Q, c_mask, q_mask, scale: float, p: float, seed_c: int, seed_q: int):
+        dt = C.dtype
+        if dt not in (torch.float32, torch.bfloat16) or Q.dtype != dt:
+            raise TypeError("structured_attention_long: C and Q must both be float32 or bfloat16")
+        C, Q = _chk(C, "C", dt), _chk(Q, "Q", dt)
+        c_mask, q_mask = _chk(c_mask, "c_mask"), _chk(q_mask, "q_mask")
+        N, NA, Lqa, D = C.shape
+        _, Li, Lr, _ = Q.shape
+        Cf, Qf = C.float(), Q.float()
+        Cn, Qn = torch.empty_like(Cf), torch.empty_like(Qf)
+        _call("stage_l2norm_fwd", _ptr(Cf), _ptr(Cn), None, N * NA * Lqa, D, EPS_L2, float(p), int(seed_c), _stream())
+        _call("stage_l2norm_fwd", _ptr(Qf), _ptr(Qn), None, N * Li * Lr, D, EPS_L2, float(p), int(seed_q), _stream())
+        Cn, Qn = Cn.to(dt), Qn.to(dt)
+        A = torch.empty(N, NA, Li, Lqa, D, dtype=dt, device=C.device)
+        S = torch.empty(N, NA, Li, Lqa, Lr, dtype=torch.float32, device=C.device)
+        Sn = torch.empty_like(S)
+        _call("stage_str_attn_long_fwd", _ptr(Cn), _ptr(Q), _ptr(Qn), _ptr(c_mask), _ptr(q_mask), _ptr(A), _ptr(S), _ptr(Sn),
+              N, NA, Li, Lqa, Lr, D, float(scale), int(dt == torch.bfloat16), _stream())
+        ctx.save_for_backward(C, Q, Cn, Qn, Sn, A)
+        ctx.cfg = (float(scale), float(p), int(seed_c), int(seed_q))
+        ctx.mark_non_differentiable(Sn)
+        ctx.set_materialize_grads(False)
+        return A, S, Sn
+
+    @_on_device
+    def backward(ctx, dA, dS, _dSn):
+        C, Q, Cn, Qn, Sn, A = ctx.saved_tensors
+        scale, p, seed_c, seed_q = ctx.cfg
+        dt = C.dtype
+        N, NA, Lqa, D = C.shape
+        _, Li, Lr, _ = Q.shape
+        dA = _chk(dA, "dA", dt) if dA is not None else torch.zeros_like(A)
+        dS_ext = _chk(dS, "dS") if dS is not None else None
+        dS_ws = torch.empty_like(Sn)
+        dQ = torch.empty(Q.shape, dtype=torch.float32, device=Q.device)
+        dQn, dCn = torch.empty_like(dQ), torch.empty(C.shape, dtype=torch.float32, device=C.device)
+        lib = _lib.load()
+        wsb = lib.stage_str_attn_long_bwd_ws_bytes(N, NA, Lqa, D)
+        ws = _workspace(wsb, C.device)
+        _call("stage_str_attn_long_bwd", _ptr(dA), _ptr(A), _ptr(dS_ext), _ptr(Cn), _ptr(Q), _ptr(Qn), _ptr(Sn), _ptr(dS_ws),
+              _ptr(dQ), _ptr(dQn), _ptr(dCn), N, NA, Li, Lqa, Lr, D, scale, int(dt == torch.bfloat16), _ptr(ws), wsb, _stream())
+        Cf, Qf = C.float(), Q.float()
+        _call("stage_l2norm_bwd", _ptr(dQn), _ptr(Qf), _ptr(dQ), N * Li * Lr, D, EPS_L2, p, seed_q, 1, _stream())
+        dC = torch.empty_like(Cf)
+        _call("stage_l2norm_bwd", _ptr(dCn), _ptr(Cf), _ptr(dC), N * NA * Lqa, D, EPS_L2, p, seed_c, 0, _stream())
+        return dC.to(dt), dQ.to(dt), None, None, None, None, None, None
+
+
+def structured_attention_long(C, Q, c_mask, q_mask, scale: float, p: float = 0.0, seed_c: int = 0, seed_q: int = 0):
+    """As ``structured_attention`` for any Lr and D in {16,32,64,128,256}; C, Q fp32 or bf16 (A in the same type)."""
+    return _StrAttnLong.apply(C, Q, c_mask, q_mask, scale, p, seed_c, seed_q)
+
+
 def structured_attention(C, Q, c_mask, q_mask, scale: float, p: float = 0.0, seed_c: int = 0, seed_q: int = 0):
     """C (N,NA,Lqa,D), Q (N,Li,Lr,D), c_mask (N,NA,Lqa), q_mask (N,Li,Lr) -> A (N,NA,Li,Lqa,D), raw S, normalised S."""
+    if Q.shape[2] > 64 or C.dtype == torch.bfloat16:    # long rows (512 subtitle words) / bf16 storage: csrc/str_attn_long.hip
+        return _StrAttnLong.apply(C, Q, c_mask, q_mask, scale, p, seed_c, seed_q)
     return _StrAttn.apply(C, Q, c_mask, q_mask, scale, p, seed_c, seed_q)
 
 
