@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 # Parameter gradients: this network is ill-conditioned in fp32 (LayerNorms over padded / near-constant rows amplify by
 # rstd ~ 316): against an fp64 evaluation of the same graph the REFERENCE's own fp32 gradients are off by up to 4.4e-3
-# (concat_fc.2.weight of mid_train; tools/debug_f64.py prints the table), the HIP path by up to 2.4e-3.  So gradients
+# (concat_fc.2.weight of mid_train; tools/fp64_gradient_check.py prints the table), the HIP path by up to 2.4e-3.  So gradients
 # are held to 6e-3 relative-to-(1+|g|) against the reference and, separately, to 4e-3 against fp64.
 GTOL = 6e-3
 
