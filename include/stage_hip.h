@@ -51,8 +51,9 @@ int stage_str_attn_bwd(const float* dA, const float* dS_raw_ext, const float* Cn
 /* Fused single-pass backward (D == 128, Lr even <= 64, Lqa >= 4, NA*Lqa <= 256; otherwise STAGE_ERR_SHAPE -> use
  * stage_str_attn_bwd): same mathematics (model/context_query_attention.py:58-61, 81, 95-101), but dA is read from HBM
  * once and dS never leaves the compute unit.  q_mask (N, Li, Lr) lets region tiles / frames without a valid region be
- * skipped (their gradient is exactly zero when dS_raw_ext is NULL).  ws sized by stage_str_attn_bwd_fused_ws_bytes.   */
-size_t stage_str_attn_bwd_fused_ws_bytes(int N, int NA, int Lqa, int D);
+ * skipped: their gradient is exactly zero unless dS_raw_ext is non-zero in the skipped columns, which a scan of those
+ * columns detects per frame (such frames are processed in full).  ws sized by stage_str_attn_bwd_fused_ws_bytes.      */
+size_t stage_str_attn_bwd_fused_ws_bytes(int N, int NA, int Li, int Lqa, int D);
 int stage_str_attn_bwd_fused(const float* dA, const float* dS_raw_ext, const float* Cn, const float* Q, const float* Qn,
                              const float* S_norm, const float* q_mask, float* dQraw, float* dQn, float* dCn, int N,
                              int NA, int Li, int Lqa, int Lr, int D, float scale, void* ws, size_t ws_bytes,

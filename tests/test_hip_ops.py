@@ -465,12 +465,15 @@ def test_k1_d128_region_sweep(ops, Lr):
 
 @pytest.mark.parametrize("N,Li,Lr,Lqa,ext", [(2, 7, 20, 40, False), (2, 7, 20, 40, True), (1, 5, 50, 40, False),
                                               (1, 5, 50, 40, True), (1, 6, 36, 40, False), (1, 4, 24, 23, False),
-                                              (2, 5, 8, 40, False), (1, 3, 64, 12, True)])
+                                              (2, 5, 8, 40, False), (1, 3, 64, 12, True), (2, 7, 20, 40, "valid"),
+                                              (2, 7, 20, 40, "pad"), (1, 5, 50, 40, "valid"), (1, 5, 50, 40, "pad")])
 def test_k1_backward_fused_paths(ops, N, Li, Lr, Lqa, ext):
     """Single-pass backward (csrc/str_attn_bwd_fused.hip), every dispatch: uniform row walk with dA kept in LDS (Lr = 20,
     8), uniform walk with the re-read from L2 (Lr = 50, 36, or STAGE_K1_BWD_NOLDSA), per-lane walk (Lqa = 23, 12); with
-    the gradient on raw_s (nothing skipped) and without it (padded region tiles / empty frames skipped, their gradients
-    are exact zeros).  Held to the oracle AND to the three-kernel path on the same inputs."""
+    the gradient on raw_s and without it (padded region tiles / empty frames skipped, their gradients are exact zeros).
+    ext: True = dense gradient on raw_s (every column processed); "valid" = sparse, on valid regions only, as the
+    supervised-attention loss produces it (the skips stay on); "pad" = a few non-zeros on padded regions and in an empty
+    frame (those frames fall back to all columns).  Held to the oracle AND to the three-kernel path on the same inputs."""
     import os
     from tvqaplus_amd.synth import make_batch
     D = 128
@@ -481,6 +484,19 @@ def test_k1_backward_fused_paths(ops, N, Li, Lr, Lqa, ext):
     cm, qm = b.qas_mask.view(N, 5, 1, Lqa), b.vid_mask.view(N, 1, Li, Lr)
     gA = torch.randn(N, 5, Li, Lqa, D, generator=g)
     gS = torch.randn(N, 5, Li, Lqa, Lr, generator=g) * 0.1 if ext else None
+    pair = (cm.view(N, 5, 1, Lqa, 1) * qm.view(N, 1, Li, 1, Lr))
+    if ext == "valid":
+        gS = gS * pair * (torch.rand(gS.shape, generator=g) < 0.05)
+    elif ext == "pad":
+        gS = gS * pair * (torch.rand(gS.shape, generator=g) < 0.05)
+        nreg = qm.view(N, Li, Lr).sum(-1)
+        short = (nreg > 0) & (nreg <= Lr - 4)            # frames with padded regions
+        empty_f = nreg == 0
+        assert bool(short.any()) and bool(empty_f.any())
+        n0, i0 = [int(v[0]) for v in torch.nonzero(short, as_tuple=True)]
+        n1, i1 = [int(v[0]) for v in torch.nonzero(empty_f, as_tuple=True)]
+        gS[n0, 2, i0, 3, Lr - 1] = 0.7                   # last (padded) region column
+        gS[n1, 0, i1, Lqa - 1, 1] = -0.4                 # a frame without any valid region
     Cc, Qc = C.clone().requires_grad_(), Q.clone().requires_grad_()
     Ao, So, _, _ = O.structured_attention(Cc, Qc, cm, qm, 10.0)
     ((Ao * gA).sum() + ((So * gS).sum() if ext else 0.0)).backward()
@@ -495,7 +511,7 @@ def test_k1_backward_fused_paths(ops, N, Li, Lr, Lqa, ext):
     check("dC", fused[0].view_as(C), Cc.grad, 1e-3)
     check("dQ", fused[1].view_as(Q), Qc.grad, 1e-3)
     # frames without a valid region: the reference's gradient is exactly zero there when no gradient reaches raw_s
-    if not ext:
+    if not ext or ext == "valid":
         empty = (qm.view(N, Li, Lr).sum(-1) == 0)
         assert bool(empty.any())
         assert float(fused[1].view(N, Li, Lr, D)[empty].abs().max()) == 0.0

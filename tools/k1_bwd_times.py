@@ -1,5 +1,6 @@
 """K1 backward at the BASELINE shapes: fused single-pass kernel vs the three-kernel path (same inputs): max differences
-and per-launch times (microseconds, events on the launch stream).  LR=20 video stream, LR=50 subtitle stream."""
+and per-launch times (microseconds, events on the launch stream).  LR=20 video stream, LR=50 subtitle stream.
+EXT=1 dense gradient on raw_s, EXT=sparse on 1 % of the valid entries."""
 import os, sys, torch, torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tvqaplus_amd import _lib
@@ -9,7 +10,7 @@ if os.environ.get("LIB"):
 lib = _lib.load()
 dev = "cuda"
 N, NA, Li, Lqa, Lr, D = int(os.environ.get("NB", 16)), 5, int(os.environ.get("LI", 300)), 40, int(os.environ.get("LR", 20)), 128
-EXT = os.environ.get("EXT") is not None
+EXT = bool(os.environ.get("EXT"))
 g = torch.Generator().manual_seed(2018)
 b = make_batch(N=N, Li=Li, Lr=Lr, Lw=2, Lqa=Lqa, wd_size=4, vfeat_size=4, seed=2018, ragged=os.environ.get("DENSE") is None)
 C = torch.randn(N, NA, Lqa, D, generator=g).to(dev)
@@ -24,9 +25,12 @@ _lib.check(lib.stage_str_attn_fwd(Cn.data_ptr(), Q.data_ptr(), cm.data_ptr(), qm
                                   N, NA, Li, Lqa, Lr, D, 10.0, 0.1, 12, st), "fwd")
 dA = torch.randn(A.shape, generator=g).to(dev)
 ext = (torch.randn(S.shape, generator=g) * 0.1).to(dev) if EXT else None
+if os.environ.get("EXT") == "sparse":   # as the supervised-attention loss produces it: a few labelled (valid) regions
+    pair = (cm.view(N, NA, 1, Lqa, 1) * qm.view(N, 1, Li, 1, Lr))
+    ext = ext * pair * (torch.rand(S.shape, generator=g).to(dev) < 0.01)
 ep = ext.data_ptr() if EXT else None
 del A, S
-wsb = max(lib.stage_str_attn_bwd_ws_bytes(N, NA, Lqa, D), lib.stage_str_attn_bwd_fused_ws_bytes(N, NA, Lqa, D))
+wsb = max(lib.stage_str_attn_bwd_ws_bytes(N, NA, Lqa, D), lib.stage_str_attn_bwd_fused_ws_bytes(N, NA, Li, Lqa, D))
 ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
 dS = torch.empty_like(Sn)
 out = {k: [torch.empty_like(Q), torch.empty_like(Q), torch.empty_like(C)] for k in ("old", "new")}

@@ -12,6 +12,8 @@ g = torch.Generator().manual_seed(2018)
 b = make_batch(N=N, Li=Li, Lr=Lr, Lw=2, Lqa=Lqa, wd_size=4, vfeat_size=4, seed=2018, ragged=os.environ.get("DENSE") is None)
 Cn = F.normalize(torch.randn(N, NA, Lqa, D, generator=g), dim=-1).to(dev)
 Q = torch.randn(N, Li, Lr, D, generator=g).to(dev)
+if os.environ.get("CONST"):   # constant operands: the matrix cores draw far less power (DESIGN.md finding 14)
+    Cn = torch.full_like(Cn, D ** -0.5); Q = torch.full_like(Q, 0.5)
 cm, qm = b.qas_mask.to(dev).contiguous(), b.vid_mask.to(dev).contiguous()
 A = torch.empty(N, NA, Li, Lqa, D, device=dev); S = torch.empty(N, NA, Li, Lqa, Lr, device=dev); Sn = torch.empty_like(S)
 st = torch.cuda.current_stream()
@@ -21,7 +23,10 @@ def launch():
                                       N, NA, Li, Lqa, Lr, D, 10.0, p, 1, st.cuda_stream), "k1")
 for _ in range(5): launch()
 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(40)]
+gap = float(os.environ.get("GAP", 0))   # idle milliseconds in front of every launch (power / clock recovery)
 for s, e in ev:
+    if gap:
+        torch.cuda.synchronize(); import time; time.sleep(gap * 1e-3)
     s.record(st); launch(); e.record(st)
 torch.cuda.synchronize()
 t = [s.elapsed_time(e) * 1e3 for s, e in ev]

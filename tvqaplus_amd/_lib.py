@@ -25,7 +25,7 @@ SIGNATURES = {
     "stage_str_attn_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, U64, P]),
     "stage_str_attn_bwd_ws_bytes": (SZ, [I, I, I, I]),
     "stage_str_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, SZ, P]),
-    "stage_str_attn_bwd_fused_ws_bytes": (SZ, [I, I, I, I]),
+    "stage_str_attn_bwd_fused_ws_bytes": (SZ, [I, I, I, I, I]),
     "stage_str_attn_bwd_fused": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, SZ, P]),
     "stage_str_attn_long_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, I, P]),
     "stage_str_attn_long_bwd_ws_bytes": (SZ, [I, I, I, I]),

@@ -32,6 +32,7 @@
 #define FLDQ 132        // padded LDS row of the raw region tile
 #define FUS_MAX_WGS 1024
 #define FUS_TABLE_BYTES(G, N) ((((size_t)(G) * sizeof(int4) + (size_t)(N) * sizeof(int2)) + 255) & ~(size_t)255)
+#define FUS_FRAME_BYTES(N, Li) (((size_t)(N) * (size_t)(Li) + 255) & ~(size_t)255)   // one byte per frame (fus_ext_scan_kernel)
 #ifndef FUS_ABL
 #define FUS_ABL 0   // developer ablation bits (tools/build_variant.sh; results are wrong with any bit set): 1 no phase 2, 2 no dP MFMAs,
 #endif              // 4 no dCn MFMAs, 8 no LDS copy of dA, 16 no G store, 32 no phase-2 MFMAs, 64 no dQ stores
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OC
     const float* __restrict__ dA, const float* __restrict__ ext, const float* __restrict__ Cn, const float* __restrict__ Q,
     const float* __restrict__ Qn, const float* __restrict__ Sn, const float* __restrict__ qmask, float* __restrict__ dQraw,
     float* __restrict__ dQn, float* __restrict__ part, int N, int NA, int Li, int Lqa, int Lr, float scale,
-    const int4* __restrict__ sched, unsigned long long* __restrict__ tim) {
+    const int4* __restrict__ sched, const unsigned char* __restrict__ fnv, unsigned long long* __restrict__ tim) {
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = tim ? __builtin_readcyclecounter() : 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int LT = FusLay<RT>::LT, TPW = 16 / NW, NT = 64 * NW;
@@ -508,15 +509,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OC
 #pragma unroll
         for (int dt = 0; dt < 8; dt++) dcn[s][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
-
     // staging map: a wave-step covers 8 region rows x 8 sixteen-byte pieces (128 contiguous bytes per row); 8 rows per
     // 32-lane half keep the transposed ds_write_b32 of Qn^T at 2-way bank conflicts (free) instead of 16-way
     constexpr int UNITS = RT * 2 * 4, NST = (UNITS + NW - 1) / NW;
     for (int i = chunk; i < Li; i += nchunks) {
         const long frame = (long)n * Li + i;
-        const float mv = lane < Lr ? qmask[frame * Lr + lane] : 0.f;
-        const unsigned long long bal = __ballot(mv != 0.f);
-        const int nvalid = HAS_EXT ? Lr : (bal ? 64 - __builtin_clzll(bal) : 0);
+        // columns to process: up to the last valid region; with a gradient on raw_s the per-frame table of fus_ext_scan_kernel
+        // (the last valid region, or Lr when that gradient is non-zero in a column that would be skipped)
+        int nvalid;
+        if (HAS_EXT) {
+            nvalid = (int)fnv[frame];
+        } else {
+            const float mv = lane < Lr ? qmask[frame * Lr + lane] : 0.f;
+            const unsigned long long bal = __ballot(mv != 0.f);
+            nvalid = bal ? 64 - __builtin_clzll(bal) : 0;
+        }
         if (nvalid == 0) {   // uniform over the workgroup: no region contributes, both gradients of the frame are zero
             for (int e = tid; e < Lr * 32; e += NT) {
                 st4(dQraw + frame * Lr * FD + 4 * e, f4zero());
@@ -584,13 +591,41 @@ __global__ __launch_bounds__(256) void fus_slab_sum_kernel(const float* __restri
     st4(out + e * 4, acc);
 }
 
+// Gradient on raw_s (dS_raw_ext): which columns of a frame must be processed.  Region tiles behind the last valid region are
+// skipped by the main kernel (P = 0 there, so the softmax part of dS is exactly 0) -- unless the gradient on raw_s is
+// non-zero in them: the scores of padded regions are cos - 1e10, d/dcos = 1, so such a gradient reaches Qn and Cn like any
+// other.  One workgroup per frame scans the columns that would be skipped (thread c = context row c) and writes
+// fnv[frame] = last valid region + 1, or Lr on a hit.  The supervised-attention loss only touches labelled (valid)
+// regions: no hits, empty frames and padded tiles stay skipped, and the scan reads about a third of the tensor.
+__global__ __launch_bounds__(256) void fus_ext_scan_kernel(const float* __restrict__ qmask, const float* __restrict__ ext,
+                                                           unsigned char* __restrict__ fnv, int NA, int Li, int Lqa, int Lr) {
+    const long frame = blockIdx.x;                 // n*Li + i
+    const int n = (int)(frame / Li), i = (int)(frame % Li), tid = threadIdx.x, CR = NA * Lqa;
+    const float mv = tid < Lr ? qmask[frame * Lr + tid] : 0.f;      // Lr <= 64: wave 0 holds the whole mask row
+    const unsigned long long bal = __ballot(mv != 0.f);
+    __shared__ int nv_sh;
+    if (tid == 0) nv_sh = bal ? 64 - __builtin_clzll(bal) : 0;
+    __syncthreads();
+    const int nv = nv_sh, thr = ((nv + 15) >> 4) << 4;
+    int hit = 0;
+    if (thr < Lr && tid < CR) {
+        const float* er = ext + ((((long)n * NA + tid / Lqa) * Li + i) * Lqa + tid % Lqa) * Lr;
+        for (int col = thr; col < Lr; col += 2) {
+            const float2 v = ld2(er + col);
+            hit |= (v.x != 0.f) | (v.y != 0.f);
+        }
+    }
+    hit = __syncthreads_or(hit);
+    if (tid == 0) fnv[frame] = (unsigned char)(hit ? Lr : nv);
+}
+
 // Schedule (one workgroup, runs in front of the main kernel): example n gets W_n of the G workgroups, W_n ~ G * V_n / sum V
-// (V_n = frames of n with a valid region; every frame when a gradient arrives on raw_s), at least one.  With one workgroup
+// (V_n = frames of n that are not skipped), at least one.  With one workgroup
 // per CU and equal shares an example with 300 valid frames ran 1.5x longer than one with 200 and the CUs of the short ones
 // idled (~17 % of the kernel at the synthetic TVQA+ length distribution).  Output: sched[b] = (n, chunk, W_n, 0) for
 // workgroup b (n = -1: unused), per_n[n] = (first workgroup, W_n).  Depends on the masks only: run-to-run deterministic.
-__global__ __launch_bounds__(256) void fus_schedule_kernel(const float* __restrict__ qmask, int N, int Li, int Lr, int G, int count_all,
-                                                           int4* __restrict__ sched, int2* __restrict__ per_n) {
+__global__ __launch_bounds__(256) void fus_schedule_kernel(const float* __restrict__ qmask, const unsigned char* __restrict__ fnv, int N,
+                                                           int Li, int Lr, int G, int4* __restrict__ sched, int2* __restrict__ per_n) {
     extern __shared__ int sh[];        // V[N], W[N]
     int* V = sh;
     int* W = sh + N;
@@ -599,10 +634,14 @@ __global__ __launch_bounds__(256) void fus_schedule_kernel(const float* __restri
     for (long f = threadIdx.x; f < (long)N * Li; f += blockDim.x) {
         // all Lr mask values of the frame requested at once (Lr is even: 8-byte loads), no early exit: a chain of dependent
         // loads per frame made this kernel cost ~25 us
-        float nz = count_all != 0 ? 1.f : 0.f;
-        const float2* qm = reinterpret_cast<const float2*>(qmask + f * Lr);
+        float nz = 0.f;
+        if (fnv) {                      // gradient on raw_s: the per-frame column counts of fus_ext_scan_kernel
+            nz = (float)fnv[f];
+        } else {
+            const float2* qm = reinterpret_cast<const float2*>(qmask + f * Lr);
 #pragma unroll 8
-        for (int r = 0; r < (Lr >> 1); r++) { const float2 v = qm[r]; nz += fabsf(v.x) + fabsf(v.y); }
+            for (int r = 0; r < (Lr >> 1); r++) { const float2 v = qm[r]; nz += fabsf(v.x) + fabsf(v.y); }
+        }
         if (nz != 0.f) atomicAdd(&V[f / Li], 1);
     }
     __syncthreads();
@@ -660,8 +699,14 @@ static int fus_launch(const float* dA, const float* ext, const float* Cn, const 
     const int G = fus_num_wgs(N, Li);
     int4* sched = (int4*)ws;
     int2* per_n = (int2*)(sched + G);
-    float* part = (float*)((char*)ws + FUS_TABLE_BYTES(G, N));
-    hipLaunchKernelGGL(fus_schedule_kernel, dim3(1), dim3(256), 2 * N * sizeof(int), st, qmask, N, Li, Lr, G, ext ? 1 : 0, sched, per_n);
+    unsigned char* fnv = (unsigned char*)ws + FUS_TABLE_BYTES(G, N);
+    float* part = (float*)((char*)ws + FUS_TABLE_BYTES(G, N) + FUS_FRAME_BYTES(N, Li));
+    if (ext) {
+        hipLaunchKernelGGL(fus_ext_scan_kernel, dim3((unsigned)((long)N * Li)), dim3(256), 0, st, qmask, ext, fnv, NA, Li, Lqa, Lr);
+        STAGE_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(fus_schedule_kernel, dim3(1), dim3(256), 2 * N * sizeof(int), st, qmask, ext ? (const unsigned char*)fnv : nullptr,
+                       N, Li, Lr, G, sched, per_n);
     STAGE_LAUNCH_CHECK();
     const size_t base = ((size_t)Lr * FLDQ + FusLay<RT>::QT_FLOATS + (size_t)CR * FusLay<RT>::LG) * sizeof(float);
     const size_t with_da = base + (size_t)CR * FD * sizeof(float);
@@ -677,7 +722,7 @@ static int fus_launch(const float* dA, const float* ext, const float* Cn, const 
         if (lds > 64 * 1024)                                                                                                    \
             (void)hipFuncSetAttribute((const void*)str_attn_bwd_fused_kernel<RT, NW, EXTV, OCC, LDSAV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((str_attn_bwd_fused_kernel<RT, NW, EXTV, OCC, LDSAV>), grid, block, lds, st, dA, ext, Cn, Q, Qn, Sn, qmask, \
-                           dQraw, dQn, part, N, NA, Li, Lqa, Lr, scale, (const int4*)sched, tim);                               \
+                           dQraw, dQn, part, N, NA, Li, Lqa, Lr, scale, (const int4*)sched, (const unsigned char*)fnv, tim);                               \
     } while (0)
     if (ext) { if (ldsa) FUS_GO(true, (NW == 8 && OCC == 2)); else FUS_GO(true, false); }
     else { if (ldsa) FUS_GO(false, (NW == 8 && OCC == 2)); else FUS_GO(false, false); }
@@ -690,9 +735,9 @@ static int fus_launch(const float* dA, const float* ext, const float* Cn, const 
     return 0;
 }
 
-extern "C" size_t stage_str_attn_bwd_fused_ws_bytes(int N, int NA, int Lqa, int D) {
-    const int G = fus_num_wgs(N);     // schedule tables + one dCn slab per workgroup
-    return FUS_TABLE_BYTES(G, N) + (size_t)G * NA * Lqa * D * sizeof(float);
+extern "C" size_t stage_str_attn_bwd_fused_ws_bytes(int N, int NA, int Li, int Lqa, int D) {
+    const int G = fus_num_wgs(N);     // schedule tables + per-frame column counts + one dCn slab per workgroup
+    return FUS_TABLE_BYTES(G, N) + FUS_FRAME_BYTES(N, Li) + (size_t)G * NA * Lqa * D * sizeof(float);
 }
 
 extern "C" int stage_str_attn_bwd_fused(const float* dA, const float* dS_raw_ext, const float* Cn, const float* Q,
@@ -702,7 +747,7 @@ extern "C" int stage_str_attn_bwd_fused(const float* dA, const float* dS_raw_ext
     if (N <= 0 || Li <= 0) return 0;
     if (D != FD || Lr < 2 || Lr > 64 || (Lr & 1) || Lqa < 4 || NA < 1 || NA * Lqa > 256 ||
         (long)NA * Li * Lqa * FD >= (1l << 29)) return STAGE_ERR_SHAPE;   // 32-bit element offsets inside an example
-    if (ws_bytes < stage_str_attn_bwd_fused_ws_bytes(N, NA, Lqa, D)) return STAGE_ERR_WORKSPACE;
+    if (ws_bytes < stage_str_attn_bwd_fused_ws_bytes(N, NA, Li, Lqa, D)) return STAGE_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int RT = (Lr + 15) / 16;
 #define FUS_ARGS dA, dS_raw_ext, Cn, Q, Qn, S_norm, q_mask, dQraw, dQn, dCn, N, NA, Li, Lqa, Lr, scale, ws, st

@@ -445,7 +445,7 @@ class _StrAttn(torch.autograd.Function):
         rc = _lib.STAGE_ERR_SHAPE
         if not _K1_BWD_UNFUSED:
             # one pass over dA, dS stays on chip (D = 128, even Lr); other shapes take the three-kernel path below
-            wsb = lib.stage_str_attn_bwd_fused_ws_bytes(N, NA, Lqa, D)
+            wsb = lib.stage_str_attn_bwd_fused_ws_bytes(N, NA, Li, Lqa, D)
             ws = _workspace(wsb, C.device)
             rc = lib.stage_str_attn_bwd_fused(_ptr(dA), _ptr(dS_ext), _ptr(Cn), _ptr(Q), _ptr(Qn), _ptr(Sn), _ptr(q_mask),
                                               _ptr(dQ), _ptr(dQn), _ptr(dCn), N, NA, Li, Lqa, Lr, D, scale, _ptr(ws), wsb,
