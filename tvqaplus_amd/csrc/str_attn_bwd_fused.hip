@@ -624,7 +624,7 @@ __global__ __launch_bounds__(256) void fus_ext_scan_kernel(const float* __restri
 // per CU and equal shares an example with 300 valid frames ran 1.5x longer than one with 200 and the CUs of the short ones
 // idled (~17 % of the kernel at the synthetic TVQA+ length distribution).  Output: sched[b] = (n, chunk, W_n, 0) for
 // workgroup b (n = -1: unused), per_n[n] = (first workgroup, W_n).  Depends on the masks only: run-to-run deterministic.
-__global__ __launch_bounds__(256) void fus_schedule_kernel(const float* __restrict__ qmask, const unsigned char* __restrict__ fnv, int N,
+__global__ __launch_bounds__(1024) void fus_schedule_kernel(const float* __restrict__ qmask, const unsigned char* __restrict__ fnv, int N,
                                                            int Li, int Lr, int G, int4* __restrict__ sched, int2* __restrict__ per_n) {
     extern __shared__ int sh[];        // V[N], W[N]
     int* V = sh;
@@ -705,7 +705,7 @@ static int fus_launch(const float* dA, const float* ext, const float* Cn, const 
         hipLaunchKernelGGL(fus_ext_scan_kernel, dim3((unsigned)((long)N * Li)), dim3(256), 0, st, qmask, ext, fnv, NA, Li, Lqa, Lr);
         STAGE_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(fus_schedule_kernel, dim3(1), dim3(256), 2 * N * sizeof(int), st, qmask, ext ? (const unsigned char*)fnv : nullptr,
+    hipLaunchKernelGGL(fus_schedule_kernel, dim3(1), dim3(1024), 2 * N * sizeof(int), st, qmask, ext ? (const unsigned char*)fnv : nullptr,
                        N, Li, Lr, G, sched, per_n);
     STAGE_LAUNCH_CHECK();
     const size_t base = ((size_t)Lr * FLDQ + FusLay<RT>::QT_FLOATS + (size_t)CR * FusLay<RT>::LG) * sizeof(float);

@@ -218,6 +218,27 @@ def cat3_layernorm(a, b, gamma, beta, rep: int = 1, inner: int = 1, p: float = 0
 # ---------------------------------------------------------------------------------------------------------------
 # Linear (+bias, +ReLU) on the matrix cores
 # ---------------------------------------------------------------------------------------------------------------
+_WT_CACHE = {}   # id(weight) -> (data_ptr, version, transposed copy); entries die with their weight (weakref callback)
+
+
+def _transposed_weight(w, w2):
+    """(K, N) copy of the (N, K) weight for the dX GEMM.  A module used several times per step (the shared encoders: video,
+    subtitle and QA streams) would transpose the same weight once per use; the copy is cached per weight object and
+    remade when the weight was written to (optimizer step, load_state_dict: the version counter) or re-pointed."""
+    import weakref
+    key = id(w)
+    hit = _WT_CACHE.get(key)
+    if hit is not None and hit[0] == w2.data_ptr() and hit[1] == w._version and hit[2].shape == (w2.shape[1], w2.shape[0]):
+        return hit[2]
+    wt = w2.t().contiguous()
+    try:
+        ref = weakref.ref(w, lambda _r, k=key: _WT_CACHE.pop(k, None))
+    except TypeError:
+        return wt
+    _WT_CACHE[key] = (w2.data_ptr(), w._version, wt, ref)
+    return wt
+
+
 class _Linear(torch.autograd.Function):
     @_on_device
     def forward(ctx, x, w, bias, relu: bool):
@@ -243,6 +264,7 @@ class _Linear(torch.autograd.Function):
         ctx.save_for_backward(x, w2, y if relu else None, mask)
         ctx.relu = relu
         ctx.wshape = w.shape
+        ctx.w_obj = w
         ctx.has_bias = bias is not None
         return y
 
@@ -257,7 +279,7 @@ class _Linear(torch.autograd.Function):
         use_mask = mask is not None and dy.data_ptr() % 16 == 0
         dx = None
         if ctx.needs_input_grad[0]:
-            wt = w2.t().contiguous()  # (K, N): dX = (dY .* gate) . W  ==  NT with the transposed weight
+            wt = _transposed_weight(ctx.w_obj, w2)  # (K, N): dX = (dY .* gate) . W  ==  NT with the transposed weight
             dx = torch.empty_like(x)
             done = False
             if use_mask:
