@@ -180,6 +180,43 @@ int stage_masked_max_fwd(const float* x, const float* mask, const int* window, f
 int stage_masked_max_bwd(const float* dout, const int* argmax, const float* mask, float* dx, long long R, int L, int D,
                          int accumulate, void* stream);
 
+/* ---- bf16 storage mode (BASELINE.json configs[4]: bf16 weights / activations, fp32 softmax and accumulation) ------
+ * Same operations and argument meaning as the fp32 entry points of the same name; every pointer typed `void*` is a
+ * tensor of bf16 (raw 16-bit words) instead of float.  Statistics, affine parameters, weights, biases, masks, arg-max
+ * indices and all parameter gradients stay fp32; a weight is rounded to bf16 while the GEMM stages it.  The attention
+ * kernel of this mode is stage_str_attn_long_* with storage == 1.  Functional path (the generic kernels instantiated
+ * on 16-bit elements), not yet a tuned one.                                                                        */
+int stage_layernorm_fwd_bf16(const void* x, const void* res, int res_period, void* sum_out, const float* gamma,
+                             const float* beta, void* y, float* mean, float* rstd, long long rows, int K, float eps,
+                             float p_drop, unsigned long long seed, void* stream);
+int stage_layernorm_bwd_bf16(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                             void* dx, const void* dx_add, float* dgamma, float* dbeta, long long rows, int K,
+                             float p_drop, unsigned long long seed, void* ws, size_t ws_bytes, void* stream);
+int stage_cat3_layernorm_fwd_bf16(const void* a, const void* b, const float* gamma, const float* beta, void* y,
+                                  float* mean, float* rstd, long long rows, int D, int rep, int inner, float eps,
+                                  float p_drop, unsigned long long seed, void* stream);
+/* da_full (rows, D) stays fp32 (reduce it over `rep` with stage_reduce_rep); db (rows, D) is bf16 */
+int stage_cat3_layernorm_bwd_bf16(const void* dy, const void* a, const void* b, const float* mean, const float* rstd,
+                                  const float* gamma, float* da_full, void* db, float* dgamma, float* dbeta,
+                                  long long rows, int D, int rep, int inner, float p_drop, unsigned long long seed,
+                                  void* ws, size_t ws_bytes, void* stream);
+int stage_l2norm_fwd_bf16(const void* x, void* y, float* norm_out, long long rows, int K, float eps, float p_drop,
+                          unsigned long long seed, void* stream);
+int stage_l2norm_bwd_bf16(const void* dy, const void* x, void* dx, long long rows, int K, float eps, float p_drop,
+                          unsigned long long seed, int accumulate, void* stream);
+int stage_gemm_nt_bf16(const void* X, const void* gate, const float* W, const float* bias, const void* residual, void* Y,
+                       long long M, int N, int K, int relu, void* stream);
+int stage_gemm_tn_bf16(const void* dY, const void* gate, const void* X, float* dW, float* db, long long M, int N, int K,
+                       void* ws, size_t ws_bytes, void* stream);
+int stage_dwconv_fwd_bf16(const void* in, const float* w, const float* bias, void* out, long long M, int L, int D, int k,
+                          void* stream);
+int stage_dwconv_bwd_bf16(const void* dout, const void* in, const float* w, void* din, float* dw, float* db, long long M,
+                          int L, int D, int k, void* ws, size_t ws_bytes, void* stream);
+int stage_masked_max_fwd_bf16(const void* x, const float* mask, const int* window, void* out, int* argmax, long long R,
+                              int L, int D, void* stream);
+int stage_masked_max_bwd_bf16(const void* dout, const int* argmax, const float* mask, void* dx, long long R, int L, int D,
+                              int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -189,6 +189,31 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 __device__ __forceinline__ void st4_stream(float* p, float4 v) {
     __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p));
 }
+
+// ---- storage-typed element access (float, or bf16 as raw 16-bit words; arithmetic is always fp32) ----
+// The bf16 storage mode (BASELINE.json configs[4]) keeps activations as bf16 in HBM: 4 elements = one 8-byte access.
+struct stage_bf16 { unsigned short bits; };
+__device__ __forceinline__ unsigned stage_pk_bf16(float lo, float hi) {   // round to nearest even, lo in the low half
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float4 ldv4(const float* p) { return ld4(p); }
+__device__ __forceinline__ float4 ldv4(const stage_bf16* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xFFFF0000u));
+}
+__device__ __forceinline__ float4 ldv4s(const float* p) { return ld4s(p); }
+__device__ __forceinline__ float4 ldv4s(const stage_bf16* p) { return ldv4(p); }
+__device__ __forceinline__ void stv4(float* p, float4 v) { st4(p, v); }
+__device__ __forceinline__ void stv4(stage_bf16* p, float4 v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(stage_pk_bf16(v.x, v.y), stage_pk_bf16(v.z, v.w));
+}
+__device__ __forceinline__ float ldv1(const float* p) { return *p; }
+__device__ __forceinline__ float ldv1(const stage_bf16* p) { return __uint_as_float((unsigned)p->bits << 16); }
+__device__ __forceinline__ void stv1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stv1(stage_bf16* p, float v) { p->bits = (unsigned short)(stage_pk_bf16(v, 0.f) & 0xFFFFu); }
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }

@@ -32,8 +32,9 @@ extern "C" int stage_add_pe(const float* x, const float* pe, float* y, long long
 }
 
 // out[m,l,:] = bias + sum_t w[:,t] * in[m, l+t-pad, :]           w: (D,1,k) as stored by nn.Conv1d
-__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                                                         const float* __restrict__ bias, float* __restrict__ out,
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ in, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, T* __restrict__ out,
                                                          long rows, int L, int D, int k) {
     extern __shared__ __attribute__((aligned(16))) float wT[];  // [k][D] + bias[D]
     for (int i = threadIdx.x; i < k * D; i += blockDim.x) {
@@ -52,17 +53,18 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
         for (int t = 0; t < k; t++) {
             const int ll = l + t - pad;
             if (ll >= 0 && ll < L) {
-                const float4 v = ld4(in + ((row + (t - pad)) * D4 + q) * 4);
+                const float4 v = ldv4(in + ((row + (t - pad)) * D4 + q) * 4);
                 acc = f4add(acc, f4mul(v, ld4(&wT[t * D + 4 * q])));
             }
         }
-        st4(out + e * 4, acc);
+        stv4(out + e * 4, acc);
     }
 }
 
 // din[m,l,:] = sum_t w[:,t] * dout[m, l-t+pad, :] ; partial dw[t][d], db[d] per block.
-__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ in,
-                                                         const float* __restrict__ w, float* __restrict__ din,
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ in,
+                                                         const float* __restrict__ w, T* __restrict__ din,
                                                          float* __restrict__ part, long rows, int L, int D, int k) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // wT [k][D]  then reduction scratch
     for (int i = threadIdx.x; i < k * D; i += blockDim.x) {
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
     if (active) {
         for (long row = (long)blockIdx.x * rpi + rsub; row < rows; row += (long)gridDim.x * rpi) {
             const int l = (int)(row % L);
-            const float4 go = ld4(dout + (row * D4 + q) * 4);
+            const float4 go = ldv4(dout + (row * D4 + q) * 4);
             ab = f4add(ab, go);
             float4 gi = f4zero();
 #pragma unroll
@@ -88,13 +90,13 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
                 if (t < k) {
                     const int lf = l + t - pad;  // forward tap: out[l] uses in[l+t-pad]
                     if (lf >= 0 && lf < L)
-                        aw[t] = f4add(aw[t], f4mul(go, ld4(in + ((row + (t - pad)) * D4 + q) * 4)));
+                        aw[t] = f4add(aw[t], f4mul(go, ldv4(in + ((row + (t - pad)) * D4 + q) * 4)));
                     const int lb = l - t + pad;  // din[l] collects dout[l-t+pad] * w[t]
                     if (lb >= 0 && lb < L)
-                        gi = f4add(gi, f4mul(ld4(dout + ((row - t + pad) * D4 + q) * 4), ld4(&sm[t * D + 4 * q])));
+                        gi = f4add(gi, f4mul(ldv4(dout + ((row - t + pad) * D4 + q) * 4), ld4(&sm[t * D + 4 * q])));
                 }
             }
-            st4(din + (row * D4 + q) * 4, gi);
+            stv4(din + (row * D4 + q) * 4, gi);
         }
     }
     __syncthreads();
@@ -267,7 +269,7 @@ extern "C" int stage_dwconv_fwd(const float* in, const float* w, const float* bi
         return 0;
     }
     const int grid = stage_grid_for(M * L * (D / 4), 256, GRID_CAP);
-    hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(grid), dim3(256), (size_t)(k + 1) * D * sizeof(float),
+    hipLaunchKernelGGL(dwconv_fwd_kernel<float>, dim3(grid), dim3(256), (size_t)(k + 1) * D * sizeof(float),
                        (hipStream_t)stream, in, w, bias, out, (long)(M * L), L, D, k);
     STAGE_LAUNCH_CHECK();
     return 0;
@@ -304,9 +306,45 @@ extern "C" int stage_dwconv_bwd(const float* dout, const float* in, const float*
         }
     } else {
         grid = stage_grid_for(M * L, rpi * 8, DW_PART_CAP);
-        hipLaunchKernelGGL(dwconv_bwd_kernel, dim3(grid), dim3(256), lds * sizeof(float), st, dout, in, w, din,
+        hipLaunchKernelGGL(dwconv_bwd_kernel<float>, dim3(grid), dim3(256), lds * sizeof(float), st, dout, in, w, din,
                            (float*)ws, (long)(M * L), L, D, k);
     }
+    STAGE_LAUNCH_CHECK();
+    stage_colreduce((const float*)ws, dw, db, grid, (long)(k + 1) * D, (k + 1) * D, D, k, st);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+// bf16 storage mode (BASELINE.json configs[4]): the generic kernels on 16-bit activations; weights, bias and their
+// gradients stay fp32
+extern "C" int stage_dwconv_fwd_bf16(const void* in, const float* w, const float* bias, void* out, long long M, int L, int D,
+                                     int k, void* stream) {
+    if (M <= 0) return 0;
+    if (D % 4 != 0 || k < 1 || k > KMAX || (k & 1) == 0) return STAGE_ERR_SHAPE;
+    const int grid = stage_grid_for(M * L * (D / 4), 256, GRID_CAP);
+    hipLaunchKernelGGL(dwconv_fwd_kernel<stage_bf16>, dim3(grid), dim3(256), (size_t)(k + 1) * D * sizeof(float),
+                       (hipStream_t)stream, (const stage_bf16*)in, w, bias, (stage_bf16*)out, (long)(M * L), L, D, k);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int stage_dwconv_bwd_bf16(const void* dout, const void* in, const float* w, void* din, float* dw, float* db,
+                                     long long M, int L, int D, int k, void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (D % 4 != 0 || D / 4 > 256 || k < 1 || k > KMAX || (k & 1) == 0) return STAGE_ERR_SHAPE;
+    if (ws_bytes < stage_dwconv_bwd_ws_bytes(D, k)) return STAGE_ERR_WORKSPACE;
+    if (M <= 0) {
+        (void)hipMemsetAsync(dw, 0, sizeof(float) * D * k, st);
+        (void)hipMemsetAsync(db, 0, sizeof(float) * D, st);
+        return 0;
+    }
+    const int rpi = 256 / (D / 4);
+    size_t lds = (size_t)k * D;
+    const size_t red = (size_t)rpi * (k + 1) * D;
+    if (red > lds) lds = red;
+    const int grid = stage_grid_for(M * L, rpi * 8, DW_PART_CAP);
+    hipLaunchKernelGGL(dwconv_bwd_kernel<stage_bf16>, dim3(grid), dim3(256), lds * sizeof(float), st, (const stage_bf16*)dout,
+                       (const stage_bf16*)in, w, (stage_bf16*)din, (float*)ws, (long)(M * L), L, D, k);
     STAGE_LAUNCH_CHECK();
     stage_colreduce((const float*)ws, dw, db, grid, (long)(k + 1) * D, (k + 1) * D, D, k, st);
     STAGE_LAUNCH_CHECK();

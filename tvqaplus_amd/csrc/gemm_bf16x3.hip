@@ -41,26 +41,28 @@ __device__ __forceinline__ void splitn(float a, float b, unsigned (&out)[NSPLIT]
         b -= __uint_as_float(out[s] & 0xFFFF0000u);
     }
 }
-__device__ __forceinline__ float4 load4_guard_b(const float* __restrict__ base, long row, long ld, int col, long nrows,
+template <typename T>
+__device__ __forceinline__ float4 load4_guard_b(const T* __restrict__ base, long row, long ld, int col, long nrows,
                                                 int ncols, bool vec) {
     if (row >= nrows || col >= ncols) return f4zero();
-    const float* p = base + row * ld + col;
-    if (vec && col + 3 < ncols) return ld4(p);
+    const T* p = base + row * ld + col;
+    if (vec && col + 3 < ncols) return ldv4(p);
     float4 v = f4zero();
-    v.x = p[0];
-    if (col + 1 < ncols) v.y = p[1];
-    if (col + 2 < ncols) v.z = p[2];
-    if (col + 3 < ncols) v.w = p[3];
+    v.x = ldv1(p);
+    if (col + 1 < ncols) v.y = ldv1(p + 1);
+    if (col + 2 < ncols) v.z = ldv1(p + 2);
+    if (col + 3 < ncols) v.w = ldv1(p + 3);
     return v;
 }
 // branch-free variant for 16-B aligned operands with ncols % 4 == 0: clamp the address, select zero afterwards.  The
 // guarded form above compiles to one exec-masked branch + s_waitcnt per load (loads serialised); this one lets the
 // compiler issue a whole fetch back to back under a single wait.
-__device__ __forceinline__ float4 load4_clamp(const float* __restrict__ base, long row, long ld, int col, long nrows,
+template <typename T>
+__device__ __forceinline__ float4 load4_clamp(const T* __restrict__ base, long row, long ld, int col, long nrows,
                                               int ncols) {
     const long r = row < nrows ? row : nrows - 1;
     const int c = col < ncols ? col : ncols - 4;
-    float4 v = ld4(base + r * ld + c);
+    float4 v = ldv4(base + r * ld + c);
     const bool ok = row < nrows && col < ncols;
     v.x = ok ? v.x : 0.f;
     v.y = ok ? v.y : 0.f;
@@ -68,8 +70,8 @@ __device__ __forceinline__ float4 load4_clamp(const float* __restrict__ base, lo
     v.w = ok ? v.w : 0.f;
     return v;
 }
-template <bool FAST>
-__device__ __forceinline__ float4 load4_b(const float* __restrict__ base, long row, long ld, int col, long nrows, int ncols,
+template <bool FAST, typename T>
+__device__ __forceinline__ float4 load4_b(const T* __restrict__ base, long row, long ld, int col, long nrows, int ncols,
                                           bool vec) {
     if (FAST) return load4_clamp(base, row, ld, col, nrows, ncols);
     return load4_guard_b(base, row, ld, col, nrows, ncols, vec);
@@ -100,11 +102,11 @@ __device__ __forceinline__ void mma_terms(f32x16 (&acc)[2][2], const bf16x8 (&a)
 // ------------------------------------------------------------------------------------------------
 // NT:  Y = epi(Xg . W^T + bias)
 // ------------------------------------------------------------------------------------------------
-template <int NSPLIT, bool FAST>
-__global__ __launch_bounds__(256, 2) void gemm_nt_split_kernel(const float* __restrict__ X, const float* __restrict__ G,
+template <int NSPLIT, bool FAST, typename T = float>   // T: storage of X / gate / residual / Y (float, or bf16 with NSPLIT = 1)
+__global__ __launch_bounds__(256, 2) void gemm_nt_split_kernel(const T* __restrict__ X, const T* __restrict__ G,
                                                                const float* __restrict__ W,
                                                                const float* __restrict__ bias,
-                                                               const float* __restrict__ R, float* __restrict__ Y,
+                                                               const T* __restrict__ R, T* __restrict__ Y,
                                                                long M, int N, int K, int relu, int vecX, int vecW) {
     __shared__ __attribute__((aligned(16))) unsigned short Ap[NSPLIT * PLANE], Bp[NSPLIT * PLANE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -185,8 +187,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_split_kernel(const float* __re
                 if (m < M) {
                     float v = acc[mi][ni][r] + bsv;
                     if (relu) v = fmaxf(v, 0.f);
-                    if (R) v += R[m * N + n];
-                    Y[m * N + n] = v;
+                    if (R) v += ldv1(R + m * N + n);
+                    stv1(Y + m * N + n, v);
                 }
             }
         }
@@ -222,9 +224,9 @@ extern "C" int stage_gemm_nt_bf16x3(const float* X, const float* gate, const flo
 // ------------------------------------------------------------------------------------------------
 #define TN_MAX_SPLIT 128
 
-template <int NSPLIT, bool FAST>
-__global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(const float* __restrict__ dY, const float* __restrict__ G,
-                                                               const float* __restrict__ X, float* __restrict__ part,
+template <int NSPLIT, bool FAST, typename T = float>
+__global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(const T* __restrict__ dY, const T* __restrict__ G,
+                                                               const T* __restrict__ X, float* __restrict__ part,
                                                                float* __restrict__ part_b, long M, int N, int K,
                                                                long rows_per_split, int vecY, int vecX) {
     // transposed planes: [column][m]
@@ -385,6 +387,65 @@ extern "C" int stage_gemm_tn_bf16x3(const float* dY, const float* gate, const fl
     if (split_depth() == 2) { if (fast) LAUNCH_TN(2, true); else LAUNCH_TN(2, false); }
     else { if (fast) LAUNCH_TN(3, true); else LAUNCH_TN(3, false); }
 #undef LAUNCH_TN
+    STAGE_LAUNCH_CHECK();
+    const long C = (long)N * K;
+    hipLaunchKernelGGL(slab_reduce_b_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, part, dW, S, C);
+    if (db) hipLaunchKernelGGL(slab_reduce_b_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part_b, db, S, (long)N);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 storage mode (BASELINE.json configs[4]: bf16 weights / activations): X, gate, residual and Y are bf16, the fp32
+// master weight is rounded to bf16 while it is staged (NSPLIT = 1: ONE bf16 product per term, exact in fp32, fp32
+// accumulation); bias, weight / bias gradients stay fp32.  8-byte alignment of the bf16 operands selects the vector path.
+// ------------------------------------------------------------------------------------------------
+extern "C" int stage_gemm_nt_bf16(const void* X, const void* gate, const float* W, const float* bias, const void* residual,
+                                  void* Y, long long M, int N, int K, int relu, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (K <= 0) return STAGE_ERR_SHAPE;
+    const int vecX = (K % 4 == 0) && (((uintptr_t)X & 7) == 0) && (!gate || ((uintptr_t)gate & 7) == 0);
+    const int vecW = (K % 4 == 0) && (((uintptr_t)W & 15) == 0);
+    dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
+    const bool fast = vecX && vecW && K >= 4;
+    typedef stage_bf16 B;
+    if (fast)
+        hipLaunchKernelGGL((gemm_nt_split_kernel<1, true, B>), grid, dim3(256), 0, (hipStream_t)stream, (const B*)X, (const B*)gate, W,
+                           bias, (const B*)residual, (B*)Y, (long)M, N, K, relu, vecX, vecW);
+    else
+        hipLaunchKernelGGL((gemm_nt_split_kernel<1, false, B>), grid, dim3(256), 0, (hipStream_t)stream, (const B*)X, (const B*)gate, W,
+                           bias, (const B*)residual, (B*)Y, (long)M, N, K, relu, vecX, vecW);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+// workspace: stage_gemm_tn_ws_bytes(M, N, K)
+extern "C" int stage_gemm_tn_bf16(const void* dY, const void* gate, const void* X, float* dW, float* db, long long M, int N,
+                                  int K, void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= 0 || K <= 0) return 0;
+    if (M <= 0) {
+        (void)hipMemsetAsync(dW, 0, sizeof(float) * (size_t)N * K, st);
+        if (db) (void)hipMemsetAsync(db, 0, sizeof(float) * N, st);
+        return 0;
+    }
+    const int S = tn_splits_b(M, N, K);
+    if (ws_bytes < (size_t)S * ((size_t)N * K + N) * sizeof(float)) return STAGE_ERR_WORKSPACE;
+    long rps = (M + S - 1) / S;
+    rps = (rps + BK - 1) / BK * BK;
+    float* part = (float*)ws;
+    float* part_b = part + (size_t)S * N * K;
+    const int vecY = (N % 4 == 0) && (((uintptr_t)dY & 7) == 0) && (!gate || ((uintptr_t)gate & 7) == 0);
+    const int vecX = (K % 4 == 0) && (((uintptr_t)X & 7) == 0);
+    dim3 grid((N + BM - 1) / BM, (K + BN - 1) / BN, S);
+    const bool fast = vecY && vecX && N >= 4 && K >= 4;
+    typedef stage_bf16 B;
+    if (fast)
+        hipLaunchKernelGGL((gemm_tn_split_kernel<1, true, B>), grid, dim3(256), 0, st, (const B*)dY, (const B*)gate, (const B*)X, part,
+                           db ? part_b : (float*)nullptr, (long)M, N, K, rps, vecY, vecX);
+    else
+        hipLaunchKernelGGL((gemm_tn_split_kernel<1, false, B>), grid, dim3(256), 0, st, (const B*)dY, (const B*)gate, (const B*)X, part,
+                           db ? part_b : (float*)nullptr, (long)M, N, K, rps, vecY, vecX);
     STAGE_LAUNCH_CHECK();
     const long C = (long)N * K;
     hipLaunchKernelGGL(slab_reduce_b_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, part, dW, S, C);

@@ -19,14 +19,16 @@
 // LayerNorm forward.  MODE 0: plain row of K floats.  MODE 1: virtual row [a, b, a*b] with K = 3*D.
 // For MODE 1 the a-row may be broadcast: a_row = (row / (rep*inner)) * inner + row % inner.
 // ------------------------------------------------------------------------------------------------
-struct RowSrc {
-    const float* x;   // MODE 0: x ; MODE 1: a
-    const float* b;   // MODE 1: b ; MODE 0: optional residual added before the norm (x + res), may be NULL
+template <typename T> struct RowSrcT {
+    const T* x;       // MODE 0: x ; MODE 1: a
+    const T* b;       // MODE 1: b ; MODE 0: optional residual added before the norm (x + res), may be NULL
     int D;            // MODE 1: width of a / b
     int rep, inner;   // MODE 1: broadcast description of a (rep == 1 -> none)
                       // MODE 0: inner = residual period in rows (0: res row == row; L: res row = row % L -> pe table)
-    float* sum_out;   // MODE 0: where to write x + res (NULL: not needed)
+    T* sum_out;       // MODE 0: where to write x + res (NULL: not needed)
 };
+typedef RowSrcT<float> RowSrc;   // T = stage_bf16: bf16 storage (generic kernels only; statistics, affine parameters and
+                                 // all arithmetic stay fp32)
 
 __device__ __forceinline__ long a_row_of(long row, int rep, int inner) {
     if (rep == 1) return row;
@@ -34,9 +36,9 @@ __device__ __forceinline__ long a_row_of(long row, int rep, int inner) {
     return g * inner + row % inner;
 }
 
-template <int MODE, bool DROP>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(RowSrc src, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, float* __restrict__ y,
+template <int MODE, bool DROP, typename T = float>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(RowSrcT<T> src, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, long rows,
                                                      int K, float eps, int LPR, uint64_t seed, uint32_t th,
                                                      float inv_keep) {
@@ -54,11 +56,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(RowSrc src, const float* __
             for (int t = 0; t < MAXV; t++) {
                 int j = sl + t * LPR;
                 if (ok && j < K4) {
-                    v[t] = ld4(src.x + row * K + 4 * j);
+                    v[t] = ldv4(src.x + row * K + 4 * j);
                     if (src.b) {
                         const long rr = src.inner > 0 ? row % src.inner : row;
-                        v[t] = f4add(v[t], ld4(src.b + rr * K + 4 * j));
-                        if (src.sum_out) st4(src.sum_out + row * K + 4 * j, v[t]);
+                        v[t] = f4add(v[t], ldv4(src.b + rr * K + 4 * j));
+                        if (src.sum_out) stv4(src.sum_out + row * K + 4 * j, v[t]);
                     }
                     s += f4hsum(v[t]);
                 } else v[t] = f4zero();
@@ -69,8 +71,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(RowSrc src, const float* __
             const int D4 = src.D >> 2;
             if (ok && sl < D4) {
                 long ar = a_row_of(row, src.rep, src.inner);
-                v[0] = ld4(src.x + ar * src.D + 4 * sl);
-                v[1] = ld4(src.b + row * src.D + 4 * sl);
+                v[0] = ldv4(src.x + ar * src.D + 4 * sl);
+                v[1] = ldv4(src.b + row * src.D + 4 * sl);
                 v[2] = f4mul(v[0], v[1]);
                 s = f4hsum(v[0]) + f4hsum(v[1]) + f4hsum(v[2]);
             } else { v[0] = v[1] = v[2] = f4zero(); }
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(RowSrc src, const float* __
                 o.z = (v[t].z - mu) * rs * g.z + bb.z;
                 o.w = (v[t].w - mu) * rs * g.w + bb.w;
                 if (DROP) o = f4mul(o, drop4(seed, (uint64_t)row * K4 + j, th, inv_keep));
-                st4(y + row * K + 4 * j, o);
+                stv4(y + row * K + 4 * j, o);
             }
         }
     }
@@ -127,11 +129,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(RowSrc src, const float* __
 // LayerNorm backward: dx (MODE 0) or da_full/db (MODE 1) + per-block partial dgamma/dbeta.
 // part layout: [gridDim.x][2][K]  (0: dgamma, 1: dbeta), reduced by colreduce_kernel.
 // ------------------------------------------------------------------------------------------------
-template <int MODE, bool DROP>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(RowSrc src, const float* __restrict__ dy,
+template <int MODE, bool DROP, typename T = float, typename TDX = T>   // TDX: dx (MODE 1: the unreduced da rows, kept fp32)
+__global__ __launch_bounds__(256) void ln_bwd_kernel(RowSrcT<T> src, const T* __restrict__ dy,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                     const float* __restrict__ gamma, float* __restrict__ dx,
-                                                     float* __restrict__ db_out, float* __restrict__ part, long rows,
+                                                     const float* __restrict__ gamma, TDX* __restrict__ dx,
+                                                     T* __restrict__ db_out, float* __restrict__ part, long rows,
                                                      int K, int LPR, uint64_t seed, uint32_t th, float inv_keep) {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [wpb*RPW][2][K]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
@@ -153,8 +155,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(RowSrc src, const float* __
         const int nv = (MODE == 0) ? MAXV : 3;
         if (MODE == 1 && ok && sl < D4) {
             long ar = a_row_of(row, src.rep, src.inner);
-            av = ld4(src.x + ar * src.D + 4 * sl);
-            bv = ld4(src.b + row * src.D + 4 * sl);
+            av = ldv4(src.x + ar * src.D + 4 * sl);
+            bv = ldv4(src.b + row * src.D + 4 * sl);
         }
 #pragma unroll
         for (int t = 0; t < nv; t++) {
@@ -162,9 +164,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(RowSrc src, const float* __
             bool live = ok && ((MODE == 0) ? (j < K4) : (sl < D4));
             if (live) {
                 float4 xv;
-                if (MODE == 0) xv = ld4(src.x + row * K + 4 * j);
+                if (MODE == 0) xv = ldv4(src.x + row * K + 4 * j);
                 else xv = (t == 0) ? av : ((t == 1) ? bv : f4mul(av, bv));
-                float4 d = ld4(dy + row * K + 4 * j);
+                float4 d = ldv4(dy + row * K + 4 * j);
                 if (DROP) d = f4mul(d, drop4(seed, (uint64_t)row * K4 + j, th, inv_keep));
                 float4 gm = ld4(gamma + 4 * j);
                 xh[t] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
@@ -191,8 +193,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(RowSrc src, const float* __
                 o.w = rs * (g[t].w - s1 - xh[t].w * s2);
                 if (MODE == 0) {
                     if (dx) {
-                        if (src.b) o = f4add(o, ld4(src.b + row * K + 4 * j));  // + gradient of the exported sum
-                        st4(dx + row * K + 4 * j, o);
+                        if (src.b) o = f4add(o, ldv4(src.b + row * K + 4 * j));  // + gradient of the exported sum
+                        stv4(dx + row * K + 4 * j, o);
                     }
                 }
                 else dz[t] = o;
@@ -200,8 +202,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(RowSrc src, const float* __
         }
         if (MODE == 1 && sl < D4) {
             // z = [a, b, a*b]:  da = dz0 + dz2*b ; db = dz1 + dz2*a
-            st4(dx + row * src.D + 4 * sl, f4add(dz[0], f4mul(dz[2], bv)));
-            st4(db_out + row * src.D + 4 * sl, f4add(dz[1], f4mul(dz[2], av)));
+            stv4(dx + row * src.D + 4 * sl, f4add(dz[0], f4mul(dz[2], bv)));
+            stv4(db_out + row * src.D + 4 * sl, f4add(dz[1], f4mul(dz[2], av)));
         }
     }
     // block reduction of the per-lane column partials
@@ -775,8 +777,8 @@ extern "C" int stage_reduce_rep(const float* in, float* out, long long groups, i
 // ------------------------------------------------------------------------------------------------
 // L2 row normalisation  y = drop(x / max(||x||, eps))   (F.normalize p=2, eps 1e-12) and its backward.
 // ------------------------------------------------------------------------------------------------
-template <bool DROP>
-__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <bool DROP, typename T = float>
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                          float* __restrict__ nrm, long rows, int K, float eps, int LPR,
                                                          uint64_t seed, uint32_t th, float inv_keep) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
@@ -791,7 +793,7 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict
         for (int t = 0; t < MAXV; t++) {
             int j = sl + t * LPR;
             if (ok && j < K4) {
-                v[t] = ld4(x + row * K + 4 * j);
+                v[t] = ldv4(x + row * K + 4 * j);
                 s += f4hsum(f4mul(v[t], v[t]));
             } else v[t] = f4zero();
         }
@@ -805,7 +807,7 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict
             if (j < K4) {
                 float4 o = make_float4(v[t].x / n, v[t].y / n, v[t].z / n, v[t].w / n);
                 if (DROP) o = f4mul(o, drop4(seed, (uint64_t)row * K4 + j, th, inv_keep));
-                st4(y + row * K + 4 * j, o);
+                stv4(y + row * K + 4 * j, o);
             }
         }
     }
@@ -813,9 +815,9 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict
 
 // dx = (g - xh * <xh, g>) / n   with g = dy * dropmask, xh = x / n, n = max(||x||, eps); if ||x|| <= eps the clamp is
 // a constant and dx = g / eps (what autograd gives for clamp_min).
-template <bool DROP>
-__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                         float* __restrict__ dx, long rows, int K, float eps, int LPR,
+template <bool DROP, typename T = float>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                         T* __restrict__ dx, long rows, int K, float eps, int LPR,
                                                          uint64_t seed, uint32_t th, float inv_keep, int accumulate) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int RPW = 64 / LPR, sub = lane / LPR, sl = lane % LPR;
@@ -829,8 +831,8 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
         for (int t = 0; t < MAXV; t++) {
             int j = sl + t * LPR;
             if (ok && j < K4) {
-                v[t] = ld4(x + row * K + 4 * j);
-                g[t] = ld4(dy + row * K + 4 * j);
+                v[t] = ldv4(x + row * K + 4 * j);
+                g[t] = ldv4(dy + row * K + 4 * j);
                 if (DROP) g[t] = f4mul(g[t], drop4(seed, (uint64_t)row * K4 + j, th, inv_keep));
                 s += f4hsum(f4mul(v[t], v[t]));
                 dot += f4hsum(f4mul(v[t], g[t]));
@@ -849,9 +851,9 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
             if (j < K4) {
                 float4 o = make_float4(g[t].x / n - v[t].x * c, g[t].y / n - v[t].y * c, g[t].z / n - v[t].z * c,
                                        g[t].w / n - v[t].w * c);
-                float* p = dx + row * K + 4 * j;
-                if (accumulate) o = f4add(o, ld4(p));
-                st4(p, o);
+                T* p = dx + row * K + 4 * j;
+                if (accumulate) o = f4add(o, ldv4(p));
+                stv4(p, o);
             }
         }
     }
@@ -898,8 +900,9 @@ extern "C" int stage_l2norm_bwd(const float* dy, const float* x, float* dx, long
 // reference (torch.max of an empty tensor) and yields -inf / idx -1 here.
 // Backward: dx[r, idx, d] = dout[r,d] * m[r, idx]; zero elsewhere (the whole dx is written).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void masked_max_fwd_kernel(const float* __restrict__ x, const float* __restrict__ m,
-                                                             const int* __restrict__ win, float* __restrict__ out,
+template <typename T>
+__global__ __launch_bounds__(256) void masked_max_fwd_kernel(const T* __restrict__ x, const float* __restrict__ m,
+                                                             const int* __restrict__ win, T* __restrict__ out,
                                                              int* __restrict__ idx, long R, int L, int D4) {
     const long total = R * D4;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -909,7 +912,7 @@ __global__ __launch_bounds__(256) void masked_max_fwd_kernel(const float* __rest
         if (win) { st = max(0, win[2 * r]); ed = min(L, win[2 * r + 1]); }
         float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         int4 bi = make_int4(-1, -1, -1, -1);
-        const float* px = x + (r * L) * (long)D4 * 4 + 4 * q;
+        const T* px = x + (r * L) * (long)D4 * 4 + 4 * q;
         // 8 positions per step, all 16 loads issued before the first compare (clamped addresses; a one-position loop keeps
         // a single load in flight per lane); strict > in ascending order keeps the first maximum, as torch.max does
         for (int l0 = st; l0 < ed; l0 += 8) {
@@ -918,7 +921,7 @@ __global__ __launch_bounds__(256) void masked_max_fwd_kernel(const float* __rest
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int l = min(l0 + u, ed - 1);
-                v[u] = ld4s(px + (long)l * D4 * 4);
+                v[u] = ldv4s(px + (long)l * D4 * 4);
                 mk[u] = m[r * L + l];
             }
 #pragma unroll
@@ -934,13 +937,14 @@ __global__ __launch_bounds__(256) void masked_max_fwd_kernel(const float* __rest
                 }
             }
         }
-        st4(out + e * 4, best);
+        stv4(out + e * 4, best);
         *reinterpret_cast<int4*>(idx + e * 4) = bi;
     }
 }
 
-__global__ __launch_bounds__(256) void masked_max_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ idx,
-                                                             const float* __restrict__ m, float* __restrict__ dx,
+template <typename T>
+__global__ __launch_bounds__(256) void masked_max_bwd_kernel(const T* __restrict__ dout, const int* __restrict__ idx,
+                                                             const float* __restrict__ m, T* __restrict__ dx,
                                                              long R, int L, int D4, int accumulate) {
     const long total = R * L * D4;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -949,12 +953,12 @@ __global__ __launch_bounds__(256) void masked_max_bwd_kernel(const float* __rest
         const int l = (int)(rl % L);
         const long r = rl / L;
         const int4 bi = *reinterpret_cast<const int4*>(idx + (r * D4 + q) * 4);
-        const float4 g = ld4(dout + (r * D4 + q) * 4);
+        const float4 g = ldv4(dout + (r * D4 + q) * 4);
         const float mk = m[rl];
         float4 o = make_float4(bi.x == l ? g.x * mk : 0.f, bi.y == l ? g.y * mk : 0.f, bi.z == l ? g.z * mk : 0.f,
                                bi.w == l ? g.w * mk : 0.f);
-        if (accumulate) o = f4add(o, ld4(dx + e * 4));
-        st4(dx + e * 4, o);
+        if (accumulate) o = f4add(o, ldv4(dx + e * 4));
+        stv4(dx + e * 4, o);
     }
 }
 
@@ -963,7 +967,7 @@ extern "C" int stage_masked_max_fwd(const float* x, const float* mask, const int
     if (R <= 0) return 0;
     if (D % 4 != 0 || L < 1) return STAGE_ERR_SHAPE;
     const int grid = stage_grid_for(R * (D / 4), 256, GRID_CAP * 8);
-    hipLaunchKernelGGL(masked_max_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mask, window, out,
+    hipLaunchKernelGGL(masked_max_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mask, window, out,
                        argmax, (long)R, L, D / 4);
     STAGE_LAUNCH_CHECK();
     return 0;
@@ -974,8 +978,152 @@ extern "C" int stage_masked_max_bwd(const float* dout, const int* argmax, const 
     if (R <= 0) return 0;
     if (D % 4 != 0 || L < 1) return STAGE_ERR_SHAPE;
     const int grid = stage_grid_for(R * L * (D / 4), 256, GRID_CAP * 8);
-    hipLaunchKernelGGL(masked_max_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dout, argmax, mask, dx,
+    hipLaunchKernelGGL(masked_max_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dout, argmax, mask, dx,
                        (long)R, L, D / 4, accumulate);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 storage mode (BASELINE.json configs[4]): the same generic kernels instantiated on 16-bit activations.  Statistics,
+// affine parameters, masks, arg-max indices, parameter gradients and every intermediate stay fp32; only the tensors that
+// stream through HBM between kernels are bf16.  Pointers to bf16 data cross the C ABI as void*.
+// ------------------------------------------------------------------------------------------------
+typedef stage_bf16 B16;
+
+template <int MODE>
+static int ln_fwd_launch_b(RowSrcT<B16> src, const float* gamma, const float* beta, B16* y, float* mean, float* rstd,
+                           long long rows, int K, int LPR, float eps, float p_drop, unsigned long long seed, hipStream_t st) {
+    const int rows_per_block = 4 * (64 / LPR);
+    const int grid = stage_grid_for(rows, rows_per_block, GRID_CAP * 4);
+    if (p_drop > 0.f)
+        hipLaunchKernelGGL((ln_fwd_kernel<MODE, true, B16>), dim3(grid), dim3(256), 0, st, src, gamma, beta, y, mean, rstd,
+                           (long)rows, K, eps, LPR, (uint64_t)seed, drop_thresh16(p_drop), 1.0f / (1.0f - p_drop));
+    else
+        hipLaunchKernelGGL((ln_fwd_kernel<MODE, false, B16>), dim3(grid), dim3(256), 0, st, src, gamma, beta, y, mean, rstd,
+                           (long)rows, K, eps, LPR, (uint64_t)0, 0u, 1.0f);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int MODE, typename TDX>
+static int ln_bwd_launch_b(RowSrcT<B16> src, const B16* dy, const float* mean, const float* rstd, const float* gamma, TDX* dx,
+                           B16* db_out, float* dgamma, float* dbeta, long long rows, int K, int LPR, float p_drop,
+                           unsigned long long seed, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (ws_bytes < stage_ln_bwd_ws_bytes(K)) return STAGE_ERR_WORKSPACE;
+    if (rows <= 0) {
+        (void)hipMemsetAsync(dgamma, 0, sizeof(float) * K, st);
+        (void)hipMemsetAsync(dbeta, 0, sizeof(float) * K, st);
+        return 0;
+    }
+    const int rows_per_block = 4 * (64 / LPR);
+    const int grid = stage_grid_for(rows, rows_per_block * 8, PART_CAP);
+    const size_t lds = (size_t)rows_per_block * 2 * K * sizeof(float);
+    float* part = (float*)ws;
+    if (p_drop > 0.f)
+        hipLaunchKernelGGL((ln_bwd_kernel<MODE, true, B16, TDX>), dim3(grid), dim3(256), lds, st, src, dy, mean, rstd, gamma, dx,
+                           db_out, part, (long)rows, K, LPR, (uint64_t)seed, drop_thresh16(p_drop), 1.0f / (1.0f - p_drop));
+    else
+        hipLaunchKernelGGL((ln_bwd_kernel<MODE, false, B16, TDX>), dim3(grid), dim3(256), lds, st, src, dy, mean, rstd, gamma, dx,
+                           db_out, part, (long)rows, K, LPR, (uint64_t)0, 0u, 1.0f);
+    STAGE_LAUNCH_CHECK();
+    stage_colreduce(part, dgamma, dbeta, grid, (long)2 * K, 2 * K, K, 1, st);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int stage_layernorm_fwd_bf16(const void* x, const void* res, int res_period, void* sum_out, const float* gamma,
+                                        const float* beta, void* y, float* mean, float* rstd, long long rows, int K,
+                                        float eps, float p_drop, unsigned long long seed, void* stream) {
+    if (rows <= 0) return 0;
+    if (K % 4 != 0 || K > 4 * MAXV * 64) return STAGE_ERR_SHAPE;
+    RowSrcT<B16> src{(const B16*)x, (const B16*)res, 0, 1, res_period, (B16*)sum_out};
+    return ln_fwd_launch_b<0>(src, gamma, beta, (B16*)y, mean, rstd, rows, K, ln_lpr(K / 4), eps, p_drop, seed, (hipStream_t)stream);
+}
+
+extern "C" int stage_layernorm_bwd_bf16(const void* dy, const void* x, const float* mean, const float* rstd,
+                                        const float* gamma, void* dx, const void* dx_add, float* dgamma, float* dbeta,
+                                        long long rows, int K, float p_drop, unsigned long long seed, void* ws,
+                                        size_t ws_bytes, void* stream) {
+    if (K % 4 != 0 || K > 4 * MAXV * 64) return STAGE_ERR_SHAPE;
+    RowSrcT<B16> src{(const B16*)x, (const B16*)dx_add, 0, 1, 0, nullptr};
+    return ln_bwd_launch_b<0, B16>(src, (const B16*)dy, mean, rstd, gamma, (B16*)dx, nullptr, dgamma, dbeta, rows, K,
+                                   ln_lpr(K / 4), p_drop, seed, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int stage_cat3_layernorm_fwd_bf16(const void* a, const void* b, const float* gamma, const float* beta, void* y,
+                                             float* mean, float* rstd, long long rows, int D, int rep, int inner, float eps,
+                                             float p_drop, unsigned long long seed, void* stream) {
+    if (rows <= 0) return 0;
+    if (D % 4 != 0 || D > 256 || rep < 1 || inner < 1) return STAGE_ERR_SHAPE;
+    RowSrcT<B16> src{(const B16*)a, (const B16*)b, D, rep, inner, nullptr};
+    return ln_fwd_launch_b<1>(src, gamma, beta, (B16*)y, mean, rstd, rows, 3 * D, ln_lpr(D / 4), eps, p_drop, seed,
+                              (hipStream_t)stream);
+}
+
+// da_full[rows, D] stays fp32 (scratch, reduced over `rep` by stage_reduce_rep), db[rows, D] is bf16
+extern "C" int stage_cat3_layernorm_bwd_bf16(const void* dy, const void* a, const void* b, const float* mean,
+                                             const float* rstd, const float* gamma, float* da_full, void* db, float* dgamma,
+                                             float* dbeta, long long rows, int D, int rep, int inner, float p_drop,
+                                             unsigned long long seed, void* ws, size_t ws_bytes, void* stream) {
+    if (D % 4 != 0 || D > 256 || rep < 1 || inner < 1) return STAGE_ERR_SHAPE;
+    RowSrcT<B16> src{(const B16*)a, (const B16*)b, D, rep, inner, nullptr};
+    return ln_bwd_launch_b<1, float>(src, (const B16*)dy, mean, rstd, gamma, da_full, (B16*)db, dgamma, dbeta, rows, 3 * D,
+                                     ln_lpr(D / 4), p_drop, seed, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int stage_l2norm_fwd_bf16(const void* x, void* y, float* norm_out, long long rows, int K, float eps, float p_drop,
+                                     unsigned long long seed, void* stream) {
+    if (rows <= 0) return 0;
+    if (K % 4 != 0 || K > 4 * MAXV * 64) return STAGE_ERR_SHAPE;
+    const int LPR = ln_lpr(K / 4);
+    const int grid = stage_grid_for(rows, 4 * (64 / LPR), GRID_CAP * 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (p_drop > 0.f)
+        hipLaunchKernelGGL((l2norm_fwd_kernel<true, B16>), dim3(grid), dim3(256), 0, st, (const B16*)x, (B16*)y, norm_out,
+                           (long)rows, K, eps, LPR, (uint64_t)seed, drop_thresh16(p_drop), 1.0f / (1.0f - p_drop));
+    else
+        hipLaunchKernelGGL((l2norm_fwd_kernel<false, B16>), dim3(grid), dim3(256), 0, st, (const B16*)x, (B16*)y, norm_out,
+                           (long)rows, K, eps, LPR, (uint64_t)0, 0u, 1.0f);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int stage_l2norm_bwd_bf16(const void* dy, const void* x, void* dx, long long rows, int K, float eps, float p_drop,
+                                     unsigned long long seed, int accumulate, void* stream) {
+    if (rows <= 0) return 0;
+    if (K % 4 != 0 || K > 4 * MAXV * 64) return STAGE_ERR_SHAPE;
+    const int LPR = ln_lpr(K / 4);
+    const int grid = stage_grid_for(rows, 4 * (64 / LPR), GRID_CAP * 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (p_drop > 0.f)
+        hipLaunchKernelGGL((l2norm_bwd_kernel<true, B16>), dim3(grid), dim3(256), 0, st, (const B16*)dy, (const B16*)x, (B16*)dx,
+                           (long)rows, K, eps, LPR, (uint64_t)seed, drop_thresh16(p_drop), 1.0f / (1.0f - p_drop), accumulate);
+    else
+        hipLaunchKernelGGL((l2norm_bwd_kernel<false, B16>), dim3(grid), dim3(256), 0, st, (const B16*)dy, (const B16*)x, (B16*)dx,
+                           (long)rows, K, eps, LPR, (uint64_t)0, 0u, 1.0f, accumulate);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int stage_masked_max_fwd_bf16(const void* x, const float* mask, const int* window, void* out, int* argmax,
+                                         long long R, int L, int D, void* stream) {
+    if (R <= 0) return 0;
+    if (D % 4 != 0 || L < 1) return STAGE_ERR_SHAPE;
+    const int grid = stage_grid_for(R * (D / 4), 256, GRID_CAP * 8);
+    hipLaunchKernelGGL(masked_max_fwd_kernel<B16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const B16*)x, mask, window,
+                       (B16*)out, argmax, (long)R, L, D / 4);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int stage_masked_max_bwd_bf16(const void* dout, const int* argmax, const float* mask, void* dx, long long R, int L,
+                                         int D, int accumulate, void* stream) {
+    if (R <= 0) return 0;
+    if (D % 4 != 0 || L < 1) return STAGE_ERR_SHAPE;
+    const int grid = stage_grid_for(R * L * (D / 4), 256, GRID_CAP * 8);
+    hipLaunchKernelGGL(masked_max_bwd_kernel<B16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const B16*)dout, argmax, mask,
+                       (B16*)dx, (long)R, L, D / 4, accumulate);
     STAGE_LAUNCH_CHECK();
     return 0;
 }

@@ -43,6 +43,24 @@ def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+_BF16 = torch.bfloat16
+
+
+def _act(t: torch.Tensor, name: str, like: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """An activation tensor: float32, or bfloat16 in the bf16 storage mode (BASELINE.json configs[4]: the tensors that
+    stream through HBM between kernels are bf16, parameters / statistics / masks stay fp32).  All activations of one
+    op share one type."""
+    if t.dtype not in (torch.float32, _BF16):
+        raise TypeError("%s: expected float32 or bfloat16, got %s" % (name, t.dtype))
+    if like is not None and t.dtype != like.dtype:
+        raise TypeError("%s: %s, but the op runs in %s" % (name, t.dtype, like.dtype))
+    return _chk(t, name, t.dtype)
+
+
+def _sfx(t: torch.Tensor) -> str:
+    return "_bf16" if t.dtype == _BF16 else ""
+
+
 def _on_device(fn):
     """Run an autograd forward / backward on the device of its tensors.  The reference driver moves the model with
     ``model.to(cuda:N)`` without ``torch.cuda.set_device`` (``--device_ids 1``): buffers then live on cuda:N while the
@@ -97,16 +115,18 @@ def _call(name: str, *args):
 class _LayerNorm(torch.autograd.Function):
     @_on_device
     def forward(ctx, x, res, gamma, beta, res_period: int, want_sum: bool, p: float, seed: int):
-        x = _chk(x, "x")
+        x = _act(x, "x")
         K = x.shape[-1]
         rows = x.numel() // K
-        res_c = None if res is None else _chk(res, "res")
+        if res is not None and res_period > 0 and res.dtype != x.dtype:
+            res = res.to(x.dtype)          # the (L, D) position table follows the storage type
+        res_c = None if res is None else _act(res, "res", x)
         gamma, beta = _chk(gamma, "gamma"), _chk(beta, "beta")
         y = torch.empty_like(x)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
         s = torch.empty_like(x) if (want_sum and res_c is not None) else None
-        _call("stage_layernorm_fwd", _ptr(x), _ptr(res_c), int(res_period), _ptr(s), _ptr(gamma), _ptr(beta), _ptr(y),
+        _call("stage_layernorm_fwd" + _sfx(x), _ptr(x), _ptr(res_c), int(res_period), _ptr(s), _ptr(gamma), _ptr(beta), _ptr(y),
               _ptr(mean), _ptr(rstd), rows, K, EPS_LN, float(p), int(seed), _stream())
         if res_c is not None and s is None:
             # backward needs the normalised input; recompute-free path requires the sum -> always keep it when training
@@ -130,7 +150,7 @@ class _LayerNorm(torch.autograd.Function):
         rows = xin.numel() // K
         if dy is None:       # only the exported sum was used downstream
             dy = torch.zeros_like(xin)
-        dy = _chk(dy, "dy")
+        dy = _act(dy, "dy", xin)
         x_needs = ctx.needs_input_grad[0]
         res_needs = ctx.needs_input_grad[1] and ctx.res_full
         need_dx = x_needs or res_needs
@@ -141,8 +161,8 @@ class _LayerNorm(torch.autograd.Function):
         ws = _workspace(wsb, xin.device)
         dadd = None  # gradient arriving through the exported sum (next residual branch), fused into the dx store
         if dx is not None and ctx.has_res and dsum is not None and dsum.numel() == dx.numel():
-            dadd = _chk(dsum, "dsum")
-        _call("stage_layernorm_bwd", _ptr(dy), _ptr(xin), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dx), _ptr(dadd),
+            dadd = _act(dsum, "dsum", xin)
+        _call("stage_layernorm_bwd" + _sfx(xin), _ptr(dy), _ptr(xin), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dx), _ptr(dadd),
               _ptr(dgamma), _ptr(dbeta), rows, K, ctx.p, ctx.seed, _ptr(ws), wsb, _stream())
         return (dx if x_needs else None), (dx if res_needs else None), dgamma, dbeta, None, None, None, None
 
@@ -160,15 +180,16 @@ def layernorm(x, gamma, beta, p: float = 0.0, seed: int = 0, res=None, res_perio
 class _Cat3LayerNorm(torch.autograd.Function):
     @_on_device
     def forward(ctx, a, b, gamma, beta, rep: int, inner: int, p: float, seed: int):
-        a, b = _chk(a, "a"), _chk(b, "b")
+        b = _act(b, "b")
+        a = _act(a, "a", b)
         D = b.shape[-1]
         rows = b.numel() // D
         gamma, beta = _chk(gamma, "gamma"), _chk(beta, "beta")
         assert a.numel() * rep == b.numel(), (a.shape, b.shape, rep)
-        y = torch.empty(b.shape[:-1] + (3 * D,), dtype=torch.float32, device=b.device)
+        y = torch.empty(b.shape[:-1] + (3 * D,), dtype=b.dtype, device=b.device)
         mean = torch.empty(rows, dtype=torch.float32, device=b.device)
         rstd = torch.empty_like(mean)
-        _call("stage_cat3_layernorm_fwd", _ptr(a), _ptr(b), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd),
+        _call("stage_cat3_layernorm_fwd" + _sfx(b), _ptr(a), _ptr(b), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd),
               rows, D, int(rep), int(inner), EPS_LN, float(p), int(seed), _stream())
         ctx.save_for_backward(a, b, mean, rstd, gamma)
         ctx.cfg = (int(rep), int(inner), float(p), int(seed))
@@ -180,11 +201,24 @@ class _Cat3LayerNorm(torch.autograd.Function):
         rep, inner, p, seed = ctx.cfg
         D = b.shape[-1]
         rows = b.numel() // D
-        dy = _chk(dy, "dy")
+        dy = _act(dy, "dy", b)
         db = torch.empty_like(b)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         lib = _lib.load()
         d4 = D // 4
+        if b.dtype == _BF16:
+            # bf16 storage: the unreduced da rows stay fp32 (scratch), reduced over the broadcast, rounded once
+            da_full = torch.empty(b.shape, dtype=torch.float32, device=b.device)
+            wsb = lib.stage_ln_bwd_ws_bytes(3 * D)
+            ws = _workspace(wsb, b.device)
+            _call("stage_cat3_layernorm_bwd_bf16", _ptr(dy), _ptr(a), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(gamma),
+                  _ptr(da_full), _ptr(db), _ptr(dgamma), _ptr(dbeta), rows, D, rep, inner, p, seed, _ptr(ws), wsb, _stream())
+            if rep > 1:
+                da = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+                _call("stage_reduce_rep", _ptr(da_full), _ptr(da), a.numel() // (inner * D), rep, inner * D, _stream())
+            else:
+                da = da_full.view(a.shape)
+            return da.to(_BF16), db, dgamma, dbeta, None, None, None, None
         if rep > 1 and D % 4 == 0 and 4 <= d4 <= 64 and (d4 & (d4 - 1)) == 0 and inner <= 64:
             # broadcast reduction fused into the backward kernel: no (rows, D) intermediate
             da = torch.empty_like(a)
@@ -242,15 +276,21 @@ def _transposed_weight(w, w2):
 class _Linear(torch.autograd.Function):
     @_on_device
     def forward(ctx, x, w, bias, relu: bool):
-        x = _chk(x, "x")
+        x = _act(x, "x")
+        bf = x.dtype == _BF16
         w2 = _chk(w, "w").reshape(w.shape[0], -1)  # (N, K) ; pointwise Conv1d weights are (N, K, 1)
         N, K = w2.shape
         assert x.shape[-1] == K, (x.shape, w.shape)
         M = x.numel() // K
         bias_c = None if bias is None else _chk(bias, "bias")
-        y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+        y = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
         lib = _lib.load()
         mask = None
+        if bf:      # bf16 storage: bf16 operands, the fp32 weight is rounded to bf16 while it is staged, fp32 accumulation
+            _call("stage_gemm_nt_bf16", _ptr(x), None, _ptr(w2), _ptr(bias_c), None, _ptr(y), M, N, K, int(relu), _stream())
+            ctx.save_for_backward(x, w2, y if relu else None, None)
+            ctx.relu, ctx.wshape, ctx.w_obj, ctx.has_bias = relu, w.shape, w, bias is not None
+            return y
         if relu and lib.stage_gemm_mask_supported(M, N, K) and x.data_ptr() % 16 == 0 and w2.data_ptr() % 16 == 0:
             # Linear + ReLU on the streaming kernel: also emit the ReLU bit mask (1 bit per output) for the backward GEMMs
             mask = torch.empty((N + 31) // 32, M, dtype=torch.int32, device=x.device)   # word-major [ceil(N/32)][M]
@@ -273,9 +313,21 @@ class _Linear(torch.autograd.Function):
         x, w2, y, mask = ctx.saved_tensors
         N, K = w2.shape
         M = x.numel() // K
-        dy = _chk(dy, "dy")
+        dy = _act(dy, "dy", x)
         gate = y if ctx.relu else None
         lib = _lib.load()
+        if x.dtype == _BF16:
+            dx = None
+            if ctx.needs_input_grad[0]:
+                wt = _transposed_weight(ctx.w_obj, w2)
+                dx = torch.empty_like(x)
+                _call("stage_gemm_nt_bf16", _ptr(dy), _ptr(gate), _ptr(wt), None, None, _ptr(dx), M, K, N, 0, _stream())
+            dw = torch.empty_like(w2)
+            db = torch.empty(N, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            wsb = lib.stage_gemm_tn_ws_bytes(M, N, K)
+            ws = _workspace(wsb, x.device)
+            _call("stage_gemm_tn_bf16", _ptr(dy), _ptr(gate), _ptr(x), _ptr(dw), _ptr(db), M, N, K, _ptr(ws), wsb, _stream())
+            return dx, dw.view(ctx.wshape), db, None
         use_mask = mask is not None and dy.data_ptr() % 16 == 0
         dx = None
         if ctx.needs_input_grad[0]:
@@ -314,12 +366,12 @@ def linear(x, w, bias=None, relu: bool = False):
 class _DWConv(torch.autograd.Function):
     @_on_device
     def forward(ctx, x, w, bias):
-        x = _chk(x, "x")  # (M, L, D)
+        x = _act(x, "x")  # (M, L, D)
         M, L, D = x.shape
         w, bias = _chk(w, "w"), _chk(bias, "bias")
         k = w.shape[-1]
         y = torch.empty_like(x)
-        _call("stage_dwconv_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), M, L, D, k, _stream())
+        _call("stage_dwconv_fwd" + _sfx(x), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), M, L, D, k, _stream())
         ctx.save_for_backward(x, w)
         return y
 
@@ -328,14 +380,14 @@ class _DWConv(torch.autograd.Function):
         x, w = ctx.saved_tensors
         M, L, D = x.shape
         k = w.shape[-1]
-        dy = _chk(dy, "dy")
+        dy = _act(dy, "dy", x)
         dx = torch.empty_like(x)
         dw = torch.empty_like(w)
         db = torch.empty(D, dtype=torch.float32, device=x.device)
         lib = _lib.load()
         wsb = lib.stage_dwconv_bwd_ws_bytes(D, k)
         ws = _workspace(wsb, x.device)
-        _call("stage_dwconv_bwd", _ptr(dy), _ptr(x), _ptr(w), _ptr(dx), _ptr(dw), _ptr(db), M, L, D, k, _ptr(ws), wsb,
+        _call("stage_dwconv_bwd" + _sfx(x), _ptr(dy), _ptr(x), _ptr(w), _ptr(dx), _ptr(dw), _ptr(db), M, L, D, k, _ptr(ws), wsb,
               _stream())
         return dx, dw, db
 
@@ -347,9 +399,9 @@ def dwconv(x, w, bias):
 # ---------------------------------------------------------------------------------------------------------------
 # fused LayerNorm (+ residual, + dropout) -> depthwise Conv1d (the LayerNorm output is never materialised)
 # ---------------------------------------------------------------------------------------------------------------
-def ln_dwconv_supported(D: int, k: int) -> bool:
+def ln_dwconv_supported(D: int, k: int, dtype=torch.float32) -> bool:
     d4 = D // 4
-    return D % 4 == 0 and 4 <= d4 <= 64 and (d4 & (d4 - 1)) == 0 and 1 <= k <= 9 and k % 2 == 1
+    return dtype == torch.float32 and D % 4 == 0 and 4 <= d4 <= 64 and (d4 & (d4 - 1)) == 0 and 1 <= k <= 9 and k % 2 == 1
 
 
 class _LnDwConv(torch.autograd.Function):
@@ -412,11 +464,11 @@ def ln_dwconv(x, gamma, beta, w, bias, p: float = 0.0, seed: int = 0, res=None, 
 # L2 normalisation of raw features (no gradient needed: inputs are data) -- model/stage.py:256
 # ---------------------------------------------------------------------------------------------------------------
 def l2norm(x: torch.Tensor, p: float = 0.0, seed: int = 0) -> torch.Tensor:
-    x = _chk(x, "x")
+    x = _act(x, "x")
     K = x.shape[-1]
     y = torch.empty_like(x)
     with torch.cuda.device(x.device):
-        _call("stage_l2norm_fwd", _ptr(x), _ptr(y), None, x.numel() // K, K, EPS_L2, float(p), int(seed), _stream())
+        _call("stage_l2norm_fwd" + _sfx(x), _ptr(x), _ptr(y), None, x.numel() // K, K, EPS_L2, float(p), int(seed), _stream())
     return y
 
 
@@ -559,12 +611,12 @@ def structured_attention(C, Q, c_mask, q_mask, scale: float, p: float = 0.0, see
 class _MaskedMax(torch.autograd.Function):
     @_on_device
     def forward(ctx, x, mask, window):
-        x, mask = _chk(x, "x"), _chk(mask, "mask")  # (R, L, D), (R, L)
+        x, mask = _act(x, "x"), _chk(mask, "mask")  # (R, L, D), (R, L)
         R, L, D = x.shape
         win = None if window is None else _chk(window, "window", torch.int32)
-        out = torch.empty(R, D, dtype=torch.float32, device=x.device)
+        out = torch.empty(R, D, dtype=x.dtype, device=x.device)
         idx = torch.empty(R, D, dtype=torch.int32, device=x.device)
-        _call("stage_masked_max_fwd", _ptr(x), _ptr(mask), _ptr(win), _ptr(out), _ptr(idx), R, L, D, _stream())
+        _call("stage_masked_max_fwd" + _sfx(x), _ptr(x), _ptr(mask), _ptr(win), _ptr(out), _ptr(idx), R, L, D, _stream())
         ctx.save_for_backward(idx, mask)
         ctx.shape = (R, L, D)
         return out
@@ -573,9 +625,9 @@ class _MaskedMax(torch.autograd.Function):
     def backward(ctx, dout):
         idx, mask = ctx.saved_tensors
         R, L, D = ctx.shape
-        dout = _chk(dout, "dout")
-        dx = torch.empty(R, L, D, dtype=torch.float32, device=dout.device)
-        _call("stage_masked_max_bwd", _ptr(dout), _ptr(idx), _ptr(mask), _ptr(dx), R, L, D, 0, _stream())
+        dout = _act(dout, "dout")
+        dx = torch.empty(R, L, D, dtype=dout.dtype, device=dout.device)
+        _call("stage_masked_max_bwd" + _sfx(dout), _ptr(dout), _ptr(idx), _ptr(mask), _ptr(dx), R, L, D, 0, _stream())
         return dx, None, None
 
 

@@ -194,6 +194,15 @@ class STAGE(nn.Module):
                                                relu=False)
         # developer switch: False (or STAGE_NO_FUSE_LN_DWCONV=1) = separate LayerNorm and depthwise-conv kernels
         self.fuse_ln_dwconv = os.environ.get("STAGE_NO_FUSE_LN_DWCONV") is None
+        # storage type of the activations between kernels: fp32 (the reference's), or bf16 with ``opt.storage_dtype = "bf16"``
+        # (BASELINE.json configs[4]: bf16 weights / activations, fp32 softmax / statistics / accumulation; parameters stay
+        # fp32 master copies, a weight is rounded to bf16 when a GEMM stages it; scores, losses and logits are fp32)
+        sd = str(_opt(opt, "storage_dtype", "fp32")).lower()
+        if sd not in ("fp32", "float32", "bf16", "bfloat16"):
+            raise ValueError("opt.storage_dtype must be 'fp32' or 'bf16', got %r" % sd)
+        self.storage = torch.bfloat16 if sd in ("bf16", "bfloat16") else torch.float32
+        if self.storage == torch.bfloat16 and (opt.input_encoder_n_heads or opt.cls_encoder_n_heads):
+            raise NotImplementedError("bf16 storage with n_heads > 0: the self-attention core has no bf16 storage path yet")
         self._span_host = None      # pinned landing buffer of the per-step proposal spans (get_proposals)
         # counter-based dropout stream (csrc/common.h): seeded lazily from the seed of torch's default generator at the first
         # use (so torch.manual_seed() before training takes effect, as for the reference's nn.Dropout) and mixed with the
@@ -228,7 +237,7 @@ class STAGE(nn.Module):
         for i in range(blk.n_conv):
             c = blk.conv[i]
             ln, drop = blk.layer_norm[i], (i % 2 == 0)
-            if self.fuse_ln_dwconv and ops.ln_dwconv_supported(D, c.depthwise_conv.weight.shape[-1]):
+            if self.fuse_ln_dwconv and ops.ln_dwconv_supported(D, c.depthwise_conv.weight.shape[-1], pending.dtype):
                 # LayerNorm output only feeds the depthwise conv: one fused pass, never materialised
                 h, cur = ops.ln_dwconv(pending, ln.weight, ln.bias, c.depthwise_conv.weight, c.depthwise_conv.bias,
                                        p=self._p() if drop else 0.0, seed=self._seed() if drop else 0, res=cur,
@@ -260,6 +269,8 @@ class STAGE(nn.Module):
     def base_encoder(self, data, data_mask, init_encoder, downsize_encoder, input_encoder, l2_normalize=False):
         """model/stage.py:350-363 (+ the F.normalize of :256 when l2_normalize)."""
         M, L, _ = data.shape
+        if data.dtype != self.storage:
+            data = data.to(self.storage)      # bf16 storage: features are rounded once on entry
         if l2_normalize:
             data = ops.l2norm(data)
         y, _ = self._ln(data, init_encoder[0], drop=True)
@@ -373,7 +384,7 @@ class STAGE(nn.Module):
         st_lw, ed_lw = self.temporal_scoring_st_layers[0], self.temporal_scoring_ed_layers[0]
         t_st, first = self._linear_wrapper(h, st_lw, res=enc)                            # first = enc + h
         t_ed, _ = self._linear_wrapper(first, ed_lw)
-        t_scores = torch.cat([t_st, t_ed], dim=-1).view(N, NA, Li, 2)
+        t_scores = torch.cat([t_st, t_ed], dim=-1).view(N, NA, Li, 2).float()   # scores / losses are fp32 in every storage mode
         tm = ts_labels_mask.view(N, 1, Li, 1)
         t_scores = t_scores * tm + (1 - tm) * NEG                                        # :521 mask_logits
         first = first.view(N, NA, Li, D)
@@ -383,7 +394,7 @@ class STAGE(nn.Module):
         else:
             pooled = ops.masked_max(first.view(N * NA, Li, D), mx_mask.view(N * NA, Li)).view(N, NA, D)
         logits, _ = self._linear_wrapper(pooled.reshape(-1, pooled.shape[-1]), self.classifier)
-        return logits.view(-1, NA), targets, t_scores
+        return logits.view(-1, NA).float(), targets, t_scores
 
     def get_ts_loss(self, temporal_scores, ts_labels, answer_indices, cand_offset: int = 0):
         """model/stage.py:539-555.  ``cand_offset``: global index of local candidate 0 when the candidates of an example
