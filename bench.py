@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--att_imgs", type=int, default=4, help="annotated frames per question (synthetic att_labels)")
     ap.add_argument("--att_words", type=int, default=3, help="labelled object words per annotated frame")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--storage", choices=["fp32", "bf16"], default="fp32",
+                    help="bf16: the bf16 storage mode (BASELINE configs[4]); the headline line is the fp32 default")
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--only_roofline", action="store_true")
     ap.add_argument("--cpu_seconds", type=float, default=20.0, help="CPU-baseline time budget")
@@ -205,7 +207,7 @@ def main():
     torch.manual_seed(2018)
     sup = not args.no_sup_att
     opt = make_opt(hsz=args.hsz, add_local=True, dropout=0.1, use_sup_att=sup, input_encoder_n_heads=args.heads,
-                   cls_encoder_n_heads=args.heads)
+                   cls_encoder_n_heads=args.heads, storage_dtype=args.storage)
     import contextlib
     with contextlib.redirect_stdout(open(os.devnull, "w")):
         model = STAGE(opt)
@@ -267,14 +269,17 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic" + (" (re-sent from pinned host memory every step)" if args.h2d else ""),
+            "dtype": "f32" if args.storage == "fp32" else "bf16", "data": "synthetic" + (" (re-sent from pinned host memory every step)" if args.h2d else ""),
             "config": {"workload": "STAGE train step B=%d/GPU x5 cand x%d frames x%d regions x%d sub x%d QA words, hsz=%d, "
-                                   "add_local%s%s, dropout 0.1, %s masks; fp32 via %s bf16-split MFMA GEMMs"
+                                   "add_local%s%s, dropout 0.1, %s masks; %s"
                                    % (n_local, args.frames, args.regions, args.sub_words, args.qa_words, args.hsz,
                                       " + supervised attention loss" if sup else "",
                                       (" + %d-head self-attention" % args.heads) if args.heads else "",
                                       "all-ones" if args.dense else "ragged",
-                                      "exact 3-term" if args.gemm_terms == 3 else "2-term (hi+mid, ~2^-17 products)"),
+                                      "bf16 activations / bf16-rounded weights, fp32 statistics, softmax and accumulation"
+                                      if args.storage == "bf16" else
+                                      ("fp32 via %s bf16-split MFMA GEMMs"
+                                       % ("exact 3-term" if args.gemm_terms == 3 else "2-term (hi+mid, ~2^-17 products)"))),
                        "step": "fwd + loss (main.py:55-60) + bwd + grad all-reduce + clip_grad_norm_ + Adam",
                        "global_batch": n_global, "parallelism": "dp%d (example-sharded, flat 2.2MB grad "
                                                                   "all-reduce over RCCL)" % world,
