@@ -184,8 +184,8 @@ int stage_masked_max_bwd(const float* dout, const int* argmax, const float* mask
  * Same operations and argument meaning as the fp32 entry points of the same name; every pointer typed `void*` is a
  * tensor of bf16 (raw 16-bit words) instead of float.  Statistics, affine parameters, weights, biases, masks, arg-max
  * indices and all parameter gradients stay fp32; a weight is rounded to bf16 while the GEMM stages it.  The attention
- * kernel of this mode is stage_str_attn_long_* with storage == 1.  Functional path (the generic kernels instantiated
- * on 16-bit elements), not yet a tuned one.                                                                        */
+ * kernel of this mode is stage_str_attn_long_* with storage == 1.  The row / conv kernels are the fp32 ones instantiated
+ * on 16-bit elements; the GEMMs are the tiled kernels with one bf16 term (not yet the streaming ones).                                                                     */
 int stage_layernorm_fwd_bf16(const void* x, const void* res, int res_period, void* sum_out, const float* gamma,
                              const float* beta, void* y, float* mean, float* rstd, long long rows, int K, float eps,
                              float p_drop, unsigned long long seed, void* stream);
@@ -200,6 +200,11 @@ int stage_cat3_layernorm_bwd_bf16(const void* dy, const void* a, const void* b, 
                                   const float* gamma, float* da_full, void* db, float* dgamma, float* dbeta,
                                   long long rows, int D, int rep, int inner, float p_drop, unsigned long long seed,
                                   void* ws, size_t ws_bytes, void* stream);
+/* da (rows / rep, D) fp32 (a sum over the `rep` frames), db (rows, D) bf16; ws as for the fp32 entry point */
+int stage_cat3_layernorm_bwd_reduced_bf16(const void* dy, const void* a, const void* b, const float* mean,
+                                          const float* rstd, const float* gamma, float* da, void* db, float* dgamma,
+                                          float* dbeta, long long rows, int D, int rep, int inner, float p_drop,
+                                          unsigned long long seed, void* ws, size_t ws_bytes, void* stream);
 int stage_l2norm_fwd_bf16(const void* x, void* y, float* norm_out, long long rows, int K, float eps, float p_drop,
                           unsigned long long seed, void* stream);
 int stage_l2norm_bwd_bf16(const void* dy, const void* x, void* dx, long long rows, int K, float eps, float p_drop,
@@ -212,6 +217,14 @@ int stage_dwconv_fwd_bf16(const void* in, const float* w, const float* bias, voi
                           void* stream);
 int stage_dwconv_bwd_bf16(const void* dout, const void* in, const float* w, void* din, float* dw, float* db, long long M,
                           int L, int D, int k, void* ws, size_t ws_bytes, void* stream);
+int stage_ln_dwconv_fwd_bf16(const void* x, const void* res, int res_period, void* sum_out, const float* gamma,
+                             const float* beta, const float* w, const float* bias, void* h, float* mean, float* rstd,
+                             long long M, int L, int D, int k, float eps, float p_drop, unsigned long long seed,
+                             void* stream);
+int stage_ln_dwconv_bwd_bf16(const void* dh, const void* xin, const float* mean, const float* rstd, const float* gamma,
+                             const float* beta, const float* w, void* dx, const void* dx_add, float* dgamma, float* dbeta,
+                             float* dw, float* db, long long M, int L, int D, int k, float p_drop, unsigned long long seed,
+                             void* ws, size_t ws_bytes, void* stream);
 int stage_masked_max_fwd_bf16(const void* x, const float* mask, const int* window, void* out, int* argmax, long long R,
                               int L, int D, void* stream);
 int stage_masked_max_bwd_bf16(const void* dout, const int* argmax, const float* mask, void* dx, long long R, int L, int D,

@@ -148,6 +148,36 @@ def test_dwconv_bf16(ops, M, L, D, k):
     check("db", bd.grad, bc.grad, PTOL)
 
 
+@pytest.mark.parametrize("M,L,D,k,period", [(6, 20, 128, 7, 20), (3, 40, 256, 5, 0), (2, 50, 64, 3, 0)])
+def test_ln_dwconv_bf16(ops, M, L, D, k, period):
+    """fused LayerNorm (+ residual / position rows) -> depthwise conv on bf16 activations"""
+    assert ops.ln_dwconv_supported(D, k, BF)
+    g = torch.Generator().manual_seed(M + L + D)
+    x = rb(torch.randn(M, L, D, generator=g))
+    res = rb(torch.randn((L + 1, D) if period else (M, L, D), generator=g))
+    gw, gb = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    w, b = torch.randn(D, 1, k, generator=g) * 0.3, torch.randn(D, generator=g)
+    gh, gs = rb(torch.randn(M, L, D, generator=g)), rb(torch.randn(M, L, D, generator=g))
+    xc, rc = x.clone().requires_grad_(), res.clone().requires_grad_(not period)
+    pc = [t.clone().requires_grad_() for t in (gw, gb, w, b)]
+    sc = xc + (rc[:L] if period else rc)
+    yc = F.layer_norm(sc, (D,), pc[0], pc[1], 1e-5)
+    hc = F.conv1d(yc.transpose(1, 2), pc[2], pc[3], padding=k // 2, groups=D).transpose(1, 2)
+    ((hc * gh).sum() + (sc * gs).sum()).backward()
+    xd, rd = devb(x, True), devb(res, not period)
+    pd = [dev(t, True) for t in (gw, gb, w, b)]
+    h, s = ops.ln_dwconv(xd, pd[0], pd[1], pd[2], pd[3], res=rd, res_period=period)
+    assert h.dtype == BF and s.dtype == BF
+    check("h", h, hc, ULP2)
+    check("sum", s, sc, ULP2)
+    ((h.float() * gh.cuda()).sum() + (s.float() * gs.cuda()).sum()).backward()
+    # the backward sees the sum as it was stored (bf16): x_hat, and with it dx, carries that rounding through 1/sigma
+    check("dx", xd.grad, xc.grad, 4 * ULP2)
+    for name, a, c in zip(("dgamma", "dbeta", "dw", "db"), pd, pc):
+        e = float((a.grad.cpu() - c.grad).abs().max()) / max(1.0, float(c.grad.pow(2).mean().sqrt()))
+        assert e < 3e-2, "%s: %.3e of the gradient's rms" % (name, e)
+
+
 def test_l2norm_and_masked_max_bf16(ops):
     g = torch.Generator().manual_seed(5)
     x = rb(torch.randn(50, 300, generator=g))

@@ -63,12 +63,15 @@ SIGNATURES = {
     "stage_layernorm_bwd_bf16": (I, [P, P, P, P, P, P, P, P, P, LL, I, F, U64, P, SZ, P]),
     "stage_cat3_layernorm_fwd_bf16": (I, [P, P, P, P, P, P, P, LL, I, I, I, F, F, U64, P]),
     "stage_cat3_layernorm_bwd_bf16": (I, [P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, U64, P, SZ, P]),
+    "stage_cat3_layernorm_bwd_reduced_bf16": (I, [P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, U64, P, SZ, P]),
     "stage_l2norm_fwd_bf16": (I, [P, P, P, LL, I, F, F, U64, P]),
     "stage_l2norm_bwd_bf16": (I, [P, P, P, LL, I, F, F, U64, I, P]),
     "stage_gemm_nt_bf16": (I, [P, P, P, P, P, P, LL, I, I, I, P]),
     "stage_gemm_tn_bf16": (I, [P, P, P, P, P, LL, I, I, P, SZ, P]),
     "stage_dwconv_fwd_bf16": (I, [P, P, P, P, LL, I, I, I, P]),
     "stage_dwconv_bwd_bf16": (I, [P, P, P, P, P, P, LL, I, I, I, P, SZ, P]),
+    "stage_ln_dwconv_fwd_bf16": (I, [P, P, I, P, P, P, P, P, P, P, P, LL, I, I, I, F, F, U64, P]),
+    "stage_ln_dwconv_bwd_bf16": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, U64, P, SZ, P]),
     "stage_masked_max_fwd_bf16": (I, [P, P, P, P, P, LL, I, I, P]),
     "stage_masked_max_bwd_bf16": (I, [P, P, P, P, LL, I, I, I, P]),
 }

@@ -210,6 +210,8 @@ __device__ __forceinline__ void stv4(float* p, float4 v) { st4(p, v); }
 __device__ __forceinline__ void stv4(stage_bf16* p, float4 v) {
     *reinterpret_cast<uint2*>(p) = make_uint2(stage_pk_bf16(v.x, v.y), stage_pk_bf16(v.z, v.w));
 }
+__device__ __forceinline__ void stv4s(float* p, float4 v) { st4_stream(p, v); }     // written once, not re-read here
+__device__ __forceinline__ void stv4s(stage_bf16* p, float4 v) { stv4(p, v); }
 __device__ __forceinline__ float ldv1(const float* p) { return *p; }
 __device__ __forceinline__ float ldv1(const stage_bf16* p) { return __uint_as_float((unsigned)p->bits << 16); }
 __device__ __forceinline__ void stv1(float* p, float v) { *p = v; }

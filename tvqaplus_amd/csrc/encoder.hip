@@ -124,9 +124,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ d
 // loads per output element.  Same arithmetic order over the taps as the kernels above.
 // ------------------------------------------------------------------------------------------------
 
-template <int KT>
-__global__ __launch_bounds__(256) void dwconv_fwd_sw_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                                                            const float* __restrict__ bias, float* __restrict__ out,
+template <int KT, typename T = float>
+__global__ __launch_bounds__(256) void dwconv_fwd_sw_kernel(const T* __restrict__ in, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, T* __restrict__ out,
                                                             long M, int L, int D, int clen) {
     constexpr int pad = KT / 2;
     const int D4 = D >> 2, rpi = blockDim.x / D4;
@@ -142,12 +142,12 @@ __global__ __launch_bounds__(256) void dwconv_fwd_sw_kernel(const float* __restr
     for (long it = (long)blockIdx.x * rpi + rsub; it < items; it += (long)gridDim.x * rpi) {
         const long m = it / chunks;
         const int l0 = (int)(it % chunks) * clen, l1 = min(L, l0 + clen);
-        const float* base = in + (m * L) * D + 4 * q;
+        const T* base = in + (m * L) * D + 4 * q;
         float4 win[KT];   // win[t] = in[l + t - pad] for the current l
 #pragma unroll
         for (int t = 0; t < KT - 1; t++) {
             const int ll = l0 + t - pad;
-            const float4 v = ld4(base + (long)min(max(ll, 0), L - 1) * D);
+            const float4 v = ldv4(base + (long)min(max(ll, 0), L - 1) * D);
             win[t + 1] = (ll >= 0 && ll < L) ? v : f4zero();
         }
 #pragma unroll 4
@@ -155,19 +155,19 @@ __global__ __launch_bounds__(256) void dwconv_fwd_sw_kernel(const float* __restr
 #pragma unroll
             for (int t = 0; t < KT - 1; t++) win[t] = win[t + 1];
             const int ll = l + pad;
-            const float4 v = ld4(base + (long)min(ll, L - 1) * D);
+            const float4 v = ldv4(base + (long)min(ll, L - 1) * D);
             win[KT - 1] = ll < L ? v : f4zero();
             float4 acc = bq;
 #pragma unroll
             for (int t = 0; t < KT; t++) acc = f4add(acc, f4mul(win[t], wt[t]));
-            st4_stream(out + ((m * L + l) * D + 4 * q), acc);
+            stv4s(out + ((m * L + l) * D + 4 * q), acc);
         }
     }
 }
 
-template <int KT>
-__global__ __launch_bounds__(256) void dwconv_bwd_sw_kernel(const float* __restrict__ dout, const float* __restrict__ in,
-                                                            const float* __restrict__ w, float* __restrict__ din,
+template <int KT, typename T = float>
+__global__ __launch_bounds__(256) void dwconv_bwd_sw_kernel(const T* __restrict__ dout, const T* __restrict__ in,
+                                                            const float* __restrict__ w, T* __restrict__ din,
                                                             float* __restrict__ part, long M, int L, int D, int clen) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // reduction scratch [rpi][KT + 1][D]
     constexpr int pad = KT / 2;
@@ -187,14 +187,14 @@ __global__ __launch_bounds__(256) void dwconv_bwd_sw_kernel(const float* __restr
         for (long it = (long)blockIdx.x * rpi + rsub; it < items; it += (long)gridDim.x * rpi) {
             const long m = it / chunks;
             const int l0 = (int)(it % chunks) * clen, l1 = min(L, l0 + clen);
-            const float* bi = in + (m * L) * D + 4 * q;
-            const float* bo = dout + (m * L) * D + 4 * q;
+            const T* bi = in + (m * L) * D + 4 * q;
+            const T* bo = dout + (m * L) * D + 4 * q;
             float4 wi[KT], wo[KT];   // wi[t] = in[l + t - pad], wo[t] = dout[l + t - pad]
 #pragma unroll
             for (int t = 0; t < KT - 1; t++) {
                 const int ll = l0 + t - pad;
                 const long ro = (long)min(max(ll, 0), L - 1) * D;
-                const float4 vi = ld4(bi + ro), vo = ld4(bo + ro);
+                const float4 vi = ldv4(bi + ro), vo = ldv4(bo + ro);
                 const bool ok = ll >= 0 && ll < L;
                 wi[t + 1] = ok ? vi : f4zero();
                 wo[t + 1] = ok ? vo : f4zero();
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_sw_kernel(const float* __restr
                 for (int t = 0; t < KT - 1; t++) { wi[t] = wi[t + 1]; wo[t] = wo[t + 1]; }
                 const int ll = l + pad;
                 const long ro = (long)min(ll, L - 1) * D;
-                const float4 vi = ld4(bi + ro), vo = ld4(bo + ro);
+                const float4 vi = ldv4(bi + ro), vo = ldv4(bo + ro);
                 wi[KT - 1] = ll < L ? vi : f4zero();
                 wo[KT - 1] = ll < L ? vo : f4zero();
                 const float4 go = wo[pad];
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_sw_kernel(const float* __restr
                     aw[t] = f4add(aw[t], f4mul(go, wi[t]));                 // dw[t] += dout[l] * in[l + t - pad]
                     gi = f4add(gi, f4mul(wo[KT - 1 - t], wt[t]));           // din[l] += dout[l - t + pad] * w[t]
                 }
-                st4_stream(din + ((m * L + l) * D + 4 * q), gi);
+                stv4s(din + ((m * L + l) * D + 4 * q), gi);
             }
         }
     }
@@ -248,8 +248,8 @@ __global__ void dwconv_final_kernel(const float* __restrict__ part, float* __res
     else db[d] = s;
 }
 
-extern "C" int stage_dwconv_fwd(const float* in, const float* w, const float* bias, float* out, long long M, int L,
-                                int D, int k, void* stream) {
+template <typename T>
+static int dwconv_fwd_t(const T* in, const float* w, const float* bias, T* out, long long M, int L, int D, int k, void* stream) {
     if (M <= 0) return 0;
     if (D % 4 != 0 || k < 1 || k > KMAX || (k & 1) == 0) return STAGE_ERR_SHAPE;
     if (D / 4 <= 256 && !getenv("STAGE_DWCONV_GENERIC")) {
@@ -259,26 +259,32 @@ extern "C" int stage_dwconv_fwd(const float* in, const float* w, const float* bi
         const int gridw = stage_grid_for(items, rpi, GRID_CAP * 4);
         hipStream_t st = (hipStream_t)stream;
         switch (k) {
-            case 1: hipLaunchKernelGGL(dwconv_fwd_sw_kernel<1>, dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D, clen); break;
-            case 3: hipLaunchKernelGGL(dwconv_fwd_sw_kernel<3>, dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D, clen); break;
-            case 5: hipLaunchKernelGGL(dwconv_fwd_sw_kernel<5>, dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D, clen); break;
-            case 7: hipLaunchKernelGGL(dwconv_fwd_sw_kernel<7>, dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D, clen); break;
-            default: hipLaunchKernelGGL(dwconv_fwd_sw_kernel<9>, dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D, clen); break;
+            case 1: hipLaunchKernelGGL((dwconv_fwd_sw_kernel<1, T>), dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D, clen); break;
+            case 3: hipLaunchKernelGGL((dwconv_fwd_sw_kernel<3, T>), dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D, clen); break;
+            case 5: hipLaunchKernelGGL((dwconv_fwd_sw_kernel<5, T>), dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D, clen); break;
+            case 7: hipLaunchKernelGGL((dwconv_fwd_sw_kernel<7, T>), dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D, clen); break;
+            default: hipLaunchKernelGGL((dwconv_fwd_sw_kernel<9, T>), dim3(gridw), dim3(256), 0, st, in, w, bias, out, (long)M, L, D, clen); break;
         }
         STAGE_LAUNCH_CHECK();
         return 0;
     }
     const int grid = stage_grid_for(M * L * (D / 4), 256, GRID_CAP);
-    hipLaunchKernelGGL(dwconv_fwd_kernel<float>, dim3(grid), dim3(256), (size_t)(k + 1) * D * sizeof(float),
+    hipLaunchKernelGGL(dwconv_fwd_kernel<T>, dim3(grid), dim3(256), (size_t)(k + 1) * D * sizeof(float),
                        (hipStream_t)stream, in, w, bias, out, (long)(M * L), L, D, k);
     STAGE_LAUNCH_CHECK();
     return 0;
 }
 
+extern "C" int stage_dwconv_fwd(const float* in, const float* w, const float* bias, float* out, long long M, int L,
+                                int D, int k, void* stream) {
+    return dwconv_fwd_t<float>(in, w, bias, out, M, L, D, k, stream);
+}
+
 extern "C" size_t stage_dwconv_bwd_ws_bytes(int D, int k) { return (size_t)DW_PART_CAP * (k + 1) * D * sizeof(float); }
 
-extern "C" int stage_dwconv_bwd(const float* dout, const float* in, const float* w, float* din, float* dw, float* db,
-                                long long M, int L, int D, int k, void* ws, size_t ws_bytes, void* stream) {
+template <typename T>
+static int dwconv_bwd_t(const T* dout, const T* in, const float* w, T* din, float* dw, float* db, long long M, int L, int D,
+                        int k, void* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (D % 4 != 0 || D / 4 > 256 || k < 1 || k > KMAX || (k & 1) == 0) return STAGE_ERR_SHAPE;
     if (ws_bytes < stage_dwconv_bwd_ws_bytes(D, k)) return STAGE_ERR_WORKSPACE;
@@ -298,15 +304,15 @@ extern "C" int stage_dwconv_bwd(const float* dout, const float* in, const float*
         grid = stage_grid_for(items, rpi, DW_PART_CAP);
         const size_t ldb = red * sizeof(float);
         switch (k) {
-            case 1: hipLaunchKernelGGL(dwconv_bwd_sw_kernel<1>, dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D, clen); break;
-            case 3: hipLaunchKernelGGL(dwconv_bwd_sw_kernel<3>, dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D, clen); break;
-            case 5: hipLaunchKernelGGL(dwconv_bwd_sw_kernel<5>, dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D, clen); break;
-            case 7: hipLaunchKernelGGL(dwconv_bwd_sw_kernel<7>, dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D, clen); break;
-            default: hipLaunchKernelGGL(dwconv_bwd_sw_kernel<9>, dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D, clen); break;
+            case 1: hipLaunchKernelGGL((dwconv_bwd_sw_kernel<1, T>), dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D, clen); break;
+            case 3: hipLaunchKernelGGL((dwconv_bwd_sw_kernel<3, T>), dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D, clen); break;
+            case 5: hipLaunchKernelGGL((dwconv_bwd_sw_kernel<5, T>), dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D, clen); break;
+            case 7: hipLaunchKernelGGL((dwconv_bwd_sw_kernel<7, T>), dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D, clen); break;
+            default: hipLaunchKernelGGL((dwconv_bwd_sw_kernel<9, T>), dim3(grid), dim3(256), ldb, st, dout, in, w, din, (float*)ws, (long)M, L, D, clen); break;
         }
     } else {
         grid = stage_grid_for(M * L, rpi * 8, DW_PART_CAP);
-        hipLaunchKernelGGL(dwconv_bwd_kernel<float>, dim3(grid), dim3(256), lds * sizeof(float), st, dout, in, w, din,
+        hipLaunchKernelGGL(dwconv_bwd_kernel<T>, dim3(grid), dim3(256), lds * sizeof(float), st, dout, in, w, din,
                            (float*)ws, (long)(M * L), L, D, k);
     }
     STAGE_LAUNCH_CHECK();
@@ -315,38 +321,20 @@ extern "C" int stage_dwconv_bwd(const float* dout, const float* in, const float*
     return 0;
 }
 
-// bf16 storage mode (BASELINE.json configs[4]): the generic kernels on 16-bit activations; weights, bias and their
-// gradients stay fp32
+extern "C" int stage_dwconv_bwd(const float* dout, const float* in, const float* w, float* din, float* dw, float* db,
+                                long long M, int L, int D, int k, void* ws, size_t ws_bytes, void* stream) {
+    return dwconv_bwd_t<float>(dout, in, w, din, dw, db, M, L, D, k, ws, ws_bytes, stream);
+}
+
+// bf16 storage mode (BASELINE.json configs[4]): the same kernels on 16-bit activations; weights, bias and their gradients
+// stay fp32
 extern "C" int stage_dwconv_fwd_bf16(const void* in, const float* w, const float* bias, void* out, long long M, int L, int D,
                                      int k, void* stream) {
-    if (M <= 0) return 0;
-    if (D % 4 != 0 || k < 1 || k > KMAX || (k & 1) == 0) return STAGE_ERR_SHAPE;
-    const int grid = stage_grid_for(M * L * (D / 4), 256, GRID_CAP);
-    hipLaunchKernelGGL(dwconv_fwd_kernel<stage_bf16>, dim3(grid), dim3(256), (size_t)(k + 1) * D * sizeof(float),
-                       (hipStream_t)stream, (const stage_bf16*)in, w, bias, (stage_bf16*)out, (long)(M * L), L, D, k);
-    STAGE_LAUNCH_CHECK();
-    return 0;
+    return dwconv_fwd_t<stage_bf16>((const stage_bf16*)in, w, bias, (stage_bf16*)out, M, L, D, k, stream);
 }
 
 extern "C" int stage_dwconv_bwd_bf16(const void* dout, const void* in, const float* w, void* din, float* dw, float* db,
                                      long long M, int L, int D, int k, void* ws, size_t ws_bytes, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    if (D % 4 != 0 || D / 4 > 256 || k < 1 || k > KMAX || (k & 1) == 0) return STAGE_ERR_SHAPE;
-    if (ws_bytes < stage_dwconv_bwd_ws_bytes(D, k)) return STAGE_ERR_WORKSPACE;
-    if (M <= 0) {
-        (void)hipMemsetAsync(dw, 0, sizeof(float) * D * k, st);
-        (void)hipMemsetAsync(db, 0, sizeof(float) * D, st);
-        return 0;
-    }
-    const int rpi = 256 / (D / 4);
-    size_t lds = (size_t)k * D;
-    const size_t red = (size_t)rpi * (k + 1) * D;
-    if (red > lds) lds = red;
-    const int grid = stage_grid_for(M * L, rpi * 8, DW_PART_CAP);
-    hipLaunchKernelGGL(dwconv_bwd_kernel<stage_bf16>, dim3(grid), dim3(256), lds * sizeof(float), st, (const stage_bf16*)dout,
-                       (const stage_bf16*)in, w, (stage_bf16*)din, (float*)ws, (long)(M * L), L, D, k);
-    STAGE_LAUNCH_CHECK();
-    stage_colreduce((const float*)ws, dw, db, grid, (long)(k + 1) * D, (k + 1) * D, D, k, st);
-    STAGE_LAUNCH_CHECK();
-    return 0;
+    return dwconv_bwd_t<stage_bf16>((const stage_bf16*)dout, (const stage_bf16*)in, w, (stage_bf16*)din, dw, db, M, L, D, k, ws,
+                                    ws_bytes, stream);
 }

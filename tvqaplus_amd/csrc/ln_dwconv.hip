@@ -15,12 +15,12 @@
 #define LD_GRID_CAP 16384
 #define LD_PART_CAP 512
 
-template <int KT, bool DROP>
-__global__ __launch_bounds__(256) void ln_dwconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
-                                                            int res_period, float* __restrict__ sum_out,
+template <int KT, bool DROP, typename T = float>
+__global__ __launch_bounds__(256) void ln_dwconv_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                            int res_period, T* __restrict__ sum_out,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ w, const float* __restrict__ bias,
-                                                            float* __restrict__ h, float* __restrict__ mean,
+                                                            T* __restrict__ h, float* __restrict__ mean,
                                                             float* __restrict__ rstd, long M, int L, int D, float eps,
                                                             uint64_t seed, uint32_t th, float inv_keep, int clen) {
     constexpr int pad = KT / 2;
@@ -44,8 +44,8 @@ __global__ __launch_bounds__(256) void ln_dwconv_fwd_kernel(const float* __restr
         // guarded load in the middle of the chain makes the compiler wait for every load before it.
         auto load_row = [&](int ll, float4& v) {
             const long row = m * L + min(max(ll, 0), L - 1);
-            v = ld4(x + row * D + 4 * q);
-            if (res) v = f4add(v, ld4(res + (res_period > 0 ? (long)((unsigned long)row % (unsigned)res_period) : row) * D + 4 * q));
+            v = ldv4(x + row * D + 4 * q);
+            if (res) v = f4add(v, ldv4(res + (res_period > 0 ? (long)((unsigned long)row % (unsigned)res_period) : row) * D + 4 * q));
         };
         auto norm_row = [&](int ll, const float4& v, float& mu, float& rs) -> float4 {
             const bool inside = ll >= 0 && ll < L;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void ln_dwconv_fwd_kernel(const float* __restr
         auto export_row = [&](int ll, const float4& v, float mu, float rs) {   // the chunk's own rows only
             if (ll >= l0 && ll < l1) {
                 const long row = m * L + ll;
-                if (sum_out) st4(sum_out + row * D + 4 * q, v);
+                if (sum_out) stv4(sum_out + row * D + 4 * q, v);
                 if (q == 0) {
                     mean[row] = mu;
                     rstd[row] = rs;
@@ -99,19 +99,19 @@ __global__ __launch_bounds__(256) void ln_dwconv_fwd_kernel(const float* __restr
                 float4 acc = bq;
 #pragma unroll
                 for (int t = 0; t < KT; t++) acc = f4add(acc, f4mul(win[t], wt[t]));
-                if (l + u < l1) st4_stream(h + ((m * L + l + u) * D + 4 * q), acc);
+                if (l + u < l1) stv4s(h + ((m * L + l + u) * D + 4 * q), acc);
             }
         }
     }
 }
 
 // dx = LN-backward(conv-backward(dh)) + dx_add ; partials of dw/db (conv) and dgamma/dbeta (LayerNorm) per workgroup.
-template <int KT, bool DROP>
-__global__ __launch_bounds__(256) void ln_dwconv_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ xin,
+template <int KT, bool DROP, typename T = float>
+__global__ __launch_bounds__(256) void ln_dwconv_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ xin,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            const float* __restrict__ w, float* __restrict__ dx,
-                                                            const float* __restrict__ dx_add, float* __restrict__ part_conv,
+                                                            const float* __restrict__ w, T* __restrict__ dx,
+                                                            const T* __restrict__ dx_add, float* __restrict__ part_conv,
                                                             float* __restrict__ part_ln, long M, int L, int D,
                                                             uint64_t seed, uint32_t th, float inv_keep, int clen) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // reduction scratch [rpi][KT + 1][D]
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void ln_dwconv_bwd_kernel(const float* __restr
         auto y_row = [&](int ll) -> float4 {
             const bool inside = ll >= 0 && ll < L;
             const long row = m * L + min(max(ll, 0), L - 1);
-            const float4 v = ld4(xin + row * D + 4 * q);
+            const float4 v = ldv4(xin + row * D + 4 * q);
             const float mu = mean[row], rs = rstd[row];
             float4 o;
             o.x = (v.x - mu) * rs * gm.x + bt.x;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void ln_dwconv_bwd_kernel(const float* __restr
         };
         auto dh_row = [&](int ll) -> float4 {
             const bool inside = ll >= 0 && ll < L;
-            const float4 v = ld4(dh + (m * L + min(max(ll, 0), L - 1)) * D + 4 * q);
+            const float4 v = ldv4(dh + (m * L + min(max(ll, 0), L - 1)) * D + 4 * q);
             return inside ? v : f4zero();
         };
         float4 wy[KT], wo[KT];   // wy[t] = y[l + t - pad], wo[t] = dh[l + t - pad]
@@ -166,10 +166,10 @@ __global__ __launch_bounds__(256) void ln_dwconv_bwd_kernel(const float* __restr
                 ny[u] = y_row(l + u + pad);
                 no[u] = dh_row(l + u + pad);
                 const long row = m * L + min(l + u, L - 1);
-                cv[u] = ld4(xin + row * D + 4 * q);
+                cv[u] = ldv4(xin + row * D + 4 * q);
                 cmu[u] = mean[row];
                 crs[u] = rstd[row];
-                if (dx && dx_add) ca[u] = ld4(dx_add + row * D + 4 * q);
+                if (dx && dx_add) ca[u] = ldv4(dx_add + row * D + 4 * q);
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void ln_dwconv_bwd_kernel(const float* __restr
                     o.z = rs * (g.z - s1 - xh.z * s2);
                     o.w = rs * (g.w - s1 - xh.w * s2);
                     if (dx_add) o = f4add(o, ca[u]);
-                    st4(dx + row * D + 4 * q, o);
+                    stv4(dx + row * D + 4 * q, o);
                 }
             }
         }
@@ -238,10 +238,10 @@ static bool ld_shape_ok(int D, int k) {
     return D % 4 == 0 && D4 >= 4 && D4 <= 64 && (D4 & (D4 - 1)) == 0 && k >= 1 && k <= 9 && (k & 1) == 1;
 }
 
-extern "C" int stage_ln_dwconv_fwd(const float* x, const float* res, int res_period, float* sum_out, const float* gamma,
-                                   const float* beta, const float* w, const float* bias, float* h, float* mean,
-                                   float* rstd, long long M, int L, int D, int k, float eps, float p_drop,
-                                   unsigned long long seed, void* stream) {
+template <typename T>
+static int ln_dwconv_fwd_t(const T* x, const T* res, int res_period, T* sum_out, const float* gamma, const float* beta,
+                           const float* w, const float* bias, T* h, float* mean, float* rstd, long long M, int L, int D, int k,
+                           float eps, float p_drop, unsigned long long seed, void* stream) {
     if (M <= 0 || L <= 0) return 0;
     if (!ld_shape_ok(D, k)) return STAGE_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
@@ -254,7 +254,7 @@ extern "C" int stage_ln_dwconv_fwd(const float* x, const float* res, int res_per
     const uint32_t th = dr ? drop_thresh16(p_drop) : 0u;
     const float ik = dr ? 1.0f / (1.0f - p_drop) : 1.0f;
 #define LD_FWD(KV, DR)                                                                                                   \
-    hipLaunchKernelGGL((ln_dwconv_fwd_kernel<KV, DR>), dim3(grid), dim3(256), 0, st, x, res, res_period, sum_out, gamma,  \
+    hipLaunchKernelGGL((ln_dwconv_fwd_kernel<KV, DR, T>), dim3(grid), dim3(256), 0, st, x, res, res_period, sum_out, gamma,  \
                        beta, w, bias, h, mean, rstd, (long)M, L, D, eps, sd, th, ik, clen)
     switch (k) {
         case 1: if (dr) LD_FWD(1, true); else LD_FWD(1, false); break;
@@ -268,12 +268,29 @@ extern "C" int stage_ln_dwconv_fwd(const float* x, const float* res, int res_per
     return 0;
 }
 
+extern "C" int stage_ln_dwconv_fwd(const float* x, const float* res, int res_period, float* sum_out, const float* gamma,
+                                   const float* beta, const float* w, const float* bias, float* h, float* mean,
+                                   float* rstd, long long M, int L, int D, int k, float eps, float p_drop,
+                                   unsigned long long seed, void* stream) {
+    return ln_dwconv_fwd_t<float>(x, res, res_period, sum_out, gamma, beta, w, bias, h, mean, rstd, M, L, D, k, eps, p_drop, seed,
+                                  stream);
+}
+extern "C" int stage_ln_dwconv_fwd_bf16(const void* x, const void* res, int res_period, void* sum_out, const float* gamma,
+                                        const float* beta, const float* w, const float* bias, void* h, float* mean,
+                                        float* rstd, long long M, int L, int D, int k, float eps, float p_drop,
+                                        unsigned long long seed, void* stream) {
+    typedef stage_bf16 B;
+    return ln_dwconv_fwd_t<B>((const B*)x, (const B*)res, res_period, (B*)sum_out, gamma, beta, w, bias, (B*)h, mean, rstd, M, L, D,
+                              k, eps, p_drop, seed, stream);
+}
+
 extern "C" size_t stage_ln_dwconv_bwd_ws_bytes(int D, int k) { return (size_t)LD_PART_CAP * (k + 3) * D * sizeof(float); }
 
-extern "C" int stage_ln_dwconv_bwd(const float* dh, const float* xin, const float* mean, const float* rstd,
-                                   const float* gamma, const float* beta, const float* w, float* dx, const float* dx_add,
-                                   float* dgamma, float* dbeta, float* dw, float* db, long long M, int L, int D, int k,
-                                   float p_drop, unsigned long long seed, void* ws, size_t ws_bytes, void* stream) {
+template <typename T>
+static int ln_dwconv_bwd_t(const T* dh, const T* xin, const float* mean, const float* rstd, const float* gamma,
+                           const float* beta, const float* w, T* dx, const T* dx_add, float* dgamma, float* dbeta, float* dw,
+                           float* db, long long M, int L, int D, int k, float p_drop, unsigned long long seed, void* ws,
+                           size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (!ld_shape_ok(D, k)) return STAGE_ERR_SHAPE;
     if (ws_bytes < stage_ln_dwconv_bwd_ws_bytes(D, k)) return STAGE_ERR_WORKSPACE;
@@ -296,7 +313,7 @@ extern "C" int stage_ln_dwconv_bwd(const float* dh, const float* xin, const floa
     const uint32_t th = dr ? drop_thresh16(p_drop) : 0u;
     const float ik = dr ? 1.0f / (1.0f - p_drop) : 1.0f;
 #define LD_BWD(KV, DR)                                                                                                    \
-    hipLaunchKernelGGL((ln_dwconv_bwd_kernel<KV, DR>), dim3(grid), dim3(256), lds, st, dh, xin, mean, rstd, gamma, beta, w, \
+    hipLaunchKernelGGL((ln_dwconv_bwd_kernel<KV, DR, T>), dim3(grid), dim3(256), lds, st, dh, xin, mean, rstd, gamma, beta, w, \
                        dx, dx_add, part_conv, part_ln, (long)M, L, D, sd, th, ik, clen)
     switch (k) {
         case 1: if (dr) LD_BWD(1, true); else LD_BWD(1, false); break;
@@ -311,4 +328,21 @@ extern "C" int stage_ln_dwconv_bwd(const float* dh, const float* xin, const floa
     stage_colreduce(part_ln, dgamma, dbeta, grid, (long)2 * D, 2 * D, D, 1, st);
     STAGE_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int stage_ln_dwconv_bwd(const float* dh, const float* xin, const float* mean, const float* rstd,
+                                   const float* gamma, const float* beta, const float* w, float* dx, const float* dx_add,
+                                   float* dgamma, float* dbeta, float* dw, float* db, long long M, int L, int D, int k,
+                                   float p_drop, unsigned long long seed, void* ws, size_t ws_bytes, void* stream) {
+    return ln_dwconv_bwd_t<float>(dh, xin, mean, rstd, gamma, beta, w, dx, dx_add, dgamma, dbeta, dw, db, M, L, D, k, p_drop, seed,
+                                  ws, ws_bytes, stream);
+}
+// bf16 storage mode: activations (dh, xin, dx, dx_add) bf16; statistics, parameters and their gradients fp32
+extern "C" int stage_ln_dwconv_bwd_bf16(const void* dh, const void* xin, const float* mean, const float* rstd,
+                                        const float* gamma, const float* beta, const float* w, void* dx, const void* dx_add,
+                                        float* dgamma, float* dbeta, float* dw, float* db, long long M, int L, int D, int k,
+                                        float p_drop, unsigned long long seed, void* ws, size_t ws_bytes, void* stream) {
+    typedef stage_bf16 B;
+    return ln_dwconv_bwd_t<B>((const B*)dh, (const B*)xin, mean, rstd, gamma, beta, w, (B*)dx, (const B*)dx_add, dgamma, dbeta, dw,
+                              db, M, L, D, k, p_drop, seed, ws, ws_bytes, stream);
 }

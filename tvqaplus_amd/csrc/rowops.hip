@@ -243,9 +243,9 @@ __device__ __forceinline__ long a_row_fast(long row, int rep, int inner) {
     return (long)(gq * (unsigned)inner + r % (unsigned)inner);
 }
 
-template <int MODE, bool DROP, int NQ0>
-__global__ __launch_bounds__(256) void ln_fwd_fast_kernel(RowSrc src, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float* __restrict__ y,
+template <int MODE, bool DROP, int NQ0, typename T = float>
+__global__ __launch_bounds__(256) void ln_fwd_fast_kernel(RowSrcT<T> src, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, T* __restrict__ y,
                                                           float* __restrict__ mean, float* __restrict__ rstd, long rows,
                                                           int K, float eps, int LPR, uint64_t seed, uint32_t th,
                                                           float inv_keep) {
@@ -277,12 +277,12 @@ __global__ __launch_bounds__(256) void ln_fwd_fast_kernel(RowSrc src, const floa
                 const long rr = src.b ? (src.inner > 0 ? (long)((unsigned)rc % (unsigned)src.inner) : rc) : 0;
 #pragma unroll
                 for (int t = 0; t < NQ; t++) {
-                    v[u][t] = ld4s(src.x + rc * K + 4 * jc[t]);
-                    if (src.b) rv[u][t] = ld4(src.b + rr * K + 4 * jc[t]);
+                    v[u][t] = ldv4s(src.x + rc * K + 4 * jc[t]);
+                    if (src.b) rv[u][t] = ldv4(src.b + rr * K + 4 * jc[t]);
                 }
             } else {
-                v[u][0] = ld4(src.x + a_row_fast(rc, src.rep, src.inner) * D + 4 * sl);
-                v[u][1] = ld4s(src.b + rc * D + 4 * sl);
+                v[u][0] = ldv4(src.x + a_row_fast(rc, src.rep, src.inner) * D + 4 * sl);
+                v[u][1] = ldv4s(src.b + rc * D + 4 * sl);
             }
         }
 #pragma unroll
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void ln_fwd_fast_kernel(RowSrc src, const floa
                 for (int t = 0; t < NQ; t++) {
                     if (src.b) {
                         v[u][t] = f4add(v[u][t], rv[u][t]);
-                        if (src.sum_out && ok && jok[t]) st4(src.sum_out + row[u] * K + 4 * jq[t], v[u][t]);
+                        if (src.sum_out && ok && jok[t]) stv4(src.sum_out + row[u] * K + 4 * jq[t], v[u][t]);
                     }
                     if (!jok[t]) v[u][t] = f4zero();
                     s += f4hsum(v[u][t]);
@@ -325,17 +325,17 @@ __global__ __launch_bounds__(256) void ln_fwd_fast_kernel(RowSrc src, const floa
                 o.z = (v[u][t].z - mu) * rs * gm[t].z + bt[t].z;
                 o.w = (v[u][t].w - mu) * rs * gm[t].w + bt[t].w;
                 if (DROP) o = f4mul(o, drop4(seed, (uint64_t)row[u] * K4 + jq[t], th, inv_keep));
-                if (ok && jok[t]) st4(y + row[u] * K + 4 * jq[t], o);
+                if (ok && jok[t]) stv4(y + row[u] * K + 4 * jq[t], o);
             }
         }
     }
 }
 
-template <int MODE, bool DROP, int NQ0>
-__global__ __launch_bounds__(256) void ln_bwd_fast_kernel(RowSrc src, const float* __restrict__ dy,
+template <int MODE, bool DROP, int NQ0, typename T = float, typename TDX = T>
+__global__ __launch_bounds__(256) void ln_bwd_fast_kernel(RowSrcT<T> src, const T* __restrict__ dy,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                          const float* __restrict__ gamma, float* __restrict__ dx,
-                                                          float* __restrict__ db_out, float* __restrict__ part, long rows,
+                                                          const float* __restrict__ gamma, TDX* __restrict__ dx,
+                                                          T* __restrict__ db_out, float* __restrict__ part, long rows,
                                                           int K, int LPR, uint64_t seed, uint32_t th, float inv_keep) {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [wpb*RPW][2][K]
     constexpr int NQ = (MODE == 0) ? NQ0 : 3;
@@ -369,15 +369,15 @@ __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(RowSrc src, const floa
             if (MODE == 0) {
 #pragma unroll
                 for (int t = 0; t < NQ; t++) {
-                    xv[u][t] = ld4s(src.x + rc * K + 4 * jc[t]);
-                    if (dx && src.b) ra[u][t] = ld4(src.b + rc * K + 4 * jc[t]);
+                    xv[u][t] = ldv4s(src.x + rc * K + 4 * jc[t]);
+                    if (dx && src.b) ra[u][t] = ldv4(src.b + rc * K + 4 * jc[t]);
                 }
             } else {
-                xv[u][0] = ld4(src.x + a_row_fast(rc, src.rep, src.inner) * D + 4 * sl);
-                xv[u][1] = ld4s(src.b + rc * D + 4 * sl);
+                xv[u][0] = ldv4(src.x + a_row_fast(rc, src.rep, src.inner) * D + 4 * sl);
+                xv[u][1] = ldv4s(src.b + rc * D + 4 * sl);
             }
 #pragma unroll
-            for (int t = 0; t < NQ; t++) d[u][t] = ld4s(dy + rc * K + 4 * jc[t]);
+            for (int t = 0; t < NQ; t++) d[u][t] = ldv4s(dy + rc * K + 4 * jc[t]);
         }
 #pragma unroll
         for (int u = 0; u < LN_UR; u++) {
@@ -412,13 +412,13 @@ __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(RowSrc src, const floa
 #pragma unroll
                     for (int t = 0; t < NQ; t++) {
                         if (src.b) dz[t] = f4add(dz[t], ra[u][t]);  // + gradient of the exported sum
-                        if (jok[t]) st4(dx + row[u] * K + 4 * jq[t], dz[t]);
+                        if (jok[t]) stv4(dx + row[u] * K + 4 * jq[t], dz[t]);
                     }
                 }
             } else if (ok) {
                 // z = [a, b, a*b]:  da = dz0 + dz2*b ; db = dz1 + dz2*a
-                st4(dx + row[u] * D + 4 * sl, f4add(dz[0], f4mul(dz[NQ - 1], xv[u][NX - 1])));
-                st4(db_out + row[u] * D + 4 * sl, f4add(dz[NQ > 1 ? 1 : 0], f4mul(dz[NQ - 1], xv[u][0])));
+                stv4(dx + row[u] * D + 4 * sl, f4add(dz[0], f4mul(dz[NQ - 1], xv[u][NX - 1])));
+                stv4(db_out + row[u] * D + 4 * sl, f4add(dz[NQ > 1 ? 1 : 0], f4mul(dz[NQ - 1], xv[u][0])));
             }
         }
     }
@@ -447,11 +447,11 @@ __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(RowSrc src, const floa
 // (group, chunk, in) is written -- instead of a full (rows, D) tensor that stage_reduce_rep reads back (2 x 491 MB at the
 // full config).  `a` is loaded once per workgroup.  da_part: [G][CH][inner][D].
 // ------------------------------------------------------------------------------------------------
-template <bool DROP, int KI>
-__global__ __launch_bounds__(256) void cat3_ln_bwd_rep_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                              const float* __restrict__ dy, const float* __restrict__ mean,
+template <bool DROP, int KI, typename T = float>
+__global__ __launch_bounds__(256) void cat3_ln_bwd_rep_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                              const T* __restrict__ dy, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                              float* __restrict__ da_part, float* __restrict__ db,
+                                                              float* __restrict__ da_part, T* __restrict__ db,
                                                               float* __restrict__ part, int D, int rep, int inner, int CH,
                                                               int fpc, uint64_t seed, uint32_t th, float inv_keep) {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [RB][2][K]
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256) void cat3_ln_bwd_rep_kernel(const float* __res
         const int in = slot + RB * k;
         iok[k] = in < inner;
         inx[k] = iok[k] ? in : inner - 1;
-        av[k] = ld4(a + ((long)g * inner + inx[k]) * D + 4 * sl);
+        av[k] = ldv4(a + ((long)g * inner + inx[k]) * D + 4 * sl);
         dacc[k] = f4zero();
     }
     for (int f = f0; f < f1; f++) {
@@ -482,9 +482,9 @@ __global__ __launch_bounds__(256) void cat3_ln_bwd_rep_kernel(const float* __res
 #pragma unroll
         for (int k = 0; k < KI; k++) {
             const long row = rbase + inx[k];
-            bv[k] = ld4s(b + row * D + 4 * sl);
+            bv[k] = ldv4s(b + row * D + 4 * sl);
 #pragma unroll
-            for (int t = 0; t < 3; t++) d[k][t] = ld4s(dy + row * K + 4 * (t * D4 + sl));
+            for (int t = 0; t < 3; t++) d[k][t] = ldv4s(dy + row * K + 4 * (t * D4 + sl));
             mu[k] = mean[row];
             rs[k] = rstd[row];
         }
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void cat3_ln_bwd_rep_kernel(const float* __res
             // z = [a, b, a*b]:  da = dz0 + dz2*b ; db = dz1 + dz2*a
             if (iok[k]) {
                 dacc[k] = f4add(dacc[k], f4add(dz[0], f4mul(dz[2], bv[k])));
-                st4(db + row * D + 4 * sl, f4add(dz[1], f4mul(dz[2], av[k])));
+                stv4(db + row * D + 4 * sl, f4add(dz[1], f4mul(dz[2], av[k])));
             }
         }
     }
@@ -559,8 +559,8 @@ static int ln_lpr(int K4) {
 
 extern "C" size_t stage_ln_bwd_ws_bytes(int K) { return (size_t)PART_CAP * 2 * (size_t)K * sizeof(float); }
 
-template <int MODE>
-static int ln_fwd_launch(RowSrc src, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+template <int MODE, typename T = float>
+static int ln_fwd_launch(RowSrcT<T> src, const float* gamma, const float* beta, T* y, float* mean, float* rstd,
                          long long rows, int K, int LPR, float eps, float p_drop, unsigned long long seed,
                          hipStream_t st) {
     const int rows_per_block = 4 * (64 / LPR);
@@ -573,7 +573,7 @@ static int ln_fwd_launch(RowSrc src, const float* gamma, const float* beta, floa
         const uint32_t th = dr ? drop_thresh16(p_drop) : 0u;
         const float ik = dr ? 1.0f / (1.0f - p_drop) : 1.0f;
 #define LN_FWD_FAST(DR, NQV)                                                                                           \
-    hipLaunchKernelGGL((ln_fwd_fast_kernel<MODE, DR, NQV>), dim3(gridf), dim3(256), 0, st, src, gamma, beta, y, mean, rstd, \
+    hipLaunchKernelGGL((ln_fwd_fast_kernel<MODE, DR, NQV, T>), dim3(gridf), dim3(256), 0, st, src, gamma, beta, y, mean, rstd, \
                        (long)rows, K, eps, LPR, sd, th, ik)
         switch (MODE == 0 ? nq : 1) {
             case 1: if (dr) LN_FWD_FAST(true, 1); else LN_FWD_FAST(false, 1); break;
@@ -587,18 +587,18 @@ static int ln_fwd_launch(RowSrc src, const float* gamma, const float* beta, floa
     }
     const int grid = stage_grid_for(rows, rows_per_block, GRID_CAP * 4);
     if (p_drop > 0.f)
-        hipLaunchKernelGGL((ln_fwd_kernel<MODE, true>), dim3(grid), dim3(256), 0, st, src, gamma, beta, y, mean, rstd,
+        hipLaunchKernelGGL((ln_fwd_kernel<MODE, true, T>), dim3(grid), dim3(256), 0, st, src, gamma, beta, y, mean, rstd,
                            (long)rows, K, eps, LPR, (uint64_t)seed, drop_thresh16(p_drop), 1.0f / (1.0f - p_drop));
     else
-        hipLaunchKernelGGL((ln_fwd_kernel<MODE, false>), dim3(grid), dim3(256), 0, st, src, gamma, beta, y, mean, rstd,
+        hipLaunchKernelGGL((ln_fwd_kernel<MODE, false, T>), dim3(grid), dim3(256), 0, st, src, gamma, beta, y, mean, rstd,
                            (long)rows, K, eps, LPR, (uint64_t)0, 0u, 1.0f);
     STAGE_LAUNCH_CHECK();
     return 0;
 }
 
-template <int MODE>
-static int ln_bwd_launch(RowSrc src, const float* dy, const float* mean, const float* rstd, const float* gamma,
-                         float* dx, float* db_out, float* dgamma, float* dbeta, long long rows, int K, int LPR,
+template <int MODE, typename T = float, typename TDX = T>
+static int ln_bwd_launch(RowSrcT<T> src, const T* dy, const float* mean, const float* rstd, const float* gamma,
+                         TDX* dx, T* db_out, float* dgamma, float* dbeta, long long rows, int K, int LPR,
                          float p_drop, unsigned long long seed, void* ws, size_t ws_bytes, hipStream_t st) {
     if (ws_bytes < stage_ln_bwd_ws_bytes(K)) return STAGE_ERR_WORKSPACE;
     if (rows <= 0) {
@@ -619,7 +619,7 @@ static int ln_bwd_launch(RowSrc src, const float* dy, const float* mean, const f
         const uint32_t th = dr ? drop_thresh16(p_drop) : 0u;
         const float ik = dr ? 1.0f / (1.0f - p_drop) : 1.0f;
 #define LN_BWD_FAST(DR, NQV)                                                                                            \
-    hipLaunchKernelGGL((ln_bwd_fast_kernel<MODE, DR, NQV>), dim3(grid), dim3(256), lds, st, src, dy, mean, rstd, gamma, dx, \
+    hipLaunchKernelGGL((ln_bwd_fast_kernel<MODE, DR, NQV, T, TDX>), dim3(grid), dim3(256), lds, st, src, dy, mean, rstd, gamma, dx, \
                        db_out, part, (long)rows, K, LPR, sd, th, ik)
         switch (MODE == 0 ? nq : 1) {
             case 1: if (dr) LN_BWD_FAST(true, 1); else LN_BWD_FAST(false, 1); break;
@@ -630,11 +630,11 @@ static int ln_bwd_launch(RowSrc src, const float* dy, const float* mean, const f
 #undef LN_BWD_FAST
     }
     else if (p_drop > 0.f)
-        hipLaunchKernelGGL((ln_bwd_kernel<MODE, true>), dim3(grid), dim3(256), lds, st, src, dy, mean, rstd, gamma, dx,
+        hipLaunchKernelGGL((ln_bwd_kernel<MODE, true, T, TDX>), dim3(grid), dim3(256), lds, st, src, dy, mean, rstd, gamma, dx,
                            db_out, part, (long)rows, K, LPR, (uint64_t)seed, drop_thresh16(p_drop),
                            1.0f / (1.0f - p_drop));
     else
-        hipLaunchKernelGGL((ln_bwd_kernel<MODE, false>), dim3(grid), dim3(256), lds, st, src, dy, mean, rstd, gamma, dx,
+        hipLaunchKernelGGL((ln_bwd_kernel<MODE, false, T, TDX>), dim3(grid), dim3(256), lds, st, src, dy, mean, rstd, gamma, dx,
                            db_out, part, (long)rows, K, LPR, (uint64_t)0, 0u, 1.0f);
     STAGE_LAUNCH_CHECK();
     // one launch for both: column c = t*K + d of the [2][K] partial rows goes to dgamma[d] (t = 0) or dbeta[d] (t = 1)
@@ -649,7 +649,7 @@ extern "C" int stage_layernorm_fwd(const float* x, const float* res, int res_per
     if (rows <= 0) return 0;
     if (K % 4 != 0 || K > 4 * MAXV * 64) return STAGE_ERR_SHAPE;
     RowSrc src{x, res, 0, 1, res_period, sum_out};
-    return ln_fwd_launch<0>(src, gamma, beta, y, mean, rstd, rows, K, ln_lpr(K / 4), eps, p_drop, seed,
+    return ln_fwd_launch<0, float>(src, gamma, beta, y, mean, rstd, rows, K, ln_lpr(K / 4), eps, p_drop, seed,
                             (hipStream_t)stream);
 }
 
@@ -659,7 +659,7 @@ extern "C" int stage_layernorm_bwd(const float* dy, const float* x, const float*
                                    size_t ws_bytes, void* stream) {
     if (K % 4 != 0 || K > 4 * MAXV * 64) return STAGE_ERR_SHAPE;
     RowSrc src{x, dx_add, 0, 1, 0, nullptr};
-    return ln_bwd_launch<0>(src, dy, mean, rstd, gamma, dx, nullptr, dgamma, dbeta, rows, K, ln_lpr(K / 4), p_drop,
+    return ln_bwd_launch<0, float, float>(src, dy, mean, rstd, gamma, dx, (float*)nullptr, dgamma, dbeta, rows, K, ln_lpr(K / 4), p_drop,
                             seed, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -670,7 +670,7 @@ extern "C" int stage_cat3_layernorm_fwd(const float* a, const float* b, const fl
     if (rows <= 0) return 0;
     if (D % 4 != 0 || D > 256 || rep < 1 || inner < 1) return STAGE_ERR_SHAPE;
     RowSrc src{a, b, D, rep, inner, nullptr};
-    return ln_fwd_launch<1>(src, gamma, beta, y, mean, rstd, rows, 3 * D, ln_lpr(D / 4), eps, p_drop, seed,
+    return ln_fwd_launch<1, float>(src, gamma, beta, y, mean, rstd, rows, 3 * D, ln_lpr(D / 4), eps, p_drop, seed,
                             (hipStream_t)stream);
 }
 
@@ -682,7 +682,7 @@ extern "C" int stage_cat3_layernorm_bwd(const float* dy, const float* a, const f
                                         void* stream) {
     if (D % 4 != 0 || D > 256 || rep < 1 || inner < 1) return STAGE_ERR_SHAPE;
     RowSrc src{a, b, D, rep, inner, nullptr};
-    return ln_bwd_launch<1>(src, dy, mean, rstd, gamma, da_full, db, dgamma, dbeta, rows, 3 * D, ln_lpr(D / 4),
+    return ln_bwd_launch<1, float, float>(src, dy, mean, rstd, gamma, da_full, db, dgamma, dbeta, rows, 3 * D, ln_lpr(D / 4),
                             p_drop, seed, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -702,11 +702,10 @@ extern "C" size_t stage_cat3_layernorm_bwd_reduced_ws_bytes(long long rows, int 
     return ((size_t)groups * CH * 2 * 3 * D + (size_t)groups * CH * inner * D) * sizeof(float);
 }
 // da[rows/rep, D] already reduced over `rep`; requires rep > 1, D/4 a power of two in [4, 64], inner <= 64
-extern "C" int stage_cat3_layernorm_bwd_reduced(const float* dy, const float* a, const float* b, const float* mean,
-                                                const float* rstd, const float* gamma, float* da, float* db,
-                                                float* dgamma, float* dbeta, long long rows, int D, int rep, int inner,
-                                                float p_drop, unsigned long long seed, void* ws, size_t ws_bytes,
-                                                void* stream) {
+template <typename T>
+static int cat3_bwd_reduced_t(const T* dy, const T* a, const T* b, const float* mean, const float* rstd, const float* gamma,
+                              float* da, T* db, float* dgamma, float* dbeta, long long rows, int D, int rep, int inner,
+                              float p_drop, unsigned long long seed, void* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int D4 = D / 4;
     if (D % 4 != 0 || D4 < 4 || D4 > 64 || (D4 & (D4 - 1)) != 0 || rep < 2 || inner < 1 || inner > 64 ||
@@ -727,7 +726,7 @@ extern "C" int stage_cat3_layernorm_bwd_reduced(const float* dy, const float* a,
     const uint32_t th = dr ? drop_thresh16(p_drop) : 0u;
     const float ik = dr ? 1.0f / (1.0f - p_drop) : 1.0f;
 #define CAT3_REP(DR, KIV)                                                                                               \
-    hipLaunchKernelGGL((cat3_ln_bwd_rep_kernel<DR, KIV>), dim3(grid), dim3(256), lds, st, a, b, dy, mean, rstd, gamma,    \
+    hipLaunchKernelGGL((cat3_ln_bwd_rep_kernel<DR, KIV, T>), dim3(grid), dim3(256), lds, st, a, b, dy, mean, rstd, gamma,    \
                        da_part, db, part, D, rep, inner, CH, fpc, sd, th, ik)
     if (KI > 8) return STAGE_ERR_SHAPE;
     switch (KI) {
@@ -745,6 +744,15 @@ extern "C" int stage_cat3_layernorm_bwd_reduced(const float* dy, const float* a,
     stage_colreduce(part, dgamma, dbeta, grid, (long)2 * K, 2 * K, K, 1, st);
     STAGE_LAUNCH_CHECK();
     return stage_reduce_rep(da_part, da, groups, CH, (long long)inner * D, stream);
+}
+
+extern "C" int stage_cat3_layernorm_bwd_reduced(const float* dy, const float* a, const float* b, const float* mean,
+                                                const float* rstd, const float* gamma, float* da, float* db,
+                                                float* dgamma, float* dbeta, long long rows, int D, int rep, int inner,
+                                                float p_drop, unsigned long long seed, void* ws, size_t ws_bytes,
+                                                void* stream) {
+    return cat3_bwd_reduced_t<float>(dy, a, b, mean, rstd, gamma, da, db, dgamma, dbeta, rows, D, rep, inner, p_drop, seed, ws,
+                                     ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -991,54 +999,13 @@ extern "C" int stage_masked_max_bwd(const float* dout, const int* argmax, const 
 // ------------------------------------------------------------------------------------------------
 typedef stage_bf16 B16;
 
-template <int MODE>
-static int ln_fwd_launch_b(RowSrcT<B16> src, const float* gamma, const float* beta, B16* y, float* mean, float* rstd,
-                           long long rows, int K, int LPR, float eps, float p_drop, unsigned long long seed, hipStream_t st) {
-    const int rows_per_block = 4 * (64 / LPR);
-    const int grid = stage_grid_for(rows, rows_per_block, GRID_CAP * 4);
-    if (p_drop > 0.f)
-        hipLaunchKernelGGL((ln_fwd_kernel<MODE, true, B16>), dim3(grid), dim3(256), 0, st, src, gamma, beta, y, mean, rstd,
-                           (long)rows, K, eps, LPR, (uint64_t)seed, drop_thresh16(p_drop), 1.0f / (1.0f - p_drop));
-    else
-        hipLaunchKernelGGL((ln_fwd_kernel<MODE, false, B16>), dim3(grid), dim3(256), 0, st, src, gamma, beta, y, mean, rstd,
-                           (long)rows, K, eps, LPR, (uint64_t)0, 0u, 1.0f);
-    STAGE_LAUNCH_CHECK();
-    return 0;
-}
-
-template <int MODE, typename TDX>
-static int ln_bwd_launch_b(RowSrcT<B16> src, const B16* dy, const float* mean, const float* rstd, const float* gamma, TDX* dx,
-                           B16* db_out, float* dgamma, float* dbeta, long long rows, int K, int LPR, float p_drop,
-                           unsigned long long seed, void* ws, size_t ws_bytes, hipStream_t st) {
-    if (ws_bytes < stage_ln_bwd_ws_bytes(K)) return STAGE_ERR_WORKSPACE;
-    if (rows <= 0) {
-        (void)hipMemsetAsync(dgamma, 0, sizeof(float) * K, st);
-        (void)hipMemsetAsync(dbeta, 0, sizeof(float) * K, st);
-        return 0;
-    }
-    const int rows_per_block = 4 * (64 / LPR);
-    const int grid = stage_grid_for(rows, rows_per_block * 8, PART_CAP);
-    const size_t lds = (size_t)rows_per_block * 2 * K * sizeof(float);
-    float* part = (float*)ws;
-    if (p_drop > 0.f)
-        hipLaunchKernelGGL((ln_bwd_kernel<MODE, true, B16, TDX>), dim3(grid), dim3(256), lds, st, src, dy, mean, rstd, gamma, dx,
-                           db_out, part, (long)rows, K, LPR, (uint64_t)seed, drop_thresh16(p_drop), 1.0f / (1.0f - p_drop));
-    else
-        hipLaunchKernelGGL((ln_bwd_kernel<MODE, false, B16, TDX>), dim3(grid), dim3(256), lds, st, src, dy, mean, rstd, gamma, dx,
-                           db_out, part, (long)rows, K, LPR, (uint64_t)0, 0u, 1.0f);
-    STAGE_LAUNCH_CHECK();
-    stage_colreduce(part, dgamma, dbeta, grid, (long)2 * K, 2 * K, K, 1, st);
-    STAGE_LAUNCH_CHECK();
-    return 0;
-}
-
 extern "C" int stage_layernorm_fwd_bf16(const void* x, const void* res, int res_period, void* sum_out, const float* gamma,
                                         const float* beta, void* y, float* mean, float* rstd, long long rows, int K,
                                         float eps, float p_drop, unsigned long long seed, void* stream) {
     if (rows <= 0) return 0;
     if (K % 4 != 0 || K > 4 * MAXV * 64) return STAGE_ERR_SHAPE;
     RowSrcT<B16> src{(const B16*)x, (const B16*)res, 0, 1, res_period, (B16*)sum_out};
-    return ln_fwd_launch_b<0>(src, gamma, beta, (B16*)y, mean, rstd, rows, K, ln_lpr(K / 4), eps, p_drop, seed, (hipStream_t)stream);
+    return ln_fwd_launch<0, B16>(src, gamma, beta, (B16*)y, mean, rstd, rows, K, ln_lpr(K / 4), eps, p_drop, seed, (hipStream_t)stream);
 }
 
 extern "C" int stage_layernorm_bwd_bf16(const void* dy, const void* x, const float* mean, const float* rstd,
@@ -1047,7 +1014,7 @@ extern "C" int stage_layernorm_bwd_bf16(const void* dy, const void* x, const flo
                                         size_t ws_bytes, void* stream) {
     if (K % 4 != 0 || K > 4 * MAXV * 64) return STAGE_ERR_SHAPE;
     RowSrcT<B16> src{(const B16*)x, (const B16*)dx_add, 0, 1, 0, nullptr};
-    return ln_bwd_launch_b<0, B16>(src, (const B16*)dy, mean, rstd, gamma, (B16*)dx, nullptr, dgamma, dbeta, rows, K,
+    return ln_bwd_launch<0, B16, B16>(src, (const B16*)dy, mean, rstd, gamma, (B16*)dx, (B16*)nullptr, dgamma, dbeta, rows, K,
                                    ln_lpr(K / 4), p_drop, seed, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -1057,7 +1024,7 @@ extern "C" int stage_cat3_layernorm_fwd_bf16(const void* a, const void* b, const
     if (rows <= 0) return 0;
     if (D % 4 != 0 || D > 256 || rep < 1 || inner < 1) return STAGE_ERR_SHAPE;
     RowSrcT<B16> src{(const B16*)a, (const B16*)b, D, rep, inner, nullptr};
-    return ln_fwd_launch_b<1>(src, gamma, beta, (B16*)y, mean, rstd, rows, 3 * D, ln_lpr(D / 4), eps, p_drop, seed,
+    return ln_fwd_launch<1, B16>(src, gamma, beta, (B16*)y, mean, rstd, rows, 3 * D, ln_lpr(D / 4), eps, p_drop, seed,
                               (hipStream_t)stream);
 }
 
@@ -1068,7 +1035,7 @@ extern "C" int stage_cat3_layernorm_bwd_bf16(const void* dy, const void* a, cons
                                              unsigned long long seed, void* ws, size_t ws_bytes, void* stream) {
     if (D % 4 != 0 || D > 256 || rep < 1 || inner < 1) return STAGE_ERR_SHAPE;
     RowSrcT<B16> src{(const B16*)a, (const B16*)b, D, rep, inner, nullptr};
-    return ln_bwd_launch_b<1, float>(src, (const B16*)dy, mean, rstd, gamma, da_full, (B16*)db, dgamma, dbeta, rows, 3 * D,
+    return ln_bwd_launch<1, B16, float>(src, (const B16*)dy, mean, rstd, gamma, da_full, (B16*)db, dgamma, dbeta, rows, 3 * D,
                                      ln_lpr(D / 4), p_drop, seed, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -1126,4 +1093,14 @@ extern "C" int stage_masked_max_bwd_bf16(const void* dout, const int* argmax, co
                        (B16*)dx, (long)R, L, D / 4, accumulate);
     STAGE_LAUNCH_CHECK();
     return 0;
+}
+
+// da (rows / rep, D) comes back in fp32 (it is a sum over the `rep` frames), db (rows, D) in bf16
+extern "C" int stage_cat3_layernorm_bwd_reduced_bf16(const void* dy, const void* a, const void* b, const float* mean,
+                                                     const float* rstd, const float* gamma, float* da, void* db,
+                                                     float* dgamma, float* dbeta, long long rows, int D, int rep, int inner,
+                                                     float p_drop, unsigned long long seed, void* ws, size_t ws_bytes,
+                                                     void* stream) {
+    return cat3_bwd_reduced_t<B16>((const B16*)dy, (const B16*)a, (const B16*)b, mean, rstd, gamma, da, (B16*)db, dgamma, dbeta,
+                                   rows, D, rep, inner, p_drop, seed, ws, ws_bytes, stream);
 }

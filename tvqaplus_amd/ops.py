@@ -207,7 +207,17 @@ class _Cat3LayerNorm(torch.autograd.Function):
         lib = _lib.load()
         d4 = D // 4
         if b.dtype == _BF16:
-            # bf16 storage: the unreduced da rows stay fp32 (scratch), reduced over the broadcast, rounded once
+            if rep > 1 and D % 4 == 0 and 4 <= d4 <= 64 and (d4 & (d4 - 1)) == 0 and inner <= 64:
+                da = torch.empty(a.shape, dtype=torch.float32, device=a.device)   # a sum over the frames: fp32, rounded once
+                wsb = lib.stage_cat3_layernorm_bwd_reduced_ws_bytes(rows, D, rep, inner)
+                ws = _workspace(wsb, b.device)
+                rc = lib.stage_cat3_layernorm_bwd_reduced_bf16(_ptr(dy), _ptr(a), _ptr(b), _ptr(mean), _ptr(rstd), _ptr(gamma),
+                                                               _ptr(da), _ptr(db), _ptr(dgamma), _ptr(dbeta), rows, D, rep, inner,
+                                                               p, seed, _ptr(ws), wsb, _stream())
+                if rc != _lib.STAGE_ERR_SHAPE:
+                    _lib.check(rc, "stage_cat3_layernorm_bwd_reduced_bf16")
+                    return da.to(_BF16), db, dgamma, dbeta, None, None, None, None
+            # the unreduced da rows stay fp32 (scratch), reduced over the broadcast, rounded once
             da_full = torch.empty(b.shape, dtype=torch.float32, device=b.device)
             wsb = lib.stage_ln_bwd_ws_bytes(3 * D)
             ws = _workspace(wsb, b.device)
@@ -401,22 +411,24 @@ def dwconv(x, w, bias):
 # ---------------------------------------------------------------------------------------------------------------
 def ln_dwconv_supported(D: int, k: int, dtype=torch.float32) -> bool:
     d4 = D // 4
-    return dtype == torch.float32 and D % 4 == 0 and 4 <= d4 <= 64 and (d4 & (d4 - 1)) == 0 and 1 <= k <= 9 and k % 2 == 1
+    return dtype in (torch.float32, _BF16) and D % 4 == 0 and 4 <= d4 <= 64 and (d4 & (d4 - 1)) == 0 and 1 <= k <= 9 and k % 2 == 1
 
 
 class _LnDwConv(torch.autograd.Function):
     @_on_device
     def forward(ctx, x, res, gamma, beta, w, bias, res_period: int, p: float, seed: int):
-        x = _chk(x, "x")  # (M, L, D)
+        x = _act(x, "x")  # (M, L, D)
         M, L, D = x.shape
-        res_c = None if res is None else _chk(res, "res")
+        if res is not None and res_period > 0 and res.dtype != x.dtype:
+            res = res.to(x.dtype)          # the (L, D) position table follows the storage type
+        res_c = None if res is None else _act(res, "res", x)
         gamma, beta, w, bias = _chk(gamma, "gamma"), _chk(beta, "beta"), _chk(w, "w"), _chk(bias, "bias")
         k = w.shape[-1]
         h = torch.empty_like(x)
         mean = torch.empty(M * L, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
         s = torch.empty_like(x) if res_c is not None else None
-        _call("stage_ln_dwconv_fwd", _ptr(x), _ptr(res_c), int(res_period), _ptr(s), _ptr(gamma), _ptr(beta), _ptr(w),
+        _call("stage_ln_dwconv_fwd" + _sfx(x), _ptr(x), _ptr(res_c), int(res_period), _ptr(s), _ptr(gamma), _ptr(beta), _ptr(w),
               _ptr(bias), _ptr(h), _ptr(mean), _ptr(rstd), M, L, D, k, EPS_LN, float(p), int(seed), _stream())
         xin = s if res_c is not None else x
         ctx.save_for_backward(xin, mean, rstd, gamma, beta, w)
@@ -435,7 +447,7 @@ class _LnDwConv(torch.autograd.Function):
         k = w.shape[-1]
         if dh is None:
             dh = torch.zeros_like(xin)
-        dh = _chk(dh, "dh")
+        dh = _act(dh, "dh", xin)
         x_needs = ctx.needs_input_grad[0]
         res_needs = ctx.needs_input_grad[1] and ctx.res_full
         dx = torch.empty_like(xin) if (x_needs or res_needs) else None
@@ -447,8 +459,8 @@ class _LnDwConv(torch.autograd.Function):
         ws = _workspace(wsb, xin.device)
         dadd = None  # gradient arriving through the exported sum (next residual branch), fused into the dx store
         if dx is not None and ctx.has_res and dsum is not None and dsum.numel() == dx.numel():
-            dadd = _chk(dsum, "dsum")
-        _call("stage_ln_dwconv_bwd", _ptr(dh), _ptr(xin), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(w),
+            dadd = _act(dsum, "dsum", xin)
+        _call("stage_ln_dwconv_bwd" + _sfx(xin), _ptr(dh), _ptr(xin), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(w),
               _ptr(dx), _ptr(dadd), _ptr(dgamma), _ptr(dbeta), _ptr(dw), _ptr(db), M, L, D, k, ctx.p, ctx.seed,
               _ptr(ws), wsb, _stream())
         return (dx if x_needs else None), (dx if res_needs else None), dgamma, dbeta, dw, db, None, None, None
