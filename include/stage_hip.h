@@ -211,6 +211,7 @@ int stage_l2norm_bwd_bf16(const void* dy, const void* x, void* dx, long long row
                           unsigned long long seed, int accumulate, void* stream);
 int stage_gemm_nt_bf16(const void* X, const void* gate, const float* W, const float* bias, const void* residual, void* Y,
                        long long M, int N, int K, int relu, void* stream);
+size_t stage_gemm_tn_bf16_ws_bytes(long long M, int N, int K);
 int stage_gemm_tn_bf16(const void* dY, const void* gate, const void* X, float* dW, float* db, long long M, int N, int K,
                        void* ws, size_t ws_bytes, void* stream);
 int stage_dwconv_fwd_bf16(const void* in, const float* w, const float* bias, void* out, long long M, int L, int D, int k,

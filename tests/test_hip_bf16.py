@@ -106,7 +106,11 @@ def test_cat3_layernorm_bf16(ops, G, rep, inner, D):
 
 
 @pytest.mark.parametrize("M,N,K,relu", [(300, 128, 384, True), (1000, 256, 256, True), (77, 1, 128, False),
-                                         (5000, 300, 768, True), (4133, 256, 300, False), (130, 48, 20, True)])
+                                         (5000, 300, 768, True), (4133, 256, 300, False), (130, 48, 20, True),
+                                         # the streaming kernel (M >= 4096, K % 8 == 0, K <= 384, N % 128 == 0): ragged last
+                                         # row tile, 1..6 k-chunks with a ragged last one, 1..3 column tiles, ReLU gate
+                                         (4200, 128, 128, True), (5000, 384, 128, True), (4500, 128, 384, True),
+                                         (4097, 256, 256, False), (6000, 128, 200, True), (8200, 128, 72, True)])
 def test_linear_bf16(ops, M, N, K, relu):
     g = torch.Generator().manual_seed(M + N + K)
     x = rb(torch.randn(M, K, generator=g))

@@ -7,7 +7,7 @@ from tvqaplus_amd.stage import STAGE
 from tvqaplus_amd.synth import make_batch, make_opt
 sup = "--no_sup_att" not in sys.argv
 torch.manual_seed(2018)
-opt = make_opt(hsz=128, add_local=True, dropout=0.1, use_sup_att=sup)
+opt = make_opt(hsz=128, add_local=True, dropout=0.1, use_sup_att=sup, storage_dtype=os.environ.get("STORAGE", "fp32"))
 with contextlib.redirect_stdout(open(os.devnull, "w")):
     model = STAGE(opt).cuda().train()
 params = [p for p in model.parameters() if p.requires_grad]

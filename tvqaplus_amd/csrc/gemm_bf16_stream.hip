@@ -1,0 +1,331 @@
+// bf16 storage mode (BASELINE.json configs[4]): the tall-skinny Linear / 1x1-conv forward and dX GEMMs as HBM-streaming
+// kernels on 16-bit activations.
+//
+//   Y[M, N] = epi( (X .* [gate > 0]) [M, K] . W[N, K]^T + bias )        X, gate, Y: bf16   W, bias: fp32 master copies
+//
+// Same idea as gemm_stream.hip (the fp32 path), minus everything the 16-bit operands make unnecessary: the activations ARE
+// bf16, so there is no split and ONE v_mfma_f32_32x32x16_bf16 per term; the weight tile (128 output columns x K <= 384) is
+// rounded to bf16 once per workgroup and stays in LDS; every wave walks 32-row tiles of X, loading its rows straight from
+// HBM in MFMA operand layout (lane (row, half) reads 128 contiguous bytes of a 128-element chunk: the contraction index is
+// permuted the same way on both operands, which is free), the next chunk / next tile requested before the current one is
+// multiplied.  The product is accumulated TRANSPOSED (weight fragment = A operand): a lane then owns four consecutive output
+// columns of one row, packs them to 8 bytes, and the tile leaves through a per-wave LDS staging area as full 128-byte lines
+// (a direct store would write 8-byte pieces of 32 different lines per instruction -- what the memory system handles worst).
+// Shapes outside (K % 8 == 0, K <= 384, N % 128 == 0, M >= 4096, 8-byte aligned operands) take the tiled kernel of
+// gemm_bf16x3.hip.
+#include <stdlib.h>
+#include "common.h"
+#include "../../include/stage_hip.h"
+
+#define GB_BN 128                 // output columns per workgroup
+#define GB_WAVES 8
+#define GB_KC 64                  // k per chunk (4 MFMA steps): lane (row, half) reads 64 contiguous bytes
+#define GB_STG (64 + 8)           // bf16 per row of the store staging area (64 columns + pad: 144-byte stride)
+
+typedef __bf16 gb_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned gb_gate1(unsigned v, unsigned gg) {
+    // keep the bf16 halves of v whose gate half is > 0 (ReLU backward with the saved bf16 output as gate)
+    const unsigned lo = ((int)(gg << 16) > 0) ? 0x0000FFFFu : 0u;
+    const unsigned hi = ((int)(gg & 0xFFFF0000u) > 0) ? 0xFFFF0000u : 0u;
+    return v & (lo | hi);
+}
+__device__ __forceinline__ uint4 gb_gate(uint4 v, uint4 g) {
+    return make_uint4(gb_gate1(v.x, g.x), gb_gate1(v.y, g.y), gb_gate1(v.z, g.z), gb_gate1(v.w, g.w));
+}
+
+struct GbBuf { uint4 x[4], g[4]; };
+
+template <bool HAS_GATE, int NKC>
+__global__ __launch_bounds__(64 * GB_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_bf16_stream_kernel(
+    const stage_bf16* __restrict__ X, const stage_bf16* __restrict__ G, const float* __restrict__ W,
+    const float* __restrict__ bias, stage_bf16* __restrict__ Y, long M, int N, int K, int Kp, int relu) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+    unsigned short* Wl = lds;                                            // [GB_BN][Kp] bf16, natural k order, zero padded
+    unsigned short* stg = Wl + GB_BN * Kp;                               // [GB_WAVES][32][GB_STG]
+    float* bias_s = reinterpret_cast<float*>(stg + GB_WAVES * 32 * GB_STG);   // [GB_BN]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * GB_BN;
+    // ---- weight tile -> LDS (rounded to bf16 once) ----
+    const int K4p = Kp >> 2;
+    for (int e = tid; e < GB_BN * K4p; e += 64 * GB_WAVES) {
+        const int n = e / K4p, q = e - n * K4p;
+        float4 v = f4zero();
+        if (4 * q < K) v = ld4(W + (long)(n0 + n) * K + 4 * q);          // K % 4 == 0, n0 + n < N by the launcher
+        *reinterpret_cast<uint2*>(&Wl[n * Kp + 4 * q]) = make_uint2(stage_pk_bf16(v.x, v.y), stage_pk_bf16(v.z, v.w));
+    }
+    if (tid < GB_BN) bias_s[tid] = bias ? bias[n0 + tid] : 0.f;
+    __syncthreads();
+
+    const long MT = (M + 31) >> 5;
+    const long nw = (long)gridDim.x * GB_WAVES;
+    unsigned short* my_stg = stg + wave * 32 * GB_STG;
+    // this lane's 32 elements of chunk c of row `row`: k = 64 c + 32 h + 8 s .. +7  (s = MFMA step; the same permutation of
+    // the contraction index on the weight side)
+    auto fetch = [&](GbBuf& b, long row, int c) {
+        const long rc = row < M ? row : M - 1;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int k = c * GB_KC + 32 * h + 8 * s;
+            const long off = rc * K + (k < K ? k : 0);                   // past K: any valid address, zeroed at use
+            b.x[s] = *reinterpret_cast<const uint4*>(X + off);
+            if (HAS_GATE) b.g[s] = *reinterpret_cast<const uint4*>(G + off);
+        }
+    };
+    long t = (long)blockIdx.x * GB_WAVES + wave;
+    GbBuf b0, b1, bn;
+    if (t < MT) fetch(b0, t * 32 + l31, 0);
+    for (; t < MT; t += nw) {
+        const long row = t * 32 + l31;
+        f32x16 acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[nt][r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NKC; c++) {
+            GbBuf& cur = (c & 1) ? b1 : b0;
+            GbBuf& nxt = (c & 1) ? b0 : b1;
+            if (c + 1 < NKC) fetch(nxt, row, c + 1);
+            else fetch(bn, (t + nw) * 32 + l31, 0);      // first chunk of the next tile, ahead of this tile's stores (clamped row)
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const int k = c * GB_KC + 32 * h + 8 * s;
+                uint4 xv = cur.x[s];
+                if (HAS_GATE) xv = gb_gate(xv, cur.g[s]);
+                if (k >= K) xv = make_uint4(0u, 0u, 0u, 0u);
+                const gb_bf16x8 b = __builtin_bit_cast(gb_bf16x8, xv);
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) {
+                    const gb_bf16x8 a = __builtin_bit_cast(gb_bf16x8, *reinterpret_cast<const uint4*>(&Wl[(nt * 32 + l31) * Kp + k]));
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nt], 0, 0, 0);   // D[n][m]
+                }
+            }
+        }
+        // ---- epilogue: D[n][m], lane = row m (l31), registers = columns 8 (r >> 2) + 4 h + (r & 3) of n-tile nt ----
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+#pragma unroll
+            for (int nt2 = 0; nt2 < 2; nt2++) {
+                const int nt = 2 * p + nt2;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const float4 bs = ld4(&bias_s[32 * nt + 8 * g + 4 * h]);
+                    float4 v = make_float4(acc[nt][4 * g + 0] + bs.x, acc[nt][4 * g + 1] + bs.y, acc[nt][4 * g + 2] + bs.z,
+                                           acc[nt][4 * g + 3] + bs.w);
+                    if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                    *reinterpret_cast<uint2*>(&my_stg[l31 * GB_STG + 32 * nt2 + 8 * g + 4 * h]) =
+                        make_uint2(stage_pk_bf16(v.x, v.y), stage_pk_bf16(v.z, v.w));
+                }
+            }
+            // the wave's own staging rows: the LDS operations of one wave complete in order, no barrier
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int r = 8 * i + (lane >> 3), c8 = (lane & 7) * 8;
+                const uint4 v = *reinterpret_cast<const uint4*>(&my_stg[r * GB_STG + c8]);
+                const long m = t * 32 + r;
+                if (m < M) *reinterpret_cast<uint4*>(Y + m * N + n0 + 64 * p + c8) = v;
+            }
+        }
+        b0 = bn;
+    }
+}
+
+// returns 1 if the shape / alignment is not handled here (caller falls back to the tiled kernel), 0 on launch
+int stage_gemm_nt_bf16_stream(const void* X, const void* gate, const float* W, const float* bias, void* Y, long long M, int N,
+                              int K, int relu, void* stream) {
+    static const bool off = getenv("STAGE_GEMM_BF16_TILED") != nullptr;   // developer switch: tiled kernel everywhere
+    if (off || M < 4096 || K % 8 != 0 || K < 64 || K > 384 || N % GB_BN != 0) return 1;
+    if (((uintptr_t)X & 15) || ((uintptr_t)Y & 15) || ((uintptr_t)W & 15) || (gate && ((uintptr_t)gate & 15))) return 1;
+    const int nkc = (K + GB_KC - 1) / GB_KC;
+    int Kp = nkc * GB_KC;                           // whole chunks, zero padded
+    Kp += ((Kp / 8) % 2 == 0) ? 8 : 16;             // odd number of 16-byte slots per row: conflict-free ds_read_b128
+    const size_t lds = (size_t)GB_BN * Kp * 2 + (size_t)GB_WAVES * 32 * GB_STG * 2 + GB_BN * sizeof(float);
+    if (lds > 160 * 1024) return 1;
+    const long MT = (M + 31) / 32;
+    long gx = (MT + GB_WAVES - 1) / GB_WAVES;
+    const int n_tiles = N / GB_BN;
+    const long cap = 256 / n_tiles > 0 ? 256 / n_tiles : 1;
+    if (gx > cap) gx = cap;
+    dim3 grid((unsigned)gx, (unsigned)n_tiles), block(64 * GB_WAVES);
+    typedef stage_bf16 B;
+#define GB_GO(GT, NK)                                                                                                          \
+    do {                                                                                                                       \
+        (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_stream_kernel<GT, NK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((gemm_nt_bf16_stream_kernel<GT, NK>), grid, block, lds, (hipStream_t)stream, (const B*)X, (const B*)gate, W, \
+                           bias, (B*)Y, (long)M, N, K, Kp, relu);                                                              \
+    } while (0)
+#define GB_NK(NK) do { if (gate) GB_GO(true, NK); else GB_GO(false, NK); } while (0)
+    switch (nkc) {
+        case 1: GB_NK(1); break;
+        case 2: GB_NK(2); break;
+        case 3: GB_NK(3); break;
+        case 4: GB_NK(4); break;
+        case 5: GB_NK(5); break;
+        default: GB_NK(6); break;
+    }
+#undef GB_NK
+#undef GB_GO
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient on 16-bit activations:  dW[N, K] = sum_m (dY .* [gate > 0])[m, n] X[m, k] ,  db[n] = sum_m (...)[m, n]
+// The contraction runs over the ROWS, so an MFMA operand is 8 consecutive rows of one column.  A lane loads one dword (two
+// adjacent bf16 columns) from each of its 8 rows -- 32 lanes x 4 bytes = one full 128-byte line per row and instruction, as in
+// the fp32 kernel -- and repacks the 8 dwords into the operands of its even and its odd column with eight v_perm_b32.  A wave
+// owns a 64 x 64 patch of dW (even / odd columns of 64 dY columns x even / odd of 64 X columns = 2 x 2 MFMA tiles) and
+// walks its row slab 16 rows at a time; the waves of a workgroup cover the patches of a (<= 12 patches) group and, when there
+// are fewer, interleave the 16-row steps of the slab.  Every (slab, interleave) pair writes one fp32 partial; the ordered slab
+// sum of gemm_bf16x3.hip finishes (deterministic, no atomics).
+// ---------------------------------------------------------------------------------------------------------------------
+struct TbStep { unsigned y[8], g[8], x[8]; };
+
+template <bool HAS_GATE>
+__global__ __launch_bounds__(768) void gemm_tn_bf16_stream_kernel(const stage_bf16* __restrict__ dY, const stage_bf16* __restrict__ G,
+                                                                    const stage_bf16* __restrict__ X, float* __restrict__ part,
+                                                                    float* __restrict__ part_b, long M, int N, int K, long rows_per_slab,
+                                                                    int P, int RS, int KPn) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+    const int pl = wave % P + blockIdx.y * P;               // patch index: pn = pl / KPn (64 dY columns), pk = pl % KPn (64 X columns)
+    const int rs = wave / P;
+    const int NPn = N >> 6;
+    if (pl >= NPn * KPn) return;
+    const int pn = pl / KPn, pk = pl - pn * KPn;
+    const long mbeg = (long)blockIdx.x * rows_per_slab, mend = min(M, mbeg + rows_per_slab);
+    const unsigned* yb = reinterpret_cast<const unsigned*>(dY) + (pn * 32 + l31);      // dword = columns 64 pn + 2 l31, +1
+    const unsigned* gb = reinterpret_cast<const unsigned*>(HAS_GATE ? G : dY) + (pn * 32 + l31);
+    const unsigned* xb = reinterpret_cast<const unsigned*>(X) + (pk * 32 + l31);
+    const long ldy = N >> 1, ldx = K >> 1;                   // row strides in dwords
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int e = 0; e < 2; e++)
+#pragma unroll
+        for (int f = 0; f < 2; f++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[e][f][r] = 0.f;
+    float bs0 = 0.f, bs1 = 0.f;                              // column sums of the (gated) dY dwords of this lane (pk == 0 only)
+    auto fetch = [&](TbStep& s, long m0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const long r = min(m0 + 8 * h + j, M - 1);       // rows past the slab are zeroed at use
+            s.y[j] = yb[r * ldy];
+            if (HAS_GATE) s.g[j] = gb[r * ldy];
+            s.x[j] = xb[r * ldx];
+        }
+    };
+    auto step = [&](TbStep& s, long m0) {
+        unsigned y[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            unsigned v = s.y[j];
+            if (HAS_GATE) v = gb_gate1(v, s.g[j]);
+            if (m0 + 8 * h + j >= mend) v = 0u;
+            y[j] = v;
+        }
+        if (part_b && pk == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                bs0 += __uint_as_float(y[j] << 16);
+                bs1 += __uint_as_float(y[j] & 0xFFFF0000u);
+            }
+        }
+        // operands: dword q of column c holds rows (2q, 2q+1): even column = low halves, odd column = high halves
+        uint4 ae, ao, be, bo;
+        ae.x = __builtin_amdgcn_perm(y[1], y[0], 0x05040100u); ao.x = __builtin_amdgcn_perm(y[1], y[0], 0x07060302u);
+        ae.y = __builtin_amdgcn_perm(y[3], y[2], 0x05040100u); ao.y = __builtin_amdgcn_perm(y[3], y[2], 0x07060302u);
+        ae.z = __builtin_amdgcn_perm(y[5], y[4], 0x05040100u); ao.z = __builtin_amdgcn_perm(y[5], y[4], 0x07060302u);
+        ae.w = __builtin_amdgcn_perm(y[7], y[6], 0x05040100u); ao.w = __builtin_amdgcn_perm(y[7], y[6], 0x07060302u);
+        be.x = __builtin_amdgcn_perm(s.x[1], s.x[0], 0x05040100u); bo.x = __builtin_amdgcn_perm(s.x[1], s.x[0], 0x07060302u);
+        be.y = __builtin_amdgcn_perm(s.x[3], s.x[2], 0x05040100u); bo.y = __builtin_amdgcn_perm(s.x[3], s.x[2], 0x07060302u);
+        be.z = __builtin_amdgcn_perm(s.x[5], s.x[4], 0x05040100u); bo.z = __builtin_amdgcn_perm(s.x[5], s.x[4], 0x07060302u);
+        be.w = __builtin_amdgcn_perm(s.x[7], s.x[6], 0x05040100u); bo.w = __builtin_amdgcn_perm(s.x[7], s.x[6], 0x07060302u);
+        const gb_bf16x8 A0 = __builtin_bit_cast(gb_bf16x8, ae), A1 = __builtin_bit_cast(gb_bf16x8, ao);
+        const gb_bf16x8 B0 = __builtin_bit_cast(gb_bf16x8, be), B1 = __builtin_bit_cast(gb_bf16x8, bo);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc[1][1], 0, 0, 0);
+    };
+    // X rows past the slab: the dY operand is zero there, but a NaN in a clamped X row would still poison 0 * NaN -- the
+    // clamp reads row M - 1 at worst (a real row), and rows of OTHER slabs are finite wherever this tensor is finite at all
+    const long stride = 16L * RS;
+    long m0 = mbeg + 16L * rs;
+    TbStep s0, s1;
+    if (m0 < mend) fetch(s0, m0);
+    for (; m0 < mend; m0 += 2 * stride) {
+        const bool more1 = m0 + stride < mend;
+        if (more1) fetch(s1, m0 + stride);
+        step(s0, m0);
+        if (m0 + 2 * stride < mend) fetch(s0, m0 + 2 * stride);
+        if (more1) step(s1, m0 + stride);
+    }
+    // ---- partial of this (slab, interleave): D[i][j] -> dW[n = 64 pn + 2 i + e][k = 64 pk + 2 j + f] ----
+    float* po = part + ((size_t)blockIdx.x * RS + rs) * (size_t)N * K;
+#pragma unroll
+    for (int e = 0; e < 2; e++)
+#pragma unroll
+        for (int f = 0; f < 2; f++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+                po[(size_t)(64 * pn + 2 * i + e) * K + 64 * pk + 2 * l31 + f] = acc[e][f][r];
+            }
+    if (part_b && pk == 0) {
+        bs0 += __shfl_xor(bs0, 32);
+        bs1 += __shfl_xor(bs1, 32);
+        if (h == 0) {
+            float* pb = part_b + ((size_t)blockIdx.x * RS + rs) * N + 64 * pn + 2 * l31;
+            pb[0] = bs0;
+            pb[1] = bs1;
+        }
+    }
+}
+
+// slabs x interleaves of the streaming TN kernel for a shape (0: not handled)
+static int tb_plan(long long M, int N, int K, int* P, int* RS, int* KPn, int* GY, long* rps) {
+    if (M < 4096 || N % 64 != 0 || K % 64 != 0) return 0;
+    *KPn = K / 64;
+    const int total = (N / 64) * *KPn;
+    *GY = (total + 11) / 12;                    // <= 12 waves per workgroup (768 threads: 168 registers per lane)
+    *P = (total + *GY - 1) / *GY;
+    *RS = *GY == 1 ? (12 / *P) : 1;
+    if (*RS < 1) *RS = 1;
+    // one resident workgroup per CU: 256 / GY slabs, at least 32 steps of 16 rows per interleave
+    long S = 256 / *GY;
+    const long max_by_rows = (M + 16L * 32 * *RS - 1) / (16L * 32 * *RS);
+    if (S > max_by_rows) S = max_by_rows;
+    if (S < 1) S = 1;
+    long r = (M + S - 1) / S;
+    r = (r + 16L * *RS - 1) / (16L * *RS) * (16L * *RS);
+    *rps = r;
+    return (int)((M + r - 1) / r);
+}
+
+size_t stage_gemm_tn_bf16_stream_ws_bytes(long long M, int N, int K) {
+    int P, RS, KPn, GY; long rps;
+    const int S = tb_plan(M, N, K, &P, &RS, &KPn, &GY, &rps);
+    return (size_t)S * RS * ((size_t)N * K + N) * sizeof(float);
+}
+
+// returns 1 if the shape / alignment is not handled here, 0 on launch; *slabs = number of partials written
+int stage_gemm_tn_bf16_stream(const void* dY, const void* gate, const void* X, float* part, float* part_b, long long M, int N,
+                              int K, int* slabs, void* stream) {
+    static const bool off = getenv("STAGE_GEMM_BF16_TILED") != nullptr;
+    int P, RS, KPn, GY; long rps;
+    const int S = off ? 0 : tb_plan(M, N, K, &P, &RS, &KPn, &GY, &rps);
+    if (S == 0 || ((uintptr_t)dY & 3) || ((uintptr_t)X & 3) || (gate && ((uintptr_t)gate & 3))) return 1;
+    typedef stage_bf16 B;
+    dim3 grid((unsigned)S, (unsigned)GY), block(64 * P * RS);
+    if (gate)
+        hipLaunchKernelGGL(gemm_tn_bf16_stream_kernel<true>, grid, block, 0, (hipStream_t)stream, (const B*)dY, (const B*)gate,
+                           (const B*)X, part, part_b, (long)M, N, K, rps, P, RS, KPn);
+    else
+        hipLaunchKernelGGL(gemm_tn_bf16_stream_kernel<false>, grid, block, 0, (hipStream_t)stream, (const B*)dY, (const B*)gate,
+                           (const B*)X, part, part_b, (long)M, N, K, rps, P, RS, KPn);
+    STAGE_LAUNCH_CHECK();
+    *slabs = S * RS;
+    return 0;
+}

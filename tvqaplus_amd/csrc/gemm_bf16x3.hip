@@ -400,10 +400,17 @@ extern "C" int stage_gemm_tn_bf16x3(const float* dY, const float* gate, const fl
 // master weight is rounded to bf16 while it is staged (NSPLIT = 1: ONE bf16 product per term, exact in fp32, fp32
 // accumulation); bias, weight / bias gradients stay fp32.  8-byte alignment of the bf16 operands selects the vector path.
 // ------------------------------------------------------------------------------------------------
+int stage_gemm_nt_bf16_stream(const void* X, const void* gate, const float* W, const float* bias, void* Y, long long M, int N,
+                              int K, int relu, void* stream);   // gemm_bf16_stream.hip; 1 = shape not handled there
+
 extern "C" int stage_gemm_nt_bf16(const void* X, const void* gate, const float* W, const float* bias, const void* residual,
                                   void* Y, long long M, int N, int K, int relu, void* stream) {
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0) return STAGE_ERR_SHAPE;
+    if (!residual) {
+        const int rc = stage_gemm_nt_bf16_stream(X, gate, W, bias, Y, M, N, K, relu, stream);
+        if (rc != 1) return rc;
+    }
     const int vecX = (K % 4 == 0) && (((uintptr_t)X & 7) == 0) && (!gate || ((uintptr_t)gate & 7) == 0);
     const int vecW = (K % 4 == 0) && (((uintptr_t)W & 15) == 0);
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
@@ -419,7 +426,18 @@ extern "C" int stage_gemm_nt_bf16(const void* X, const void* gate, const float* 
     return 0;
 }
 
-// workspace: stage_gemm_tn_ws_bytes(M, N, K)
+size_t stage_gemm_tn_bf16_stream_ws_bytes(long long M, int N, int K);                       // gemm_bf16_stream.hip
+int stage_gemm_tn_bf16_stream(const void* dY, const void* gate, const void* X, float* part, float* part_b, long long M, int N,
+                              int K, int* slabs, void* stream);                             // 1 = shape not handled there
+
+extern "C" size_t stage_gemm_tn_bf16_ws_bytes(long long M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const size_t tiled = (size_t)tn_splits_b(M, N, K) * ((size_t)N * K + N) * sizeof(float);
+    const size_t strm = stage_gemm_tn_bf16_stream_ws_bytes(M, N, K);
+    return tiled > strm ? tiled : strm;
+}
+
+// workspace: stage_gemm_tn_bf16_ws_bytes(M, N, K)
 extern "C" int stage_gemm_tn_bf16(const void* dY, const void* gate, const void* X, float* dW, float* db, long long M, int N,
                                   int K, void* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -428,6 +446,24 @@ extern "C" int stage_gemm_tn_bf16(const void* dY, const void* gate, const void* 
         (void)hipMemsetAsync(dW, 0, sizeof(float) * (size_t)N * K, st);
         if (db) (void)hipMemsetAsync(db, 0, sizeof(float) * N, st);
         return 0;
+    }
+    {   // streaming kernel (gemm_bf16_stream.hip) when the shape allows it and the workspace holds its partials
+        const size_t need = stage_gemm_tn_bf16_stream_ws_bytes(M, N, K);
+        if (need && ws_bytes >= need) {
+            const size_t nslab = need / (((size_t)N * K + N) * sizeof(float));
+            float* part = (float*)ws;
+            float* part_b = part + nslab * (size_t)N * K;
+            int slabs = 0;
+            const int rc = stage_gemm_tn_bf16_stream(dY, gate, X, part, db ? part_b : (float*)nullptr, M, N, K, &slabs, stream);
+            if (rc == 0) {
+                const long C = (long)N * K;
+                hipLaunchKernelGGL(slab_reduce_b_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, part, dW, slabs, C);
+                if (db) hipLaunchKernelGGL(slab_reduce_b_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part_b, db, slabs, (long)N);
+                STAGE_LAUNCH_CHECK();
+                return 0;
+            }
+            if (rc != 1) return rc;
+        }
     }
     const int S = tn_splits_b(M, N, K);
     if (ws_bytes < (size_t)S * ((size_t)N * K + N) * sizeof(float)) return STAGE_ERR_WORKSPACE;

@@ -334,7 +334,7 @@ class _Linear(torch.autograd.Function):
                 _call("stage_gemm_nt_bf16", _ptr(dy), _ptr(gate), _ptr(wt), None, None, _ptr(dx), M, K, N, 0, _stream())
             dw = torch.empty_like(w2)
             db = torch.empty(N, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-            wsb = lib.stage_gemm_tn_ws_bytes(M, N, K)
+            wsb = lib.stage_gemm_tn_bf16_ws_bytes(M, N, K)
             ws = _workspace(wsb, x.device)
             _call("stage_gemm_tn_bf16", _ptr(dy), _ptr(gate), _ptr(x), _ptr(dw), _ptr(db), M, N, K, _ptr(ws), wsb, _stream())
             return dx, dw.view(ctx.wshape), db, None
