@@ -186,6 +186,15 @@ int stage_masked_max_bwd(const float* dout, const int* argmax, const float* mask
  * indices and all parameter gradients stay fp32; a weight is rounded to bf16 while the GEMM stages it.  The attention
  * kernel of this mode is stage_str_attn_long_* with storage == 1.  The row / conv kernels are the fp32 ones instantiated
  * on 16-bit elements; the GEMMs are the tiled kernels with one bf16 term (not yet the streaming ones).                                                                     */
+/* K1 fast kernels on bf16 Q / A / dA (D == 128, Lr <= 64; STAGE_ERR_SHAPE otherwise -> stage_str_attn_long_*): Cn, the
+ * masks, both score maps and the three gradients leaving the backward stay fp32.                                    */
+int stage_str_attn_fwd_bf16(const float* Cn, const void* Q, const float* c_mask, const float* q_mask, void* A,
+                            float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D, float scale,
+                            float p_drop, unsigned long long seed, void* stream);
+int stage_str_attn_bwd_fused_bf16(const void* dA, const float* dS_raw_ext, const float* Cn, const void* Q, const void* Qn,
+                                  const float* S_norm, const float* q_mask, float* dQraw, float* dQn, float* dCn, int N,
+                                  int NA, int Li, int Lqa, int Lr, int D, float scale, void* ws, size_t ws_bytes,
+                                  void* stream);
 int stage_layernorm_fwd_bf16(const void* x, const void* res, int res_period, void* sum_out, const float* gamma,
                              const float* beta, void* y, float* mean, float* rstd, long long rows, int K, float eps,
                              float p_drop, unsigned long long seed, void* stream);

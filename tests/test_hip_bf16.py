@@ -207,6 +207,34 @@ def test_l2norm_and_masked_max_bf16(ops):
         check("dmax", vd.grad, vc.grad, ULP2)
 
 
+@pytest.mark.parametrize("N,Li,Lr,Lqa,ext", [(2, 7, 20, 40, False), (2, 5, 50, 40, True), (1, 4, 36, 23, False), (2, 6, 8, 12, True)])
+def test_k1_fast_kernels_bf16(ops, N, Li, Lr, Lqa, ext):
+    """StructuredAttention at D = 128 on bf16 Q / A / dA: the register-resident and LDS-staged forward kernels and the fused
+    backward instantiated on 16-bit storage (Cn, the score maps and the arithmetic stay fp32)."""
+    from tvqaplus_amd.synth import make_batch
+    D = 128
+    g = torch.Generator().manual_seed(7 * Lr + Lqa)
+    b = make_batch(N=N, Li=Li, Lr=Lr, Lw=2, Lqa=Lqa, wd_size=4, vfeat_size=4, seed=Lr + Li, empty_frames=True)
+    C = rb(torch.randn(N, 5, 1, Lqa, D, generator=g))
+    Q = rb(torch.randn(N, 1, Li, Lr, D, generator=g) * 2)
+    cm, qm = b.qas_mask.view(N, 5, 1, Lqa), b.vid_mask.view(N, 1, Li, Lr)
+    gA = rb(torch.randn(N, 5, Li, Lqa, D, generator=g))
+    gS = (torch.randn(N, 5, Li, Lqa, Lr, generator=g) * 0.1 * (cm.view(N, 5, 1, Lqa, 1) * qm.view(N, 1, Li, 1, Lr))) if ext else None
+    Cc, Qc = C.clone().requires_grad_(), Q.clone().requires_grad_()
+    Ao, So, _, Sno = O.structured_attention(Cc, Qc, cm, qm, 10.0)
+    ((Ao * gA).sum() + ((So * gS).sum() if ext else 0.0)).backward()
+    Cd, Qd = devb(C.view(N, 5, Lqa, D), True), devb(Q.view(N, Li, Lr, D), True)
+    A, S, Sn = ops.structured_attention(Cd, Qd, cm.view(N, 5, Lqa).cuda(), qm.view(N, Li, Lr).cuda(), 10.0)
+    assert A.dtype == BF and S.dtype == torch.float32
+    check("A", A, Ao.detach(), ULP2)
+    check("S", S, So.detach(), 2e-4)
+    check("S_norm", Sn, Sno.detach(), 2e-4)
+    ((A.float() * gA.cuda()).sum() + ((S * gS.cuda()).sum() if ext else 0.0)).backward()
+    assert Qd.grad.dtype == BF and Cd.grad.dtype == BF
+    check("dC", Cd.grad.view_as(C), Cc.grad, 2 * ULP2)
+    check("dQ", Qd.grad.view_as(Q), Qc.grad, 2 * ULP2)
+
+
 def _cos(a, b):
     a, b = a.double().flatten(), b.double().flatten()
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))

@@ -59,6 +59,8 @@ SIGNATURES = {
     "stage_masked_max_fwd": (I, [P, P, P, P, P, LL, I, I, P]),
     "stage_masked_max_bwd": (I, [P, P, P, P, LL, I, I, I, P]),
     # bf16 storage mode: same argument lists as the fp32 entry points of the same name
+    "stage_str_attn_fwd_bf16": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, U64, P]),
+    "stage_str_attn_bwd_fused_bf16": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, SZ, P]),
     "stage_layernorm_fwd_bf16": (I, [P, P, I, P, P, P, P, P, P, LL, I, F, F, U64, P]),
     "stage_layernorm_bwd_bf16": (I, [P, P, P, P, P, P, P, P, P, LL, I, F, U64, P, SZ, P]),
     "stage_cat3_layernorm_fwd_bf16": (I, [P, P, P, P, P, P, P, LL, I, I, I, F, F, U64, P]),

@@ -77,8 +77,8 @@ __device__ __forceinline__ int fswz(int c) { return ((c & 1) << 5) | (((c >> 1) 
 // instruction touches 64 different lines and the eight instructions of a tile re-touch them; with 100+ KB of tiles in flight
 // per CU the 32 KB vector L1 evicts them in between and refills them up to eight times (measured ~9 GB/s per CU instead of
 // ~25).  The tile is transposed through the LDS copy that phase 2 needs anyway.
-template <int NRT, bool HAS_EXT, bool COAL = false>   // NRT = pieces fetched
-__device__ __forceinline__ void fus_p1_fetch(FusTile<NRT, HAS_EXT>& T, const float* __restrict__ dAf, const float* __restrict__ Snf,
+template <int NRT, bool HAS_EXT, bool COAL = false, typename TD = float>   // NRT = pieces fetched; TD = storage type of dA
+__device__ __forceinline__ void fus_p1_fetch(FusTile<NRT, HAS_EXT>& T, const TD* __restrict__ dAf, const float* __restrict__ Snf,
                                              const float* __restrict__ extf, unsigned rel, int Lr, int g, int tile = 0, int lane = 0,
                                              int NA = 0, int Li = 0, int Lqa = 1) {
     if (COAL) {
@@ -89,7 +89,7 @@ __device__ __forceinline__ void fus_p1_fetch(FusTile<NRT, HAS_EXT>& T, const flo
         for (int i = 0; i < 8; i++) {
             const bool ok = c < CR;
             const unsigned r = ok ? (unsigned)(a * Li * Lqa + w) : (unsigned)((NA - 1) * Li * Lqa + Lqa - 1);
-            T.gv[i] = ld4(dAf + (r * FD + 4u * (lane & 31)));
+            T.gv[i] = ldv4(dAf + (r * FD + 4u * (lane & 31)));
             c += 2; w += 2;
             const bool wrap = w >= Lqa;        // Lqa >= 4: at most one wrap per step
             w -= wrap ? Lqa : 0;
@@ -98,7 +98,7 @@ __device__ __forceinline__ void fus_p1_fetch(FusTile<NRT, HAS_EXT>& T, const flo
     } else {
         const unsigned offa = rel * FD + 4u * fchunk(g, 0);
 #pragma unroll
-        for (int m = 0; m < 8; m++) T.gv[m] = ld4(dAf + (offa + 4u * m));
+        for (int m = 0; m < 8; m++) T.gv[m] = ldv4(dAf + (offa + 4u * m));
     }
     const unsigned offs = rel * (unsigned)Lr;
 #pragma unroll
@@ -216,11 +216,18 @@ template <int E> struct FusVec;
 template <> struct FusVec<4> { typedef float4 T; };
 template <> struct FusVec<2> { typedef float2 T; };
 template <int E> __device__ __forceinline__ typename FusVec<E>::T fus_ldv(const float* p) { return *reinterpret_cast<const typename FusVec<E>::T*>(p); }
+// bf16 storage: E consecutive bf16 -> E floats
+template <int E> __device__ __forceinline__ typename FusVec<E>::T fus_ldv(const stage_bf16* p);
+template <> __device__ __forceinline__ float4 fus_ldv<4>(const stage_bf16* p) { return ldv4(p); }
+template <> __device__ __forceinline__ float2 fus_ldv<2>(const stage_bf16* p) {
+    const unsigned u = *reinterpret_cast<const unsigned*>(p);
+    return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xFFFF0000u));
+}
 __device__ __forceinline__ float fus_elt(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
 __device__ __forceinline__ float fus_elt(const float2& v, int e) { return e == 0 ? v.x : v.y; }
 
-template <int RT, int NRT, int E, bool RAW, bool PIPE>
-__device__ __forceinline__ void fus_p2(const float* __restrict__ dA, const float* __restrict__ Sn, const float* __restrict__ Cn,
+template <int RT, int NRT, int E, bool RAW, bool PIPE, typename TD = float>
+__device__ __forceinline__ void fus_p2(const TD* __restrict__ dA, const float* __restrict__ Sn, const float* __restrict__ Cn,
                                        const float* Gs, float* __restrict__ out, long frame, int n, int i, int NA, int Li,
                                        int Lqa, int Lr, int d0, int c15, int g) {
     typedef typename FusVec<E>::T vec_t;
@@ -321,8 +328,8 @@ __device__ __forceinline__ void fus_p2(const float* __restrict__ dA, const float
 // of a k-step sit in the same answer block, so the row pointer advances in scalar registers and every load is
 // (scalar base) + (constant lane offset) -- no vector address arithmetic, no validity selects between the MFMAs.
 // dAf / Snf / outf are the frame bases of fus_p1_fetch, Cnn = Cn + n*CR*128.
-template <int RT, int NRT, int E, bool RAW, bool PIPE, bool LDSA = false, int UG = FUS_U>
-__device__ __forceinline__ void fus_p2_unif(const float* __restrict__ dAf, const float* __restrict__ Snf,
+template <int RT, int NRT, int E, bool RAW, bool PIPE, bool LDSA = false, int UG = FUS_U, typename TD = float>
+__device__ __forceinline__ void fus_p2_unif(const TD* __restrict__ dAf, const float* __restrict__ Snf,
                                             const float* __restrict__ Cnn, const float* Gs, float* __restrict__ outf, int NA,
                                             int Li, int Lqa, int Lr, int d0, int c15, int g, const float* dAs = nullptr) {
     typedef typename FusVec<E>::T vec_t;
@@ -338,7 +345,8 @@ __device__ __forceinline__ void fus_p2_unif(const float* __restrict__ dAf, const
 #pragma unroll
     for (int rt = 0; rt < NRT; rt++)
         offA[rt] = RAW ? (unsigned)(g * Lr + min(rt * 16 + c15, Lr - 1)) : (unsigned)(g * LG + gcol<RT>(g, rt * 16 + c15));
-    const float* pB = RAW ? dAf : Cnn;                    // row 4*step of the B operand (uniform)
+    const TD* pBd = dAf;                                  // row 4*step of the B operand (uniform): dA rows (RAW) ...
+    const float* pBc = Cnn;                               // ... or Cn rows
     const float* pA = Snf;
     const long jumpB = (long)(Li - 1) * Lqa * FD, jumpA = (long)(Li - 1) * Lqa * Lr;
     const int wq_n = Lqa >> 2;
@@ -348,17 +356,18 @@ __device__ __forceinline__ void fus_p2_unif(const float* __restrict__ dAf, const
 #pragma unroll
         for (int u = 0; u < UG; u++) {
             // fswz(4k + g) = fswz(g) ^ (((2k) & 7) << 2) (g < 4 sets disjoint bits); bs = 4k * FD
-            bv[u] = (RAW && LDSA) ? fus_ldv<E>(dAs + bs + (offB ^ (unsigned)(((bs >> 8) & 7) << 2))) : fus_ldv<E>(pB + offB);
+            bv[u] = (RAW && LDSA) ? fus_ldv<E>(dAs + bs + (offB ^ (unsigned)(((bs >> 8) & 7) << 2))) : (RAW ? fus_ldv<E>(pBd + offB) : fus_ldv<E>(pBc + offB));
 #pragma unroll
             for (int rt = 0; rt < NRT; rt++) av[u][rt] = RAW ? pA[offA[rt]] : Gs[gs + offA[rt]];
-            pB += 4 * FD;
+            pBd += 4 * FD;
+            pBc += 4 * FD;
             gs += 4 * LG;
             bs += 4 * FD;
             if (RAW) {
                 pA += 4 * Lr;
                 const bool wrap = ++wq == wq_n;       // uniform
                 wq = wrap ? 0 : wq;
-                pB += wrap ? jumpB : 0;
+                pBd += wrap ? jumpB : 0;
                 pA += wrap ? jumpA : 0;
             }
         }
@@ -409,8 +418,8 @@ __device__ __forceinline__ void fus_p2_unif(const float* __restrict__ dAf, const
 }
 
 // one frame: phase 1 over the wave's tiles (slot s -> tile wave + NW*s), barrier, phase 2
-template <int RT, int NRT, int NW, bool HAS_EXT, bool PIPE, bool LDSA>
-__device__ __forceinline__ void fus_frame(const float* __restrict__ dA, const float* __restrict__ ext,
+template <int RT, int NRT, int NW, bool HAS_EXT, bool PIPE, bool LDSA, typename TD = float>
+__device__ __forceinline__ void fus_frame(const TD* __restrict__ dA, const float* __restrict__ ext,
                                           const float* __restrict__ Cn, const float* __restrict__ Sn, const float* Qr,
                                           const float* QnT, float* Gs, float* dAs, float* __restrict__ dQraw, float* __restrict__ dQn,
                                           long frame, int n, int i, int NA, int Li, int Lqa, int Lr, float scale,
@@ -424,21 +433,21 @@ __device__ __forceinline__ void fus_frame(const float* __restrict__ dA, const fl
     asm volatile("" : "+v"(l));
     const int c15 = l & 15, g = l >> 4;
     const long rowbase = ((long)n * NA * Li + i) * Lqa;     // uniform
-    const float* dAf = dA + rowbase * FD;
+    const TD* dAf = dA + rowbase * FD;
     const float* Snf = Sn + rowbase * Lr;
     const float* extf = HAS_EXT ? ext + rowbase * Lr : nullptr;
     if (PIPE) {
         FusTile<NRT, HAS_EXT> Ta, Tb;
-        if (ntiles > 0) fus_p1_fetch<NRT, HAS_EXT, LDSA>(Ta, dAf, Snf, extf, orel[0], Lr, g, wave, l, NA, Li, Lqa);
+        if (ntiles > 0) fus_p1_fetch<NRT, HAS_EXT, LDSA, TD>(Ta, dAf, Snf, extf, orel[0], Lr, g, wave, l, NA, Li, Lqa);
 #pragma unroll
         for (int s = 0; s < TPW; s++) {
             if (s < ntiles) {
                 const int c = (wave + NW * s) * 16 + c15;
                 if (s & 1) {
-                    if (s + 1 < TPW && s + 1 < ntiles) fus_p1_fetch<NRT, HAS_EXT, LDSA>(Ta, dAf, Snf, extf, orel[s + 1 < TPW ? s + 1 : 0], Lr, g, wave + NW * (s + 1), l, NA, Li, Lqa);
+                    if (s + 1 < TPW && s + 1 < ntiles) fus_p1_fetch<NRT, HAS_EXT, LDSA, TD>(Ta, dAf, Snf, extf, orel[s + 1 < TPW ? s + 1 : 0], Lr, g, wave + NW * (s + 1), l, NA, Li, Lqa);
                     fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(Tb, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, dAs, CR);
                 } else {
-                    if (s + 1 < TPW && s + 1 < ntiles) fus_p1_fetch<NRT, HAS_EXT, LDSA>(Tb, dAf, Snf, extf, orel[s + 1 < TPW ? s + 1 : 0], Lr, g, wave + NW * (s + 1), l, NA, Li, Lqa);
+                    if (s + 1 < TPW && s + 1 < ntiles) fus_p1_fetch<NRT, HAS_EXT, LDSA, TD>(Tb, dAf, Snf, extf, orel[s + 1 < TPW ? s + 1 : 0], Lr, g, wave + NW * (s + 1), l, NA, Li, Lqa);
                     fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(Ta, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, dAs, CR);
                 }
             }
@@ -449,7 +458,7 @@ __device__ __forceinline__ void fus_frame(const float* __restrict__ dA, const fl
             if (s < ntiles) {
                 const int c = (wave + NW * s) * 16 + c15;
                 FusTile<NRT, HAS_EXT> T;
-                fus_p1_fetch<NRT, HAS_EXT, LDSA>(T, dAf, Snf, extf, orel[s], Lr, g, wave + NW * s, l, NA, Li, Lqa);
+                fus_p1_fetch<NRT, HAS_EXT, LDSA, TD>(T, dAf, Snf, extf, orel[s], Lr, g, wave + NW * s, l, NA, Li, Lqa);
                 fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(T, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, dAs, CR);
             }
         }
@@ -463,18 +472,20 @@ __device__ __forceinline__ void fus_frame(const float* __restrict__ dA, const fl
     const bool unif = (Lqa & 3) == 0 && ((CR >> 2) % UG) == 0;
     if (FUS_ABL & 1) return;
     if (unif) {
-        if (wave < NW / 2) fus_p2_unif<RT, NRT, E, true, PIPE, LDSA, UG>(dAf, Snf, nullptr, Gs, dQraw + frame * Lr * FD, NA, Li, Lqa, Lr, d0, c15, g, dAs);
-        else fus_p2_unif<RT, NRT, E, false, PIPE, false, UG>(dAf, Snf, Cn + (long)n * CR * FD, Gs, dQn + frame * Lr * FD, NA, Li, Lqa, Lr, d0, c15, g);
+        if (wave < NW / 2) fus_p2_unif<RT, NRT, E, true, PIPE, LDSA, UG, TD>(dAf, Snf, nullptr, Gs, dQraw + frame * Lr * FD, NA, Li, Lqa, Lr, d0, c15, g, dAs);
+        else fus_p2_unif<RT, NRT, E, false, PIPE, false, UG, TD>(dAf, Snf, Cn + (long)n * CR * FD, Gs, dQn + frame * Lr * FD, NA, Li, Lqa, Lr, d0, c15, g);
     } else {
-        if (wave < NW / 2) fus_p2<RT, NRT, E, true, PIPE>(dA, Sn, Cn, Gs, dQraw, frame, n, i, NA, Li, Lqa, Lr, d0, c15, g);
-        else fus_p2<RT, NRT, E, false, PIPE>(dA, Sn, Cn, Gs, dQn, frame, n, i, NA, Li, Lqa, Lr, d0, c15, g);
+        if (wave < NW / 2) fus_p2<RT, NRT, E, true, PIPE, TD>(dA, Sn, Cn, Gs, dQraw, frame, n, i, NA, Li, Lqa, Lr, d0, c15, g);
+        else fus_p2<RT, NRT, E, false, PIPE, TD>(dA, Sn, Cn, Gs, dQn, frame, n, i, NA, Li, Lqa, Lr, d0, c15, g);
     }
 }
 
-template <int RT, int NW, bool HAS_EXT, int OCC, bool LDSA>
+// TD: storage type of dA, Q and Qn (float, or bf16 in the bf16 storage mode: converted as they are loaded; the LDS images, the
+// score maps, Cn and all three gradients are fp32)
+template <int RT, int NW, bool HAS_EXT, int OCC, bool LDSA, typename TD = float>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void str_attn_bwd_fused_kernel(
-    const float* __restrict__ dA, const float* __restrict__ ext, const float* __restrict__ Cn, const float* __restrict__ Q,
-    const float* __restrict__ Qn, const float* __restrict__ Sn, const float* __restrict__ qmask, float* __restrict__ dQraw,
+    const TD* __restrict__ dA, const float* __restrict__ ext, const float* __restrict__ Cn, const TD* __restrict__ Q,
+    const TD* __restrict__ Qn, const float* __restrict__ Sn, const float* __restrict__ qmask, float* __restrict__ dQraw,
     float* __restrict__ dQn, float* __restrict__ part, int N, int NA, int Li, int Lqa, int Lr, float scale,
     const int4* __restrict__ sched, const unsigned char* __restrict__ fnv, unsigned long long* __restrict__ tim) {
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = tim ? __builtin_readcyclecounter() : 0;
@@ -537,8 +548,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OC
             const int u = wave + NW * s;
             const int r = 8 * (u >> 2) + (lane & 7), q = 8 * (u & 3) + (lane >> 3);
             if (u < UNITS && r < Lr) {
-                const float4 vq = ld4(Q + (frame * Lr + r) * FD + 4 * q);
-                const float4 vn = ld4(Qn + (frame * Lr + r) * FD + 4 * q);
+                const float4 vq = ldv4(Q + (frame * Lr + r) * FD + 4 * q);
+                const float4 vn = ldv4(Qn + (frame * Lr + r) * FD + 4 * q);
                 st4(&Qr[r * FLDQ + 4 * q], vq);
                 QnT[(4 * q + 0) * LT + r] = vn.x;
                 QnT[(4 * q + 1) * LT + r] = vn.y;
@@ -551,7 +562,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OC
         TICK(1);
         const int nrt = (nvalid + 15) >> 4;
 #define FUS_FRAME(NRTV)                                                                                                  \
-    fus_frame<RT, (NRTV) <= RT ? (NRTV) : RT, NW, HAS_EXT, (OCC == 2 && NW == 8), LDSA>(dA, ext, Cn, Sn, Qr, QnT, Gs, dAs, dQraw, dQn, frame, n, i, NA, Li, \
+    fus_frame<RT, (NRTV) <= RT ? (NRTV) : RT, NW, HAS_EXT, (OCC == 2 && NW == 8), LDSA, TD>(dA, ext, Cn, Sn, Qr, QnT, Gs, dAs, dQraw, dQn, frame, n, i, NA, Li, \
                                                          Lqa, Lr, scale, orel, ntiles, dcn, wave, lane, tim, tacc, tlast)
         if (RT == 1 || nrt == 1) FUS_FRAME(1);
         else if (RT == 2 || nrt == 2) FUS_FRAME(2);
@@ -691,8 +702,8 @@ static int fus_num_wgs(int N, int Li = 1 << 20) {
     return G > N ? G : N;
 }
 
-template <int RT, int NW, int OCC>
-static int fus_launch(const float* dA, const float* ext, const float* Cn, const float* Q, const float* Qn, const float* Sn,
+template <int RT, int NW, int OCC, typename TD>
+static int fus_launch(const TD* dA, const float* ext, const float* Cn, const TD* Q, const TD* Qn, const float* Sn,
                       const float* qmask, float* dQraw, float* dQn, float* dCn, int N, int NA, int Li, int Lqa, int Lr,
                       float scale, void* ws, hipStream_t st) {
     const int CR = NA * Lqa;
@@ -720,8 +731,8 @@ static int fus_launch(const float* dA, const float* ext, const float* Cn, const 
 #define FUS_GO(EXTV, LDSAV)                                                                                                     \
     do {                                                                                                                        \
         if (lds > 64 * 1024)                                                                                                    \
-            (void)hipFuncSetAttribute((const void*)str_attn_bwd_fused_kernel<RT, NW, EXTV, OCC, LDSAV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((str_attn_bwd_fused_kernel<RT, NW, EXTV, OCC, LDSAV>), grid, block, lds, st, dA, ext, Cn, Q, Qn, Sn, qmask, \
+            (void)hipFuncSetAttribute((const void*)str_attn_bwd_fused_kernel<RT, NW, EXTV, OCC, LDSAV, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((str_attn_bwd_fused_kernel<RT, NW, EXTV, OCC, LDSAV, TD>), grid, block, lds, st, dA, ext, Cn, Q, Qn, Sn, qmask, \
                            dQraw, dQn, part, N, NA, Li, Lqa, Lr, scale, (const int4*)sched, (const unsigned char*)fnv, tim);                               \
     } while (0)
     if (ext) { if (ldsa) FUS_GO(true, (NW == 8 && OCC == 2)); else FUS_GO(true, false); }
@@ -740,10 +751,10 @@ extern "C" size_t stage_str_attn_bwd_fused_ws_bytes(int N, int NA, int Li, int L
     return FUS_TABLE_BYTES(G, N) + FUS_FRAME_BYTES(N, Li) + (size_t)G * NA * Lqa * D * sizeof(float);
 }
 
-extern "C" int stage_str_attn_bwd_fused(const float* dA, const float* dS_raw_ext, const float* Cn, const float* Q,
-                                        const float* Qn, const float* S_norm, const float* q_mask, float* dQraw,
-                                        float* dQn, float* dCn, int N, int NA, int Li, int Lqa, int Lr, int D, float scale,
-                                        void* ws, size_t ws_bytes, void* stream) {
+template <typename TD>
+static int str_attn_bwd_fused_t(const TD* dA, const float* dS_raw_ext, const float* Cn, const TD* Q, const TD* Qn,
+                                const float* S_norm, const float* q_mask, float* dQraw, float* dQn, float* dCn, int N, int NA,
+                                int Li, int Lqa, int Lr, int D, float scale, void* ws, size_t ws_bytes, void* stream) {
     if (N <= 0 || Li <= 0) return 0;
     if (D != FD || Lr < 2 || Lr > 64 || (Lr & 1) || Lqa < 4 || NA < 1 || NA * Lqa > 256 ||
         (long)NA * Li * Lqa * FD >= (1l << 29)) return STAGE_ERR_SHAPE;   // 32-bit element offsets inside an example
@@ -752,10 +763,28 @@ extern "C" int stage_str_attn_bwd_fused(const float* dA, const float* dS_raw_ext
     const int RT = (Lr + 15) / 16;
 #define FUS_ARGS dA, dS_raw_ext, Cn, Q, Qn, S_norm, q_mask, dQraw, dQn, dCn, N, NA, Li, Lqa, Lr, scale, ws, st
     switch (RT) {
-        case 1: return fus_launch<1, 8, 2>(FUS_ARGS);
-        case 2: return fus_launch<2, 8, 2>(FUS_ARGS);
-        case 3: return fus_launch<3, 8, 2>(FUS_ARGS);
-        default: return fus_launch<4, 8, 2>(FUS_ARGS);
+        case 1: return fus_launch<1, 8, 2, TD>(FUS_ARGS);
+        case 2: return fus_launch<2, 8, 2, TD>(FUS_ARGS);
+        case 3: return fus_launch<3, 8, 2, TD>(FUS_ARGS);
+        default: return fus_launch<4, 8, 2, TD>(FUS_ARGS);
     }
 #undef FUS_ARGS
+}
+
+extern "C" int stage_str_attn_bwd_fused(const float* dA, const float* dS_raw_ext, const float* Cn, const float* Q,
+                                        const float* Qn, const float* S_norm, const float* q_mask, float* dQraw,
+                                        float* dQn, float* dCn, int N, int NA, int Li, int Lqa, int Lr, int D, float scale,
+                                        void* ws, size_t ws_bytes, void* stream) {
+    return str_attn_bwd_fused_t<float>(dA, dS_raw_ext, Cn, Q, Qn, S_norm, q_mask, dQraw, dQn, dCn, N, NA, Li, Lqa, Lr, D, scale, ws,
+                                       ws_bytes, stream);
+}
+
+// bf16 storage mode: dA, Q, Qn are bf16; the score maps, Cn and the three gradients (dQraw, dQn, dCn) stay fp32
+extern "C" int stage_str_attn_bwd_fused_bf16(const void* dA, const float* dS_raw_ext, const float* Cn, const void* Q,
+                                             const void* Qn, const float* S_norm, const float* q_mask, float* dQraw,
+                                             float* dQn, float* dCn, int N, int NA, int Li, int Lqa, int Lr, int D, float scale,
+                                             void* ws, size_t ws_bytes, void* stream) {
+    typedef stage_bf16 B;
+    return str_attn_bwd_fused_t<B>((const B*)dA, dS_raw_ext, Cn, (const B*)Q, (const B*)Qn, S_norm, q_mask, dQraw, dQn, dCn, N, NA,
+                                   Li, Lqa, Lr, D, scale, ws, ws_bytes, stream);
 }

@@ -35,6 +35,9 @@ extern "C" int stage_str_attn_fwd_v1(const float* Cn, const float* Q, const floa
 int stage_str_attn_fwd_reg(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A,
                            float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D, float scale,
                            float p_drop, unsigned long long seed, void* stream);
+int stage_str_attn_fwd_reg_bf16(const float* Cn, const void* Q, const float* c_mask, const float* q_mask, void* A, float* S_raw,
+                                float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D, float scale, float p_drop,
+                                unsigned long long seed, void* stream);
 
 #define DD 128          // row width
 #define LDQ (DD + 4)    // padded LDS row stride (floats): ds_read_b128 of 16 rows x one chunk is conflict free
@@ -49,10 +52,11 @@ __device__ __forceinline__ int dchunk(int g, int m) {
 // WGF = true (3-4 region tiles): ONE copy of the frame per 4-wave workgroup instead of one per wave -- the frame is staged
 // cooperatively (a quarter of the work per wave), the waves take the context tiles round-robin, and the 27 KB copy no
 // longer limits the CU to 5 waves (8 fit their registers).  Items are whole frames handed out per workgroup.
-template <int RT, int KL, bool PERM, bool TRAIN, bool VEC_S, bool WGF>
+// TQ: storage type of Q and A (float, or bf16 in the bf16 storage mode); the LDS copy, Cn and the score maps are fp32
+template <int RT, int KL, bool PERM, bool TRAIN, bool VEC_S, bool WGF, typename TQ = float>
 __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
-    const float* __restrict__ Cn, const float* __restrict__ Q, const float* __restrict__ cmask,
-    const float* __restrict__ qmask, float* __restrict__ A, float* __restrict__ S, float* __restrict__ Sn, int N,
+    const float* __restrict__ Cn, const TQ* __restrict__ Q, const float* __restrict__ cmask,
+    const float* __restrict__ qmask, TQ* __restrict__ A, float* __restrict__ S, float* __restrict__ Sn, int N,
     int NA, int Li, int Lqa, int Lr, float scale, int slices, int tiles_per_slice, uint64_t seed, uint32_t th,
     float inv_keep, unsigned int* __restrict__ ticket, unsigned int ticket_base, unsigned long long* __restrict__ tim) {
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = tim ? __builtin_readcyclecounter() : 0;
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int r = r0 + 2 * j + srow;
-                v[j] = r < Lr ? ld4(Q + (frame * Lr + r) * DD + 4 * sq) : f4zero();
+                v[j] = r < Lr ? ldv4(Q + (frame * Lr + r) * DD + 4 * sq) : f4zero();
                 pmv[j] = (r < Lr && sq == 0) ? qmask[frame * Lr + r] : 0.f;
             }
 #pragma unroll
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
             const int c_lo = tile0 * 16, c_hi = min(CR, tile1 * 16);
             for (int c = c_lo + (lane >> 5) + (WGF ? 2 * wave : 0); c < c_hi; c += WGF ? 8 : 2) {
                 const long orow = ((long)(n * NA + c / Lqa) * Li + i) * Lqa + c % Lqa;
-                st4(A + orow * DD + 4 * sq, f4zero());
+                stv4(A + orow * DD + 4 * sq, f4zero());
                 for (int r = sq; r < Lr; r += 32) { S[orow * Lr + r] = STAGE_NEG; Sn[orow * Lr + r] = 0.f; }
             }
             item = next_item;
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
                     }
 #pragma unroll
                 for (int u = 0; u < NU; u++)
-                    st4(A + orow[u] * DD + dt * 16 + 4 * g, make_float4(o[u][0], o[u][1], o[u][2], o[u][3]));
+                    stv4(A + orow[u] * DD + dt * 16 + 4 * g, make_float4(o[u][0], o[u][1], o[u][2], o[u][3]));
             }
         };
 
@@ -393,8 +397,8 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
 #undef TICK
 }
 
-template <int RT, int KL, bool PERM, bool TRAIN, bool VEC_S>
-static int launch_d128_t(const float* Cn, const float* Q, const float* cm, const float* qm, float* A, float* S, float* Sn,
+template <int RT, int KL, bool PERM, bool TRAIN, bool VEC_S, typename TQ>
+static int launch_d128_t(const float* Cn, const TQ* Q, const float* cm, const float* qm, TQ* A, float* S, float* Sn,
                          int N, int NA, int Li, int Lqa, int Lr, float scale, float p_drop, unsigned long long seed,
                          hipStream_t st) {
     const int CR = NA * Lqa, CT = (CR + 15) / 16;
@@ -412,7 +416,7 @@ static int launch_d128_t(const float* Cn, const float* Q, const float* cm, const
     if constexpr (RT >= 3) if (!no_wgf) {
         // one frame copy per 4-wave workgroup (kernel comment); two workgroups per CU by registers
         const size_t lds = ((size_t)(Lr + 1) * LDQ + 2 * RT * 16 + (size_t)CT * 16 + 4) * sizeof(float);
-        auto kern = str_attn_fwd_d128_kernel<RT, KL, PERM, TRAIN, VEC_S, true>;
+        auto kern = str_attn_fwd_d128_kernel<RT, KL, PERM, TRAIN, VEC_S, true, TQ>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         long wg_per_cu = (long)((160 * 1024) / ((lds + 511) / 512 * 512));
         if (wg_per_cu > 2) wg_per_cu = 2;
@@ -439,7 +443,7 @@ static int launch_d128_t(const float* Cn, const float* Q, const float* cm, const
     }
     if (getenv("STAGE_K1_WPB")) wpb = atoi(getenv("STAGE_K1_WPB"));
     const size_t lds = wpb * wave_bytes;
-    auto kern = str_attn_fwd_d128_kernel<RT, KL, PERM, TRAIN, VEC_S, false>;
+    auto kern = str_attn_fwd_d128_kernel<RT, KL, PERM, TRAIN, VEC_S, false, TQ>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const long items = (long)N * Li * slices;
     int waves_per_cu = best > 0 ? best : 1;
@@ -455,19 +459,35 @@ static int launch_d128_t(const float* Cn, const float* Q, const float* cm, const
     return 0;
 }
 
-template <int RT, bool TRAIN>
-static int launch_d128(const float* Cn, const float* Q, const float* cm, const float* qm, float* A, float* S, float* Sn,
+template <int RT, bool TRAIN, typename TQ>
+static int launch_d128(const float* Cn, const TQ* Q, const float* cm, const float* qm, TQ* A, float* S, float* Sn,
                        int N, int NA, int Li, int Lqa, int Lr, float scale, float p_drop, unsigned long long seed,
                        hipStream_t st) {
     const int rem = Lr - 16 * (RT - 1);
     const bool vec = (Lr & 3) == 0;
 #define ARGS Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st
-    if (rem == 16) return vec ? launch_d128_t<RT, 4, false, TRAIN, true>(ARGS) : launch_d128_t<RT, 4, false, TRAIN, false>(ARGS);
+    if (rem == 16) return vec ? launch_d128_t<RT, 4, false, TRAIN, true, TQ>(ARGS) : launch_d128_t<RT, 4, false, TRAIN, false, TQ>(ARGS);
     switch ((rem + 3) / 4) {
-        case 1: return vec ? launch_d128_t<RT, 1, true, TRAIN, true>(ARGS) : launch_d128_t<RT, 1, true, TRAIN, false>(ARGS);
-        case 2: return vec ? launch_d128_t<RT, 2, true, TRAIN, true>(ARGS) : launch_d128_t<RT, 2, true, TRAIN, false>(ARGS);
-        case 3: return vec ? launch_d128_t<RT, 3, true, TRAIN, true>(ARGS) : launch_d128_t<RT, 3, true, TRAIN, false>(ARGS);
-        default: return vec ? launch_d128_t<RT, 4, true, TRAIN, true>(ARGS) : launch_d128_t<RT, 4, true, TRAIN, false>(ARGS);
+        case 1: return vec ? launch_d128_t<RT, 1, true, TRAIN, true, TQ>(ARGS) : launch_d128_t<RT, 1, true, TRAIN, false, TQ>(ARGS);
+        case 2: return vec ? launch_d128_t<RT, 2, true, TRAIN, true, TQ>(ARGS) : launch_d128_t<RT, 2, true, TRAIN, false, TQ>(ARGS);
+        case 3: return vec ? launch_d128_t<RT, 3, true, TRAIN, true, TQ>(ARGS) : launch_d128_t<RT, 3, true, TRAIN, false, TQ>(ARGS);
+        default: return vec ? launch_d128_t<RT, 4, true, TRAIN, true, TQ>(ARGS) : launch_d128_t<RT, 4, true, TRAIN, false, TQ>(ARGS);
+    }
+#undef ARGS
+}
+
+template <typename TQ>
+static int str_attn_fwd_d128_t(const float* Cn, const TQ* Q, const float* c_mask, const float* q_mask, TQ* A, float* S_raw,
+                               float* S_norm, int N, int NA, int Li, int Lqa, int Lr, float scale, float p_drop,
+                               unsigned long long seed, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const bool train = p_drop > 0.f;
+#define ARGS Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st
+    switch ((Lr + 15) / 16) {
+        case 1: return train ? launch_d128<1, true, TQ>(ARGS) : launch_d128<1, false, TQ>(ARGS);
+        case 2: return train ? launch_d128<2, true, TQ>(ARGS) : launch_d128<2, false, TQ>(ARGS);
+        case 3: return train ? launch_d128<3, true, TQ>(ARGS) : launch_d128<3, false, TQ>(ARGS);
+        default: return train ? launch_d128<4, true, TQ>(ARGS) : launch_d128<4, false, TQ>(ARGS);
     }
 #undef ARGS
 }
@@ -485,14 +505,21 @@ extern "C" int stage_str_attn_fwd(const float* Cn, const float* Q, const float* 
                                               seed, stream);
         if (rc != 1) return rc;
     }
-    hipStream_t st = (hipStream_t)stream;
-    const bool train = p_drop > 0.f;
-#define ARGS Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st
-    switch ((Lr + 15) / 16) {
-        case 1: return train ? launch_d128<1, true>(ARGS) : launch_d128<1, false>(ARGS);
-        case 2: return train ? launch_d128<2, true>(ARGS) : launch_d128<2, false>(ARGS);
-        case 3: return train ? launch_d128<3, true>(ARGS) : launch_d128<3, false>(ARGS);
-        default: return train ? launch_d128<4, true>(ARGS) : launch_d128<4, false>(ARGS);
+    return str_attn_fwd_d128_t<float>(Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, scale, p_drop, seed, stream);
+}
+
+// bf16 storage mode: Q and A are bf16 (Cn, masks and the score maps stay fp32).  D == 128 and Lr <= 64 only (the fast
+// kernels); other shapes return STAGE_ERR_SHAPE and the caller takes stage_str_attn_long_fwd.
+extern "C" int stage_str_attn_fwd_bf16(const float* Cn, const void* Q, const float* c_mask, const float* q_mask, void* A,
+                                       float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D, float scale,
+                                       float p_drop, unsigned long long seed, void* stream) {
+    if (N <= 0 || Li <= 0) return 0;
+    if (D != DD || Lr < 1 || Lr > 64 || Lqa < 1 || NA < 1) return STAGE_ERR_SHAPE;
+    if (!getenv("STAGE_K1_LDS")) {
+        const int rc = stage_str_attn_fwd_reg_bf16(Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, D, scale, p_drop,
+                                                   seed, stream);
+        if (rc != 1) return rc;
     }
-#undef ARGS
+    return str_attn_fwd_d128_t<stage_bf16>(Cn, (const stage_bf16*)Q, c_mask, q_mask, (stage_bf16*)A, S_raw, S_norm, N, NA, Li, Lqa,
+                                           Lr, scale, p_drop, seed, stream);
 }

@@ -31,13 +31,16 @@
 #else
 #define ST4_OUT(p, v) st4((p), (v))
 #endif
+__device__ __forceinline__ void st4_out(float* p, float4 v) { ST4_OUT(p, v); }
+__device__ __forceinline__ void st4_out(stage_bf16* p, float4 v) { stv4(p, v); }   // bf16 storage: 8 bytes per lane, 128 per row half
 #define RD 128          // row width (floats)
 #define RNCH 8          // 4-float chunks per lane group
 
-template <int RT, int KL, bool PERM, bool TRAIN, bool VEC_S>
+// TQ: storage type of Q and A (float, or bf16 in the bf16 storage mode; Cn -- small, L2 resident -- and the score maps stay fp32)
+template <int RT, int KL, bool PERM, bool TRAIN, bool VEC_S, typename TQ = float>
 __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
-    const float* __restrict__ Cn, const float* __restrict__ Q, const float* __restrict__ cmask,
-    const float* __restrict__ qmask, float* __restrict__ A, float* __restrict__ S, float* __restrict__ Sn, int N,
+    const float* __restrict__ Cn, const TQ* __restrict__ Q, const float* __restrict__ cmask,
+    const float* __restrict__ qmask, TQ* __restrict__ A, float* __restrict__ S, float* __restrict__ Sn, int N,
     int NA, int Li, int Lqa, int Lr, float scale, int slices, int tiles_per_slice, uint64_t seed, uint32_t th,
     float inv_keep, unsigned int* __restrict__ ticket, unsigned int ticket_base, int static_rounds) {
     constexpr int NK2 = (RT - 1) * 4 + KL;            // stage-2 k-steps (4 regions each)
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
         const int n = (int)(frame / Li), i = (int)(frame % Li);
         const int tile0 = slice * tiles_per_slice;
         const int tile1 = min(CT, tile0 + tiles_per_slice);
-        const float* qf = Q + frame * Lr * RD;
+        const TQ* qf = Q + frame * Lr * RD;
         row_k0 = ((unsigned)n * NA * Li + i) * Lqa;
 
         // region fed by this lane as stage-1 A row (i = c15), per region tile.  Derived per item from an opaque copy of
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
         for (int rt = 0; rt < RT; rt++) {
             const int rc = min(areg[rt], Lr - 1);
 #pragma unroll
-            for (int m = 0; m < RNCH; m++) qa[rt][m] = (K1_ABL & 128) ? make_float4(rc, m, g, 1.f) : ld4(qf + rc * RD + 4 * (4 * m + g));
+            for (int m = 0; m < RNCH; m++) qa[rt][m] = (K1_ABL & 128) ? make_float4(rc, m, g, 1.f) : ldv4(qf + rc * RD + 4 * (4 * m + g));
         }
         float4 q2[NK2][2];
         float qmk[RT][4];
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
             for (int k = 0; k < ((rt == RT - 1) ? KL : 4); k++) {
                 const int rc = min(Rk(rt, k), Lr - 1);
 #pragma unroll
-                for (int b = 0; b < 2; b++) q2[rt * 4 + k][b] = (K1_ABL & 128) ? make_float4(rc, b, c15, 1.f) : ld4(qf + rc * RD + 64 * b + 4 * c15);
+                for (int b = 0; b < 2; b++) q2[rt * 4 + k][b] = (K1_ABL & 128) ? make_float4(rc, b, c15, 1.f) : ldv4(qf + rc * RD + 64 * b + 4 * c15);
             }
 #pragma unroll
         for (int rt = 0; rt < RT; rt++)
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
             const int sq = lane & 31;
             for (int c = c_lo + (lane >> 5); c < c_hi; c += 2) {
                 const unsigned orow = out_row(c);
-                st4(A + (size_t)orow * RD + 4 * sq, f4zero());
+                stv4(A + (size_t)orow * RD + 4 * sq, f4zero());
                 for (int r = sq; r < Lr; r += 32) { S[(size_t)orow * Lr + r] = STAGE_NEG; Sn[(size_t)orow * Lr + r] = 0.f; }
             }
             item = next_item;
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++)
                     if (!(K1_ABL & 1) || o[0][reg] == 1.2345e30f)
-                        ST4_OUT(A + arow4[reg] + 64 * b, make_float4(o[0][reg], o[1][reg], o[2][reg], o[3][reg]));
+                        st4_out(A + arow4[reg] + 64 * b, make_float4(o[0][reg], o[1][reg], o[2][reg], o[3][reg]));
             }
             if (!(K1_ABL & 32)) WAIT_CF(NST);   // only this tile's stores may still be in flight
         }
@@ -331,8 +334,8 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
     }
 }
 
-template <int RT, int KL, bool PERM, bool TRAIN, bool VEC_S>
-static int launch_reg_t(const float* Cn, const float* Q, const float* cm, const float* qm, float* A, float* S, float* Sn,
+template <int RT, int KL, bool PERM, bool TRAIN, bool VEC_S, typename TQ>
+static int launch_reg_t(const float* Cn, const TQ* Q, const float* cm, const float* qm, TQ* A, float* S, float* Sn,
                         int N, int NA, int Li, int Lqa, int Lr, float scale, float p_drop, unsigned long long seed,
                         hipStream_t st) {
     const int CR = NA * Lqa, CT = (CR + 15) / 16;
@@ -362,40 +365,53 @@ static int launch_reg_t(const float* Cn, const float* Q, const float* cm, const 
     const long draws = items - (long)(static_rounds - 1) * entering;
     const StageTicket tk = stage_next_ticket((unsigned int)draws);
     if (!tk.word) return (int)hipErrorOutOfMemory;
-    hipLaunchKernelGGL((str_attn_fwd_reg_kernel<RT, KL, PERM, TRAIN, VEC_S>), dim3((unsigned)blocks), dim3(256), 0, st, Cn, Q,
+    hipLaunchKernelGGL((str_attn_fwd_reg_kernel<RT, KL, PERM, TRAIN, VEC_S, TQ>), dim3((unsigned)blocks), dim3(256), 0, st, Cn, Q,
                        cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, slices, tps, (uint64_t)seed, th, ik, tk.word, tk.base,
                        static_rounds);
     STAGE_LAUNCH_CHECK_TICKET(tk);
     return 0;
 }
 
-template <int RT, bool TRAIN>
-static int launch_reg(const float* Cn, const float* Q, const float* cm, const float* qm, float* A, float* S, float* Sn,
+template <int RT, bool TRAIN, typename TQ>
+static int launch_reg(const float* Cn, const TQ* Q, const float* cm, const float* qm, TQ* A, float* S, float* Sn,
                       int N, int NA, int Li, int Lqa, int Lr, float scale, float p_drop, unsigned long long seed,
                       hipStream_t st) {
     const int rem = Lr - 16 * (RT - 1);
     const bool vec = (Lr & 3) == 0;
 #define ARGS Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st
-    if (rem == 16) return vec ? launch_reg_t<RT, 4, false, TRAIN, true>(ARGS) : launch_reg_t<RT, 4, false, TRAIN, false>(ARGS);
+    if (rem == 16) return vec ? launch_reg_t<RT, 4, false, TRAIN, true, TQ>(ARGS) : launch_reg_t<RT, 4, false, TRAIN, false, TQ>(ARGS);
     switch ((rem + 3) / 4) {
-        case 1: return vec ? launch_reg_t<RT, 1, true, TRAIN, true>(ARGS) : launch_reg_t<RT, 1, true, TRAIN, false>(ARGS);
-        case 2: return vec ? launch_reg_t<RT, 2, true, TRAIN, true>(ARGS) : launch_reg_t<RT, 2, true, TRAIN, false>(ARGS);
-        case 3: return vec ? launch_reg_t<RT, 3, true, TRAIN, true>(ARGS) : launch_reg_t<RT, 3, true, TRAIN, false>(ARGS);
-        default: return vec ? launch_reg_t<RT, 4, true, TRAIN, true>(ARGS) : launch_reg_t<RT, 4, true, TRAIN, false>(ARGS);
+        case 1: return vec ? launch_reg_t<RT, 1, true, TRAIN, true, TQ>(ARGS) : launch_reg_t<RT, 1, true, TRAIN, false, TQ>(ARGS);
+        case 2: return vec ? launch_reg_t<RT, 2, true, TRAIN, true, TQ>(ARGS) : launch_reg_t<RT, 2, true, TRAIN, false, TQ>(ARGS);
+        case 3: return vec ? launch_reg_t<RT, 3, true, TRAIN, true, TQ>(ARGS) : launch_reg_t<RT, 3, true, TRAIN, false, TQ>(ARGS);
+        default: return vec ? launch_reg_t<RT, 4, true, TRAIN, true, TQ>(ARGS) : launch_reg_t<RT, 4, true, TRAIN, false, TQ>(ARGS);
     }
 #undef ARGS
 }
 
 // returns 1 when the shape is not handled here (caller falls back to the LDS-staged kernel), 0 on launch, other = error
-int stage_str_attn_fwd_reg(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A,
-                           float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D, float scale,
-                           float p_drop, unsigned long long seed, void* stream) {
+template <typename TQ>
+static int str_attn_fwd_reg_t(const float* Cn, const TQ* Q, const float* c_mask, const float* q_mask, TQ* A, float* S_raw,
+                              float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D, float scale, float p_drop,
+                              unsigned long long seed, void* stream) {
     if (D != RD || Lr > 32 || (long)NA * Lqa >= (1 << 22)) return 1;
     if ((long)N * NA * Li * Lqa >= (1l << 24) || (long)(Li - 1) * Lqa >= (1l << 24)) return 1;   // 24-bit row arithmetic
     hipStream_t st = (hipStream_t)stream;
     const bool train = p_drop > 0.f;
 #define ARGS Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st
-    if (Lr <= 16) return train ? launch_reg<1, true>(ARGS) : launch_reg<1, false>(ARGS);
-    return train ? launch_reg<2, true>(ARGS) : launch_reg<2, false>(ARGS);
+    if (Lr <= 16) return train ? launch_reg<1, true, TQ>(ARGS) : launch_reg<1, false, TQ>(ARGS);
+    return train ? launch_reg<2, true, TQ>(ARGS) : launch_reg<2, false, TQ>(ARGS);
 #undef ARGS
+}
+
+int stage_str_attn_fwd_reg(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A,
+                           float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D, float scale,
+                           float p_drop, unsigned long long seed, void* stream) {
+    return str_attn_fwd_reg_t<float>(Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, D, scale, p_drop, seed, stream);
+}
+int stage_str_attn_fwd_reg_bf16(const float* Cn, const void* Q, const float* c_mask, const float* q_mask, void* A, float* S_raw,
+                                float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D, float scale, float p_drop,
+                                unsigned long long seed, void* stream) {
+    return str_attn_fwd_reg_t<stage_bf16>(Cn, (const stage_bf16*)Q, c_mask, q_mask, (stage_bf16*)A, S_raw, S_norm, N, NA, Li, Lqa,
+                                          Lr, D, scale, p_drop, seed, stream);
 }

@@ -493,20 +493,26 @@ _K1_BWD_UNFUSED = _os.environ.get("STAGE_K1_BWD_UNFUSED") is not None   # develo
 
 
 class _StrAttn(torch.autograd.Function):
+    """The fast kernels (D = 128, Lr <= 64).  fp32, or bf16 storage: Q, A and dA are bf16 and are converted as the kernels load
+    / store them; the context side (N*NA*Lqa rows: small) is normalised in fp32, the score maps are fp32."""
+
     @_on_device
     def forward(ctx, C, Q, c_mask, q_mask, scale: float, p: float, seed_c: int, seed_q: int):
-        C, Q = _chk(C, "C"), _chk(Q, "Q")                    # (N, NA, Lqa, D), (N, Li, Lr, D)
+        Q = _act(Q, "Q")
+        C = _act(C, "C", Q)                                  # (N, NA, Lqa, D), (N, Li, Lr, D)
+        bf = Q.dtype == _BF16
         c_mask, q_mask = _chk(c_mask, "c_mask"), _chk(q_mask, "q_mask")
         N, NA, Lqa, D = C.shape
         _, Li, Lr, _ = Q.shape
-        Cn = torch.empty_like(C)
-        _call("stage_l2norm_fwd", _ptr(C), _ptr(Cn), None, N * NA * Lqa, D, EPS_L2, float(p), int(seed_c), _stream())
-        A = torch.empty(N, NA, Li, Lqa, D, dtype=torch.float32, device=C.device)
+        Cf = C.float() if bf else C
+        Cn = torch.empty_like(Cf)
+        _call("stage_l2norm_fwd", _ptr(Cf), _ptr(Cn), None, N * NA * Lqa, D, EPS_L2, float(p), int(seed_c), _stream())
+        A = torch.empty(N, NA, Li, Lqa, D, dtype=Q.dtype, device=C.device)
         S = torch.empty(N, NA, Li, Lqa, Lr, dtype=torch.float32, device=C.device)
         Sn = torch.empty_like(S)
-        _call("stage_str_attn_fwd", _ptr(Cn), _ptr(Q), _ptr(c_mask), _ptr(q_mask), _ptr(A), _ptr(S), _ptr(Sn), N, NA, Li,
+        _call("stage_str_attn_fwd" + _sfx(Q), _ptr(Cn), _ptr(Q), _ptr(c_mask), _ptr(q_mask), _ptr(A), _ptr(S), _ptr(Sn), N, NA, Li,
               Lqa, Lr, D, float(scale), float(p), int(seed_q), _stream())
-        ctx.save_for_backward(C, Q, Cn, Sn, q_mask)
+        ctx.save_for_backward(Cf, Q, Cn, Sn, q_mask)
         ctx.cfg = (float(scale), float(p), int(seed_c), int(seed_q))
         ctx.mark_non_differentiable(Sn)
         # raw S only receives a gradient when the supervised attention loss is on: without this autograd hands the
@@ -516,37 +522,43 @@ class _StrAttn(torch.autograd.Function):
 
     @_on_device
     def backward(ctx, dA, dS, _dSn):
-        C, Q, Cn, Sn, q_mask = ctx.saved_tensors
+        Cf, Q, Cn, Sn, q_mask = ctx.saved_tensors
         scale, p, seed_c, seed_q = ctx.cfg
-        N, NA, Lqa, D = C.shape
+        bf = Q.dtype == _BF16
+        N, NA, Lqa, D = Cf.shape
         _, Li, Lr, _ = Q.shape
-        dA = _chk(dA, "dA") if dA is not None else torch.zeros(N, NA, Li, Lqa, D, device=C.device)
+        dA = _act(dA, "dA", Q) if dA is not None else torch.zeros(N, NA, Li, Lqa, D, dtype=Q.dtype, device=Q.device)
         dS_ext = _chk(dS, "dS") if dS is not None else None
         Qn = torch.empty_like(Q)
-        _call("stage_l2norm_fwd", _ptr(Q), _ptr(Qn), None, N * Li * Lr, D, EPS_L2, p, seed_q, _stream())
-        dQ = torch.empty_like(Q)       # receives the value-path gradient, then the normalised-path one on top
-        dQn = torch.empty_like(Q)
-        dCn = torch.empty_like(C)
+        _call("stage_l2norm_fwd" + _sfx(Q), _ptr(Q), _ptr(Qn), None, N * Li * Lr, D, EPS_L2, p, seed_q, _stream())
+        dQ = torch.empty(Q.shape, dtype=torch.float32, device=Q.device)   # receives the value-path gradient, then the normalised-path one on top
+        dQn = torch.empty_like(dQ)
+        dCn = torch.empty_like(Cf)
         lib = _lib.load()
         rc = _lib.STAGE_ERR_SHAPE
         if not _K1_BWD_UNFUSED:
             # one pass over dA, dS stays on chip (D = 128, even Lr); other shapes take the three-kernel path below
             wsb = lib.stage_str_attn_bwd_fused_ws_bytes(N, NA, Li, Lqa, D)
-            ws = _workspace(wsb, C.device)
-            rc = lib.stage_str_attn_bwd_fused(_ptr(dA), _ptr(dS_ext), _ptr(Cn), _ptr(Q), _ptr(Qn), _ptr(Sn), _ptr(q_mask),
-                                              _ptr(dQ), _ptr(dQn), _ptr(dCn), N, NA, Li, Lqa, Lr, D, scale, _ptr(ws), wsb,
-                                              _stream())
+            ws = _workspace(wsb, Q.device)
+            fn = lib.stage_str_attn_bwd_fused_bf16 if bf else lib.stage_str_attn_bwd_fused
+            rc = fn(_ptr(dA), _ptr(dS_ext), _ptr(Cn), _ptr(Q), _ptr(Qn), _ptr(Sn), _ptr(q_mask), _ptr(dQ), _ptr(dQn), _ptr(dCn),
+                    N, NA, Li, Lqa, Lr, D, scale, _ptr(ws), wsb, _stream())
             if rc != _lib.STAGE_ERR_SHAPE:
                 _lib.check(rc, "stage_str_attn_bwd_fused")
+        Qf = Q.float() if bf else Q
         if rc == _lib.STAGE_ERR_SHAPE:
+            # three-kernel path (fp32 operands; in the bf16 mode the casts are plumbing for the shapes the fused kernel rejects)
+            dAf, Qnf = (dA.float(), Qn.float()) if bf else (dA, Qn)
             dS_out = torch.empty_like(Sn)
             wsb = lib.stage_str_attn_bwd_ws_bytes(N, NA, Lqa, D)
-            ws = _workspace(wsb, C.device)
-            _call("stage_str_attn_bwd", _ptr(dA), _ptr(dS_ext), _ptr(Cn), _ptr(Q), _ptr(Qn), _ptr(Sn), _ptr(dS_out),
+            ws = _workspace(wsb, Q.device)
+            _call("stage_str_attn_bwd", _ptr(dAf), _ptr(dS_ext), _ptr(Cn), _ptr(Qf), _ptr(Qnf), _ptr(Sn), _ptr(dS_out),
                   _ptr(dQ), _ptr(dQn), _ptr(dCn), N, NA, Li, Lqa, Lr, D, scale, _ptr(ws), wsb, _stream())
-        _call("stage_l2norm_bwd", _ptr(dQn), _ptr(Q), _ptr(dQ), N * Li * Lr, D, EPS_L2, p, seed_q, 1, _stream())
-        dC = torch.empty_like(C)
-        _call("stage_l2norm_bwd", _ptr(dCn), _ptr(C), _ptr(dC), N * NA * Lqa, D, EPS_L2, p, seed_c, 0, _stream())
+        _call("stage_l2norm_bwd", _ptr(dQn), _ptr(Qf), _ptr(dQ), N * Li * Lr, D, EPS_L2, p, seed_q, 1, _stream())
+        dC = torch.empty_like(Cf)
+        _call("stage_l2norm_bwd", _ptr(dCn), _ptr(Cf), _ptr(dC), N * NA * Lqa, D, EPS_L2, p, seed_c, 0, _stream())
+        if bf:
+            return dC.to(_BF16), dQ.to(_BF16), None, None, None, None, None, None
         return dC, dQ, None, None, None, None, None, None
 
 
@@ -612,7 +624,8 @@ def structured_attention_long(C, Q, c_mask, q_mask, scale: float, p: float = 0.0
 
 def structured_attention(C, Q, c_mask, q_mask, scale: float, p: float = 0.0, seed_c: int = 0, seed_q: int = 0):
     """C (N,NA,Lqa,D), Q (N,Li,Lr,D), c_mask (N,NA,Lqa), q_mask (N,Li,Lr) -> A (N,NA,Li,Lqa,D), raw S, normalised S."""
-    if Q.shape[2] > 64 or C.dtype == torch.bfloat16:    # long rows (512 subtitle words) / bf16 storage: csrc/str_attn_long.hip
+    # long rows (512 subtitle words) and bf16 shapes outside the fast kernels (D != 128): csrc/str_attn_long.hip
+    if Q.shape[2] > 64 or (C.dtype == torch.bfloat16 and C.shape[-1] != 128):
         return _StrAttnLong.apply(C, Q, c_mask, q_mask, scale, p, seed_c, seed_q)
     return _StrAttn.apply(C, Q, c_mask, q_mask, scale, p, seed_c, seed_q)
 
