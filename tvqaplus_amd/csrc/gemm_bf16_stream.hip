@@ -192,7 +192,8 @@ __global__ __launch_bounds__(768) void gemm_tn_bf16_stream_kernel(const stage_bf
     const int pl = wave % P + blockIdx.y * P;               // patch index: pn = pl / KPn (64 dY columns), pk = pl % KPn (64 X columns)
     const int rs = wave / P;
     const int NPn = N >> 6;
-    if (pl >= NPn * KPn) return;
+    const bool idle = pl >= NPn * KPn;    // (only with several patch groups, where RS == 1 and no barrier follows)
+    if (idle) return;
     const int pn = pl / KPn, pk = pl - pn * KPn;
     const long mbeg = (long)blockIdx.x * rows_per_slab, mend = min(M, mbeg + rows_per_slab);
     const unsigned* yb = reinterpret_cast<const unsigned*>(dY) + (pn * 32 + l31);      // dword = columns 64 pn + 2 l31, +1
@@ -262,8 +263,36 @@ __global__ __launch_bounds__(768) void gemm_tn_bf16_stream_kernel(const stage_bf
         if (m0 + 2 * stride < mend) fetch(s0, m0 + 2 * stride);
         if (more1) step(s1, m0 + stride);
     }
-    // ---- partial of this (slab, interleave): D[i][j] -> dW[n = 64 pn + 2 i + e][k = 64 pk + 2 j + f] ----
-    float* po = part + ((size_t)blockIdx.x * RS + rs) * (size_t)N * K;
+    // ---- the RS interleaves of a patch are summed through LDS (fixed order: deterministic), interleave 0 writes the slab ----
+    extern __shared__ __attribute__((aligned(16))) float red[];         // [(RS - 1) * P waves][66][64]: 64 accumulators + 2 bias sums per lane
+    if (RS > 1) {
+        if (rs > 0) {
+            float* mine = red + (size_t)((rs - 1) * P + wave % P) * 66 * 64 + lane;
+#pragma unroll
+            for (int e = 0; e < 2; e++)
+#pragma unroll
+                for (int f = 0; f < 2; f++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) mine[(size_t)((e * 2 + f) * 16 + r) * 64] = acc[e][f][r];
+            mine[(size_t)64 * 64] = bs0;
+            mine[(size_t)65 * 64] = bs1;
+        }
+        __syncthreads();
+        if (rs > 0) return;
+        for (int o = 1; o < RS; o++) {
+            const float* theirs = red + (size_t)((o - 1) * P + wave % P) * 66 * 64 + lane;
+#pragma unroll
+            for (int e = 0; e < 2; e++)
+#pragma unroll
+                for (int f = 0; f < 2; f++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[e][f][r] += theirs[(size_t)((e * 2 + f) * 16 + r) * 64];
+            bs0 += theirs[(size_t)64 * 64];
+            bs1 += theirs[(size_t)65 * 64];
+        }
+    }
+    // ---- partial of this slab: D[i][j] -> dW[n = 64 pn + 2 i + e][k = 64 pk + 2 j + f] ----
+    float* po = part + (size_t)blockIdx.x * (size_t)N * K;
 #pragma unroll
     for (int e = 0; e < 2; e++)
 #pragma unroll
@@ -277,7 +306,7 @@ __global__ __launch_bounds__(768) void gemm_tn_bf16_stream_kernel(const stage_bf
         bs0 += __shfl_xor(bs0, 32);
         bs1 += __shfl_xor(bs1, 32);
         if (h == 0) {
-            float* pb = part_b + ((size_t)blockIdx.x * RS + rs) * N + 64 * pn + 2 * l31;
+            float* pb = part_b + (size_t)blockIdx.x * N + 64 * pn + 2 * l31;
             pb[0] = bs0;
             pb[1] = bs1;
         }
@@ -292,6 +321,7 @@ static int tb_plan(long long M, int N, int K, int* P, int* RS, int* KPn, int* GY
     *GY = (total + 11) / 12;                    // <= 12 waves per workgroup (768 threads: 168 registers per lane)
     *P = (total + *GY - 1) / *GY;
     *RS = *GY == 1 ? (12 / *P) : 1;
+    if (*RS > 1 + 8 / *P) *RS = 1 + 8 / *P;    // LDS for the in-workgroup sum: (RS - 1) * P * 16.5 KB <= 132 KB
     if (*RS < 1) *RS = 1;
     // one resident workgroup per CU: 256 / GY slabs, at least 32 steps of 16 rows per interleave
     long S = 256 / *GY;
@@ -307,7 +337,7 @@ static int tb_plan(long long M, int N, int K, int* P, int* RS, int* KPn, int* GY
 size_t stage_gemm_tn_bf16_stream_ws_bytes(long long M, int N, int K) {
     int P, RS, KPn, GY; long rps;
     const int S = tb_plan(M, N, K, &P, &RS, &KPn, &GY, &rps);
-    return (size_t)S * RS * ((size_t)N * K + N) * sizeof(float);
+    return (size_t)S * ((size_t)N * K + N) * sizeof(float);
 }
 
 // returns 1 if the shape / alignment is not handled here, 0 on launch; *slabs = number of partials written
@@ -319,13 +349,18 @@ int stage_gemm_tn_bf16_stream(const void* dY, const void* gate, const void* X, f
     if (S == 0 || ((uintptr_t)dY & 3) || ((uintptr_t)X & 3) || (gate && ((uintptr_t)gate & 3))) return 1;
     typedef stage_bf16 B;
     dim3 grid((unsigned)S, (unsigned)GY), block(64 * P * RS);
+    const size_t lds = (size_t)(RS - 1) * P * 66 * 64 * sizeof(float);
+    if (lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     if (gate)
-        hipLaunchKernelGGL(gemm_tn_bf16_stream_kernel<true>, grid, block, 0, (hipStream_t)stream, (const B*)dY, (const B*)gate,
+        hipLaunchKernelGGL(gemm_tn_bf16_stream_kernel<true>, grid, block, lds, (hipStream_t)stream, (const B*)dY, (const B*)gate,
                            (const B*)X, part, part_b, (long)M, N, K, rps, P, RS, KPn);
     else
-        hipLaunchKernelGGL(gemm_tn_bf16_stream_kernel<false>, grid, block, 0, (hipStream_t)stream, (const B*)dY, (const B*)gate,
+        hipLaunchKernelGGL(gemm_tn_bf16_stream_kernel<false>, grid, block, lds, (hipStream_t)stream, (const B*)dY, (const B*)gate,
                            (const B*)X, part, part_b, (long)M, N, K, rps, P, RS, KPn);
     STAGE_LAUNCH_CHECK();
-    *slabs = S * RS;
+    *slabs = S;
     return 0;
 }
