@@ -110,7 +110,9 @@ def test_cat3_layernorm_bf16(ops, G, rep, inner, D):
                                          # the streaming kernel (M >= 4096, K % 8 == 0, K <= 384, N % 128 == 0): ragged last
                                          # row tile, 1..6 k-chunks with a ragged last one, 1..3 column tiles, ReLU gate
                                          (4200, 128, 128, True), (5000, 384, 128, True), (4500, 128, 384, True),
-                                         (4097, 256, 256, False), (6000, 128, 200, True), (8200, 128, 72, True)])
+                                         (4097, 256, 256, False), (6000, 128, 200, True), (8200, 128, 72, True),
+                                         # its 64-column variant: wide K, N % 128 != 0, 8-byte-aligned rows (K = 300)
+                                         (4500, 300, 128, True), (4300, 44, 768, True), (4200, 192, 100, False)])
 def test_linear_bf16(ops, M, N, K, relu):
     g = torch.Generator().manual_seed(M + N + K)
     x = rb(torch.randn(M, K, generator=g))

@@ -132,12 +132,156 @@ __global__ __launch_bounds__(64 * GB_WAVES) __attribute__((amdgpu_waves_per_eu(2
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same kernel for the shapes the 128-column one rejects: wide K (the 768 / 300-wide input layers: a 64-column weight tile
+// of K <= 960 still fits the LDS), N not a multiple of 128 (300), rows that are only 8-byte aligned (K or N % 8 == 4).
+// 64 output columns per workgroup, run-time chunk count, 8-byte loads / stores where 16 are not aligned, and the XCD-aware
+// 1-D grid of gemm_stream.hip: the ceil(N / 64) column tiles of a row group sit on one XCD, so their re-reads of X hit its L2.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool HAS_GATE, bool X16>
+__global__ __launch_bounds__(64 * GB_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_bf16_stream64_kernel(
+    const stage_bf16* __restrict__ X, const stage_bf16* __restrict__ G, const float* __restrict__ W,
+    const float* __restrict__ bias, stage_bf16* __restrict__ Y, long M, int N, int K, int Kp, int relu, int gx, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+    unsigned short* Wl = lds;                                            // [64][Kp]
+    unsigned short* stg = Wl + 64 * Kp;                                  // [GB_WAVES][32][GB_STG]
+    float* bias_s = reinterpret_cast<float*>(stg + GB_WAVES * 32 * GB_STG);   // [64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int r8 = blockIdx.x & 7, tq = blockIdx.x >> 3;
+    const int by = tq % n_tiles, bx = (tq / n_tiles) * 8 + r8;           // id = 8 (n_tiles q + by) + r,  bx = 8 q + r
+    const int n0 = by * 64;
+    const int nkc = (K + GB_KC - 1) / GB_KC;
+    const int K4p = Kp >> 2;
+    for (int e = tid; e < 64 * K4p; e += 64 * GB_WAVES) {
+        const int n = e / K4p, q = e - n * K4p;
+        float4 v = f4zero();
+        if (4 * q < K && n0 + n < N) v = ld4(W + (long)(n0 + n) * K + 4 * q);
+        *reinterpret_cast<uint2*>(&Wl[n * Kp + 4 * q]) = make_uint2(stage_pk_bf16(v.x, v.y), stage_pk_bf16(v.z, v.w));
+    }
+    if (tid < 64) bias_s[tid] = (bias && n0 + tid < N) ? bias[n0 + tid] : 0.f;
+    __syncthreads();
+
+    const long MT = (M + 31) >> 5;
+    const long nw = (long)gx * GB_WAVES;
+    unsigned short* my_stg = stg + wave * 32 * GB_STG;
+    auto ld8 = [&](const stage_bf16* p, long rowoff, int k) -> uint4 {       // 8 elements at k (k % 8 == 0), zero past K
+        if (X16) {
+            const uint4 v = *reinterpret_cast<const uint4*>(p + rowoff + (k < K ? k : 0));
+            return k < K ? v : make_uint4(0u, 0u, 0u, 0u);
+        }
+        const uint2 a = *reinterpret_cast<const uint2*>(p + rowoff + (k < K ? k : 0));
+        const uint2 b = *reinterpret_cast<const uint2*>(p + rowoff + (k + 4 < K ? k + 4 : 0));
+        return make_uint4(k < K ? a.x : 0u, k < K ? a.y : 0u, k + 4 < K ? b.x : 0u, k + 4 < K ? b.y : 0u);
+    };
+    auto fetch = [&](GbBuf& b, long row, int c) {
+        const long ro = (row < M ? row : M - 1) * K;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int k = c * GB_KC + 32 * h + 8 * s;
+            b.x[s] = ld8(X, ro, k);
+            if (HAS_GATE) b.g[s] = ld8(G, ro, k);
+        }
+    };
+    f32x16 acc[2];
+    auto mul = [&](GbBuf& cur, int c) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int k = c * GB_KC + 32 * h + 8 * s;
+            uint4 xv = cur.x[s];
+            if (HAS_GATE) xv = gb_gate(xv, cur.g[s]);
+            const gb_bf16x8 b = __builtin_bit_cast(gb_bf16x8, xv);
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) {
+                const gb_bf16x8 a = __builtin_bit_cast(gb_bf16x8, *reinterpret_cast<const uint4*>(&Wl[(nt * 32 + l31) * Kp + k]));
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nt], 0, 0, 0);   // D[n][m]
+            }
+        }
+    };
+    long t = (long)bx * GB_WAVES + wave;
+    GbBuf b0, b1, bn;
+    if (t < MT) fetch(b0, t * 32 + l31, 0);
+    for (; t < MT; t += nw) {
+        const long row = t * 32 + l31;
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[nt][r] = 0.f;
+#pragma unroll 1
+        for (int c = 0; c < nkc; c += 2) {
+            const bool has1 = c + 1 < nkc;
+            if (has1) fetch(b1, row, c + 1);
+            else fetch(bn, (t + nw) * 32 + l31, 0);
+            mul(b0, c);
+            if (has1) {
+                if (c + 2 < nkc) fetch(b0, row, c + 2);
+                else fetch(bn, (t + nw) * 32 + l31, 0);
+                mul(b1, c + 1);
+            }
+        }
+        // ---- epilogue (one 64-column pass): D[n][m], lane = row m, registers = columns 8 (r >> 2) + 4 h + (r & 3) of n-tile nt ----
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const float4 bs = ld4(&bias_s[32 * nt + 8 * g + 4 * h]);
+                float4 v = make_float4(acc[nt][4 * g + 0] + bs.x, acc[nt][4 * g + 1] + bs.y, acc[nt][4 * g + 2] + bs.z,
+                                       acc[nt][4 * g + 3] + bs.w);
+                if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                *reinterpret_cast<uint2*>(&my_stg[l31 * GB_STG + 32 * nt + 8 * g + 4 * h]) =
+                    make_uint2(stage_pk_bf16(v.x, v.y), stage_pk_bf16(v.z, v.w));
+            }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {                 // 8-byte pieces: rows are 8-byte aligned for any N % 4 == 0
+            const int r = 4 * i + (lane >> 4), c4 = (lane & 15) * 4;
+            const uint2 v = *reinterpret_cast<const uint2*>(&my_stg[r * GB_STG + c4]);
+            const long m = t * 32 + r;
+            if (m < M && n0 + c4 < N) *reinterpret_cast<uint2*>(Y + m * N + n0 + c4) = v;
+        }
+        b0 = bn;
+    }
+}
+
 // returns 1 if the shape / alignment is not handled here (caller falls back to the tiled kernel), 0 on launch
+static int gb_launch64(const void* X, const void* gate, const float* W, const float* bias, void* Y, long long M, int N, int K,
+                       int relu, void* stream) {
+    if (M < 4096 || K % 4 != 0 || K < 64 || N % 4 != 0 || N < 4) return 1;
+    if (((uintptr_t)X & 7) || ((uintptr_t)Y & 7) || ((uintptr_t)W & 15) || (gate && ((uintptr_t)gate & 7))) return 1;
+    const int nkc = (K + GB_KC - 1) / GB_KC;
+    int Kp = nkc * GB_KC;
+    Kp += ((Kp / 8) % 2 == 0) ? 8 : 16;
+    const size_t lds = (size_t)64 * Kp * 2 + (size_t)GB_WAVES * 32 * GB_STG * 2 + 64 * sizeof(float);
+    if (lds > 160 * 1024) return 1;
+    const bool x16 = K % 8 == 0 && !((uintptr_t)X & 15) && (!gate || !((uintptr_t)gate & 15));
+    if (gate && !x16) return 1;   // 8-byte pieces + gating: measured slower than the tiled kernel (960000 x 300 -> 768: 1.04 vs 0.88 ms)
+    const long MT = (M + 31) / 32;
+    const int n_tiles = (N + 63) / 64;
+    long gx = (256 / n_tiles) / 8 * 8;
+    if (gx < 8) gx = 8;
+    const long need = ((MT + GB_WAVES - 1) / GB_WAVES + 7) / 8 * 8;
+    if (gx > need) gx = need;
+    dim3 grid((unsigned)(gx * n_tiles)), block(64 * GB_WAVES);
+    typedef stage_bf16 B;
+#define GB64(GT, XV)                                                                                                            \
+    do {                                                                                                                        \
+        (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_stream64_kernel<GT, XV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((gemm_nt_bf16_stream64_kernel<GT, XV>), grid, block, lds, (hipStream_t)stream, (const B*)X, (const B*)gate, W, \
+                           bias, (B*)Y, (long)M, N, K, Kp, relu, (int)gx, n_tiles);                                             \
+    } while (0)
+    if (gate) { if (x16) GB64(true, true); else GB64(true, false); }
+    else { if (x16) GB64(false, true); else GB64(false, false); }
+#undef GB64
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
 int stage_gemm_nt_bf16_stream(const void* X, const void* gate, const float* W, const float* bias, void* Y, long long M, int N,
                               int K, int relu, void* stream) {
     static const bool off = getenv("STAGE_GEMM_BF16_TILED") != nullptr;   // developer switch: tiled kernel everywhere
-    if (off || M < 4096 || K % 8 != 0 || K < 64 || K > 384 || N % GB_BN != 0) return 1;
-    if (((uintptr_t)X & 15) || ((uintptr_t)Y & 15) || ((uintptr_t)W & 15) || (gate && ((uintptr_t)gate & 15))) return 1;
+    if (off) return 1;
+    if (M < 4096 || K % 8 != 0 || K < 64 || K > 384 || N % GB_BN != 0 ||
+        ((uintptr_t)X & 15) || ((uintptr_t)Y & 15) || ((uintptr_t)W & 15) || (gate && ((uintptr_t)gate & 15)))
+        return gb_launch64(X, gate, W, bias, Y, M, N, K, relu, stream);   // wide K / ragged N / 8-byte rows
     const int nkc = (K + GB_KC - 1) / GB_KC;
     int Kp = nkc * GB_KC;                           // whole chunks, zero padded
     Kp += ((Kp / 8) % 2 == 0) ? 8 : 16;             // odd number of 16-byte slots per row: conflict-free ds_read_b128
