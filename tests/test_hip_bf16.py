@@ -287,3 +287,39 @@ def test_whole_model_bf16_vs_fp32_oracle(hip_device, hsz, Lw, add_local):
     assert vals[0] >= 0.96 and vals[len(vals) // 2] >= 0.98, "cosines below 0.99: %s" % low
     # the optimiser sees fp32 master weights and fp32 gradients: one Adam step runs as usual
     torch.optim.Adam(model.parameters(), lr=1e-3).step()
+
+
+def test_bf16_full_size_step_tracks_fp32(hip_device):
+    """BASELINE configs[1] shapes (B = 16 x 5 x 300 frames x 20 regions x 50 words, hsz = 128, add_local) in both storage
+    modes with the same parameters and batch: the bf16 step's logits, span scores and loss track the fp32 HIP step (the
+    size-independent property at full size: the two modes are the same function up to bf16 rounding), every gradient finite."""
+    from tvqaplus_amd.stage import STAGE
+    from tvqaplus_amd.synth import make_batch, make_opt
+    import contextlib, io
+    torch.manual_seed(5)
+    kw = dict(hsz=128, dropout=0.0, add_local=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m32 = STAGE(make_opt(**kw)).cuda().train()
+        m16 = STAGE(make_opt(storage_dtype="bf16", **kw)).cuda().train()
+    m16.load_state_dict(m32.state_dict())
+    b = make_batch(N=16, seed=2018).to("cuda")
+    res = {}
+    for name, m in (("fp32", m32), ("bf16", m16)):
+        (out, targets), _, _, t_loss, t_scores = m(b)
+        loss = F.cross_entropy(out, targets, reduction="sum") * (16.0 / len(targets)) + 0.5 * t_loss
+        loss.backward()
+        res[name] = (out.detach().float().cpu(), t_scores.detach().float().cpu(), float(loss.detach()), targets.cpu())
+        assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters() if p.grad is not None)
+    o32, t32, l32, tg32 = res["fp32"]
+    o16, t16, l16, tg16 = res["bf16"]
+    assert abs(l16 - l32) < 3e-2 * abs(l32), (l16, l32)
+    if torch.equal(tg32, tg16):                      # same proposals (a span whose IoU sits on the threshold may flip one)
+        assert rel_err(o16, o32) < 6e-2
+    valid = t32 > -1e9
+    assert float((t16 - t32)[valid].abs().max()) < 6e-2 * (1 + float(t32[valid].abs().max()))
+    cos = []
+    for (k, p32), (_, p16) in zip(m32.named_parameters(), m16.named_parameters()):
+        if p32.grad is not None and p16.grad is not None and float(p32.grad.norm()) > 0:
+            cos.append(_cos(p16.grad.cpu(), p32.grad.cpu()))
+    cos.sort()
+    assert cos[len(cos) // 2] >= 0.95, cos[:5]
