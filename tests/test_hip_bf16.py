@@ -323,3 +323,36 @@ def test_bf16_full_size_step_tracks_fp32(hip_device):
             cos.append(_cos(p16.grad.cpu(), p32.grad.cpu()))
     cos.sort()
     assert cos[len(cos) // 2] >= 0.95, cos[:5]
+
+
+def test_linear_bf16_shape_sweep(ops):
+    """Seeded sweep over the dispatch space of the bf16 GEMMs (128-column and 64-column streaming kernels, tiled kernel;
+    ragged row tiles, every chunk count, partial column tiles, gate on / off): forward, dX, dW, db against fp32 on the
+    rounded operands."""
+    import random
+    rnd = random.Random(2018)
+    for case in range(14):
+        M = rnd.choice([4096, 4100, 4999, 6143, 9000])
+        K = rnd.choice([64, 72, 128, 136, 192, 256, 300, 320, 384, 448, 768])
+        N = rnd.choice([4, 44, 64, 128, 192, 256, 300, 384])
+        relu = rnd.random() < 0.6
+        g = torch.Generator().manual_seed(case)
+        x = rb(torch.randn(M, K, generator=g))
+        w = torch.randn(N, K, generator=g) / math.sqrt(K)
+        b = torch.randn(N, generator=g)
+        gy = rb(torch.randn(M, N, generator=g))
+        xd, wd, bd = devb(x, True), dev(w, True), dev(b, True)
+        y = ops.linear(xd, wd, bd, relu=relu)
+        xc, wc, bc = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+        yc = F.linear(xc, rb(wc.detach()) + (wc - wc.detach()), bc)
+        tag = "case %d (M=%d K=%d N=%d relu=%s) " % (case, M, K, N, relu)
+        if relu:
+            check(tag + "y", y, torch.relu(yc), ULP2)
+            yc = yc * (y.detach().float().cpu() > 0).float()
+        else:
+            check(tag + "y", y, yc, ULP2)
+        yc.backward(gy)
+        y.backward(gy.to(BF).cuda())
+        check(tag + "dx", xd.grad, xc.grad, ULP2)
+        check(tag + "dw", wd.grad, wc.grad, PTOL)
+        check(tag + "db", bd.grad, bc.grad, PTOL)
