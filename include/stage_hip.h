@@ -235,6 +235,12 @@ int stage_ln_dwconv_bwd_bf16(const void* dh, const void* xin, const float* mean,
                              const float* beta, const float* w, void* dx, const void* dx_add, float* dgamma, float* dbeta,
                              float* dw, float* db, long long M, int L, int D, int k, float p_drop, unsigned long long seed,
                              void* ws, size_t ws_bytes, void* stream);
+/* self-attention core on bf16 q / k / v / out: the matrix-core kernels only (stage_mha_core_recomputes == 1) */
+int stage_mha_core_fwd_bf16(const void* q, const void* k, const void* v, const float* mask, void* out, long long M, int L,
+                            int D, int nh, float p_drop, unsigned long long seed, void* stream);
+int stage_mha_core_bwd_bf16(const void* dout, const void* q, const void* k, const void* v, const float* mask, void* dq,
+                            void* dk, void* dv, long long M, int L, int D, int nh, float p_drop, unsigned long long seed,
+                            void* stream);
 int stage_masked_max_fwd_bf16(const void* x, const float* mask, const int* window, void* out, int* argmax, long long R,
                               int L, int D, void* stream);
 int stage_masked_max_bwd_bf16(const void* dout, const int* argmax, const float* mask, void* dx, long long R, int L, int D,

@@ -237,23 +237,55 @@ def test_k1_fast_kernels_bf16(ops, N, Li, Lr, Lqa, ext):
     check("dQ", Qd.grad.view_as(Q), Qc.grad, 2 * ULP2)
 
 
+@pytest.mark.parametrize("M,L,D,nh", [(5, 20, 128, 4), (3, 50, 128, 4), (2, 64, 64, 1), (6, 13, 32, 4), (3, 40, 256, 4)])
+def test_mha_core_bf16(ops, M, L, D, nh):
+    """self-attention core (model/self_attention.py:56-71, query-row mask quirk) on bf16 q / k / v"""
+    g = torch.Generator().manual_seed(M * L + nh)
+    q, k, v = (rb(torch.randn(M, L, D, generator=g)) for _ in range(3))
+    lens = torch.randint(0, L + 1, (M,), generator=g)
+    lens[0] = L
+    m = (torch.arange(L).unsqueeze(0) < lens.unsqueeze(1)).float()
+    go = rb(torch.randn(M, L, D, generator=g))
+    dk = D // nh
+
+    def ref(q, k, v):
+        sp = lambda t: t.view(M, L, nh, dk).transpose(1, 2)
+        sc = torch.matmul(sp(q), sp(k).transpose(-2, -1)) / math.sqrt(dk)
+        sc = sc.masked_fill(m.view(M, 1, L, 1) == 0, -1e9)
+        return torch.matmul(torch.softmax(sc, -1), sp(v)).transpose(1, 2).reshape(M, L, D)
+
+    qc, kc, vc = (t.clone().requires_grad_() for t in (q, k, v))
+    ref(qc, kc, vc).backward(go)
+    qd, kd, vd = devb(q, True), devb(k, True), devb(v, True)
+    o = ops.mha_core(qd, kd, vd, m.cuda(), nh)
+    assert o.dtype == BF
+    check("out", o, ref(q, k, v), ULP2)
+    o.backward(go.to(BF).cuda())
+    check("dq", qd.grad, qc.grad, ULP2)
+    check("dk", kd.grad, kc.grad, ULP2)
+    check("dv", vd.grad, vc.grad, ULP2)
+
+
 def _cos(a, b):
     a, b = a.double().flatten(), b.double().flatten()
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("hsz,Lw,add_local", [(128, 24, True), (256, 96, False)])
-def test_whole_model_bf16_vs_fp32_oracle(hip_device, hsz, Lw, add_local):
+@pytest.mark.parametrize("hsz,Lw,add_local,heads", [(128, 24, True, 0), (256, 96, False, 0), (64, 12, True, 4)])
+def test_whole_model_bf16_vs_fp32_oracle(hip_device, hsz, Lw, add_local, heads):
     """STAGE with opt.storage_dtype = 'bf16' (hsz = 256 with 96-word subtitle rows: the long-row attention kernel) against
     the fp32 oracle with the same parameters: forward outputs, loss, every parameter gradient."""
     from tvqaplus_amd.stage import STAGE
     from tvqaplus_amd.synth import make_batch, make_opt
     torch.manual_seed(11)
-    kw = dict(hsz=hsz, dropout=0.0, add_local=add_local, embedding_size=64, vfeat_size=48)
+    kw = dict(hsz=hsz, dropout=0.0, add_local=add_local, embedding_size=64, vfeat_size=48, input_encoder_n_heads=heads,
+              cls_encoder_n_heads=heads)
     model = STAGE(make_opt(storage_dtype="bf16", **kw)).cuda().train()
+    model.mha_dropout_override = 0.0
     assert model.storage == BF
     b = make_batch(N=2, Li=6, Lr=12, Lw=Lw, Lqa=10, wd_size=64, vfeat_size=48, seed=3)
     opt32 = make_opt(**kw)
+    opt32.mha_dropout = 0.0        # the reference's fixed attention dropout, zeroed on both sides
     P = {k: v.detach().cpu().clone().requires_grad_() for k, v in model.named_parameters()}
     ref = O.stage_forward(P, opt32, b, training=True)
     loss_ref = F.cross_entropy(ref["logits"], ref["targets"], reduction="sum") + 0.5 * ref["temporal_loss"]

@@ -75,6 +75,8 @@ SIGNATURES = {
     "stage_dwconv_bwd_bf16": (I, [P, P, P, P, P, P, LL, I, I, I, P, SZ, P]),
     "stage_ln_dwconv_fwd_bf16": (I, [P, P, I, P, P, P, P, P, P, P, P, LL, I, I, I, F, F, U64, P]),
     "stage_ln_dwconv_bwd_bf16": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, U64, P, SZ, P]),
+    "stage_mha_core_fwd_bf16": (I, [P, P, P, P, P, LL, I, I, I, F, U64, P]),
+    "stage_mha_core_bwd_bf16": (I, [P, P, P, P, P, P, P, P, LL, I, I, I, F, U64, P]),
     "stage_masked_max_fwd_bf16": (I, [P, P, P, P, P, LL, I, I, P]),
     "stage_masked_max_bwd_bf16": (I, [P, P, P, P, LL, I, I, I, P]),
 }

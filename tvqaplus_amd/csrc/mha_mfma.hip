@@ -19,6 +19,18 @@
 #include "../../include/stage_hip.h"
 
 // row fragment: lane (c15, g) <- X[row][g*KS .. g*KS + KS - 1] of the head slice (row clamped by the caller)
+// bf16 storage (TS = stage_bf16): KS consecutive bf16 of the row, converted to fp32 as they are loaded
+template <int KS>
+__device__ __forceinline__ void mha_row_frag(float (&f)[KS], const stage_bf16* __restrict__ p, int g) {
+    const stage_bf16* s = p + g * KS;
+    if (KS == 2) {
+        const unsigned u = *reinterpret_cast<const unsigned*>(s);
+        f[0] = __uint_as_float(u << 16); f[1] = __uint_as_float(u & 0xFFFF0000u);
+    } else {
+#pragma unroll
+        for (int c = 0; c < KS / 4; c++) { const float4 v = ldv4(s + 4 * c); f[4 * c] = v.x; f[4 * c + 1] = v.y; f[4 * c + 2] = v.z; f[4 * c + 3] = v.w; }
+    }
+}
 template <int KS>
 __device__ __forceinline__ void mha_row_frag(float (&f)[KS], const float* __restrict__ p, int g) {
     const float* s = p + g * KS;
@@ -39,10 +51,10 @@ __device__ __forceinline__ f32x4 mha_dot(const float (&a)[KS], const float (&b)[
 // ---------------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------------
-template <int T, int KS>
-__global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                           const float* __restrict__ v, const float* __restrict__ mask,
-                                                           float* __restrict__ out, long items, int L, int D, int nh,
+template <int T, int KS, typename TS = float>   // TS: storage type of q, k, v, out (and of dout, dq, dk, dv in the backward)
+__global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const TS* __restrict__ q, const TS* __restrict__ k,
+                                                           const TS* __restrict__ v, const float* __restrict__ mask,
+                                                           TS* __restrict__ out, long items, int L, int D, int nh,
                                                            uint64_t seed, uint32_t th, float inv_keep) {
     constexpr int DK = 4 * KS, DT = (DK + 15) / 16;
     const int lane = threadIdx.x & 63, c15 = lane & 15, g = lane >> 4;
@@ -103,11 +115,11 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const float* __restri
             for (int jt = 0; jt < T; jt++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const float a = v[base + (long)min(jt * 16 + 4 * g + r, L - 1) * D + dcol];   // P = 0 for keys >= L
+                    const float a = ldv1(v + base + (long)min(jt * 16 + 4 * g + r, L - 1) * D + dcol);   // P = 0 for keys >= L
                     o = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p[jt][r], o, 0, 0, 0);
                 }
             const int d0 = dt * 16 + 4 * g;
-            if (qi < L && d0 < DK) st4(out + base + (long)qi * D + d0, make_float4(o[0], o[1], o[2], o[3]));
+            if (qi < L && d0 < DK) stv4(out + base + (long)qi * D + d0, make_float4(o[0], o[1], o[2], o[3]));
         }
     }
 }
@@ -115,11 +127,11 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------------------------
-template <int T, int KS>
-__global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(const float* __restrict__ dout, const float* __restrict__ q,
-                                                           const float* __restrict__ k, const float* __restrict__ v,
-                                                           const float* __restrict__ mask, float* __restrict__ dq,
-                                                           float* __restrict__ dkk, float* __restrict__ dv, long items, int L,
+template <int T, int KS, typename TS = float>
+__global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(const TS* __restrict__ dout, const TS* __restrict__ q,
+                                                           const TS* __restrict__ k, const TS* __restrict__ v,
+                                                           const float* __restrict__ mask, TS* __restrict__ dq,
+                                                           TS* __restrict__ dkk, TS* __restrict__ dv, long items, int L,
                                                            int D, int nh, uint64_t seed, uint32_t th, float inv_keep) {
     constexpr int DK = 4 * KS, DT = (DK + 15) / 16;
     const int lane = threadIdx.x & 63, c15 = lane & 15, g = lane >> 4;
@@ -204,11 +216,11 @@ __global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(const float* __restri
                 for (int jt = 0; jt < T; jt++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const float a = k[base + (long)min(jt * 16 + 4 * g + r, L - 1) * D + dcol];   // dS = 0 for keys >= L
+                        const float a = ldv1(k + base + (long)min(jt * 16 + 4 * g + r, L - 1) * D + dcol);   // dS = 0 for keys >= L
                         o = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p[jt][r], o, 0, 0, 0);
                     }
                 const int d0 = dt * 16 + 4 * g;
-                if (qi < L && d0 < DK) st4(dq + base + (long)qi * D + d0, make_float4(o[0] / rs, o[1] / rs, o[2] / rs, o[3] / rs));
+                if (qi < L && d0 < DK) stv4(dq + base + (long)qi * D + d0, make_float4(o[0] / rs, o[1] / rs, o[2] / rs, o[3] / rs));
             }
         }
         // ---------------- normal layout: lane = key jt*16 + c15, registers = queries it*16 + 4g + reg -> dV, dK ----------------
@@ -273,8 +285,8 @@ __global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(const float* __restri
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const long ro = (long)min(it * 16 + 4 * g + r, L - 1) * D + dcol;
-                    ga[r] = dout[base + ro];
-                    qa[r] = q[base + ro];
+                    ga[r] = ldv1(dout + base + ro);
+                    qa[r] = ldv1(q + base + ro);
                 }
 #pragma unroll
                 for (int jt = 0; jt < T; jt++)
@@ -293,8 +305,8 @@ __global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(const float* __restri
         for (int jt = 0; jt < T; jt++) {
             const int j = jt * 16 + c15, d0 = dt * 16 + 4 * g;
             if (j < L && d0 < DK) {
-                st4(dv + base + (long)j * D + d0, make_float4(adv[dt][jt][0], adv[dt][jt][1], adv[dt][jt][2], adv[dt][jt][3]));
-                st4(dkk + base + (long)j * D + d0,
+                stv4(dv + base + (long)j * D + d0, make_float4(adv[dt][jt][0], adv[dt][jt][1], adv[dt][jt][2], adv[dt][jt][3]));
+                stv4(dkk + base + (long)j * D + d0,
                     make_float4(adk[dt][jt][0] / rs, adk[dt][jt][1] / rs, adk[dt][jt][2] / rs, adk[dt][jt][3] / rs));
             }
         }
@@ -320,14 +332,15 @@ extern "C" int stage_mha_core_recomputes(int L, int D, int nh) {
     } while (0)
 #define MHA_T(KERNEL, KSV, ...)                                                                                          \
     switch (T) {                                                                                                         \
-        case 1: hipLaunchKernelGGL((KERNEL<1, KSV>), grid, block, 0, st, __VA_ARGS__); break;                            \
-        case 2: hipLaunchKernelGGL((KERNEL<2, KSV>), grid, block, 0, st, __VA_ARGS__); break;                            \
-        case 3: hipLaunchKernelGGL((KERNEL<3, KSV>), grid, block, 0, st, __VA_ARGS__); break;                            \
-        default: hipLaunchKernelGGL((KERNEL<4, KSV>), grid, block, 0, st, __VA_ARGS__); break;                           \
+        case 1: hipLaunchKernelGGL((KERNEL<1, KSV, TS>), grid, block, 0, st, __VA_ARGS__); break;                            \
+        case 2: hipLaunchKernelGGL((KERNEL<2, KSV, TS>), grid, block, 0, st, __VA_ARGS__); break;                            \
+        case 3: hipLaunchKernelGGL((KERNEL<3, KSV, TS>), grid, block, 0, st, __VA_ARGS__); break;                            \
+        default: hipLaunchKernelGGL((KERNEL<4, KSV, TS>), grid, block, 0, st, __VA_ARGS__); break;                           \
     }
 
-int stage_mha_fwd_mfma(const float* q, const float* k, const float* v, const float* mask, float* out, long long M, int L, int D,
-                       int nh, float p_drop, unsigned long long seed, void* stream) {
+template <typename TS>
+static int mha_fwd_t(const TS* q, const TS* k, const TS* v, const float* mask, TS* out, long long M, int L, int D, int nh,
+                     float p_drop, unsigned long long seed, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int dk = D / nh;
     const long items = (long)M * nh;
@@ -339,8 +352,9 @@ int stage_mha_fwd_mfma(const float* q, const float* k, const float* v, const flo
     return 0;
 }
 
-int stage_mha_bwd_mfma(const float* dout, const float* q, const float* k, const float* v, const float* mask, float* dq, float* dk_out,
-                       float* dv, long long M, int L, int D, int nh, float p_drop, unsigned long long seed, void* stream) {
+template <typename TS>
+static int mha_bwd_t(const TS* dout, const TS* q, const TS* k, const TS* v, const float* mask, TS* dq, TS* dk_out, TS* dv,
+                     long long M, int L, int D, int nh, float p_drop, unsigned long long seed, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int dk = D / nh;
     const long items = (long)M * nh;
@@ -350,4 +364,33 @@ int stage_mha_bwd_mfma(const float* dout, const float* q, const float* k, const 
     MHA_DISPATCH(mha_bwd_mfma_kernel, dout, q, k, v, mask, dq, dk_out, dv, items, L, D, nh, (uint64_t)seed, th, ik);
     STAGE_LAUNCH_CHECK();
     return 0;
+}
+
+int stage_mha_fwd_mfma(const float* q, const float* k, const float* v, const float* mask, float* out, long long M, int L, int D,
+                       int nh, float p_drop, unsigned long long seed, void* stream) {
+    return mha_fwd_t<float>(q, k, v, mask, out, M, L, D, nh, p_drop, seed, stream);
+}
+
+int stage_mha_bwd_mfma(const float* dout, const float* q, const float* k, const float* v, const float* mask, float* dq, float* dk_out,
+                       float* dv, long long M, int L, int D, int nh, float p_drop, unsigned long long seed, void* stream) {
+    return mha_bwd_t<float>(dout, q, k, v, mask, dq, dk_out, dv, M, L, D, nh, p_drop, seed, stream);
+}
+
+// bf16 storage mode: q, k, v, out (dout, dq, dk, dv) are bf16; the mask, the scores, the softmax and every product stay fp32.
+// Only the shapes of the matrix-core kernels (stage_mha_core_recomputes == 1); others return STAGE_ERR_SHAPE.
+extern "C" int stage_mha_core_fwd_bf16(const void* q, const void* k, const void* v, const float* mask, void* out, long long M,
+                                       int L, int D, int nh, float p_drop, unsigned long long seed, void* stream) {
+    if (M <= 0) return 0;
+    if (!stage_mha_core_recomputes(L, D, nh)) return STAGE_ERR_SHAPE;
+    typedef stage_bf16 B;
+    return mha_fwd_t<B>((const B*)q, (const B*)k, (const B*)v, mask, (B*)out, M, L, D, nh, p_drop, seed, stream);
+}
+extern "C" int stage_mha_core_bwd_bf16(const void* dout, const void* q, const void* k, const void* v, const float* mask, void* dq,
+                                       void* dk, void* dv, long long M, int L, int D, int nh, float p_drop,
+                                       unsigned long long seed, void* stream) {
+    if (M <= 0) return 0;
+    if (!stage_mha_core_recomputes(L, D, nh)) return STAGE_ERR_SHAPE;
+    typedef stage_bf16 B;
+    return mha_bwd_t<B>((const B*)dout, (const B*)q, (const B*)k, (const B*)v, mask, (B*)dq, (B*)dk, (B*)dv, M, L, D, nh, p_drop,
+                        seed, stream);
 }

@@ -666,9 +666,16 @@ def masked_max(x, mask, window=None):
 class _MHACore(torch.autograd.Function):
     @_on_device
     def forward(ctx, q, k, v, mask, nh: int, p: float, seed: int):
-        q, k, v, mask = _chk(q, "q"), _chk(k, "k"), _chk(v, "v"), _chk(mask, "mask")
+        q = _act(q, "q")
+        k, v, mask = _act(k, "k", q), _act(v, "v", q), _chk(mask, "mask")
         M, L, D = q.shape
         out = torch.empty_like(q)
+        if q.dtype == _BF16:      # bf16 storage: the matrix-core kernels only (probabilities recomputed, never stored)
+            _call("stage_mha_core_fwd_bf16", _ptr(q), _ptr(k), _ptr(v), _ptr(mask), _ptr(out), M, L, D, nh, float(p), int(seed),
+                  _stream())
+            ctx.save_for_backward(q, k, v, None, mask)
+            ctx.cfg = (nh, float(p), int(seed))
+            return out
         # the matrix-core kernels recompute the probabilities in the backward: no (M, nh, L, L) tensor (614 MB for the
         # classifier encoder of the full config); only the scalar fallback shapes keep it
         probs = None
@@ -685,8 +692,12 @@ class _MHACore(torch.autograd.Function):
         q, k, v, probs, mask = ctx.saved_tensors
         nh, p, seed = ctx.cfg
         M, L, D = q.shape
-        dout = _chk(dout, "dout")
+        dout = _act(dout, "dout", q)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        if q.dtype == _BF16:
+            _call("stage_mha_core_bwd_bf16", _ptr(dout), _ptr(q), _ptr(k), _ptr(v), _ptr(mask), _ptr(dq), _ptr(dk), _ptr(dv),
+                  M, L, D, nh, p, seed, _stream())
+            return dq, dk, dv, None, None, None, None
         _call("stage_mha_core_bwd", _ptr(dout), _ptr(q), _ptr(k), _ptr(v), _ptr(probs), _ptr(mask), _ptr(dq), _ptr(dk),
               _ptr(dv), M, L, D, nh, p, seed, _stream())
         return dq, dk, dv, None, None, None, None

@@ -201,8 +201,6 @@ class STAGE(nn.Module):
         if sd not in ("fp32", "float32", "bf16", "bfloat16"):
             raise ValueError("opt.storage_dtype must be 'fp32' or 'bf16', got %r" % sd)
         self.storage = torch.bfloat16 if sd in ("bf16", "bfloat16") else torch.float32
-        if self.storage == torch.bfloat16 and (opt.input_encoder_n_heads or opt.cls_encoder_n_heads):
-            raise NotImplementedError("bf16 storage with n_heads > 0: the self-attention core has no bf16 storage path yet")
         self._span_host = None      # pinned landing buffer of the per-step proposal spans (get_proposals)
         # counter-based dropout stream (csrc/common.h): seeded lazily from the seed of torch's default generator at the first
         # use (so torch.manual_seed() before training takes effect, as for the reference's nn.Dropout) and mixed with the
