@@ -19,7 +19,8 @@ def timed(fn, reps=10):
     for _ in range(reps): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps
 U = N * NA * Li * Lqa
-for dt in (torch.bfloat16, torch.float32):
+only = os.environ.get("STRESS_ONLY")       # "bf16" / "fp32": just that whole-model step (kernel traces)
+for dt in (() if only else (torch.bfloat16, torch.float32)):
     C = torch.randn(N, NA, Lqa, D, generator=g).to(dev).to(dt).requires_grad_()
     Q = torch.randn(N, Li, Lr, D, generator=g).to(dev).to(dt).requires_grad_()
     gA = torch.randn(N, NA, Li, Lqa, D, generator=g).to(dev).to(dt)
@@ -36,7 +37,7 @@ for dt in (torch.bfloat16, torch.float32):
                       "fwd_us": round(tf * 1e6, 1), "fwd_bwd_us": round(tfb * 1e6, 1), "fwd_algorithmic_MB": round(alg / 1e6, 1),
                       "fwd_GBps": round(alg / tf / 1e9, 1), "fwd_TFLOPs": round(flops / tf / 1e12, 2)}))
 batch = make_batch(N=N, Li=Li, Lr=20, Lw=512, Lqa=40, seed=3).to(dev)
-for storage in ("bf16", "fp32"):
+for storage in ((only,) if only else ("bf16", "fp32")):
     torch.manual_seed(0)
     opt = make_opt(hsz=256, add_local=True, dropout=0.1, storage_dtype=storage)
     with contextlib.redirect_stdout(open(os.devnull, "w")):

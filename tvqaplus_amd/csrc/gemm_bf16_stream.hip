@@ -35,6 +35,9 @@ __device__ __forceinline__ uint4 gb_gate(uint4 v, uint4 g) {
 }
 
 struct GbBuf { uint4 x[4], g[4]; };
+// 16 bytes from an address that is only 8-byte aligned (rows of K % 8 == 4 elements): the hardware takes multi-dword global
+// loads at dword alignment; the type only tells the compiler not to assume more
+struct __attribute__((aligned(8))) GbU4 { unsigned x, y, z, w; };
 
 template <bool HAS_GATE, int NKC>
 __global__ __launch_bounds__(64 * GB_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_bf16_stream_kernel(
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(64 * GB_WAVES) __attribute__((amdgpu_waves_per_eu(2
 // 64 output columns per workgroup, run-time chunk count, 8-byte loads / stores where 16 are not aligned, and the XCD-aware
 // 1-D grid of gemm_stream.hip: the ceil(N / 64) column tiles of a row group sit on one XCD, so their re-reads of X hit its L2.
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool HAS_GATE, bool X16>
+template <bool HAS_GATE>
 __global__ __launch_bounds__(64 * GB_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_bf16_stream64_kernel(
     const stage_bf16* __restrict__ X, const stage_bf16* __restrict__ G, const float* __restrict__ W,
     const float* __restrict__ bias, stage_bf16* __restrict__ Y, long M, int N, int K, int Kp, int relu, int gx, int n_tiles) {
@@ -166,13 +169,15 @@ __global__ __launch_bounds__(64 * GB_WAVES) __attribute__((amdgpu_waves_per_eu(2
     const long nw = (long)gx * GB_WAVES;
     unsigned short* my_stg = stg + wave * 32 * GB_STG;
     auto ld8 = [&](const stage_bf16* p, long rowoff, int k) -> uint4 {       // 8 elements at k (k % 8 == 0), zero past K
-        if (X16) {
-            const uint4 v = *reinterpret_cast<const uint4*>(p + rowoff + (k < K ? k : 0));
-            return k < K ? v : make_uint4(0u, 0u, 0u, 0u);
+        if (k + 8 <= K) {
+            const GbU4 v = *reinterpret_cast<const GbU4*>(p + rowoff + k);
+            return make_uint4(v.x, v.y, v.z, v.w);
         }
-        const uint2 a = *reinterpret_cast<const uint2*>(p + rowoff + (k < K ? k : 0));
-        const uint2 b = *reinterpret_cast<const uint2*>(p + rowoff + (k + 4 < K ? k + 4 : 0));
-        return make_uint4(k < K ? a.x : 0u, k < K ? a.y : 0u, k + 4 < K ? b.x : 0u, k + 4 < K ? b.y : 0u);
+        if (k < K) {                                                         // K % 8 == 4: the last group is half a group
+            const uint2 a = *reinterpret_cast<const uint2*>(p + rowoff + k);
+            return make_uint4(a.x, a.y, 0u, 0u);
+        }
+        return make_uint4(0u, 0u, 0u, 0u);
     };
     auto fetch = [&](GbBuf& b, long row, int c) {
         const long ro = (row < M ? row : M - 1) * K;
@@ -252,8 +257,9 @@ static int gb_launch64(const void* X, const void* gate, const float* W, const fl
     Kp += ((Kp / 8) % 2 == 0) ? 8 : 16;
     const size_t lds = (size_t)64 * Kp * 2 + (size_t)GB_WAVES * 32 * GB_STG * 2 + 64 * sizeof(float);
     if (lds > 160 * 1024) return 1;
-    const bool x16 = K % 8 == 0 && !((uintptr_t)X & 15) && (!gate || !((uintptr_t)gate & 15));
-    if (gate && !x16) return 1;   // 8-byte pieces + gating: measured slower than the tiled kernel (960000 x 300 -> 768: 1.04 vs 0.88 ms)
+    // a gated operand in half-aligned rows with many column tiles: measured slower than the tiled kernel (2.46 M rows,
+    // 300 -> 768: 12.7 vs 9.1 ms; 240 k rows: 1.04 vs 0.88 ms)
+    if (gate && K % 8 != 0 && N > 256) return 1;
     const long MT = (M + 31) / 32;
     const int n_tiles = (N + 63) / 64;
     long gx = (256 / n_tiles) / 8 * 8;
@@ -262,14 +268,13 @@ static int gb_launch64(const void* X, const void* gate, const float* W, const fl
     if (gx > need) gx = need;
     dim3 grid((unsigned)(gx * n_tiles)), block(64 * GB_WAVES);
     typedef stage_bf16 B;
-#define GB64(GT, XV)                                                                                                            \
+#define GB64(GT)                                                                                                                \
     do {                                                                                                                        \
-        (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_stream64_kernel<GT, XV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((gemm_nt_bf16_stream64_kernel<GT, XV>), grid, block, lds, (hipStream_t)stream, (const B*)X, (const B*)gate, W, \
+        (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_stream64_kernel<GT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((gemm_nt_bf16_stream64_kernel<GT>), grid, block, lds, (hipStream_t)stream, (const B*)X, (const B*)gate, W, \
                            bias, (B*)Y, (long)M, N, K, Kp, relu, (int)gx, n_tiles);                                             \
     } while (0)
-    if (gate) { if (x16) GB64(true, true); else GB64(true, false); }
-    else { if (x16) GB64(false, true); else GB64(false, false); }
+    if (gate) GB64(true); else GB64(false);
 #undef GB64
     STAGE_LAUNCH_CHECK();
     return 0;
@@ -335,14 +340,16 @@ __global__ __launch_bounds__(768) void gemm_tn_bf16_stream_kernel(const stage_bf
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
     const int pl = wave % P + blockIdx.y * P;               // patch index: pn = pl / KPn (64 dY columns), pk = pl % KPn (64 X columns)
     const int rs = wave / P;
-    const int NPn = N >> 6;
+    const int NPn = (N + 63) >> 6;
     const bool idle = pl >= NPn * KPn;    // (only with several patch groups, where RS == 1 and no barrier follows)
     if (idle) return;
     const int pn = pl / KPn, pk = pl - pn * KPn;
     const long mbeg = (long)blockIdx.x * rows_per_slab, mend = min(M, mbeg + rows_per_slab);
-    const unsigned* yb = reinterpret_cast<const unsigned*>(dY) + (pn * 32 + l31);      // dword = columns 64 pn + 2 l31, +1
-    const unsigned* gb = reinterpret_cast<const unsigned*>(HAS_GATE ? G : dY) + (pn * 32 + l31);
-    const unsigned* xb = reinterpret_cast<const unsigned*>(X) + (pk * 32 + l31);
+    // ragged last patch (N or K not a multiple of 64; both are even): columns past the end read column 0 and are zeroed
+    const bool yok = 64 * pn + 2 * l31 < N, xok = 64 * pk + 2 * l31 < K;
+    const unsigned* yb = reinterpret_cast<const unsigned*>(dY) + (yok ? pn * 32 + l31 : 0);      // dword = columns 64 pn + 2 l31, +1
+    const unsigned* gb = reinterpret_cast<const unsigned*>(HAS_GATE ? G : dY) + (yok ? pn * 32 + l31 : 0);
+    const unsigned* xb = reinterpret_cast<const unsigned*>(X) + (xok ? pk * 32 + l31 : 0);
     const long ldy = N >> 1, ldx = K >> 1;                   // row strides in dwords
     f32x16 acc[2][2];
 #pragma unroll
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(768) void gemm_tn_bf16_stream_kernel(const stage_bf
         for (int j = 0; j < 8; j++) {
             unsigned v = s.y[j];
             if (HAS_GATE) v = gb_gate1(v, s.g[j]);
-            if (m0 + 8 * h + j >= mend) v = 0u;
+            if (m0 + 8 * h + j >= mend || !yok) v = 0u;
             y[j] = v;
         }
         if (part_b && pk == 0) {
@@ -383,6 +390,10 @@ __global__ __launch_bounds__(768) void gemm_tn_bf16_stream_kernel(const stage_bf
         ae.y = __builtin_amdgcn_perm(y[3], y[2], 0x05040100u); ao.y = __builtin_amdgcn_perm(y[3], y[2], 0x07060302u);
         ae.z = __builtin_amdgcn_perm(y[5], y[4], 0x05040100u); ao.z = __builtin_amdgcn_perm(y[5], y[4], 0x07060302u);
         ae.w = __builtin_amdgcn_perm(y[7], y[6], 0x05040100u); ao.w = __builtin_amdgcn_perm(y[7], y[6], 0x07060302u);
+        if (!xok) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) s.x[j] = 0u;
+        }
         be.x = __builtin_amdgcn_perm(s.x[1], s.x[0], 0x05040100u); bo.x = __builtin_amdgcn_perm(s.x[1], s.x[0], 0x07060302u);
         be.y = __builtin_amdgcn_perm(s.x[3], s.x[2], 0x05040100u); bo.y = __builtin_amdgcn_perm(s.x[3], s.x[2], 0x07060302u);
         be.z = __builtin_amdgcn_perm(s.x[5], s.x[4], 0x05040100u); bo.z = __builtin_amdgcn_perm(s.x[5], s.x[4], 0x07060302u);
@@ -444,12 +455,13 @@ __global__ __launch_bounds__(768) void gemm_tn_bf16_stream_kernel(const stage_bf
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-                po[(size_t)(64 * pn + 2 * i + e) * K + 64 * pk + 2 * l31 + f] = acc[e][f][r];
+                const int n = 64 * pn + 2 * i + e, k = 64 * pk + 2 * l31 + f;
+                if (n < N && k < K) po[(size_t)n * K + k] = acc[e][f][r];
             }
     if (part_b && pk == 0) {
         bs0 += __shfl_xor(bs0, 32);
         bs1 += __shfl_xor(bs1, 32);
-        if (h == 0) {
+        if (h == 0 && yok) {
             float* pb = part_b + (size_t)blockIdx.x * N + 64 * pn + 2 * l31;
             pb[0] = bs0;
             pb[1] = bs1;
@@ -459,9 +471,12 @@ __global__ __launch_bounds__(768) void gemm_tn_bf16_stream_kernel(const stage_bf
 
 // slabs x interleaves of the streaming TN kernel for a shape (0: not handled)
 static int tb_plan(long long M, int N, int K, int* P, int* RS, int* KPn, int* GY, long* rps) {
-    if (M < 4096 || N % 64 != 0 || K % 64 != 0) return 0;
-    *KPn = K / 64;
-    const int total = (N / 64) * *KPn;
+    if (M < 4096 || N % 2 != 0 || K % 2 != 0 || N < 2 || K < 2) return 0;
+    *KPn = (K + 63) / 64;
+    const int total = ((N + 63) / 64) * *KPn;
+    // more than 12 patches would need several workgroup groups, each re-reading one operand from HBM: measured slower than the
+    // tiled kernel (2.46 M rows, 768 x 300: 10.2 vs 7.5 ms) -- those shapes stay on the tiled kernel
+    if (total > 12) return 0;
     *GY = (total + 11) / 12;                    // <= 12 waves per workgroup (768 threads: 168 registers per lane)
     *P = (total + *GY - 1) / *GY;
     *RS = *GY == 1 ? (12 / *P) : 1;
