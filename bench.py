@@ -12,6 +12,8 @@ words/frame, 40 QA words, 5 candidates, B=16 per GPU (weak scaling; --scaling st
 One step = forward + loss (main.py:55-60: CE_sum * len(qids)/len(targets) + 0.1 * att_loss + 0.5 * temporal_loss, the ratio
 taken over the GATHERED batch as the reference's DataParallel does) + backward + grad all-reduce (N>1) +
 clip_grad_norm_(10) + Adam step, i.e. everything main.py:53-66 does per batch.  Inputs are resident in HBM.
+Developer flags (not the headline line): --dense (all-ones masks), --heads 4, --gemm_terms 2, --no_sup_att, --h2d,
+--storage bf16 (the bf16 storage mode of BASELINE.json configs[4] at these shapes; `dtype` then says "bf16").
 """
 import argparse
 import json
