@@ -27,12 +27,60 @@ template <typename T> __device__ __forceinline__ void lng_st(T* p, float v);
 template <> __device__ __forceinline__ void lng_st<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void lng_st<__hip_bfloat16>(__hip_bfloat16* p, float v) { *p = __float2bfloat16(v); }
 
+// NEL consecutive elements -> floats with the widest loads their alignment allows (p is NEL-element aligned)
+template <int NEL> __device__ __forceinline__ void lng_ldn(float (&f)[NEL], const float* p) {
+    if constexpr (NEL % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < NEL / 4; q++) { const float4 v = ld4(p + 4 * q); f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w; }
+    } else if constexpr (NEL == 2) { const float2 v = *reinterpret_cast<const float2*>(p); f[0] = v.x; f[1] = v.y; }
+    else f[0] = p[0];
+}
+template <int NEL> __device__ __forceinline__ void lng_ldn(float (&f)[NEL], const __hip_bfloat16* p) {
+    auto lo = [](unsigned u) { return __uint_as_float(u << 16); };
+    auto hi = [](unsigned u) { return __uint_as_float(u & 0xFFFF0000u); };
+    if constexpr (NEL % 8 == 0) {
+#pragma unroll
+        for (int q = 0; q < NEL / 8; q++) {
+            const uint4 v = *reinterpret_cast<const uint4*>(p + 8 * q);
+            f[8 * q] = lo(v.x); f[8 * q + 1] = hi(v.x); f[8 * q + 2] = lo(v.y); f[8 * q + 3] = hi(v.y);
+            f[8 * q + 4] = lo(v.z); f[8 * q + 5] = hi(v.z); f[8 * q + 6] = lo(v.w); f[8 * q + 7] = hi(v.w);
+        }
+    } else if constexpr (NEL == 4) {
+        const uint2 v = *reinterpret_cast<const uint2*>(p);
+        f[0] = lo(v.x); f[1] = hi(v.x); f[2] = lo(v.y); f[3] = hi(v.y);
+    } else if constexpr (NEL == 2) { const unsigned v = *reinterpret_cast<const unsigned*>(p); f[0] = lo(v); f[1] = hi(v); }
+    else f[0] = lng_ld<__hip_bfloat16>(p);
+}
+// The products whose contraction runs over the REGIONS (A = S_ . Q, dCn = dS . Qn) or over the context rows (dQ) take their
+// d-side operand one element per lane and k-step.  With the natural mapping (d tile dt = columns 16 dt .. 16 dt + 15) a lane
+// needs column 16 dt + c15 of a row for every tile: DT two-byte gathers per row.  The OUTPUT index may be permuted freely,
+// so tile dt is defined as the columns DT c15 + dt: a lane then needs DT CONSECUTIVE elements of the row -- one or two
+// 16-byte loads feed all DT tiles -- and it ends up owning DT consecutive output columns per accumulator register.
 // lane (c15, g) <- X[row][g*DQ .. g*DQ + DQ - 1] as floats (row fragment: element s is the operand of k-step s)
 template <typename T, int DQ>
 __device__ __forceinline__ void lng_frag(float (&f)[DQ], const T* __restrict__ row, int g) {
 #pragma unroll
     for (int s = 0; s < DQ; s++) f[s] = lng_ld<T>(row + g * DQ + s);
 }
+
+// Products whose contraction runs over d take both operands as row fragments.  On bf16 storage those operands ARE bf16, so the
+// product is exact on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16, fp32 accumulation): D / 32 instructions of ~17 cycles
+// instead of D / 4 fp32 ones of 32.  lane (c15, g) <- 8 consecutive elements at 32 s + 8 g of its row, per k-step s.
+typedef __bf16 lng_bf16x8 __attribute__((ext_vector_type(8)));
+template <int D> struct LngRowB { uint4 v[D / 32 > 0 ? D / 32 : 1]; };
+template <int D> __device__ __forceinline__ void lng_rowb(LngRowB<D>& f, const __hip_bfloat16* __restrict__ row, int g) {
+#pragma unroll
+    for (int s = 0; s < D / 32; s++) f.v[s] = *reinterpret_cast<const uint4*>(row + 32 * s + 8 * g);
+}
+template <int D> __device__ __forceinline__ f32x4 lng_dotb(const LngRowB<D>& a, const LngRowB<D>& b) {
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < D / 32; s++)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lng_bf16x8, a.v[s]), __builtin_bit_cast(lng_bf16x8, b.v[s]), acc, 0, 0, 0);
+    return acc;
+}
+template <typename T, int D> struct LngUseB { static constexpr bool value = false; };
+template <int D> struct LngUseB<__hip_bfloat16, D> { static constexpr bool value = (D % 32 == 0); };
 
 // ---------------------------------------------------------------------------------------------------------------------
 // forward
@@ -55,22 +103,32 @@ __global__ __launch_bounds__(256) void str_attn_long_fwd_kernel(const T* __restr
     const bool cvalid = c < CR;
     const long orow = ((long)(n * NA + cc / Lqa) * Li + i) * Lqa + cc % Lqa;
     const float cm = cvalid ? cmask[(long)n * CR + cc] : 0.f;
-    float cf[DQ];
-    lng_frag<T, DQ>(cf, Cn + ((long)n * CR + cc) * D, g);
+    constexpr bool USEB = LngUseB<T, D>::value;
+    float cf[USEB ? 1 : DQ];
+    LngRowB<D> cfb;
+    if constexpr (USEB) lng_rowb<D>(cfb, Cn + ((long)n * CR + cc) * D, g);
+    else lng_frag<T, DQ>(cf, Cn + ((long)n * CR + cc) * D, g);
     const T* qn = Qn + frame * Lr * (long)D;
     const T* qr = Q + frame * Lr * (long)D;
     const float* qm = qmask + frame * Lr;
     const int nb = (Lr + 15) >> 4;
+    const bool vec4 = (Lr & 3) == 0;
     // ---- pass 1: raw scores, online max / sum of exp(scale * raw) over the row ----
     float mx = -INFINITY, sum = 0.f;
     for (int rb = 0; rb < nb; rb++) {
-        float qf[DQ];
-        lng_frag<T, DQ>(qf, qn + (long)min(rb * 16 + c15, Lr - 1) * D, g);
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (USEB) {
+            LngRowB<D> qfb;
+            lng_rowb<D>(qfb, qn + (long)min(rb * 16 + c15, Lr - 1) * D, g);
+            acc = lng_dotb<D>(qfb, cfb);
+        } else {
+            float qf[DQ];
+            lng_frag<T, DQ>(qf, qn + (long)min(rb * 16 + c15, Lr - 1) * D, g);
 #pragma unroll
-        for (int s = 0; s < DQ; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[s], cf[s], acc, 0, 0, 0);
+            for (int s = 0; s < DQ; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[s], cf[s], acc, 0, 0, 0);
+        }
         // acc[k] = <Qn[r = rb*16 + 4g + k], Cn[c]>
-        float bmx = -INFINITY, xs[4];
+        float bmx = -INFINITY, xs[4], rw[4];
         {
 #pragma clang fp contract(off)
 #pragma unroll
@@ -79,11 +137,14 @@ __global__ __launch_bounds__(256) void str_attn_long_fwd_kernel(const T* __restr
                 const float msk = (r < Lr) ? cm * qm[min(r, Lr - 1)] : 0.f;
                 const float raw = acc[k] - 1e10f * (1.0f - msk);
                 xs[k] = raw * scale;             // ONE rounded product for the max and the exponent (see str_attn.hip)
+                rw[k] = raw;
                 if (r < Lr) {
                     bmx = fmaxf(bmx, xs[k]);
-                    if (cvalid) S[orow * Lr + r] = raw;
+                    if (cvalid && !vec4) S[orow * Lr + r] = raw;
                 }
             }
+            // a lane's four regions are consecutive: one 16-byte access per score map and block when Lr % 4 == 0
+            if (vec4 && cvalid && rb * 16 + 4 * g < Lr) st4(S + orow * Lr + rb * 16 + 4 * g, make_float4(rw[0], rw[1], rw[2], rw[3]));
         }
         bmx = cross_row_max(bmx);
         const float nmx = fmaxf(mx, bmx);
@@ -100,6 +161,9 @@ __global__ __launch_bounds__(256) void str_attn_long_fwd_kernel(const T* __restr
     for (int dt = 0; dt < DT; dt++) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int rb = 0; rb < nb; rb++) {
         float p[4];
+        const bool blk = rb * 16 + 4 * g < Lr;
+        float4 rv = make_float4(-1e10f, -1e10f, -1e10f, -1e10f);
+        if (vec4 && cvalid && blk) rv = ld4(S + orow * Lr + rb * 16 + 4 * g);
         {
 #pragma clang fp contract(off)
 #pragma unroll
@@ -107,31 +171,27 @@ __global__ __launch_bounds__(256) void str_attn_long_fwd_kernel(const T* __restr
                 const int r = rb * 16 + 4 * g + k, rc = min(r, Lr - 1);
                 const float msk = (r < Lr) ? cm * qm[rc] : 0.f;
                 // the value pass 1 stored (padded context rows stored nothing: any finite value, they are discarded)
-                const float raw = cvalid ? S[orow * Lr + rc] : -1e10f;
+                const float raw = vec4 ? (k == 0 ? rv.x : (k == 1 ? rv.y : (k == 2 ? rv.z : rv.w))) : (cvalid ? S[orow * Lr + rc] : -1e10f);
                 const float x = raw * scale;
                 p[k] = (r < Lr) ? expf(x - mx) / sum * msk : 0.f;
-                if (cvalid && r < Lr) Sn[orow * Lr + r] = p[k];
+                if (!vec4 && cvalid && r < Lr) Sn[orow * Lr + r] = p[k];
             }
+            if (vec4 && cvalid && blk) st4(Sn + orow * Lr + rb * 16 + 4 * g, make_float4(p[0], p[1], p[2], p[3]));
         }
+        float qd[4][DT];                 // Q[region rb*16 + 4g + k][DT c15 .. DT c15 + DT - 1]: the operands of all DT tiles
 #pragma unroll
-        for (int dt = 0; dt < DT; dt++) {
-            const int dcol = min(dt * 16 + c15, D - 1);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const float a = lng_ld<T>(qr + (long)min(rb * 16 + 4 * g + k, Lr - 1) * D + dcol);   // S_ = 0 past Lr
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p[k], o[dt], 0, 0, 0);
-            }
-        }
-    }
-    if (cvalid) {
-        T* pa = A + orow * D;
+        for (int k = 0; k < 4; k++) lng_ldn<DT>(qd[k], qr + (long)min(rb * 16 + 4 * g + k, Lr - 1) * D + DT * c15);   // S_ = 0 past Lr
 #pragma unroll
         for (int dt = 0; dt < DT; dt++)
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int d = dt * 16 + 4 * g + k;
-                if (d < D) lng_st<T>(pa + d, o[dt][k]);
-            }
+            for (int k = 0; k < 4; k++) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qd[k][dt], p[k], o[dt], 0, 0, 0);
+    }
+    if (cvalid) {   // o[dt][k] = A[c][d = DT (4g + k) + dt]: DT consecutive columns per register index k
+        T* pa = A + orow * D;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int dt = 0; dt < DT; dt++) lng_st<T>(pa + DT * (4 * g + k) + dt, o[dt][k]);
     }
 }
 
@@ -155,6 +215,7 @@ __global__ __launch_bounds__(256) void str_attn_long_bwd_ds_kernel(const T* __re
     const int c = ct * 16 + c15, cc = min(c, CR - 1);
     const bool cvalid = c < CR;
     const int nb = (Lr + 15) >> 4;
+    const bool vec4 = (Lr & 3) == 0;
     f32x4 dcn[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; dt++) dcn[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -163,6 +224,8 @@ __global__ __launch_bounds__(256) void str_attn_long_bwd_ds_kernel(const T* __re
         const long orow = ((long)(n * NA + cc / Lqa) * Li + i) * Lqa + cc % Lqa;
         float gf[DQ];
         lng_frag<T, DQ>(gf, dA + orow * D, g);
+        LngRowB<D> gfb;                                       // the same row as bf16 matrix-core fragments (bf16 storage)
+        if constexpr (LngUseB<T, D>::value) lng_rowb<D>(gfb, dA + orow * D, g);
         // <P, dP> over the whole row = <dA, A>: this lane's share of the row, then across the four lane groups
         float dot = 0.f;
         {
@@ -174,67 +237,84 @@ __global__ __launch_bounds__(256) void str_attn_long_bwd_ds_kernel(const T* __re
         const T* qr = Q + frame * Lr * (long)D;
         const T* qn = Qn + frame * Lr * (long)D;
         for (int rb = 0; rb < nb; rb++) {
-            float qf[DQ];
-            lng_frag<T, DQ>(qf, qr + (long)min(rb * 16 + c15, Lr - 1) * D, g);
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (LngUseB<T, D>::value) {
+                LngRowB<D> qfb;
+                lng_rowb<D>(qfb, qr + (long)min(rb * 16 + c15, Lr - 1) * D, g);
+                acc = lng_dotb<D>(qfb, gfb);
+            } else {
+                float qf[DQ];
+                lng_frag<T, DQ>(qf, qr + (long)min(rb * 16 + c15, Lr - 1) * D, g);
 #pragma unroll
-            for (int s = 0; s < DQ; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[s], gf[s], acc, 0, 0, 0);
+                for (int s = 0; s < DQ; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[s], gf[s], acc, 0, 0, 0);
+            }
             // acc[k] = dP[c][r = rb*16 + 4g + k]
             f32x4 G;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int r = rb * 16 + 4 * g + k;
-                float v = 0.f;
-                if (r < Lr && cvalid) {
-                    v = scale * Sn[orow * Lr + r] * (acc[k] - dot);
-                    if (ext) v += ext[orow * Lr + r];
-                    dS[orow * Lr + r] = v;
+            if (vec4) {      // a lane's four regions are consecutive: 16-byte accesses
+                float4 v = f4zero();
+                if (cvalid && rb * 16 + 4 * g < Lr) {
+                    const long off = orow * Lr + rb * 16 + 4 * g;
+                    const float4 pv = ld4(Sn + off);
+                    v = make_float4(scale * pv.x * (acc[0] - dot), scale * pv.y * (acc[1] - dot), scale * pv.z * (acc[2] - dot),
+                                    scale * pv.w * (acc[3] - dot));
+                    if (ext) v = f4add(v, ld4(ext + off));
+                    st4(dS + off, v);
                 }
-                G[k] = v;
-            }
-#pragma unroll
-            for (int dt = 0; dt < DT; dt++) {
-                const int dcol = min(dt * 16 + c15, D - 1);
+                G = (f32x4){v.x, v.y, v.z, v.w};
+            } else {
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const float a = lng_ld<T>(qn + (long)min(rb * 16 + 4 * g + k, Lr - 1) * D + dcol);   // G = 0 past Lr
-                    dcn[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, G[k], dcn[dt], 0, 0, 0);
+                    const int r = rb * 16 + 4 * g + k;
+                    float v = 0.f;
+                    if (r < Lr && cvalid) {
+                        v = scale * Sn[orow * Lr + r] * (acc[k] - dot);
+                        if (ext) v += ext[orow * Lr + r];
+                        dS[orow * Lr + r] = v;
+                    }
+                    G[k] = v;
                 }
             }
+            float qd[4][DT];             // Qn[region][DT c15 .. + DT - 1] (d tiles permuted as in the forward)
+#pragma unroll
+            for (int k = 0; k < 4; k++) lng_ldn<DT>(qd[k], qn + (long)min(rb * 16 + 4 * g + k, Lr - 1) * D + DT * c15);   // G = 0 past Lr
+#pragma unroll
+            for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) dcn[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qd[k][dt], G[k], dcn[dt], 0, 0, 0);
         }
     }
     if (cvalid) {
         float* dst = part + (((size_t)chunk * N + n) * CR + c) * D;
 #pragma unroll
-        for (int dt = 0; dt < DT; dt++)
+        for (int k = 0; k < 4; k++)
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int d = dt * 16 + 4 * g + k;
-                if (d < D) dst[d] = dcn[dt][k];
-            }
+            for (int dt = 0; dt < DT; dt++) dst[DT * (4 * g + k) + dt] = dcn[dt][k];
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // backward B2: dQraw[r, :] = sum_c P[c, r] dA[c, :]   dQn[r, :] = sum_c dS[c, r] Cn[c, :]
-// one wave per (frame, 16-region block, 16-wide d tile pair): k-steps of 4 context rows
+// one wave per (frame, 16-region block), all DT d tiles (permuted: tile dt = columns DT c15 + dt, so a lane takes DT
+// consecutive elements of a dA / Cn row with one or two 16-byte loads and owns DT consecutive output columns); k-steps of 4
+// context rows
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int DT>
 __global__ __launch_bounds__(256) void str_attn_long_bwd_dq_kernel(const T* __restrict__ dA, const float* __restrict__ Sn,
                                                                    const float* __restrict__ dS, const T* __restrict__ Cn,
                                                                    float* __restrict__ dQraw, float* __restrict__ dQn, int N,
-                                                                   int NA, int Li, int Lqa, int Lr, int D) {
+                                                                   int NA, int Li, int Lqa, int Lr) {
+    constexpr int D = 16 * DT;
     const int lane = threadIdx.x & 63, c15 = lane & 15, g = lane >> 4;
-    const int CR = NA * Lqa, nb = (Lr + 15) >> 4, DT = (D + 15) >> 4;
+    const int CR = NA * Lqa, nb = (Lr + 15) >> 4;
     const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= (long)N * Li * nb * DT) return;
-    const int dt = (int)(item % DT);
-    const int rb = (int)((item / DT) % nb);
-    const long frame = item / ((long)DT * nb);
+    if (item >= (long)N * Li * nb) return;
+    const int rb = (int)(item % nb);
+    const long frame = item / nb;
     const int n = (int)(frame / Li), i = (int)(frame % Li);
     const int r = rb * 16 + c15, rc = min(r, Lr - 1);
-    const int dcol = min(dt * 16 + c15, D - 1);
-    f32x4 ar = (f32x4){0.f, 0.f, 0.f, 0.f}, an = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 ar[DT], an[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) ar[dt] = an[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int c0 = 0; c0 < CR; c0 += 4) {
         const int c = c0 + g;
         const bool ok = c < CR;
@@ -242,21 +322,24 @@ __global__ __launch_bounds__(256) void str_attn_long_bwd_dq_kernel(const T* __re
         const long orow = ((long)(n * NA + cc / Lqa) * Li + i) * Lqa + cc % Lqa;
         const float p = ok ? Sn[orow * Lr + rc] : 0.f;      // A operands: row = region c15, k = context row
         const float gs = ok ? dS[orow * Lr + rc] : 0.f;
-        const float da = ok ? lng_ld<T>(dA + orow * D + dcol) : 0.f;   // B operands: k = context row, column = d
-        const float cn = ok ? lng_ld<T>(Cn + ((long)n * CR + cc) * D + dcol) : 0.f;
-        ar = __builtin_amdgcn_mfma_f32_16x16x4f32(p, da, ar, 0, 0, 0);
-        an = __builtin_amdgcn_mfma_f32_16x16x4f32(gs, cn, an, 0, 0, 0);
-    }
-    // C layout: row 4g + k = region inside the block, column c15 = d inside the tile
-    const int d = dt * 16 + c15;
-    if (d < D) {
+        float da[DT], cn[DT];                               // B operands: k = context row, columns DT c15 .. + DT - 1
+        lng_ldn<DT>(da, dA + orow * D + DT * c15);
+        lng_ldn<DT>(cn, Cn + ((long)n * CR + cc) * D + DT * c15);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int rr = rb * 16 + 4 * g + k;
-            if (rr < Lr) {
-                dQraw[(frame * Lr + rr) * D + d] = ar[k];
-                dQn[(frame * Lr + rr) * D + d] = an[k];
-            }
+        for (int dt = 0; dt < DT; dt++) {                   // rows past CR: the A operands are zero (the clamped B rows are finite)
+            ar[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, da[dt], ar[dt], 0, 0, 0);
+            an[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gs, cn[dt], an[dt], 0, 0, 0);
+        }
+    }
+    // C layout: row 4g + k = region inside the block, column c15 -> d = DT c15 + dt
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int rr = rb * 16 + 4 * g + k;
+        if (rr < Lr) {
+            float* o1 = dQraw + (frame * Lr + rr) * D + DT * c15;
+            float* o2 = dQn + (frame * Lr + rr) * D + DT * c15;
+#pragma unroll
+            for (int dt = 0; dt < DT; dt++) { o1[dt] = ar[dt][k]; o2[dt] = an[dt][k]; }
         }
     }
 }
@@ -322,9 +405,18 @@ static int lng_bwd(const void* dA, const void* A, const float* ext, const void* 
     const long C = (long)N * CR * D;
     hipLaunchKernelGGL(lng_slab_sum_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, (const float*)part, dCn, nchunks, C);
     STAGE_LAUNCH_CHECK();
-    const long items2 = (long)N * Li * ((Lr + 15) / 16) * ((D + 15) / 16);
-    hipLaunchKernelGGL((str_attn_long_bwd_dq_kernel<T>), dim3((unsigned)((items2 + 3) / 4)), dim3(256), 0, st, (const T*)dA, Sn,
-                       (const float*)dS, (const T*)Cn, dQraw, dQn, N, NA, Li, Lqa, Lr, D);
+    const long items2 = (long)N * Li * ((Lr + 15) / 16);
+#define LNG_Q(DTV)                                                                                                         \
+    hipLaunchKernelGGL((str_attn_long_bwd_dq_kernel<T, DTV>), dim3((unsigned)((items2 + 3) / 4)), dim3(256), 0, st, (const T*)dA, Sn, \
+                       (const float*)dS, (const T*)Cn, dQraw, dQn, N, NA, Li, Lqa, Lr)
+    switch (D) {
+        case 16: LNG_Q(1); break;
+        case 32: LNG_Q(2); break;
+        case 64: LNG_Q(4); break;
+        case 128: LNG_Q(8); break;
+        default: LNG_Q(16); break;
+    }
+#undef LNG_Q
     STAGE_LAUNCH_CHECK();
     return 0;
 }
