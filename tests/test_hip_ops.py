@@ -635,7 +635,8 @@ def test_k1_long_rows_fp32_vs_oracle(ops, N, Li, Lr, Lqa, D):
         check("dQ vs specialised", Qd.grad, Q2.grad.cpu(), 1e-4)
 
 
-@pytest.mark.parametrize("N,Li,Lr,Lqa,D", [(2, 2, 512, 40, 256), (1, 3, 50, 40, 128)])
+@pytest.mark.parametrize("N,Li,Lr,Lqa,D", [(2, 2, 512, 40, 256), (1, 3, 50, 40, 128), (1, 2, 77, 23, 64), (1, 2, 100, 13, 32),
+                                            (1, 2, 70, 12, 16), (1, 2, 96, 40, 128)])
 def test_k1_bf16_storage_vs_fp32_oracle(ops, N, Li, Lr, Lqa, D):
     """bf16 storage (C, Q in, A out, dA in), fp32 scores / softmax / accumulation.  Tolerance rule, stated up front: the
     inputs are first rounded to bf16 and the fp32 ORACLE is evaluated on those rounded values (so only the kernel's own
