@@ -2,6 +2,9 @@
 (b) the CPU oracle on fresh seeded batches, outputs and parameter gradients.  Tolerance 1e-3 (north star)."""
 import json
 
+import contextlib
+import io
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -291,6 +294,16 @@ def test_batch_prefetcher_delivers_identical_batches(hip_device):
         a = model.forward_main(next(iter(BatchPrefetcher(host[:1], hip_device))))[0]
         b = model.forward_main(host[0].to(hip_device))[0]
     assert torch.equal(a, b)
+    # bf16 storage mode: the features are rounded to bf16 while they are staged (half the bytes over PCIe); the model output
+    # equals the one from fp32 features it rounds itself on entry
+    with contextlib.redirect_stdout(io.StringIO()):
+        m16 = STAGE(make_opt(hsz=32, embedding_size=64, vfeat_size=32, add_local=True, storage_dtype="bf16")).to(hip_device).eval()
+    d16 = next(iter(BatchPrefetcher(host[:1], hip_device, feature_dtype=torch.bfloat16)))
+    assert d16["sub_bert"].dtype == torch.bfloat16 and d16["vid_mask"].dtype == host[0]["vid_mask"].dtype
+    with torch.no_grad():
+        a16 = m16.forward_main(d16)[0]
+        b16 = m16.forward_main(host[0].to(hip_device))[0]
+    assert torch.equal(a16, b16)
 
 
 @pytest.mark.gpu

@@ -9,6 +9,10 @@ over PCIe Gen5 x16 -- more than half of the 24 ms step.  ``BatchPrefetcher`` mov
 * ``record_stream`` tells the caching allocator that the device tensors are used on the consumer's stream.
 
 Non-tensor fields (qid lists, att_labels, boxes, ...) pass through untouched.
+
+``feature_dtype=torch.bfloat16`` (for a model built with ``opt.storage_dtype = "bf16"``) rounds the three feature tensors
+(``qas_bert``, ``sub_bert``, ``vid``) to bf16 while they are copied into the pinned staging buffers: the model would round them
+on entry anyway, and the transfer is 431 MB instead of 862 MB.  Masks, labels and indices keep their types.
 """
 from __future__ import annotations
 
@@ -18,13 +22,18 @@ import torch
 
 
 class BatchPrefetcher:
-    def __init__(self, batches: Iterable, device, depth: int = 2):
+    FEATURES = ("qas_bert", "sub_bert", "vid")
+
+    def __init__(self, batches: Iterable, device, depth: int = 2, feature_dtype: Optional[torch.dtype] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("BatchPrefetcher needs a GPU (the HIP path has no CPU fallback)")
         self.src = iter(batches)
         self.device = torch.device(device)
         self.side = torch.cuda.Stream(device=self.device)
         self.depth = max(2, int(depth))
+        if feature_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError("feature_dtype must be None, torch.float32 or torch.bfloat16")
+        self.feature_dtype = feature_dtype
         self._pinned: list = [dict() for _ in range(self.depth)]   # per slot: key -> pinned staging tensor
         self._free_evt: list = [None] * self.depth                  # per slot: event after which the staging set is reusable
         self._slot = 0
@@ -34,16 +43,19 @@ class BatchPrefetcher:
 
     # -- staging ------------------------------------------------------------------------------------------------------
     def _stage(self, slot: int, key: str, t: torch.Tensor) -> torch.Tensor:
+        dt = t.dtype
+        if self.feature_dtype is not None and key in self.FEATURES and t.is_floating_point():
+            dt = self.feature_dtype
         if t.is_cuda:
-            return t
-        if t.is_pinned():
+            return t if t.dtype == dt else t.to(dt)
+        if t.is_pinned() and t.dtype == dt:
             return t
         buf: Dict[str, torch.Tensor] = self._pinned[slot]
         p = buf.get(key)
-        if p is None or p.shape != t.shape or p.dtype != t.dtype:
-            p = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        if p is None or p.shape != t.shape or p.dtype != dt:
+            p = torch.empty(t.shape, dtype=dt, pin_memory=True)
             buf[key] = p
-        p.copy_(t)
+        p.copy_(t)                                   # converts while it stages when the feature type differs
         return p
 
     def _enqueue(self) -> bool:
