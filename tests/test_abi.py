@@ -172,3 +172,17 @@ def test_torch_custom_ops_are_registered():
         assert str(op.default._schema).startswith("stage_hip::" + name + "(")
     with pytest.raises(StageHipError):
         torch.ops.stage_hip.layernorm(torch.randn(4, 16), torch.ones(16), torch.zeros(16))
+
+
+def test_cpp_host_example_builds_against_the_c_abi(tmp_path):
+    """examples/k1_forward_host.cpp: a C++ host with nothing but the HIP runtime and include/stage_hip.h compiles and links
+    against the library (no GPU needed to link; tests/test_hip_ops.py runs it)."""
+    import shutil, subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "k1_forward_host")
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O1", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "k1_forward_host.cpp"), "-L", os.path.join(root, "tvqaplus_amd"),
+                           "-lstage_hip", "-o", exe])
+    assert os.path.getsize(exe) > 0

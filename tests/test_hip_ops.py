@@ -667,3 +667,29 @@ def test_k1_bf16_storage_vs_fp32_oracle(ops, N, Li, Lr, Lqa, D):
     check("A", A.float(), Ao, 4e-2)
     check("dC", Cd.grad.float().view_as(C), Cc.grad, 4e-2)
     check("dQ", Qd.grad.float().view_as(Q), Qc.grad, 4e-2)
+
+
+def test_cpp_host_runs_the_c_abi(ops, tmp_path):
+    """examples/k1_forward_host.cpp (C++ + HIP runtime, no torch) built here and run: its output sums equal the Python
+    binding's on the same deterministic inputs."""
+    import shutil, subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "k1_forward_host")
+    libdir = os.path.join(root, "tvqaplus_amd")
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O1", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "k1_forward_host.cpp"), "-L", libdir, "-lstage_hip", "-o", exe])
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.check_output([exe], env=env, timeout=120).decode().split()
+    sa, ss, rows = float(out[1]), float(out[3]), int(out[5])
+    N, NA, Li, Lqa, Lr, D = 2, 5, 6, 12, 20, 128
+    assert rows == N * NA * Li * Lqa
+    C = (torch.sin(0.37 * torch.arange(N * NA * Lqa * D, dtype=torch.float32)) + 0.1).view(N, NA, Lqa, D)
+    Q = (torch.cos(0.11 * torch.arange(N * Li * Lr * D, dtype=torch.float32)) * 1.5).view(N, Li, Lr, D)
+    cm = ((torch.arange(N * NA * Lqa) % Lqa) < 9).float().view(N, NA, Lqa)
+    qm = ((torch.arange(N * Li * Lr) % Lr) < 17).float().view(N, Li, Lr)
+    A, S, Sn = ops.structured_attention(C.cuda(), Q.cuda(), cm.cuda(), qm.cuda(), 10.0)
+    ra, rs = float(A.double().sum()), float(Sn.double().sum())
+    assert abs(sa - ra) < 2e-3 * (1 + abs(ra)) and abs(ss - rs) < 1e-4 * (1 + abs(rs)), (sa, ra, ss, rs)
+    assert abs(rs - N * NA * Li * 9) < 1e-2          # every valid context row's weights sum to 1
