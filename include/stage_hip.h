@@ -184,8 +184,10 @@ int stage_masked_max_bwd(const float* dout, const int* argmax, const float* mask
  * Same operations and argument meaning as the fp32 entry points of the same name; every pointer typed `void*` is a
  * tensor of bf16 (raw 16-bit words) instead of float.  Statistics, affine parameters, weights, biases, masks, arg-max
  * indices and all parameter gradients stay fp32; a weight is rounded to bf16 while the GEMM stages it.  The attention
- * kernel of this mode is stage_str_attn_long_* with storage == 1.  The row / conv kernels are the fp32 ones instantiated
- * on 16-bit elements; the GEMMs are the tiled kernels with one bf16 term (not yet the streaming ones).                                                                     */
+ * attention kernels of this mode: stage_str_attn_fwd_bf16 / stage_str_attn_bwd_fused_bf16 (D == 128, rows <= 64) and
+ * stage_str_attn_long_* with storage == 1 (any row length, D up to 256).  The row / conv kernels are the fp32 ones instantiated
+ * on 16-bit elements; the GEMMs stream 16-bit operands with one bf16 matrix-core term (gemm_bf16_stream.hip), tiled for the
+ * shapes streaming does not pay for.                                                                                   */
 /* K1 fast kernels on bf16 Q / A / dA (D == 128, Lr <= 64; STAGE_ERR_SHAPE otherwise -> stage_str_attn_long_*): Cn, the
  * masks, both score maps and the three gradients leaving the backward stay fp32.                                    */
 int stage_str_attn_fwd_bf16(const float* Cn, const void* Q, const float* c_mask, const float* q_mask, void* A,
