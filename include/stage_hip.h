@@ -183,7 +183,7 @@ int stage_masked_max_bwd(const float* dout, const int* argmax, const float* mask
 /* ---- bf16 storage mode (BASELINE.json configs[4]: bf16 weights / activations, fp32 softmax and accumulation) ------
  * Same operations and argument meaning as the fp32 entry points of the same name; every pointer typed `void*` is a
  * tensor of bf16 (raw 16-bit words) instead of float.  Statistics, affine parameters, weights, biases, masks, arg-max
- * indices and all parameter gradients stay fp32; a weight is rounded to bf16 while the GEMM stages it.  The attention
+ * indices and all parameter gradients stay fp32; a weight is rounded to bf16 while the GEMM stages it.  The
  * attention kernels of this mode: stage_str_attn_fwd_bf16 / stage_str_attn_bwd_fused_bf16 (D == 128, rows <= 64) and
  * stage_str_attn_long_* with storage == 1 (any row length, D up to 256).  The row / conv kernels are the fp32 ones instantiated
  * on 16-bit elements; the GEMMs stream 16-bit operands with one bf16 matrix-core term (gemm_bf16_stream.hip), tiled for the
