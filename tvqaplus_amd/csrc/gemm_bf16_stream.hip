@@ -338,12 +338,14 @@ __global__ __launch_bounds__(768) void gemm_tn_bf16_stream_kernel(const stage_bf
                                                                     float* __restrict__ part_b, long M, int N, int K, long rows_per_slab,
                                                                     int P, int RS, int KPn) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
-    const int pl = wave % P + blockIdx.y * P;               // patch index: pn = pl / KPn (64 dY columns), pk = pl % KPn (64 X columns)
+    const int pl = wave % P + blockIdx.y * P;               // patch index (k-major: pk = pl / NPn, pn = pl % NPn)
     const int rs = wave / P;
     const int NPn = (N + 63) >> 6;
     const bool idle = pl >= NPn * KPn;    // (only with several patch groups, where RS == 1 and no barrier follows)
     if (idle) return;
-    const int pn = pl / KPn, pk = pl - pn * KPn;
+    // k-major: a workgroup group covers ALL dY column patches for a few X column patches, so with several groups X (the wider
+    // operand) is still read once and only dY is re-read per group
+    const int pk = pl / NPn, pn = pl - pk * NPn;
     const long mbeg = (long)blockIdx.x * rows_per_slab, mend = min(M, mbeg + rows_per_slab);
     // ragged last patch (N or K not a multiple of 64; both are even): columns past the end read column 0 and are zeroed
     const bool yok = 64 * pn + 2 * l31 < N, xok = 64 * pk + 2 * l31 < K;
@@ -474,9 +476,10 @@ static int tb_plan(long long M, int N, int K, int* P, int* RS, int* KPn, int* GY
     if (M < 4096 || N % 2 != 0 || K % 2 != 0 || N < 2 || K < 2) return 0;
     *KPn = (K + 63) / 64;
     const int total = ((N + 63) / 64) * *KPn;
-    // more than 12 patches would need several workgroup groups, each re-reading one operand from HBM: measured slower than the
-    // tiled kernel (2.46 M rows, 768 x 300: 10.2 vs 7.5 ms) -- those shapes stay on the tiled kernel
-    if (total > 12) return 0;
+    // more than 12 patches need several workgroup groups, each re-reading one operand: measured slower than the tiled kernel
+    // in both group orders (2.46 M rows, 768 x 300 and 768 x 256: stress step 111.4 vs 108.9 ms) -- those shapes stay tiled
+    // unless STAGE_GEMM_BF16_TN_GROUPS is set (developer switch)
+    if (total > 12 && !getenv("STAGE_GEMM_BF16_TN_GROUPS")) return 0;
     *GY = (total + 11) / 12;                    // <= 12 waves per workgroup (768 threads: 168 registers per lane)
     *P = (total + *GY - 1) / *GY;
     *RS = *GY == 1 ? (12 / *P) : 1;
