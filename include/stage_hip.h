@@ -220,6 +220,10 @@ int stage_l2norm_fwd_bf16(const void* x, void* y, float* norm_out, long long row
                           unsigned long long seed, void* stream);
 int stage_l2norm_bwd_bf16(const void* dy, const void* x, void* dx, long long rows, int K, float eps, float p_drop,
                           unsigned long long seed, int accumulate, void* stream);
+/* dx (bf16) = add (fp32, may be NULL) + l2norm backward of (dy fp32, x bf16): folds the attention backward's two fp32
+ * gradients (raw path, normalised path) into one bf16 gradient in a single pass                                      */
+int stage_l2norm_bwd_mixed_bf16(const float* dy, const void* x, const float* add, void* dx, long long rows, int K, float eps,
+                                float p_drop, unsigned long long seed, void* stream);
 int stage_gemm_nt_bf16(const void* X, const void* gate, const float* W, const float* bias, const void* residual, void* Y,
                        long long M, int N, int K, int relu, void* stream);
 size_t stage_gemm_tn_bf16_ws_bytes(long long M, int N, int K);

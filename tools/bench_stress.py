@@ -37,7 +37,7 @@ for dt in (() if only else (torch.bfloat16, torch.float32)):
                       "fwd_us": round(tf * 1e6, 1), "fwd_bwd_us": round(tfb * 1e6, 1), "fwd_algorithmic_MB": round(alg / 1e6, 1),
                       "fwd_GBps": round(alg / tf / 1e9, 1), "fwd_TFLOPs": round(flops / tf / 1e12, 2)}))
 batch = make_batch(N=N, Li=Li, Lr=20, Lw=512, Lqa=40, seed=3).to(dev)
-for storage in ((only,) if only else ("bf16", "fp32")):
+for storage in (() if os.environ.get("STRESS_K1_ONLY") else ((only,) if only else ("bf16", "fp32"))):
     torch.manual_seed(0)
     opt = make_opt(hsz=256, add_local=True, dropout=0.1, storage_dtype=storage)
     with contextlib.redirect_stdout(open(os.devnull, "w")):

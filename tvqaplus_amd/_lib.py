@@ -68,6 +68,7 @@ SIGNATURES = {
     "stage_cat3_layernorm_bwd_reduced_bf16": (I, [P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, U64, P, SZ, P]),
     "stage_l2norm_fwd_bf16": (I, [P, P, P, LL, I, F, F, U64, P]),
     "stage_l2norm_bwd_bf16": (I, [P, P, P, LL, I, F, F, U64, I, P]),
+    "stage_l2norm_bwd_mixed_bf16": (I, [P, P, P, P, LL, I, F, F, U64, P]),
     "stage_gemm_nt_bf16": (I, [P, P, P, P, P, P, LL, I, I, I, P]),
     "stage_gemm_tn_bf16_ws_bytes": (SZ, [LL, I, I]),
     "stage_gemm_tn_bf16": (I, [P, P, P, P, P, LL, I, I, P, SZ, P]),

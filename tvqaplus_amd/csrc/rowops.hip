@@ -823,10 +823,12 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const T* __restrict__ x
 
 // dx = (g - xh * <xh, g>) / n   with g = dy * dropmask, xh = x / n, n = max(||x||, eps); if ||x|| <= eps the clamp is
 // a constant and dx = g / eps (what autograd gives for clamp_min).
-template <bool DROP, typename T = float>
-__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+// TY: type of dy and of the optional addend `add` (dx = add + ...); TX: type of x; T: type of dx (and of the in-place accumulate)
+template <bool DROP, typename T = float, typename TX = T, typename TY = T>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const TY* __restrict__ dy, const TX* __restrict__ x,
                                                          T* __restrict__ dx, long rows, int K, float eps, int LPR,
-                                                         uint64_t seed, uint32_t th, float inv_keep, int accumulate) {
+                                                         uint64_t seed, uint32_t th, float inv_keep, int accumulate,
+                                                         const TY* __restrict__ add = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int RPW = 64 / LPR, sub = lane / LPR, sl = lane % LPR;
     const int K4 = K >> 2;
@@ -861,6 +863,7 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const T* __restrict__ d
                                        g[t].w / n - v[t].w * c);
                 T* p = dx + row * K + 4 * j;
                 if (accumulate) o = f4add(o, ldv4(p));
+                if (add) o = f4add(o, ldv4(add + row * K + 4 * j));
                 stv4(p, o);
             }
         }
@@ -1103,4 +1106,24 @@ extern "C" int stage_cat3_layernorm_bwd_reduced_bf16(const void* dy, const void*
                                                      void* stream) {
     return cat3_bwd_reduced_t<B16>((const B16*)dy, (const B16*)a, (const B16*)b, mean, rstd, gamma, da, (B16*)db, dgamma, dbeta,
                                    rows, D, rep, inner, p_drop, seed, ws, ws_bytes, stream);
+}
+
+// dx (bf16) = add (fp32, may be NULL) + l2norm-backward(dy (fp32), x (bf16)): the attention backward leaves its two gradients
+// w.r.t. the raw and the normalised rows in fp32; this folds them into ONE bf16 gradient without an fp32 copy of x, an fp32
+// accumulate pass and a cast pass (rows x K each)
+extern "C" int stage_l2norm_bwd_mixed_bf16(const float* dy, const void* x, const float* add, void* dx, long long rows, int K,
+                                           float eps, float p_drop, unsigned long long seed, void* stream) {
+    if (rows <= 0) return 0;
+    if (K % 4 != 0 || K > 4 * MAXV * 64) return STAGE_ERR_SHAPE;
+    const int LPR = ln_lpr(K / 4);
+    const int grid = stage_grid_for(rows, 4 * (64 / LPR), GRID_CAP * 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (p_drop > 0.f)
+        hipLaunchKernelGGL((l2norm_bwd_kernel<true, B16, B16, float>), dim3(grid), dim3(256), 0, st, dy, (const B16*)x, (B16*)dx,
+                           (long)rows, K, eps, LPR, (uint64_t)seed, drop_thresh16(p_drop), 1.0f / (1.0f - p_drop), 0, add);
+    else
+        hipLaunchKernelGGL((l2norm_bwd_kernel<false, B16, B16, float>), dim3(grid), dim3(256), 0, st, dy, (const B16*)x, (B16*)dx,
+                           (long)rows, K, eps, LPR, (uint64_t)0, 0u, 1.0f, 0, add);
+    STAGE_LAUNCH_CHECK();
+    return 0;
 }

@@ -115,11 +115,13 @@ __global__ __launch_bounds__(256) void str_attn_long_fwd_kernel(const T* __restr
     const bool vec4 = (Lr & 3) == 0;
     // ---- pass 1: raw scores, online max / sum of exp(scale * raw) over the row ----
     float mx = -INFINITY, sum = 0.f;
+    LngRowB<D> qnext;                    // bf16 path: the next block's Qn fragments are requested before this block is scored
+    if constexpr (USEB) lng_rowb<D>(qnext, qn + (long)min(c15, Lr - 1) * D, g);
     for (int rb = 0; rb < nb; rb++) {
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
         if constexpr (USEB) {
-            LngRowB<D> qfb;
-            lng_rowb<D>(qfb, qn + (long)min(rb * 16 + c15, Lr - 1) * D, g);
+            const LngRowB<D> qfb = qnext;
+            lng_rowb<D>(qnext, qn + (long)min((rb + 1 < nb ? rb + 1 : rb) * 16 + c15, Lr - 1) * D, g);
             acc = lng_dotb<D>(qfb, cfb);
         } else {
             float qf[DQ];
@@ -159,11 +161,35 @@ __global__ __launch_bounds__(256) void str_attn_long_fwd_kernel(const T* __restr
     f32x4 o[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; dt++) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // bf16 storage with DT % 8 == 0 (D = 128, 256): the next block's Q rows (raw 16-bit words, converted where they feed the
+    // matrix cores) and scores are requested before the current block is multiplied -- the loop is one chain of memory round
+    // trips otherwise
+    constexpr bool PF = USEB && (DT % 8 == 0);
+    constexpr int NW4 = PF ? DT / 8 : 1;
+    uint4 qraw[4][NW4], qraw_n[4][NW4];
+    float4 rv_n = make_float4(-1e10f, -1e10f, -1e10f, -1e10f);
+    auto pf_load = [&](uint4 (&dst)[4][NW4], float4& rvd, int rbn) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int q = 0; q < NW4; q++)
+                dst[k][q] = *reinterpret_cast<const uint4*>(qr + (long)min(rbn * 16 + 4 * g + k, Lr - 1) * D + DT * c15 + 8 * q);
+        rvd = make_float4(-1e10f, -1e10f, -1e10f, -1e10f);
+        if (vec4 && cvalid && rbn * 16 + 4 * g < Lr) rvd = ld4(S + orow * Lr + rbn * 16 + 4 * g);
+    };
+    if constexpr (PF) pf_load(qraw_n, rv_n, 0);
     for (int rb = 0; rb < nb; rb++) {
         float p[4];
         const bool blk = rb * 16 + 4 * g < Lr;
         float4 rv = make_float4(-1e10f, -1e10f, -1e10f, -1e10f);
-        if (vec4 && cvalid && blk) rv = ld4(S + orow * Lr + rb * 16 + 4 * g);
+        if constexpr (PF) {
+            rv = rv_n;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int q = 0; q < NW4; q++) qraw[k][q] = qraw_n[k][q];
+            if (rb + 1 < nb) pf_load(qraw_n, rv_n, rb + 1);
+        } else if (vec4 && cvalid && blk) rv = ld4(S + orow * Lr + rb * 16 + 4 * g);
         {
 #pragma clang fp contract(off)
 #pragma unroll
@@ -178,13 +204,25 @@ __global__ __launch_bounds__(256) void str_attn_long_fwd_kernel(const T* __restr
             }
             if (vec4 && cvalid && blk) st4(Sn + orow * Lr + rb * 16 + 4 * g, make_float4(p[0], p[1], p[2], p[3]));
         }
-        float qd[4][DT];                 // Q[region rb*16 + 4g + k][DT c15 .. DT c15 + DT - 1]: the operands of all DT tiles
+        if constexpr (PF) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) lng_ldn<DT>(qd[k], qr + (long)min(rb * 16 + 4 * g + k, Lr - 1) * D + DT * c15);   // S_ = 0 past Lr
+            for (int dt = 0; dt < DT; dt++)
 #pragma unroll
-        for (int dt = 0; dt < DT; dt++)
+                for (int k = 0; k < 4; k++) {
+                    const uint4 w4 = qraw[k][dt / 8];
+                    const unsigned w = (dt % 8) / 2 == 0 ? w4.x : ((dt % 8) / 2 == 1 ? w4.y : ((dt % 8) / 2 == 2 ? w4.z : w4.w));
+                    const float a = (dt & 1) ? __uint_as_float(w & 0xFFFF0000u) : __uint_as_float(w << 16);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p[k], o[dt], 0, 0, 0);
+                }
+        } else {
+            float qd[4][DT];             // Q[region rb*16 + 4g + k][DT c15 .. DT c15 + DT - 1]: the operands of all DT tiles
 #pragma unroll
-            for (int k = 0; k < 4; k++) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qd[k][dt], p[k], o[dt], 0, 0, 0);
+            for (int k = 0; k < 4; k++) lng_ldn<DT>(qd[k], qr + (long)min(rb * 16 + 4 * g + k, Lr - 1) * D + DT * c15);   // S_ = 0 past Lr
+#pragma unroll
+            for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qd[k][dt], p[k], o[dt], 0, 0, 0);
+        }
     }
     if (cvalid) {   // o[dt][k] = A[c][d = DT (4g + k) + dt]: DT consecutive columns per register index k
         T* pa = A + orow * D;
@@ -298,7 +336,7 @@ __global__ __launch_bounds__(256) void str_attn_long_bwd_ds_kernel(const T* __re
 // consecutive elements of a dA / Cn row with one or two 16-byte loads and owns DT consecutive output columns); k-steps of 4
 // context rows
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, int DT>
+template <typename T, int DT, int DTW>   // DTW <= 8 d tiles per wave: 2 x DTW accumulators fit two waves per SIMD at D = 256
 __global__ __launch_bounds__(256) void str_attn_long_bwd_dq_kernel(const T* __restrict__ dA, const float* __restrict__ Sn,
                                                                    const float* __restrict__ dS, const T* __restrict__ Cn,
                                                                    float* __restrict__ dQraw, float* __restrict__ dQn, int N,
@@ -306,29 +344,40 @@ __global__ __launch_bounds__(256) void str_attn_long_bwd_dq_kernel(const T* __re
     constexpr int D = 16 * DT;
     const int lane = threadIdx.x & 63, c15 = lane & 15, g = lane >> 4;
     const int CR = NA * Lqa, nb = (Lr + 15) >> 4;
+    constexpr int NH = DT / DTW;                             // d-tile groups per region block (one wave each)
     const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= (long)N * Li * nb) return;
-    const int rb = (int)(item % nb);
-    const long frame = item / nb;
+    if (item >= (long)N * Li * nb * NH) return;
+    const int hh = (int)(item % NH);
+    const int rb = (int)((item / NH) % nb);
+    const long frame = item / ((long)NH * nb);
     const int n = (int)(frame / Li), i = (int)(frame % Li);
     const int r = rb * 16 + c15, rc = min(r, Lr - 1);
-    f32x4 ar[DT], an[DT];
+    const int dofs = DT * c15 + DTW * hh;                    // this lane's DTW consecutive columns
+    f32x4 ar[DTW], an[DTW];
 #pragma unroll
-    for (int dt = 0; dt < DT; dt++) ar[dt] = an[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int c0 = 0; c0 < CR; c0 += 4) {
+    for (int dt = 0; dt < DTW; dt++) ar[dt] = an[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // one k-step = 4 context rows; the operands of the NEXT step are requested before the current one is multiplied (the
+    // loop is a chain of memory round trips otherwise)
+    struct Step { float p, gs; float da[DTW], cn[DTW]; };
+    auto fetch = [&](Step& s, int c0) {
         const int c = c0 + g;
         const bool ok = c < CR;
         const int cc = ok ? c : CR - 1;
         const long orow = ((long)(n * NA + cc / Lqa) * Li + i) * Lqa + cc % Lqa;
-        const float p = ok ? Sn[orow * Lr + rc] : 0.f;      // A operands: row = region c15, k = context row
-        const float gs = ok ? dS[orow * Lr + rc] : 0.f;
-        float da[DT], cn[DT];                               // B operands: k = context row, columns DT c15 .. + DT - 1
-        lng_ldn<DT>(da, dA + orow * D + DT * c15);
-        lng_ldn<DT>(cn, Cn + ((long)n * CR + cc) * D + DT * c15);
+        s.p = ok ? Sn[orow * Lr + rc] : 0.f;                // A operands: row = region c15, k = context row
+        s.gs = ok ? dS[orow * Lr + rc] : 0.f;
+        lng_ldn<DTW>(s.da, dA + orow * D + dofs);           // B operands: k = context row, columns dofs .. + DTW - 1
+        lng_ldn<DTW>(s.cn, Cn + ((long)n * CR + cc) * D + dofs);
+    };
+    Step cur, nxt;
+    fetch(nxt, 0);
+    for (int c0 = 0; c0 < CR; c0 += 4) {
+        cur = nxt;
+        if (c0 + 4 < CR) fetch(nxt, c0 + 4);
 #pragma unroll
-        for (int dt = 0; dt < DT; dt++) {                   // rows past CR: the A operands are zero (the clamped B rows are finite)
-            ar[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, da[dt], ar[dt], 0, 0, 0);
-            an[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gs, cn[dt], an[dt], 0, 0, 0);
+        for (int dt = 0; dt < DTW; dt++) {                  // rows past CR: the A operands are zero (the clamped B rows are finite)
+            ar[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.p, cur.da[dt], ar[dt], 0, 0, 0);
+            an[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.gs, cur.cn[dt], an[dt], 0, 0, 0);
         }
     }
     // C layout: row 4g + k = region inside the block, column c15 -> d = DT c15 + dt
@@ -336,10 +385,10 @@ __global__ __launch_bounds__(256) void str_attn_long_bwd_dq_kernel(const T* __re
     for (int k = 0; k < 4; k++) {
         const int rr = rb * 16 + 4 * g + k;
         if (rr < Lr) {
-            float* o1 = dQraw + (frame * Lr + rr) * D + DT * c15;
-            float* o2 = dQn + (frame * Lr + rr) * D + DT * c15;
+            float* o1 = dQraw + (frame * Lr + rr) * D + dofs;
+            float* o2 = dQn + (frame * Lr + rr) * D + dofs;
 #pragma unroll
-            for (int dt = 0; dt < DT; dt++) { o1[dt] = ar[dt][k]; o2[dt] = an[dt][k]; }
+            for (int dt = 0; dt < DTW; dt++) { o1[dt] = ar[dt][k]; o2[dt] = an[dt][k]; }
         }
     }
 }
@@ -405,16 +454,19 @@ static int lng_bwd(const void* dA, const void* A, const float* ext, const void* 
     const long C = (long)N * CR * D;
     hipLaunchKernelGGL(lng_slab_sum_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, (const float*)part, dCn, nchunks, C);
     STAGE_LAUNCH_CHECK();
-    const long items2 = (long)N * Li * ((Lr + 15) / 16);
-#define LNG_Q(DTV)                                                                                                         \
-    hipLaunchKernelGGL((str_attn_long_bwd_dq_kernel<T, DTV>), dim3((unsigned)((items2 + 3) / 4)), dim3(256), 0, st, (const T*)dA, Sn, \
+    const bool dq_split = D > 128 && !(sizeof(T) == 2 && !getenv("STAGE_LONG_DQ_SPLIT"));
+    const long items2 = (long)N * Li * ((Lr + 15) / 16) * (dq_split ? D / 128 : 1);
+#define LNG_Q(DTV, DTWV)                                                                                                   \
+    hipLaunchKernelGGL((str_attn_long_bwd_dq_kernel<T, DTV, DTWV>), dim3((unsigned)((items2 + 3) / 4)), dim3(256), 0, st, (const T*)dA, Sn, \
                        (const float*)dS, (const T*)Cn, dQraw, dQn, N, NA, Li, Lqa, Lr)
     switch (D) {
-        case 16: LNG_Q(1); break;
-        case 32: LNG_Q(2); break;
-        case 64: LNG_Q(4); break;
-        case 128: LNG_Q(8); break;
-        default: LNG_Q(16); break;
+        case 16: LNG_Q(1, 1); break;
+        case 32: LNG_Q(2, 2); break;
+        case 64: LNG_Q(4, 4); break;
+        case 128: LNG_Q(8, 8); break;
+        default:
+            if (sizeof(T) == 2 && !getenv("STAGE_LONG_DQ_SPLIT")) LNG_Q(16, 16); else LNG_Q(16, 8);
+            break;
     }
 #undef LNG_Q
     STAGE_LAUNCH_CHECK();

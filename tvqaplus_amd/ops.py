@@ -545,20 +545,22 @@ class _StrAttn(torch.autograd.Function):
                     N, NA, Li, Lqa, Lr, D, scale, _ptr(ws), wsb, _stream())
             if rc != _lib.STAGE_ERR_SHAPE:
                 _lib.check(rc, "stage_str_attn_bwd_fused")
-        Qf = Q.float() if bf else Q
         if rc == _lib.STAGE_ERR_SHAPE:
             # three-kernel path (fp32 operands; in the bf16 mode the casts are plumbing for the shapes the fused kernel rejects)
-            dAf, Qnf = (dA.float(), Qn.float()) if bf else (dA, Qn)
+            dAf, Qf, Qnf = (dA.float(), Q.float(), Qn.float()) if bf else (dA, Q, Qn)
             dS_out = torch.empty_like(Sn)
             wsb = lib.stage_str_attn_bwd_ws_bytes(N, NA, Lqa, D)
             ws = _workspace(wsb, Q.device)
             _call("stage_str_attn_bwd", _ptr(dAf), _ptr(dS_ext), _ptr(Cn), _ptr(Qf), _ptr(Qnf), _ptr(Sn), _ptr(dS_out),
                   _ptr(dQ), _ptr(dQn), _ptr(dCn), N, NA, Li, Lqa, Lr, D, scale, _ptr(ws), wsb, _stream())
-        _call("stage_l2norm_bwd", _ptr(dQn), _ptr(Qf), _ptr(dQ), N * Li * Lr, D, EPS_L2, p, seed_q, 1, _stream())
         dC = torch.empty_like(Cf)
         _call("stage_l2norm_bwd", _ptr(dCn), _ptr(Cf), _ptr(dC), N * NA * Lqa, D, EPS_L2, p, seed_c, 0, _stream())
         if bf:
-            return dC.to(_BF16), dQ.to(_BF16), None, None, None, None, None, None
+            # one pass: dQ (bf16) = value-path gradient (fp32) + the normalisation's backward of dQn (fp32) at the bf16 rows of Q
+            dQb = torch.empty_like(Q)
+            _call("stage_l2norm_bwd_mixed_bf16", _ptr(dQn), _ptr(Q), _ptr(dQ), _ptr(dQb), N * Li * Lr, D, EPS_L2, p, seed_q, _stream())
+            return dC.to(_BF16), dQb, None, None, None, None, None, None
+        _call("stage_l2norm_bwd", _ptr(dQn), _ptr(Q), _ptr(dQ), N * Li * Lr, D, EPS_L2, p, seed_q, 1, _stream())
         return dC, dQ, None, None, None, None, None, None
 
 
@@ -577,11 +579,10 @@ class _StrAttnLong(torch.autograd.Function):
         c_mask, q_mask = _chk(c_mask, "c_mask"), _chk(q_mask, "q_mask")
         N, NA, Lqa, D = C.shape
         _, Li, Lr, _ = Q.shape
-        Cf, Qf = C.float(), Q.float()
-        Cn, Qn = torch.empty_like(Cf), torch.empty_like(Qf)
-        _call("stage_l2norm_fwd", _ptr(Cf), _ptr(Cn), None, N * NA * Lqa, D, EPS_L2, float(p), int(seed_c), _stream())
-        _call("stage_l2norm_fwd", _ptr(Qf), _ptr(Qn), None, N * Li * Lr, D, EPS_L2, float(p), int(seed_q), _stream())
-        Cn, Qn = Cn.to(dt), Qn.to(dt)
+        # normalised operands in the storage type (bf16: the 16-bit kernels, no fp32 copies of the big region tensor)
+        Cn, Qn = torch.empty_like(C), torch.empty_like(Q)
+        _call("stage_l2norm_fwd" + _sfx(C), _ptr(C), _ptr(Cn), None, N * NA * Lqa, D, EPS_L2, float(p), int(seed_c), _stream())
+        _call("stage_l2norm_fwd" + _sfx(Q), _ptr(Q), _ptr(Qn), None, N * Li * Lr, D, EPS_L2, float(p), int(seed_q), _stream())
         A = torch.empty(N, NA, Li, Lqa, D, dtype=dt, device=C.device)
         S = torch.empty(N, NA, Li, Lqa, Lr, dtype=torch.float32, device=C.device)
         Sn = torch.empty_like(S)
@@ -610,11 +611,15 @@ class _StrAttnLong(torch.autograd.Function):
         ws = _workspace(wsb, C.device)
         _call("stage_str_attn_long_bwd", _ptr(dA), _ptr(A), _ptr(dS_ext), _ptr(Cn), _ptr(Q), _ptr(Qn), _ptr(Sn), _ptr(dS_ws),
               _ptr(dQ), _ptr(dQn), _ptr(dCn), N, NA, Li, Lqa, Lr, D, scale, int(dt == torch.bfloat16), _ptr(ws), wsb, _stream())
-        Cf, Qf = C.float(), Q.float()
-        _call("stage_l2norm_bwd", _ptr(dQn), _ptr(Qf), _ptr(dQ), N * Li * Lr, D, EPS_L2, p, seed_q, 1, _stream())
-        dC = torch.empty_like(Cf)
-        _call("stage_l2norm_bwd", _ptr(dCn), _ptr(Cf), _ptr(dC), N * NA * Lqa, D, EPS_L2, p, seed_c, 0, _stream())
-        return dC.to(dt), dQ.to(dt), None, None, None, None, None, None
+        if dt == _BF16:
+            dQb, dCb = torch.empty_like(Q), torch.empty_like(C)
+            _call("stage_l2norm_bwd_mixed_bf16", _ptr(dQn), _ptr(Q), _ptr(dQ), _ptr(dQb), N * Li * Lr, D, EPS_L2, p, seed_q, _stream())
+            _call("stage_l2norm_bwd_mixed_bf16", _ptr(dCn), _ptr(C), None, _ptr(dCb), N * NA * Lqa, D, EPS_L2, p, seed_c, _stream())
+            return dCb, dQb, None, None, None, None, None, None
+        _call("stage_l2norm_bwd", _ptr(dQn), _ptr(Q), _ptr(dQ), N * Li * Lr, D, EPS_L2, p, seed_q, 1, _stream())
+        dC = torch.empty_like(C)
+        _call("stage_l2norm_bwd", _ptr(dCn), _ptr(C), _ptr(dC), N * NA * Lqa, D, EPS_L2, p, seed_c, 0, _stream())
+        return dC, dQ, None, None, None, None, None, None
 
 
 def structured_attention_long(C, Q, c_mask, q_mask, scale: float, p: float = 0.0, seed_c: int = 0, seed_q: int = 0):
