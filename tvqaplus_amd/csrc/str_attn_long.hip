@@ -260,13 +260,24 @@ __global__ __launch_bounds__(256) void str_attn_long_bwd_ds_kernel(const T* __re
     for (int i = chunk; i < Li; i += nchunks) {
         const long frame = (long)n * Li + i;
         const long orow = ((long)(n * NA + cc / Lqa) * Li + i) * Lqa + cc % Lqa;
-        float gf[DQ];
-        lng_frag<T, DQ>(gf, dA + orow * D, g);
-        LngRowB<D> gfb;                                       // the same row as bf16 matrix-core fragments (bf16 storage)
-        if constexpr (LngUseB<T, D>::value) lng_rowb<D>(gfb, dA + orow * D, g);
+        float gf[LngUseB<T, D>::value ? 1 : DQ];
+        LngRowB<D> gfb;                                       // bf16 storage: the row as packed bf16 matrix-core fragments
         // <P, dP> over the whole row = <dA, A>: this lane's share of the row, then across the four lane groups
         float dot = 0.f;
-        {
+        if constexpr (LngUseB<T, D>::value) {
+            lng_rowb<D>(gfb, dA + orow * D, g);
+            LngRowB<D> afb;                                   // the A row in the same (k-step, lane group) partition
+            lng_rowb<D>(afb, A + orow * D, g);
+            auto lo = [](unsigned u) { return __uint_as_float(u << 16); };
+            auto hi = [](unsigned u) { return __uint_as_float(u & 0xFFFF0000u); };
+#pragma unroll
+            for (int s = 0; s < D / 32; s++) {
+                const uint4 a = afb.v[s], b = gfb.v[s];
+                dot += lo(a.x) * lo(b.x) + hi(a.x) * hi(b.x) + lo(a.y) * lo(b.y) + hi(a.y) * hi(b.y)
+                     + lo(a.z) * lo(b.z) + hi(a.z) * hi(b.z) + lo(a.w) * lo(b.w) + hi(a.w) * hi(b.w);
+            }
+        } else {
+            lng_frag<T, DQ>(gf, dA + orow * D, g);
             const T* pa = A + orow * D + g * DQ;
 #pragma unroll
             for (int s = 0; s < DQ; s++) dot += gf[s] * lng_ld<T>(pa + s);
@@ -312,13 +323,33 @@ __global__ __launch_bounds__(256) void str_attn_long_bwd_ds_kernel(const T* __re
                     G[k] = v;
                 }
             }
-            float qd[4][DT];             // Qn[region][DT c15 .. + DT - 1] (d tiles permuted as in the forward)
+            if constexpr (LngUseB<T, D>::value && (DT % 8 == 0)) {
+                // bf16 storage: the Qn rows stay packed (half the registers: two waves per SIMD at D = 256) and are
+                // converted where they feed the matrix cores
+                uint4 qw[4][DT / 8];
 #pragma unroll
-            for (int k = 0; k < 4; k++) lng_ldn<DT>(qd[k], qn + (long)min(rb * 16 + 4 * g + k, Lr - 1) * D + DT * c15);   // G = 0 past Lr
+                for (int k = 0; k < 4; k++)
 #pragma unroll
-            for (int dt = 0; dt < DT; dt++)
+                    for (int q = 0; q < DT / 8; q++)
+                        qw[k][q] = *reinterpret_cast<const uint4*>(qn + (long)min(rb * 16 + 4 * g + k, Lr - 1) * D + DT * c15 + 8 * q);
 #pragma unroll
-                for (int k = 0; k < 4; k++) dcn[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qd[k][dt], G[k], dcn[dt], 0, 0, 0);
+                for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint4 w4 = qw[k][dt / 8];
+                        const unsigned w = (dt % 8) / 2 == 0 ? w4.x : ((dt % 8) / 2 == 1 ? w4.y : ((dt % 8) / 2 == 2 ? w4.z : w4.w));
+                        const float a = (dt & 1) ? __uint_as_float(w & 0xFFFF0000u) : __uint_as_float(w << 16);
+                        dcn[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, G[k], dcn[dt], 0, 0, 0);
+                    }
+            } else {
+                float qd[4][DT];         // Qn[region][DT c15 .. + DT - 1] (d tiles permuted as in the forward)
+#pragma unroll
+                for (int k = 0; k < 4; k++) lng_ldn<DT>(qd[k], qn + (long)min(rb * 16 + 4 * g + k, Lr - 1) * D + DT * c15);   // G = 0 past Lr
+#pragma unroll
+                for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) dcn[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qd[k][dt], G[k], dcn[dt], 0, 0, 0);
+            }
         }
     }
     if (cvalid) {
