@@ -62,6 +62,48 @@ __device__ __forceinline__ f32x16 s_mfma_terms(const sbf16x8 (&a)[3], const sbf1
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
     return acc;
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// NT kernel: fp32 products as a TWO-way fp16 split (STAGE_GEMM_NT_F16, default).  fp16 carries 11 significant bits, so
+// x = hi + lo (both round-to-nearest) holds 22-23 bits of x and the three products hi*hi + hi*lo + lo*hi reproduce the fp32
+// product to ~2^-22 -- against an fp64 product the result's error is BELOW that of a plain fp32 FMA chain (numpy emulation,
+// K = 384, relative to the result's rms: max 1.2e-6 / rms 2.1e-7; torch / numpy fp32 matmul 3.8e-6 / 3.5e-7) -- with HALF the
+// matrix-core instructions of the 3-way bf16 split and 5 instead of 11 VALU instructions per operand pair.  What fp16 lacks
+// is range, so operands are scaled by powers of two (exact) on the way in and the accumulators on the way out:
+//   * X: one exponent per ROW (= per lane, both lane halves agree through v_permlane32_swap): the row's largest magnitude
+//     seen so far is mapped into [2^11, 2^12); a later line that would pass 2^15 raises the row's exponent and the
+//     accumulators of the wave are rescaled (v_ldexp, a wave-uniform branch that real data takes once per tile at most);
+//   * W: one exponent per workgroup from a pre-pass over its (<= 128 x K) weight tile.
+// An element far below its row's maximum keeps an ABSOLUTE error of 2^-26 of that maximum (fp16 denormals) instead of
+// fp32's relative 2^-24: irrelevant for a dot product, whose error scale is the largest terms.
+#ifndef STAGE_GEMM_NT_F16
+#define STAGE_GEMM_NT_F16 1
+#endif
+typedef _Float16 sf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned h_cvt_pk(float lo, float hi) {     // round to nearest even, lo in the low half
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float h_lo_f32(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p & 0xFFFFu)); }
+__device__ __forceinline__ float h_hi_f32(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16)); }
+// (a, b) * sc -> packed fp16 pairs hi, lo with a * sc == hi + lo up to 2^-22 (sc a power of two)
+__device__ __forceinline__ void h_split2(float a, float b, float sc, unsigned& hi, unsigned& lo) {
+    const float as = a * sc, bs = b * sc;
+    hi = h_cvt_pk(as, bs);
+    lo = h_cvt_pk(as - h_lo_f32(hi), bs - h_hi_f32(hi));
+}
+// biased fp32 exponent of a magnitude -> the exponent field of the power of two that maps it into [2^11, 2^12)
+__device__ __forceinline__ int h_up_field(int eb) { return min(265 - eb, 254); }
+__device__ __forceinline__ f32x16 h_mfma_terms(const sf16x8 (&a)[2], const sf16x8 (&b)[2], f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc, 0, 0, 0);
+    return acc;
+}
+__device__ __forceinline__ float s_absmax4(float m, float4 v) {
+    return fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fabsf(v.z))), fabsf(v.w));
+}
+
 __device__ __forceinline__ float4 s_load4(const float* __restrict__ base, long row, long ld, int col, long nrows, int ncols) {
     const long r = row < nrows ? row : nrows - 1;
     const int c = col < ncols ? col : ncols - 4;
@@ -120,16 +162,45 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
 
     // weight chunk kc -> LDS planes.  float4 group q of a row covers k = 4q..4q+3 = 16u + 8c + 4h' + e  (q = 4u + 2c + h')
     // and lands at plane position 16u + 8h' + 4c + e, i.e. lane-half h' finds its 8 operand values contiguous.
-    auto load_w = [&](int kc) {
-        for (int e = tid; e < SBN * (SKC / 4); e += 64 * SWAVES) {
-            const int n = e >> 5, q = e & 31;
-            const float4 v = s_load4(W, n0 + n, K, kc * SKC + 4 * q, N, K);
+    // fp16 mode: power-of-two scale of this workgroup's weight tile (all K), from a pre-pass over its rows (L2 reads)
+    int w_up = 127;                                      // exponent field of the scale; 127 = 1.0
+    if (STAGE_GEMM_NT_F16) {
+        float wm = 0.f;
+        const int kq = K >> 2;
+        for (int e = tid; e < SBN * kq; e += 64 * SWAVES) {
+            const int n = e / kq, q = e - n * kq;
+            wm = s_absmax4(wm, s_load4(W, n0 + n, K, 4 * q, N, K));
+        }
+        wm = wave_max(wm);
+        float* red = reinterpret_cast<float*>(Wp);
+        if (lane == 0) red[wave] = wm;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SWAVES; i++) wm = fmaxf(wm, red[i]);
+        __syncthreads();                                 // the planes are written next
+        w_up = h_up_field((int)(__float_as_uint(wm) >> 23) & 0xff);
+    }
+    const float w_sc = __uint_as_float((unsigned)w_up << 23);
+    auto put_w = [&](float4 v, int n, int q) {
+        const int pos = 16 * (q >> 2) + 8 * (q & 1) + 4 * ((q >> 1) & 1);
+        if (STAGE_GEMM_NT_F16) {
+            unsigned h01, l01, h23, l23;
+            h_split2(v.x, v.y, w_sc, h01, l01);
+            h_split2(v.z, v.w, w_sc, h23, l23);
+            *reinterpret_cast<uint2*>(&Wp[n * SWS + pos]) = make_uint2(h01, h23);
+            *reinterpret_cast<uint2*>(&Wp[SPLANE + n * SWS + pos]) = make_uint2(l01, l23);
+        } else {
             unsigned s01[3], s23[3];
             s_split3(v.x, v.y, s01);
             s_split3(v.z, v.w, s23);
-            const int pos = 16 * (q >> 2) + 8 * (q & 1) + 4 * ((q >> 1) & 1);
 #pragma unroll
             for (int s = 0; s < STAGE_GEMM_TERMS; s++) *reinterpret_cast<uint2*>(&Wp[s * SPLANE + n * SWS + pos]) = make_uint2(s01[s], s23[s]);
+        }
+    };
+    auto load_w = [&](int kc) {
+        for (int e = tid; e < SBN * (SKC / 4); e += 64 * SWAVES) {
+            const int n = e >> 5, q = e & 31;
+            put_w(s_load4(W, n0 + n, K, kc * SKC + 4 * q, N, K), n, q);
         }
     };
 
@@ -151,12 +222,7 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
         for (int j = 0; j < 8; j++) {
             const int e = tid + j * 64 * SWAVES, n = e >> 5, q = e & 31;
             const bool ok = n0 + n < N && kc * SKC + 4 * q < K;
-            unsigned s01[3], s23[3];
-            s_split3(ok ? wr[j][0] : 0.f, ok ? wr[j][1] : 0.f, s01);
-            s_split3(ok ? wr[j][2] : 0.f, ok ? wr[j][3] : 0.f, s23);
-            const int pos = 16 * (q >> 2) + 8 * (q & 1) + 4 * ((q >> 1) & 1);
-#pragma unroll
-            for (int s = 0; s < STAGE_GEMM_TERMS; s++) *reinterpret_cast<uint2*>(&Wp[s * SPLANE + n * SWS + pos]) = make_uint2(s01[s], s23[s]);
+            put_w(make_float4(ok ? wr[j][0] : 0.f, ok ? wr[j][1] : 0.f, ok ? wr[j][2] : 0.f, ok ? wr[j][3] : 0.f), n, q);
         }
     };
 #define WAIT_W(n)                                                                                                      \
@@ -244,6 +310,7 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
         for (int nt = 0; nt < 4; nt++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[nt][r] = 0.f;
+        int xeb = 0;                                     // fp16 mode: biased exponent of this lane's row maximum so far
 
         for (int kc = 0; kc < nkc; kc++) {
             const int kb = kc * SKC;
@@ -266,6 +333,7 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
             }
             if (!live) continue;
             auto mul_line = [&](int buf, int L) {
+                float4 vv[4];                             // the lane's 16 values of the line: [2 up + c]
 #pragma unroll
                 for (int up = 0; up < 2; up++) {          // two 16-k MFMA steps per line
                     float4 v0 = make_float4(xa[buf][2 * up][0], xa[buf][2 * up][1], xa[buf][2 * up][2], xa[buf][2 * up][3]);
@@ -291,6 +359,51 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
                         v1.z = __int_as_float(__float_as_int(v1.z) & __builtin_amdgcn_sbfe(wbits, p0b + 10, 1));
                         v1.w = __int_as_float(__float_as_int(v1.w) & __builtin_amdgcn_sbfe(wbits, p0b + 11, 1));
                     }
+                    vv[2 * up] = v0;
+                    vv[2 * up + 1] = v1;
+                }
+                float x_sc = 1.f;
+                if (STAGE_GEMM_NT_F16) {
+                    // the row's exponent: largest magnitude of the line (both lane halves), raised only when a value would
+                    // pass 2^15 after scaling; the first line of a tile sets it (the accumulators are zero)
+                    const float m = xmax32(s_absmax4(s_absmax4(s_absmax4(s_absmax4(0.f, vv[0]), vv[1]), vv[2]), vv[3]));
+                    const int ec = (int)(__float_as_uint(m) >> 23) & 0xff;
+                    if (kc == 0 && L == 0) xeb = ec;
+                    else if (__any(ec > xeb + 3)) {
+                        const int neb = ec > xeb + 3 ? ec : xeb;
+                        const int d = h_up_field(neb) - h_up_field(xeb);          // <= 0: this row's accumulators shrink by 2^d
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int dr = __builtin_amdgcn_ds_bpermute(4 * ((r & 3) + 8 * (r >> 2) + 4 * h), d);
+#pragma unroll
+                            for (int nt = 0; nt < 4; nt++) acc[nt][r] = __builtin_ldexpf(acc[nt][r], dr);
+                        }
+                        xeb = neb;
+                    }
+                    x_sc = __uint_as_float((unsigned)h_up_field(xeb) << 23);
+                }
+#pragma unroll
+                for (int up = 0; up < 2; up++) {
+                    const float4 v0 = vv[2 * up], v1 = vv[2 * up + 1];
+                    const int koff = 16 * (2 * L + up) + 8 * h;
+                    if (STAGE_GEMM_NT_F16) {
+                        unsigned ph[4], pl[4];
+                        h_split2(v0.x, v0.y, x_sc, ph[0], pl[0]);
+                        h_split2(v0.z, v0.w, x_sc, ph[1], pl[1]);
+                        h_split2(v1.x, v1.y, x_sc, ph[2], pl[2]);
+                        h_split2(v1.z, v1.w, x_sc, ph[3], pl[3]);
+                        sf16x8 a[2], b[2];
+                        a[0] = __builtin_bit_cast(sf16x8, make_uint4(ph[0], ph[1], ph[2], ph[3]));
+                        a[1] = __builtin_bit_cast(sf16x8, make_uint4(pl[0], pl[1], pl[2], pl[3]));
+#pragma unroll
+                        for (int nt = 0; nt < 4; nt++) {
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; s2++)
+                                b[s2] = __builtin_bit_cast(sf16x8, *reinterpret_cast<const uint4*>(&Wp[s2 * SPLANE + (nt * 32 + l31) * SWS + koff]));
+                            acc[nt] = h_mfma_terms(a, b, acc[nt]);
+                        }
+                        continue;
+                    }
                     unsigned p0[3], p1[3], p2[3], p3[3];
                     sbf16x8 a[3];
                     if (GEMM_ABL & 2) {
@@ -305,7 +418,6 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
 #pragma unroll
                         for (int s = 0; s < STAGE_GEMM_TERMS; s++) a[s] = __builtin_bit_cast(sbf16x8, make_uint4(p0[s], p1[s], p2[s], p3[s]));
                     }
-                    const int koff = 16 * (2 * L + up) + 8 * h;
                     sbf16x8 b[3];
 #pragma unroll
                     for (int nt = 0; nt < 4; nt++) {
@@ -364,6 +476,15 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
         // Straight-line stores: a residual load or a per-row guard inside this loop makes the compiler put an
         // s_waitcnt vmcnt(0) in front of every store (each store then waits for the previous one to be acknowledged).
         const bool full = t * 32 + 32 <= M;
+        if (STAGE_GEMM_NT_F16) {                          // back to true units: 2^-(row scale + weight scale), per output row
+            const int dn = 254 - h_up_field(xeb) - w_up;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int dr = __builtin_amdgcn_ds_bpermute(4 * ((r & 3) + 8 * (r >> 2) + 4 * h), dn);
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) acc[nt][r] = __builtin_ldexpf(acc[nt][r], dr);
+            }
+        }
 #pragma unroll
         for (int nt = 0; nt < 4; nt++) {
             if (n0 + nt * 32 >= N) continue;              // whole column tile past N (uniform)
