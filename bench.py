@@ -12,7 +12,7 @@ words/frame, 40 QA words, 5 candidates, B=16 per GPU (weak scaling; --scaling st
 One step = forward + loss (main.py:55-60: CE_sum * len(qids)/len(targets) + 0.1 * att_loss + 0.5 * temporal_loss, the ratio
 taken over the GATHERED batch as the reference's DataParallel does) + backward + grad all-reduce (N>1) +
 clip_grad_norm_(10) + Adam step, i.e. everything main.py:53-66 does per batch.  Inputs are resident in HBM.
-Developer flags (not the headline line): --dense (all-ones masks), --heads 4, --gemm_terms 2, --no_sup_att, --h2d,
+Developer flags (not the headline line): --dense (all-ones masks), --heads 4, --no_sup_att, --h2d,
 --storage bf16 (the bf16 storage mode of BASELINE.json configs[4] at these shapes; `dtype` then says "bf16").
 """
 import argparse
@@ -42,8 +42,6 @@ def parse():
     ap.add_argument("--dense", action="store_true", help="all-ones masks instead of ragged lengths")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --bsz examples per GPU; strong: --bsz examples in total, sharded over the GPUs (SURVEY 8d)")
-    ap.add_argument("--gemm_terms", type=int, choices=(2, 3), default=3, help="bf16 terms per fp32 GEMM operand: 3 = exact split "
-                    "(default, fp32-faithful); 2 = hi + mid only (opt-in fast mode, products accurate to ~2^-17; DESIGN.md)")
     ap.add_argument("--heads", type=int, default=0, help="self-attention heads in both encoders (BASELINE config 3: 4)")
     ap.add_argument("--no_sup_att", action="store_true", help="drop the supervised attention loss term (round-1 workload)")
     ap.add_argument("--att_imgs", type=int, default=4, help="annotated frames per question (synthetic att_labels)")
@@ -192,8 +190,6 @@ def cpu_baseline(args, opt):
 
 def main():
     args = parse()
-    if args.gemm_terms == 2:
-        os.environ["STAGE_GEMM_TERMS"] = "2"       # read by tvqaplus_amd._lib at import
     from tvqaplus_amd import parallel
     from tvqaplus_amd.stage import STAGE
     from tvqaplus_amd.synth import make_batch, make_opt
@@ -280,8 +276,7 @@ def main():
                                       "all-ones" if args.dense else "ragged",
                                       "bf16 activations / bf16-rounded weights, fp32 statistics, softmax and accumulation"
                                       if args.storage == "bf16" else
-                                      ("fp32 via %s bf16-split MFMA GEMMs"
-                                       % ("exact 3-term" if args.gemm_terms == 3 else "2-term (hi+mid, ~2^-17 products)"))),
+                                      "fp32 via fp16-split MFMA GEMMs (error below an fp32 FMA chain)"),
                        "step": "fwd + loss (main.py:55-60) + bwd + grad all-reduce + clip_grad_norm_ + Adam",
                        "global_batch": n_global, "parallelism": "dp%d (example-sharded, flat 2.2MB grad "
                                                                   "all-reduce over RCCL)" % world,

@@ -153,11 +153,11 @@ def test_gemm_nt_gate_residual_c_abi(ops, M, N, K):
 
 @pytest.mark.parametrize("scale_x,scale_w", [(1e-30, 1.0), (1e-20, 1e-18), (1e18, 1e-18), (3e4, 3e4), (1.0, 1e-35)])
 def test_linear_dynamic_range(ops, scale_x, scale_w):
-    """The GEMMs compute fp32 products as an exact 3-way bf16 split (hi + mid + lo, six cross terms kept).  bf16 has fp32's
-    exponent range, but the residual terms sit 8 / 16 binades below the value: operands near the bottom of the fp32
-    range lose their mid / lo terms to flush-to-zero earlier than an fp32 FMA chain would.  Held to: tiny-but-normal and
-    huge operands reproduce torch's fp32 matmul to the usual tolerance relative to the result's scale; operands whose
-    products underflow fp32 entirely give (near-)zeros, never NaN / Inf."""
+    """The streaming GEMMs compute fp32 products as a two-way fp16 split (three products kept) on operands scaled by
+    powers of two into fp16's range -- one exponent per X row and one per weight tile (`csrc/gemm_stream.hip`); the tiled
+    fallback uses the 3-way bf16 split.  Held to: tiny-but-normal and huge operands reproduce an fp64 product to the usual
+    tolerance relative to the result's scale; operands whose products underflow fp32 entirely give (near-)zeros, never
+    NaN / Inf."""
     g = torch.Generator().manual_seed(11)
     M, N, K = 4200, 128, 384
     x = torch.randn(M, K, generator=g) * scale_x
@@ -175,30 +175,93 @@ def test_linear_dynamic_range(ops, scale_x, scale_w):
         assert err < tol, (err, tol)
 
 
-def test_two_term_gemm_library_accuracy():
-    """The opt-in fast GEMM mode (STAGE_GEMM_TERMS=2 -> libstage_hip_t2.so: hi + mid bf16 terms, three products instead of
-    six): same C ABI; against an fp64 product its error is ~1e-5 of the result's scale -- an order of magnitude above the
-    default library's (fp32-faithful, ~3e-7) and two below the 1e-3 parity bar.  Both loaded side by side."""
-    import ctypes
+def test_gemm_nt_scale_growth_inside_a_row():
+    """fp16-split NT GEMM: the row exponent is set by the first 32-k line and RAISED when a later line would leave fp16's
+    range (the wave's accumulators are rescaled).  Rows whose magnitude jumps by 1e3 .. 1e12 in the middle of the row, drops,
+    or starts at exactly zero must still match an fp64 product to fp32-class accuracy relative to the row's result."""
     from tvqaplus_amd import _lib
-    here = os.path.dirname(_lib.__file__)
-    fast = ctypes.CDLL(os.path.join(here, "libstage_hip_t2.so"))
-    exact = ctypes.CDLL(os.path.join(here, "libstage_hip.so"))
-    for lib in (fast, exact):
-        res, args = _lib.SIGNATURES["stage_gemm_nt"]
-        lib.stage_gemm_nt.restype, lib.stage_gemm_nt.argtypes = res, args
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(21)
+    st = torch.cuda.current_stream().cuda_stream
+    for (M, N, K) in ((8192, 128, 384), (4500, 200, 256), (4100, 128, 128)):
+        x = torch.randn(M, K, generator=g)
+        prof = torch.ones(M, K)
+        jump = 10.0 ** torch.randint(3, 13, (M,), generator=g).float()
+        at = torch.randint(1, K // 32, (M,), generator=g) * 32
+        cols = torch.arange(K)[None, :]
+        kind = torch.arange(M) % 4
+        prof = torch.where((kind == 0)[:, None] & (cols >= at[:, None]), jump[:, None], prof)          # jumps up at a line start
+        prof = torch.where((kind == 1)[:, None] & (cols >= at[:, None]), 1.0 / jump[:, None], prof)    # drops
+        prof = torch.where((kind == 2)[:, None] & (cols < at[:, None]), torch.zeros(()), prof)         # zero, then data
+        prof = torch.where((kind == 3)[:, None] & (cols == (at[:, None] + 5)), jump[:, None], prof)    # one huge element
+        x = x * prof * 1e-3
+        w = torch.randn(N, K, generator=g) * 0.05
+        xd, wd = x.cuda(), w.cuda()
+        y = torch.empty(M, N, device="cuda")
+        assert lib.stage_gemm_nt(xd.data_ptr(), None, wd.data_ptr(), None, None, y.data_ptr(), M, N, K, 0, st) == 0
+        ref = x.double() @ w.double().t()
+        scale = ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+        err = ((y.double().cpu() - ref).abs() / scale).max()
+        assert bool(torch.isfinite(y).all()) and float(err) < 3e-6, (M, N, K, float(err))
+
+
+@pytest.mark.parametrize("M,N,K", [(40000, 128, 128), (36000, 128, 384), (20000, 300, 768), (9000, 72, 200)])
+def test_gemm_tn_scale_growth_along_the_rows(M, N, K):
+    """fp16-split weight-gradient GEMM: the scale belongs to an operand COLUMN and follows the column's running maximum down
+    the slab; the tile's producer announces every change and the consumers rescale their accumulators.  Columns whose
+    magnitude grows by orders of magnitude along the rows (per column at a different row), in both operands, against fp64."""
+    from tvqaplus_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + K)
+    st = torch.cuda.current_stream().cuda_stream
+    rows = torch.arange(M)[:, None].float()
+
+    def ramp(C):
+        start = torch.randint(0, M, (1, C), generator=g).float()
+        decades = torch.randint(0, 9, (1, C), generator=g).float()
+        grow = 10.0 ** (decades * ((rows - start) / (0.1 * M)).clamp(0, 1))      # ramps up over 10 % of the rows
+        sign = torch.where(torch.arange(C)[None, :] % 3 == 0, -1.0, 1.0)          # every third column ramps DOWN instead
+        return torch.where(sign > 0, grow, 10.0 ** decades / grow) * 10.0 ** torch.randint(-6, 2, (1, C), generator=g).float()
+    dy = torch.randn(M, N, generator=g) * ramp(N)
+    x = torch.randn(M, K, generator=g) * ramp(K)
+    dyd, xd = dy.cuda(), x.cuda()
+    dw = torch.empty(N, K, device="cuda"); db = torch.empty(N, device="cuda")
+    wsb = lib.stage_gemm_tn_ws_bytes(M, N, K); ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device="cuda")
+    assert lib.stage_gemm_tn(dyd.data_ptr(), None, xd.data_ptr(), dw.data_ptr(), db.data_ptr(), M, N, K, ws.data_ptr(), wsb, st) == 0
+    ref = dy.double().t() @ x.double()
+    # error scale of an entry: the largest |dy| of its column times the largest |x| of its column, times sqrt(M)
+    scale = dy.abs().amax(dim=0).double()[:, None] * x.abs().amax(dim=0).double()[None, :] * (M ** 0.5)
+    err = ((dw.double().cpu() - ref).abs() / scale).max()
+    assert bool(torch.isfinite(dw).all()) and float(err) < 2e-6, float(err)
+    refb = dy.double().sum(dim=0)
+    assert float(((db.double().cpu() - refb).abs() / (dy.abs().amax(dim=0).double() * M ** 0.5)).max()) < 1e-5
+
+
+def test_gemm_accuracy_is_fp32_class():
+    """The fp16-split GEMMs against an fp64 product, next to torch's own fp32 matmul on the same operands: forward / dX
+    (stage_gemm_nt) and weight gradient (stage_gemm_tn) must not be less accurate than the fp32 library GEMM (factor 1.5
+    for the luck of one draw), and far inside the 1e-3 parity bar."""
+    from tvqaplus_amd import _lib
+    lib = _lib.load()
     g = torch.Generator().manual_seed(5)
     st = torch.cuda.current_stream().cuda_stream
-    for (M, N, K) in ((60000, 128, 384), (8192, 384, 128), (5000, 300, 768)):
+    for (M, N, K) in ((60000, 128, 384), (8192, 384, 128), (5000, 300, 768), (40000, 128, 128)):
         x = torch.randn(M, K, generator=g).cuda()
         w = (torch.randn(N, K, generator=g) * 0.1).cuda()
+        dy = torch.randn(M, N, generator=g).cuda()
         ref = x.double() @ w.double().t()
-        errs = []
-        for lib in (fast, exact):
-            y = torch.empty(M, N, device="cuda")
-            assert lib.stage_gemm_nt(x.data_ptr(), None, w.data_ptr(), None, None, y.data_ptr(), M, N, K, 0, st) == 0
-            errs.append(float((y.double() - ref).abs().max() / ref.abs().max()))
-        assert errs[1] < 2e-6 and errs[0] < 5e-5, (M, N, K, errs)
+        y = torch.empty(M, N, device="cuda")
+        assert lib.stage_gemm_nt(x.data_ptr(), None, w.data_ptr(), None, None, y.data_ptr(), M, N, K, 0, st) == 0
+        e_ours = float((y.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+        e_torch = float(((x @ w.t()).double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+        assert e_ours < 1.5 * e_torch and e_ours < 1e-6, ("nt", M, N, K, e_ours, e_torch)
+        refw = dy.double().t() @ x.double()
+        dw = torch.empty(N, K, device="cuda"); db = torch.empty(N, device="cuda")
+        wsb = lib.stage_gemm_tn_ws_bytes(M, N, K); ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device="cuda")
+        assert lib.stage_gemm_tn(dy.data_ptr(), None, x.data_ptr(), dw.data_ptr(), db.data_ptr(), M, N, K, ws.data_ptr(), wsb, st) == 0
+        e_ours = float((dw.double() - refw).pow(2).mean().sqrt() / refw.pow(2).mean().sqrt())
+        e_torch = float(((dy.t() @ x).double() - refw).pow(2).mean().sqrt() / refw.pow(2).mean().sqrt())
+        assert e_ours < 1.5 * e_torch and e_ours < 1e-6, ("tn", M, N, K, e_ours, e_torch)
 
 
 def test_linear_is_transpose_safe(ops):

@@ -10,10 +10,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_ulonglong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# STAGE_GEMM_TERMS=2: the opt-in fast GEMM mode (two bf16 terms per fp32 operand instead of the exact three; Makefile LIB2).
 # STAGE_HIP_LIB: experiment builds (tools/build_variant.sh).
-LIB_PATH = os.environ.get("STAGE_HIP_LIB") or os.path.join(
-    _HERE, "libstage_hip_t2.so" if os.environ.get("STAGE_GEMM_TERMS") == "2" else "libstage_hip.so")
+LIB_PATH = os.environ.get("STAGE_HIP_LIB") or os.path.join(_HERE, "libstage_hip.so")
 
 P = c_void_p  # every device pointer / stream travels as void*
 I, LL, F, U64, SZ = c_int, c_longlong, c_float, c_ulonglong, c_size_t

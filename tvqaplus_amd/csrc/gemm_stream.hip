@@ -100,6 +100,30 @@ __device__ __forceinline__ f32x16 h_mfma_terms(const sf16x8 (&a)[2], const sf16x
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc, 0, 0, 0);
     return acc;
 }
+// TN kernels (contraction over rows): the scale belongs to an operand COLUMN = a lane of the tile's producer.  Running
+// exponent of the column (both lane halves agree); returns the change of the scale's exponent field at this step (<= 0),
+// which the consumers of the tile apply to their accumulators before they use it.
+#ifndef STAGE_GEMM_TN_F16
+#define STAGE_GEMM_TN_F16 1
+#endif
+__device__ __forceinline__ int h_track8(const float (&v)[8], int& eb) {
+    const float m = xmax32(fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))),
+                                 fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7])))));
+    const int ec = (int)(__float_as_uint(m) >> 23) & 0xff;
+    const int neb = ec > eb + 3 ? ec : eb;
+    const int d = h_up_field(neb) - h_up_field(eb);
+    eb = neb;
+    return d;
+}
+__device__ __forceinline__ void h_split8(const float (&v)[8], int eb, uint4& hi, uint4& lo) {
+    const float sc = __uint_as_float((unsigned)h_up_field(eb) << 23);
+    h_split2(v[0], v[1], sc, hi.x, lo.x);
+    h_split2(v[2], v[3], sc, hi.y, lo.y);
+    h_split2(v[4], v[5], sc, hi.z, lo.z);
+    h_split2(v[6], v[7], sc, hi.w, lo.w);
+}
+__device__ __forceinline__ int h_row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }   // C/D row of register r
+
 __device__ __forceinline__ float s_absmax4(float m, float4 v) {
     return fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fabsf(v.z))), fabsf(v.w));
 }
@@ -789,6 +813,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_share_kernel(const float* __re
                                                                float* __restrict__ part_b, long M, int N, int K,
                                                                long rows_per_split) {
     __shared__ uint4 ex[2][4][6][64];                     // [buffer][wave][3 dY planes, 3 X planes][lane]  (48 KB)
+    __shared__ int exd[2][4][2][64];                      // fp16 mode: exponent change of the dY / X tile column at this step
+    int eby = 0, ebx = 0;                                 // fp16 mode: running exponents of the columns this lane prepares
+    int upA[2] = {254, 254}, upB[2] = {254, 254};         // and the scale fields in force for the tiles this wave consumes
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int pn = wave >> 1, pk = wave & 1;
@@ -855,6 +882,49 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_share_kernel(const float* __re
 #pragma unroll
             for (int r = 0; r < 8; r++) bsum += yv[r];
         }
+        if (STAGE_GEMM_TN_F16) {
+            const int dy_ = h_track8(yv, eby), dx_ = h_track8(xv, ebx);
+            uint4 yh, yl, xh, xl;
+            h_split8(yv, eby, yh, yl);
+            h_split8(xv, ebx, xh, xl);
+            ex[xb][wave][0][lane] = yh;
+            ex[xb][wave][1][lane] = yl;
+            ex[xb][wave][3][lane] = xh;
+            ex[xb][wave][4][lane] = xl;
+            exd[xb][wave][0][lane] = dy_;
+            exd[xb][wave][1][lane] = dx_;
+            __syncthreads();
+            sf16x8 a[2][2], b[2][2];
+            int dA[2], dB[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) {
+                    a[t][s2] = __builtin_bit_cast(sf16x8, ex[xb][pn * 2 + t][s2][lane]);
+                    b[t][s2] = __builtin_bit_cast(sf16x8, ex[xb][t * 2 + pk][3 + s2][lane]);
+                }
+                dA[t] = exd[xb][pn * 2 + t][0][lane];
+                dB[t] = exd[xb][t * 2 + pk][1][lane];
+            }
+            if (__any((dA[0] | dA[1] | dB[0] | dB[1]) != 0)) {   // a column's scale moved: bring the accumulators along
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int dr = __builtin_amdgcn_ds_bpermute(4 * h_row_of(r, h), dA[i]);
+#pragma unroll
+                        for (int j = 0; j < 2; j++) acc[i][j][r] = __builtin_ldexpf(acc[i][j][r], dr + dB[j]);
+                    }
+                    upA[i] += dA[i];
+                    upB[i] += dB[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = h_mfma_terms(a[i], b[j], acc[i][j]);
+            return;
+        }
         unsigned p[4][3], q[4][3];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -907,6 +977,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_share_kernel(const float* __re
                 step(1, m0 + 16, 1);
             }
         }
+    }
+    if (STAGE_GEMM_TN_F16) {                              // back to true units: 2^-(dY column scale + X column scale)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int ua = __builtin_amdgcn_ds_bpermute(4 * h_row_of(r, h), upA[i]);
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j][r] = __builtin_ldexpf(acc[i][j][r], 254 - ua - upB[j]);
+            }
     }
     // C/D layout of the 32x32 MFMA: col = lane & 31 (k), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (n)
     float* po = part + (size_t)split * N * K;
@@ -981,6 +1061,8 @@ __global__ __launch_bounds__(64 * TW_WAVES, 2) void gemm_tn_wide_kernel(const fl
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     float bsum = 0.f;
+    int ebu[2] = {0, 0};                                  // fp16 mode: running exponents of the two unit columns this lane prepares
+    int upA[2] = {254, 254}, upB[3] = {254, 254, 254};    // and the scale fields in force for the tiles this wave consumes
     float va[2][2][8], ga[GATE != 0 ? 2 : 1][8];          // [buffer][unit][row]
     auto fetch = [&](int buf, long m0) {
 #pragma unroll
@@ -1018,6 +1100,15 @@ __global__ __launch_bounds__(64 * TW_WAVES, 2) void gemm_tn_wide_kernel(const fl
 #pragma unroll
                 for (int r = 0; r < 8; r++) bsum += v[r];
             }
+            if (STAGE_GEMM_TN_F16) {   // planes 0 / 1 = hi / lo, the slot of plane 2 carries the exponent change of the column
+                const int du = h_track8(v, ebu[u]);
+                uint4 vh, vl;
+                h_split8(v, ebu[u], vh, vl);
+                exb[(u_mine[u] * 3 + 0) * 64 + lane] = vh;
+                exb[(u_mine[u] * 3 + 1) * 64 + lane] = vl;
+                reinterpret_cast<int*>(&exb[(u_mine[u] * 3 + 2) * 64])[lane] = du;
+                continue;
+            }
             unsigned p[4][3];
 #pragma unroll
             for (int i = 0; i < 4; i++) s_split3(v[2 * i], v[2 * i + 1], p[i]);
@@ -1025,6 +1116,41 @@ __global__ __launch_bounds__(64 * TW_WAVES, 2) void gemm_tn_wide_kernel(const fl
             for (int s = 0; s < STAGE_GEMM_TERMS; s++) exb[(u_mine[u] * 3 + s) * 64 + lane] = make_uint4(p[0][s], p[1][s], p[2][s], p[3][s]);
         }
         __syncthreads();
+        if (STAGE_GEMM_TN_F16) {
+            sf16x8 a[2][2];
+            int dA[2], dB[3];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) a[t][s2] = __builtin_bit_cast(sf16x8, exb[((pn * 2 + t) * 3 + s2) * 64 + lane]);
+                dA[t] = reinterpret_cast<const int*>(&exb[((pn * 2 + t) * 3 + 2) * 64])[lane];
+            }
+#pragma unroll
+            for (int j = 0; j < 3; j++) dB[j] = reinterpret_cast<const int*>(&exb[((TW_NA + pk * 3 + j) * 3 + 2) * 64])[lane];
+            if (__any((dA[0] | dA[1] | dB[0] | dB[1] | dB[2]) != 0)) {   // a column's scale moved: bring the accumulators along
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int dr = __builtin_amdgcn_ds_bpermute(4 * h_row_of(r, h), dA[i]);
+#pragma unroll
+                        for (int j = 0; j < 3; j++) acc[i][j][r] = __builtin_ldexpf(acc[i][j][r], dr + dB[j]);
+                    }
+                    upA[i] += dA[i];
+                }
+#pragma unroll
+                for (int j = 0; j < 3; j++) upB[j] += dB[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                sf16x8 b[2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) b[s2] = __builtin_bit_cast(sf16x8, exb[((TW_NA + pk * 3 + j) * 3 + s2) * 64 + lane]);
+#pragma unroll
+                for (int i = 0; i < 2; i++) acc[i][j] = h_mfma_terms(a[i], b, acc[i][j]);
+            }
+            return;
+        }
         sbf16x8 a[2][3];
 #pragma unroll
         for (int t = 0; t < 2; t++)
@@ -1054,6 +1180,16 @@ __global__ __launch_bounds__(64 * TW_WAVES, 2) void gemm_tn_wide_kernel(const fl
         }
     }
     // C/D layout of the 32x32 MFMA: col = lane & 31 (k), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (n)
+    if (STAGE_GEMM_TN_F16) {                              // back to true units: 2^-(dY column scale + X column scale)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int ua = __builtin_amdgcn_ds_bpermute(4 * h_row_of(r, h), upA[i]);
+#pragma unroll
+                for (int j = 0; j < 3; j++) acc[i][j][r] = __builtin_ldexpf(acc[i][j][r], 254 - ua - upB[j]);
+            }
+    }
     float* po = part + (size_t)split * N * K;
 #pragma unroll
     for (int i = 0; i < 2; i++)
