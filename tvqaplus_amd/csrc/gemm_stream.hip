@@ -16,7 +16,7 @@
 #include "../../include/stage_hip.h"
 
 #ifndef GEMM_ABL
-#define GEMM_ABL 0      // developer ablation bits (timing experiments only, results wrong): 1 one MFMA per column tile instead
+#define GEMM_ABL 0      // developer ablation bits (timing experiments only, results wrong; 64: no row-exponent tracking): 1 one MFMA per column tile instead
 #endif                  // of 6, 2 no bf16 split (raw bits as operands), 4 X lines fetched once per wave, 8 no stores,
                         // 16 weight fragments read from LDS for one of the four column tiles only; TN share kernel: 1, 2, 4 alike,
                         // 32 no barrier
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
                     vv[2 * up + 1] = v1;
                 }
                 float x_sc = 1.f;
-                if (STAGE_GEMM_NT_F16) {
+                if (STAGE_GEMM_NT_F16 && !(GEMM_ABL & 64)) {
                     // the row's exponent: largest magnitude of the line (both lane halves), raised only when a value would
                     // pass 2^15 after scaling; the first line of a tile sets it (the accumulators are zero)
                     const float m = xmax32(s_absmax4(s_absmax4(s_absmax4(s_absmax4(0.f, vv[0]), vv[1]), vv[2]), vv[3]));
@@ -412,18 +412,28 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
                     const int koff = 16 * (2 * L + up) + 8 * h;
                     if (STAGE_GEMM_NT_F16) {
                         unsigned ph[4], pl[4];
-                        h_split2(v0.x, v0.y, x_sc, ph[0], pl[0]);
-                        h_split2(v0.z, v0.w, x_sc, ph[1], pl[1]);
-                        h_split2(v1.x, v1.y, x_sc, ph[2], pl[2]);
-                        h_split2(v1.z, v1.w, x_sc, ph[3], pl[3]);
                         sf16x8 a[2], b[2];
-                        a[0] = __builtin_bit_cast(sf16x8, make_uint4(ph[0], ph[1], ph[2], ph[3]));
-                        a[1] = __builtin_bit_cast(sf16x8, make_uint4(pl[0], pl[1], pl[2], pl[3]));
+                        if (GEMM_ABL & 2) {
+                            a[0] = __builtin_bit_cast(sf16x8, v0);
+                            a[1] = __builtin_bit_cast(sf16x8, v1);
+                        } else {
+                            h_split2(v0.x, v0.y, x_sc, ph[0], pl[0]);
+                            h_split2(v0.z, v0.w, x_sc, ph[1], pl[1]);
+                            h_split2(v1.x, v1.y, x_sc, ph[2], pl[2]);
+                            h_split2(v1.z, v1.w, x_sc, ph[3], pl[3]);
+                            a[0] = __builtin_bit_cast(sf16x8, make_uint4(ph[0], ph[1], ph[2], ph[3]));
+                            a[1] = __builtin_bit_cast(sf16x8, make_uint4(pl[0], pl[1], pl[2], pl[3]));
+                        }
 #pragma unroll
                         for (int nt = 0; nt < 4; nt++) {
 #pragma unroll
                             for (int s2 = 0; s2 < 2; s2++)
-                                b[s2] = __builtin_bit_cast(sf16x8, *reinterpret_cast<const uint4*>(&Wp[s2 * SPLANE + (nt * 32 + l31) * SWS + koff]));
+                                if (!(GEMM_ABL & 16) || nt == 0)
+                                    b[s2] = __builtin_bit_cast(sf16x8, *reinterpret_cast<const uint4*>(&Wp[s2 * SPLANE + (nt * 32 + l31) * SWS + koff]));
+                            if (GEMM_ABL & 1) {
+                                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0] + a[1], b[0] + b[1], acc[nt], 0, 0, 0);
+                                continue;
+                            }
                             acc[nt] = h_mfma_terms(a, b, acc[nt]);
                         }
                         continue;
@@ -1024,7 +1034,7 @@ __global__ __launch_bounds__(64 * TW_WAVES, 2) void gemm_tn_wide_kernel(const fl
                                                                         float* __restrict__ part_b, long M, int N, int K,
                                                                         long rows_per_split) {
     extern __shared__ __attribute__((aligned(16))) uint4 exw[];   // [2 buffers][16 units][3 planes][64 lanes]  (96 KB)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // SGPR: no waterfall loops
     const int l31 = lane & 31, h = lane >> 5;
     const int pn = wave >> 2, pk = wave & 3;
     const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 384;
@@ -1064,7 +1074,10 @@ __global__ __launch_bounds__(64 * TW_WAVES, 2) void gemm_tn_wide_kernel(const fl
     int ebu[2] = {0, 0};                                  // fp16 mode: running exponents of the two unit columns this lane prepares
     int upA[2] = {254, 254}, upB[3] = {254, 254, 254};    // and the scale fields in force for the tiles this wave consumes
     float va[2][2][8], ga[GATE != 0 ? 2 : 1][8];          // [buffer][unit][row]
+    bool abl_fw[2] = {false, false};
     auto fetch = [&](int buf, long m0) {
+        if ((GEMM_ABL & 4) && abl_fw[buf]) return;
+        abl_fw[buf] = true;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int sy = (int)((m0 + r) * N * 4), sx = (int)((m0 + r) * K * 4);   // wave-uniform row offsets (bytes)
@@ -1209,6 +1222,201 @@ __global__ __launch_bounds__(64 * TW_WAVES, 2) void gemm_tn_wide_kernel(const fl
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// "Quad" variant of the wide kernel (K > 128, N % 4 == 0, K % 4 == 0, no fp32 gate): the same 128 x 384 output tile and
+// 2 x 4 consumer waves, but the operands are fetched with 16-byte loads along the ROWS.  The dword-per-row loads of the
+// kernels above cost 40 % of their run time (ablation: 697 -> 416 us at 960000 x 128^T x 384 with the operand loads
+// removed).  What makes row-wise loads possible without a transpose: the output index of a GEMM may be permuted freely, so
+// the four MFMA tiles of a 128-column group ("quad") are INTERLEAVED -- tile t holds the columns 4 l + t (l = lane position
+// 0..31).  A lane that loads the float4 at columns 4l..4l+3 of eight rows then holds one 8-row operand fragment for each of
+// the four tiles, at its own lane position.  Work split of a 32-row double step (two 16-row MFMA steps, ONE barrier): wave w
+// prepares quad w >> 1 (0 = dY, 1..3 = X) for the column groups l = 16 (w & 1) + (lane & 15); its lane group g = lane >> 4
+// takes MFMA step g >> 1, row half g & 1 -- eight dwordx4 loads per lane and double step instead of 32 dword loads, every
+// load instruction four rows x 256 contiguous bytes.  One scale exponent per COLUMN, tracked by the producer as in the
+// kernels above (a shared exponent for the four columns of a lane would save 30 VALU instructions per double step, but a
+// weak column next to a strong one would lose its relative accuracy -- and Adam normalises every weight's gradient).
+// ---------------------------------------------------------------------------------------------------------------------
+#define TQ_TILES 16     // operand tiles per workgroup: 4 of dY (one quad), 12 of X (three quads)
+template <int GATE>     // 0 none, 2 bit mask
+__global__ __launch_bounds__(64 * TW_WAVES, 2) void gemm_tn_quad_kernel(const float* __restrict__ dY, const unsigned* __restrict__ G,
+                                                                        const float* __restrict__ X, float* __restrict__ part,
+                                                                        float* __restrict__ part_b, long M, int N, int K,
+                                                                        long rows_per_split) {
+    // [2 buffers][2 MFMA steps][16 tiles][2 planes][64 lanes] uint4 (128 KB), then [2 buffers][16 tiles][32] exponent changes
+    extern __shared__ __attribute__((aligned(16))) uint4 exq[];
+    int* exd = reinterpret_cast<int*>(exq + 2 * 2 * TQ_TILES * 2 * 64);
+    // the wave index decides descriptor and leading dimension of the loads: as an SGPR value (the compiler cannot prove
+    // threadIdx.x >> 6 uniform and would wrap every buffer load into a waterfall loop)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int pn = wave >> 2, pk = wave & 3;              // consumer role: rows pn (2 dY tiles), columns pk (3 X tiles)
+    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 384;
+    const int split = blockIdx.z;
+    const long mbeg = (long)split * rows_per_split;
+    const long mend = min(M, mbeg + rows_per_split);
+    const int NWN = (N + 31) >> 5;                        // mask words per row
+    // producer role
+    const int q = wave >> 1;                              // quad: 0 = dY, 1..3 = X
+    const bool is_y = q == 0;                             // wave-uniform
+    const int pl = 16 * (wave & 1) + (lane & 15);         // column group (lane position of the fragments it writes)
+    const int pg = lane >> 4, ps = pg >> 1, ph = pg & 1;  // MFMA step and row half of its eight rows
+    const int ld = is_y ? N : K;
+    const int col = is_y ? n0 + 4 * pl : k0 + 128 * (q - 1) + 4 * pl;
+    const bool col_ok = col < ld;                         // N, K are multiples of 4: a group is inside or outside as a whole
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(is_y ? dY : X), 0, (int)(M * ld * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(GATE == 2 ? (const void*)G : (const void*)dY), 0,
+                                                                        GATE == 2 ? (int)(M * NWN * 4) : (int)(M * N * 4), 0x00020000);
+    const int voff = ((16 * ps + 8 * ph) * ld + (col_ok ? col : ld - 4)) * 4;
+    const int gcol = min(n0 + 4 * pl, N - 4);
+    const int gbit = gcol & 31;                           // bits gbit .. gbit + 3 of the mask word belong to this group
+    const int moff = (int)(((long)(gcol >> 5) * M + 16 * ps + 8 * ph) * 4);   // [word][row] mask
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    int eb[4] = {0, 0, 0, 0};                             // running exponents of the four columns this lane prepares
+    int upA[2] = {254, 254}, upB[3] = {254, 254, 254};    // scale fields in force for the tiles this wave consumes
+    const bool want_b = part_b != nullptr && blockIdx.y == 0 && is_y;
+
+    typedef unsigned tq_u4 __attribute__((ext_vector_type(4)));
+    tq_u4 va[8];
+    tq_u4 gw[2];                                          // GATE 2: the mask words of the lane's 8 rows ([word][row]: contiguous)
+    auto fetch = [&](long m0) {
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+            va[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (int)((m0 + r) * ld * 4), 0);   // rows past the end read 0
+        if (GATE == 2) {
+            // 16-byte alignment of the word row needs (word * M + m0 + 8 * ...) % 4 == 0: the host checks M % 4 == 0 and
+            // slabs start at multiples of 16
+            gw[0] = __builtin_amdgcn_raw_buffer_load_b128(rg, moff, (int)(m0 * 4), 0);
+            gw[1] = __builtin_amdgcn_raw_buffer_load_b128(rg, moff, (int)((m0 + 4) * 4), 0);
+        }
+    };
+    auto produce = [&](long m0, int xb) {
+        const bool full = m0 + 32 <= mend;
+        float v[4][8];                                    // [tile][row]
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const bool rok = (full || (m0 + 16 * ps + 8 * ph + r < mend)) && col_ok;   // rows of the next slab contribute 0
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                float y = __uint_as_float(va[r][t]);
+                if (GATE == 2 && is_y) y = ((gw[r >> 2][r & 3] >> (gbit + t)) & 1u) ? y : 0.f;
+                v[t][r] = rok ? y : 0.f;
+            }
+        }
+        if (want_b) {
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int r = 0; r < 8; r++) bsum[t] += v[t][r];
+        }
+        // per column: largest magnitude of the lane's 8 rows, then of the four lanes (lane groups g = 0..3) that hold the
+        // column's 32 rows
+        uint4* exb = exq + (size_t)((xb * 2 + ps) * TQ_TILES + 4 * q) * 2 * 64 + (ph * 32 + pl);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            float m = fmaxf(fmaxf(fmaxf(fabsf(v[t][0]), fabsf(v[t][1])), fmaxf(fabsf(v[t][2]), fabsf(v[t][3]))),
+                            fmaxf(fmaxf(fabsf(v[t][4]), fabsf(v[t][5])), fmaxf(fabsf(v[t][6]), fabsf(v[t][7]))));
+            m = xmax32(xmax16(m));
+            const int ec = (int)(__float_as_uint(m) >> 23) & 0xff;
+            const int neb = ec > eb[t] + 3 ? ec : eb[t];
+            const int d = h_up_field(neb) - h_up_field(eb[t]);
+            eb[t] = neb;
+            uint4 vh, vl;
+            h_split8(v[t], neb, vh, vl);
+            exb[(t * 2 + 0) * 64] = vh;
+            exb[(t * 2 + 1) * 64] = vl;
+            if (pg == 0) exd[(xb * TQ_TILES + 4 * q + t) * 32 + pl] = d;
+        }
+    };
+    auto consume = [&](int xb) {
+        int dA[2], dB[3];
+#pragma unroll
+        for (int i = 0; i < 2; i++) dA[i] = exd[(xb * TQ_TILES + pn * 2 + i) * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < 3; j++) dB[j] = exd[(xb * TQ_TILES + 4 + pk * 3 + j) * 32 + l31];
+        if (__any((dA[0] | dA[1] | dB[0] | dB[1] | dB[2]) != 0)) {   // a column's scale moved: bring the accumulators along
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int dr = __builtin_amdgcn_ds_bpermute(4 * h_row_of(r, h), dA[i]);
+#pragma unroll
+                    for (int j = 0; j < 3; j++) acc[i][j][r] = __builtin_ldexpf(acc[i][j][r], dr + dB[j]);
+                }
+                upA[i] += dA[i];
+            }
+#pragma unroll
+            for (int j = 0; j < 3; j++) upB[j] += dB[j];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            const uint4* exb = exq + (size_t)((xb * 2 + s2) * TQ_TILES) * 2 * 64 + lane;
+            sf16x8 a[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int p2 = 0; p2 < 2; p2++) a[i][p2] = __builtin_bit_cast(sf16x8, exb[((pn * 2 + i) * 2 + p2) * 64]);
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                sf16x8 b[2];
+#pragma unroll
+                for (int p2 = 0; p2 < 2; p2++) b[p2] = __builtin_bit_cast(sf16x8, exb[((4 + pk * 3 + j) * 2 + p2) * 64]);
+#pragma unroll
+                for (int i = 0; i < 2; i++) acc[i][j] = h_mfma_terms(a[i], b, acc[i][j]);
+            }
+        }
+    };
+    if (mbeg < mend) {   // workgroup-uniform bounds: the barriers match
+        fetch(mbeg);
+        int xb = 0;
+        for (long m0 = mbeg; m0 < mend; m0 += 32, xb ^= 1) {
+            produce(m0, xb);
+            // the raw values are dead: the next double step loads behind the MFMAs (requesting it before the split instead --
+            // both register sets live -- measured the same: 573 vs 573 us)
+            if (m0 + 32 < mend && !((GEMM_ABL & 4) && m0 > mbeg)) fetch(m0 + 32);
+            __syncthreads();
+            consume(xb);
+        }
+    }
+    // C/D layout of the 32x32 MFMA: col = lane & 31 -> k group, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> n group
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int ua = __builtin_amdgcn_ds_bpermute(4 * h_row_of(r, h), upA[i]);
+#pragma unroll
+            for (int j = 0; j < 3; j++) acc[i][j][r] = __builtin_ldexpf(acc[i][j][r], 254 - ua - upB[j]);
+        }
+    float* po = part + (size_t)split * N * K;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int idx = pk * 3 + j;
+            const int k = k0 + 128 * (idx >> 2) + 4 * l31 + (idx & 3);
+            if (k >= K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int n = n0 + 4 * h_row_of(r, h) + pn * 2 + i;
+                if (n < N) po[(size_t)n * K + k] = acc[i][j][r];
+            }
+        }
+    if (want_b) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const float sb = xsum32(bsum[t], bsum[t]);
+            const float sb2 = xsum16(sb, sb);
+            if (pg == 0 && col_ok) part_b[(size_t)split * N + col + t] = sb2;
+        }
+    }
+}
+
 // same slab rule / workspace layout as stage_gemm_tn (gemm.hip); returns 1 if not handled here
 int stage_gemm_tn_stream(const float* dY, const void* gate, int gate_kind, const float* X, float* part, float* part_b,
                          long long M, int N, int K, int* S_io, long* rows_per_split_io, void* stream) {
@@ -1235,8 +1443,28 @@ int stage_gemm_tn_stream(const float* dY, const void* gate, int gate_kind, const
         rows_per_split = rps;
         *S_io = S;
         *rows_per_split_io = rps;
-        const int lds = 2 * (TW_NA + TW_NB) * 3 * 64 * (int)sizeof(uint4);
         dim3 gridw((N + 127) / 128, (K + 383) / 384, S);
+        static const bool no_quad = getenv("STAGE_GEMM_TN_NOQUAD") != nullptr;
+        if (STAGE_GEMM_TN_F16 && !no_quad && gate_kind != 1 && N % 4 == 0 && K % 4 == 0 && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0 &&
+            (gate_kind != 2 || (M % 4 == 0 && ((uintptr_t)gate & 15) == 0 && rows_per_split % 16 == 0))) {
+            const int ldsq = 2 * 2 * TQ_TILES * 2 * 64 * (int)sizeof(uint4) + 2 * TQ_TILES * 32 * (int)sizeof(int);
+#define LAUNCH_TNQ(GT)                                                                                                 \
+    do {                                                                                                               \
+        static bool attr_done = false;                                                                                 \
+        if (!attr_done) {                                                                                              \
+            (void)hipFuncSetAttribute((const void*)gemm_tn_quad_kernel<GT>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsq); \
+            attr_done = true;                                                                                          \
+        }                                                                                                              \
+        hipLaunchKernelGGL(gemm_tn_quad_kernel<GT>, gridw, dim3(64 * TW_WAVES), ldsq, (hipStream_t)stream, dY,         \
+                           (const unsigned*)gate, X, part, part_b, (long)M, N, K, rows_per_split);                     \
+    } while (0)
+            if (gate_kind == 2) LAUNCH_TNQ(2);
+            else LAUNCH_TNQ(0);
+#undef LAUNCH_TNQ
+            STAGE_LAUNCH_CHECK();
+            return 0;
+        }
+        const int lds = 2 * (TW_NA + TW_NB) * 3 * 64 * (int)sizeof(uint4);
 #define LAUNCH_TNW(GT)                                                                                                 \
     do {                                                                                                               \
         static bool attr_done = false;                                                                                 \
