@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round profile set -> gpurun_out/${TAG}_*: bench line, kernel trace of the bench command, PMC passes of the K1 forward (video and
-# subtitle shapes) and of the fused K1 backward.  bash tools/round_profile.sh r02
+# subtitle shapes), of the fused K1 backward and of the 960000 x 384 -> 128 GEMMs (forward, weight gradient).  bash tools/round_profile.sh r02
 TAG=${1:-r02}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -11,6 +11,8 @@ bash tools/trace_bench.sh ${TAG}_bench > /dev/null 2>&1
 bash tools/pmc_run.sh ${TAG}_k1_fwd str_attn_fwd python bench.py --only_roofline > /dev/null 2>&1
 bash tools/pmc_run.sh ${TAG}_k1_bwd_vid str_attn_bwd_fused python tools/k1_bwd_times.py > /dev/null 2>&1
 LR=50 bash tools/pmc_run.sh ${TAG}_k1_bwd_sub str_attn_bwd_fused python tools/k1_bwd_times.py > /dev/null 2>&1
+bash tools/pmc_run.sh ${TAG}_gemm_nt gemm_nt_stream python tools/gemm_one.py 960000 128 384 nt > /dev/null 2>&1
+bash tools/pmc_run.sh ${TAG}_gemm_tn gemm_tn_quad python tools/gemm_one.py 960000 128 384 tn > /dev/null 2>&1
 python tools/k1_bwd_times.py > gpurun_out/${TAG}_k1_bwd_times_vid.txt 2>&1
 LR=50 python tools/k1_bwd_times.py > gpurun_out/${TAG}_k1_bwd_times_sub.txt 2>&1
 ls gpurun_out | grep ${TAG}
