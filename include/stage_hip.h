@@ -131,7 +131,10 @@ int stage_ln_dwconv_bwd(const float* dh, const float* xin, const float* mean, co
                         float* dw, float* db, long long M, int L, int D, int k, float p_drop, unsigned long long seed,
                         void* ws, size_t ws_bytes, void* stream);
 
-/* ---- nn.Linear / 1x1 Conv1d on the matrix cores (fp32 in, fp32 accumulate, exact f32 MFMA) --------------------
+/* ---- nn.Linear / 1x1 Conv1d on the matrix cores (fp32 in, fp32 out, fp32 accumulate) -----------------------------
+ * Arithmetic: fp32-faithful products -- a two-way fp16 split with exact power-of-two scaling in the streaming kernels
+ * (M >= 4096; error below an fp32 FMA chain's, DESIGN.md finding 20), the exact 3-way bf16 split / the f32 MFMA in the
+ * tiled fallbacks.
  * Y[M,N] = epi((X .* [gate>0])[M,K] . W[N,K]^T + bias) ; epi: optional ReLU then optional + residual[M,N].
  * (model/stage.py:88,101,110,117,136; LinearWrapper :23; model/cnn.py:27-28,44-46; model/self_attention.py:32,46,54)
  * `gate` (M,K) fuses a ReLU backward on the input operand (dX = (dY .* [Y>0]) . W with W passed transposed).       */

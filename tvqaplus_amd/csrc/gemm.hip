@@ -148,9 +148,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
         }
 }
 
-// Forward-form GEMMs (NT) default to the split-bf16 kernel with the exact 3-way split (gemm_bf16x3.hip: fp32-level
-// accuracy, ~15-25 % faster than the f32 MFMA at these shapes); the weight-gradient form (TN) stays on the f32 MFMA,
-// where the transposing split staging costs more than it saves.  STAGE_GEMM_F32=1 forces f32 everywhere,
+// Shapes the streaming kernels (gemm_stream.hip: two-way fp16 split) do not take: forward-form GEMMs (NT) default to the
+// tiled split-bf16 kernel with the exact 3-way split (gemm_bf16x3.hip: fp32-level accuracy, ~15-25 % faster than the f32 MFMA
+// at these shapes); the weight-gradient form (TN) stays on the f32 MFMA, where the transposing split staging costs more than it saves.  STAGE_GEMM_F32=1 forces f32 everywhere,
 // STAGE_GEMM_SPLIT_TN=1 also routes TN through the split kernel.
 extern "C" int stage_gemm_nt_bf16x3(const float* X, const float* gate, const float* W, const float* bias,
                                     const float* residual, float* Y, long long M, int N, int K, int relu, void* stream);

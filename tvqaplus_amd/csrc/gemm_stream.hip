@@ -1,8 +1,9 @@
 // Streaming NT GEMM for the tall-skinny Linear / 1x1-conv shapes of the STAGE path (M ~ 1e5..1e6 rows, N, K ~ 128..768):
 //     Y[M,N] = epi( (X (*) gate)[M,K] . W[N,K]^T + bias )           same contract as stage_gemm_nt (gemm.hip)
-// fp32 accuracy through the exact 3-way bf16 split (see gemm_bf16x3.hip), but organised for HBM streaming:
-//   * the weight tile (128 output columns x 128 k) is split ONCE per workgroup into its three bf16 planes and stays in
-//     LDS (102 KB); for K <= 128 it is never reloaded while the workgroup walks its row tiles;
+// fp32 accuracy through a two-way fp16 split with power-of-two scaling (below: STAGE_GEMM_NT_F16; the 3-way bf16 split of
+// gemm_bf16x3.hip is the other compile-time option), organised for HBM streaming:
+//   * the weight tile (128 output columns x 128 k) is split ONCE per workgroup into its two fp16 planes and stays in
+//     LDS (70 KB); for K <= 128 it is never reloaded while the workgroup walks its row tiles;
 //   * the X operand never touches LDS: every wave owns 32-row tiles and loads them straight from HBM in MFMA operand
 //     layout (lane = (row, k-half), 16 B per lane).  The MFMA contraction order is free as long as both operands agree,
 //     so k is permuted inside every 16-group such that a lane's two float4 loads (k = 8c + 4h + 0..3, c = 0,1) form its
