@@ -732,6 +732,34 @@ def test_k1_bf16_storage_vs_fp32_oracle(ops, N, Li, Lr, Lqa, D):
     check("dQ", Qd.grad.float().view_as(Q), Qc.grad, 4e-2)
 
 
+def test_k1_forward_fp16_split_scores_any_context_scale():
+    """Stage 1 of the register-resident forward (Lr <= 32, D = 128) runs as a two-way fp16 split with one power-of-two scale per
+    CONTEXT row; the region rows are normalised inside the kernel.  Context rows of wildly different magnitude (1e-6 .. 1e4,
+    nothing normalised them), a zero row and a row with one dominant element: raw scores against fp64 to fp32-class accuracy
+    relative to |context row| (a cosine-like score is bounded by it)."""
+    from tvqaplus_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(77)
+    N, NA, Li, Lqa, D = 2, 5, 7, 40, 128
+    for Lr in (20, 16, 32, 9):
+        Cn = torch.randn(N, NA, Lqa, D, generator=g) * 10.0 ** (torch.rand(N, NA, Lqa, 1, generator=g) * 10 - 6)
+        Cn[0, 0, 3] = 0.0
+        Cn[1, 2, 5, 17] = 3e6
+        Q = torch.randn(N, Li, Lr, D, generator=g) * 3.0
+        cm = torch.ones(N, NA, Lqa); qm = torch.ones(N, Li, Lr)
+        dev = "cuda"
+        Cd, Qd, cmd, qmd = Cn.to(dev), Q.to(dev), cm.to(dev), qm.to(dev)
+        A = torch.empty(N, NA, Li, Lqa, D, device=dev); S = torch.empty(N, NA, Li, Lqa, Lr, device=dev); Sn = torch.empty_like(S)
+        st = torch.cuda.current_stream().cuda_stream
+        assert lib.stage_str_attn_fwd(Cd.data_ptr(), Qd.data_ptr(), cmd.data_ptr(), qmd.data_ptr(), A.data_ptr(), S.data_ptr(),
+                                      Sn.data_ptr(), N, NA, Li, Lqa, Lr, D, 10.0, 0.0, 0, st) == 0
+        Qn = torch.nn.functional.normalize(Q.double(), dim=-1)
+        ref = torch.einsum("nawd,nird->naiwr", Cn.double(), Qn)
+        rown = Cn.double().norm(dim=-1)[:, :, None, :, None].clamp_min(1e-30)
+        err = ((S.double().cpu() - ref).abs() / rown).max()
+        assert bool(torch.isfinite(S).all()) and float(err) < 2e-6, (Lr, float(err))
+
+
 def test_cpp_host_runs_the_c_abi(ops, tmp_path):
     """examples/k1_forward_host.cpp (C++ + HIP runtime, no torch) built here and run: its output sums equal the Python
     binding's on the same deterministic inputs."""

@@ -216,6 +216,30 @@ __device__ __forceinline__ float ldv1(const float* p) { return *p; }
 __device__ __forceinline__ float ldv1(const stage_bf16* p) { return __uint_as_float((unsigned)p->bits << 16); }
 __device__ __forceinline__ void stv1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stv1(stage_bf16* p, float v) { p->bits = (unsigned short)(stage_pk_bf16(v, 0.f) & 0xFFFFu); }
+// ---- two-way fp16 split of fp32 operands for v_mfma_f32_*_f16 (gemm_stream.hip, str_attn_fwd_reg.hip; DESIGN.md finding 20) ----
+typedef _Float16 sf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned h_cvt_pk(float lo, float hi) {     // round to nearest even, lo in the low half
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float h_lo_f32(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p & 0xFFFFu)); }
+__device__ __forceinline__ float h_hi_f32(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16)); }
+// (a, b) * sc -> packed fp16 pairs hi, lo with a * sc == hi + lo up to 2^-22 (sc a power of two)
+__device__ __forceinline__ void h_split2(float a, float b, float sc, unsigned& hi, unsigned& lo) {
+    const float as = a * sc, bs = b * sc;
+    hi = h_cvt_pk(as, bs);
+    lo = h_cvt_pk(as - h_lo_f32(hi), bs - h_hi_f32(hi));
+}
+// biased fp32 exponent of a magnitude -> the exponent field of the power of two that maps it into [2^11, 2^12)
+__device__ __forceinline__ int h_up_field(int eb) { return min(265 - eb, 254); }
+// max(|a|, |b|, |c|) in ONE instruction (the compiler builds |x| as max(|x|, |x|) and then a tree of two-input maxima: 17
+// instructions for 8 values instead of 4)
+__device__ __forceinline__ float h_amax3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }

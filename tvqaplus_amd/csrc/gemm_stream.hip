@@ -79,22 +79,6 @@ __device__ __forceinline__ f32x16 s_mfma_terms(const sbf16x8 (&a)[3], const sbf1
 #ifndef STAGE_GEMM_NT_F16
 #define STAGE_GEMM_NT_F16 1
 #endif
-typedef _Float16 sf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ unsigned h_cvt_pk(float lo, float hi) {     // round to nearest even, lo in the low half
-    unsigned r;
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-__device__ __forceinline__ float h_lo_f32(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p & 0xFFFFu)); }
-__device__ __forceinline__ float h_hi_f32(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16)); }
-// (a, b) * sc -> packed fp16 pairs hi, lo with a * sc == hi + lo up to 2^-22 (sc a power of two)
-__device__ __forceinline__ void h_split2(float a, float b, float sc, unsigned& hi, unsigned& lo) {
-    const float as = a * sc, bs = b * sc;
-    hi = h_cvt_pk(as, bs);
-    lo = h_cvt_pk(as - h_lo_f32(hi), bs - h_hi_f32(hi));
-}
-// biased fp32 exponent of a magnitude -> the exponent field of the power of two that maps it into [2^11, 2^12)
-__device__ __forceinline__ int h_up_field(int eb) { return min(265 - eb, 254); }
 __device__ __forceinline__ f32x16 h_mfma_terms(const sf16x8 (&a)[2], const sf16x8 (&b)[2], f32x16 acc) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], acc, 0, 0, 0);
@@ -107,13 +91,6 @@ __device__ __forceinline__ f32x16 h_mfma_terms(const sf16x8 (&a)[2], const sf16x
 #ifndef STAGE_GEMM_TN_F16
 #define STAGE_GEMM_TN_F16 1
 #endif
-// max(|a|, |b|, |c|) in ONE instruction (the compiler builds |x| as max(|x|, |x|) and then a tree of two-input maxima: 17
-// instructions for 8 values instead of 4)
-__device__ __forceinline__ float h_amax3(float a, float b, float c) {
-    float d;
-    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
 __device__ __forceinline__ float h_amax8(const float (&v)[8]) {
     return h_amax3(h_amax3(h_amax3(h_amax3(v[0], v[1], v[2]), v[3], v[4]), v[5], v[6]), v[7], v[7]);
 }

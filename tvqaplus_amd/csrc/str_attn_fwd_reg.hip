@@ -18,6 +18,7 @@
 //   stage 2  A tile (ctx x d) = S_ . Q -> lane owns 4 consecutive d of context rows 4g+reg: 16-B stores, 256 B per row.
 // Region permutation of the LAST region tile (PERM/KL) as in str_attn_fwd.hip: tile row 4g+k holds region base + g + 4k.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "../../include/stage_hip.h"
 
@@ -33,6 +34,9 @@
 #endif
 __device__ __forceinline__ void st4_out(float* p, float4 v) { ST4_OUT(p, v); }
 __device__ __forceinline__ void st4_out(stage_bf16* p, float4 v) { stv4(p, v); }   // bf16 storage: 8 bytes per lane, 128 per row half
+#ifndef K1_F16
+#define K1_F16 1        // fp32 storage: the full 16-region tiles of stage 1 run as a two-way fp16 split on v_mfma_f32_16x16x32_f16
+#endif                  // (3 instructions of 16 cycles per 32 d instead of 8 of 32 cycles; common.h, DESIGN.md findings 20, 23)
 #define RD 128          // row width (floats)
 #define RNCH 8          // 4-float chunks per lane group
 
@@ -50,6 +54,11 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
     // context rows 4 (c15 >> 2) .. +3 over the k values lane group g holds; the 4 partial sums per score are folded by a
     // 3-instruction transpose-reduce (v_permlane16_swap / v_permlane32_swap) that leaves lane (c15, g) with region base + g of context row c15 -- the PERM layout.
     constexpr bool T4 = PERM && KL == 1;
+    constexpr int RF = T4 ? RT - 1 : RT;              // full 16-region tiles of stage 1
+    // Stage 1 of the full tiles on fp16 pairs: both operands are bounded (the region rows are normalised here: |x| <= 1/keep;
+    // the context rows get one power-of-two scale per row from their largest magnitude), the contraction index of a
+    // 32-wide MFMA step j is d = 16 (2j + c) + 4 g + e (c = 0, 1: the two float4 a lane already holds) for BOTH operands.
+    constexpr bool F16S1 = K1_F16 && RF > 0 && std::is_same<TQ, float>::value && !(K1_ABL & 8);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int c15 = lane & 15, g = lane >> 4;
     const int CR = NA * Lqa, CT = (CR + 15) >> 4;
@@ -186,6 +195,23 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
             }
         }
 
+        // fp16 pairs of the normalised region rows (scale 2^qexp: the largest magnitude 1/keep lands below 2^12)
+        const int qexp = 11 - (int)((__float_as_uint(inv_keep) >> 23) & 0xff) + 126;   // 11 - ceil(log2(1/keep)) (1/keep = 1: 10)
+        unsigned qh[F16S1 ? RF : 1][4][4], ql[F16S1 ? RF : 1][4][4];
+        if (F16S1) {
+            const float qsc = __uint_as_float((unsigned)(127 + qexp) << 23);
+#pragma unroll
+            for (int rt = 0; rt < RF; rt++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float4 u = qa[rt][2 * j], w = qa[rt][2 * j + 1];
+                    h_split2(u.x, u.y, qsc, qh[rt][j][0], ql[rt][j][0]);
+                    h_split2(u.z, u.w, qsc, qh[rt][j][1], ql[rt][j][1]);
+                    h_split2(w.x, w.y, qsc, qh[rt][j][2], ql[rt][j][2]);
+                    h_split2(w.z, w.w, qsc, qh[rt][j][3], ql[rt][j][3]);
+                }
+        }
+
         // ---- Cn fragments + context mask of a tile: untracked loads, counted waits ----
         f32x4 cf[RNCH];
         float cmv;
@@ -214,7 +240,6 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
         WAIT_CF(0);
         for (int t = tile0; t < ((K1_ABL & 64) ? tile0 + 1 : tile1); t++) {
             // ---- stage 1 ----
-            constexpr int RF = T4 ? RT - 1 : RT;        // full 16-region tiles
             f32x4 acc[RT];
 #pragma unroll
             for (int rt = 0; rt < RF; rt++) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -230,7 +255,47 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
         _Pragma("unroll") for (int rt = 0; rt < RF; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[rt][m].w, cf[m][3], acc[rt], 0, 0, 0); \
         if (TAIL) tl = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[RT - 1][m].w, cf[m][3], tl, 0, 0, 0);                    \
     }
-            if (T4 && tail_any) { S1_BODY(true) } else { S1_BODY(false) }   // one uniform branch per tile
+            if (F16S1) {
+                // scale of this lane's context row: its largest magnitude (the row is spread over the 4 lane groups) -> [2^11, 2^12)
+                float cmx = 0.f;
+#pragma unroll
+                for (int m = 0; m < RNCH; m++) cmx = h_amax3(h_amax3(cmx, cf[m][0], cf[m][1]), cf[m][2], cf[m][3]);
+                cmx = xmax32(xmax16(cmx));
+                const int cu = h_up_field((int)(__float_as_uint(cmx) >> 23) & 0xff);
+                const float csc = __uint_as_float((unsigned)cu << 23);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    unsigned bh[4], bl[4];
+                    h_split2(cf[2 * j][0], cf[2 * j][1], csc, bh[0], bl[0]);
+                    h_split2(cf[2 * j][2], cf[2 * j][3], csc, bh[1], bl[1]);
+                    h_split2(cf[2 * j + 1][0], cf[2 * j + 1][1], csc, bh[2], bl[2]);
+                    h_split2(cf[2 * j + 1][2], cf[2 * j + 1][3], csc, bh[3], bl[3]);
+                    const sf16x8 vbh = __builtin_bit_cast(sf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+                    const sf16x8 vbl = __builtin_bit_cast(sf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+#pragma unroll
+                    for (int rt = 0; rt < RF; rt++) {
+                        const sf16x8 vah = __builtin_bit_cast(sf16x8, make_uint4(qh[rt][j][0], qh[rt][j][1], qh[rt][j][2], qh[rt][j][3]));
+                        const sf16x8 val = __builtin_bit_cast(sf16x8, make_uint4(ql[rt][j][0], ql[rt][j][1], ql[rt][j][2], ql[rt][j][3]));
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(val, vbh, acc[rt], 0, 0, 0);
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vah, vbl, acc[rt], 0, 0, 0);
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vah, vbh, acc[rt], 0, 0, 0);
+                    }
+                }
+                const float inv = __builtin_ldexpf(1.0f, 127 - cu - qexp);   // back to true units (this lane's context row)
+#pragma unroll
+                for (int rt = 0; rt < RF; rt++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) acc[rt][k] *= inv;
+                if (T4 && tail_any) {
+#pragma unroll
+                    for (int m = 0; m < RNCH; m++) {
+                        tl = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[RT - 1][m].x, cf[m][0], tl, 0, 0, 0);
+                        tl = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[RT - 1][m].y, cf[m][1], tl, 0, 0, 0);
+                        tl = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[RT - 1][m].z, cf[m][2], tl, 0, 0, 0);
+                        tl = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[RT - 1][m].w, cf[m][3], tl, 0, 0, 0);
+                    }
+                }
+            } else if (T4 && tail_any) { S1_BODY(true) } else { S1_BODY(false) }   // one uniform branch per tile
 #undef S1_BODY
             if (T4) {
                 // tl[i] = partial score (this lane group's k values) of region base + i, context row c15
