@@ -733,15 +733,15 @@ def test_k1_bf16_storage_vs_fp32_oracle(ops, N, Li, Lr, Lqa, D):
 
 
 def test_k1_forward_fp16_split_scores_any_context_scale():
-    """Stage 1 of the register-resident forward (Lr <= 32, D = 128) runs as a two-way fp16 split with one power-of-two scale per
-    CONTEXT row; the region rows are normalised inside the kernel.  Context rows of wildly different magnitude (1e-6 .. 1e4,
+    """Stage 1 of the D = 128 forward kernels (register-resident for Lr <= 32, LDS-staged above) runs as a two-way fp16 split
+    with one power-of-two scale per CONTEXT row; the region rows are normalised inside the kernel.  Context rows of wildly different magnitude (1e-6 .. 1e4,
     nothing normalised them), a zero row and a row with one dominant element: raw scores against fp64 to fp32-class accuracy
     relative to |context row| (a cosine-like score is bounded by it)."""
     from tvqaplus_amd import _lib
     lib = _lib.load()
     g = torch.Generator().manual_seed(77)
     N, NA, Li, Lqa, D = 2, 5, 7, 40, 128
-    for Lr in (20, 16, 32, 9):
+    for Lr in (20, 16, 32, 9, 50, 40, 64):        # <= 32: register-resident kernel, above: LDS-staged kernel
         Cn = torch.randn(N, NA, Lqa, D, generator=g) * 10.0 ** (torch.rand(N, NA, Lqa, 1, generator=g) * 10 - 6)
         Cn[0, 0, 3] = 0.0
         Cn[1, 2, 5, 17] = 3e6

@@ -25,6 +25,7 @@
 // >= Lr alias one shared all-zero LDS row.  HBM traffic = algorithmic bytes: Q is read once per frame (the other slices
 // of the frame hit L2), Cn is L2 resident, A / S / S_ are written once.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "../../include/stage_hip.h"
 
@@ -39,6 +40,9 @@ int stage_str_attn_fwd_reg_bf16(const float* Cn, const void* Q, const float* c_m
                                 float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D, float scale, float p_drop,
                                 unsigned long long seed, void* stream);
 
+#ifndef K1_F16
+#define K1_F16 1        // WGF, fp32 storage: stage 1 as a two-way fp16 split on v_mfma_f32_16x16x32_f16 (see str_attn_fwd_reg.hip)
+#endif
 #define DD 128          // row width
 #define LDQ (DD + 4)    // padded LDS row stride (floats): ds_read_b128 of 16 rows x one chunk is conflict free
 #define NCH 8           // 4-float chunks per lane group (DD / 16)
@@ -78,12 +82,20 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
     constexpr int base_last = (RT - 1) * 16;
     // a last region tile with <= 4 regions is scored by 4x4x1 MFMA blocks instead of a padded 16-row tile (see
     // str_attn_fwd_reg.hip): lane (c15, g) feeds region base + (c15 & 3) and ends up with region base + g
-    constexpr bool T4 = PERM && KL == 1;
+    // F16L: the prepared copy holds fp16 PAIRS (row = 128 hi halves, then 128 lo halves: the same 512 bytes), written once per
+    // frame; stage 1 multiplies them with the fp16 pair of the context fragment (one power-of-two scale per context row) --
+    // 3 MFMAs of 16 cycles per 32 d and region tile instead of 8 of 32 cycles.  A lane group owns 8 consecutive chunks
+    // (dchunk), so MFMA step j takes the 8 consecutive d of chunks 2j, 2j + 1: one 16-byte LDS read per plane.  The short
+    // last tile runs as a padded 16-row tile here (12 MFMAs = 192 cycles; the 4x4x1 blocks of T4 cost 256 and need fp32 rows).
+    constexpr bool F16L = K1_F16 && WGF && std::is_same<TQ, float>::value;
+    constexpr bool T4 = PERM && KL == 1 && !F16L;
     constexpr int RF = T4 ? RT - 1 : RT;            // full 16-region tiles of stage 1
     // context tiles per step: two independent chains (MFMA, LDS reads, softmax) keep the in-order stream busy, but with
     // 3-4 region tiles the second tile's accumulators / scores / weights no longer fit (RT = 4 spilled ~70 VGPRs)
     constexpr int NU = RT >= 3 ? 1 : 2;
     const int sq = lane & 31, srow = lane >> 5;     // staging: 32 lanes per row, 2 rows per pass
+    const int qexp = 11 - (int)((__float_as_uint(inv_keep) >> 23) & 0xff) + 126;   // F16L: 2^qexp / keep < 2^12
+    const float qsc = __uint_as_float((unsigned)(127 + qexp) << 23);
 
     for (int i = lane; i < LDQ; i += 64) { Qr[Lr * LDQ + i] = 0.f; if (WGF) Qp[Lr * LDQ + i] = 0.f; }   // shared zero row(s)
     for (int i = lane; i < 2 * RT * 16; i += 64) rinv[i] = 0.f;       // zero tails of rinv / qm
@@ -152,14 +164,29 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
                 if (r < Lr) st4(&Qr[r * LDQ + 4 * sq], v[j]);
                 if (WGF && r < Lr) {
                     float4 pv4 = f4scale(v[j], (1.0f / fmaxf(sqrtf(ss), 1e-12f)) * (TRAIN ? inv_keep : 1.0f));
-                    if (TRAIN) {
+                    if (F16L) {   // dropout first (zeros stay zeros), then the fp16 pair of 2^qexp * value
+                        if (TRAIN) {
+                            const unsigned kb4 = drop4_bits(seed, (uint64_t)(frame * Lr + r) * D4 + sq, th);
+                            pv4.x = (kb4 & 1u) ? pv4.x : 0.f;
+                            pv4.y = (kb4 & 2u) ? pv4.y : 0.f;
+                            pv4.z = (kb4 & 4u) ? pv4.z : 0.f;
+                            pv4.w = (kb4 & 8u) ? pv4.w : 0.f;
+                        }
+                        unsigned h01, l01, h23, l23;
+                        h_split2(pv4.x, pv4.y, qsc, h01, l01);
+                        h_split2(pv4.z, pv4.w, qsc, h23, l23);
+                        char* prow = reinterpret_cast<char*>(&Qp[r * LDQ]);
+                        *reinterpret_cast<uint2*>(prow + 8 * sq) = make_uint2(h01, h23);
+                        *reinterpret_cast<uint2*>(prow + 256 + 8 * sq) = make_uint2(l01, l23);
+                    }
+                    if (TRAIN && !F16L) {
                         const unsigned kb4 = drop4_bits(seed, (uint64_t)(frame * Lr + r) * D4 + sq, th);
                         pv4.x = (kb4 & 1u) ? pv4.x : 0.f;
                         pv4.y = (kb4 & 2u) ? pv4.y : 0.f;
                         pv4.z = (kb4 & 4u) ? pv4.z : 0.f;
                         pv4.w = (kb4 & 8u) ? pv4.w : 0.f;
                     }
-                    st4(&Qp[r * LDQ + 4 * sq], pv4);
+                    if (!F16L) st4(&Qp[r * LDQ + 4 * sq], pv4);
                 }
                 if (r < Lr && sq == 0) {
                     rinv[r] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
@@ -244,6 +271,39 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
 #pragma unroll
             for (int u = 0; u < NU; u++) tl[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
             // ---- stage 1 ----
+            if (F16L) {
+                float cmx = 0.f;
+#pragma unroll
+                for (int m = 0; m < NCH; m++) cmx = h_amax3(h_amax3(cmx, cf[0][m][0], cf[0][m][1]), cf[0][m][2], cf[0][m][3]);
+                cmx = xmax32(xmax16(cmx));
+                const int cu = h_up_field((int)(__float_as_uint(cmx) >> 23) & 0xff);
+                const float csc = __uint_as_float((unsigned)cu << 23);
+                const int dbyte = 8 * dchunk(g, 0);         // byte offset of this lane group's first chunk in a 16-bit plane
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    unsigned bh[4], bl[4];
+                    h_split2(cf[0][2 * j][0], cf[0][2 * j][1], csc, bh[0], bl[0]);
+                    h_split2(cf[0][2 * j][2], cf[0][2 * j][3], csc, bh[1], bl[1]);
+                    h_split2(cf[0][2 * j + 1][0], cf[0][2 * j + 1][1], csc, bh[2], bl[2]);
+                    h_split2(cf[0][2 * j + 1][2], cf[0][2 * j + 1][3], csc, bh[3], bl[3]);
+                    const sf16x8 vbh = __builtin_bit_cast(sf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+                    const sf16x8 vbl = __builtin_bit_cast(sf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) {
+                        const char* prow = reinterpret_cast<const char*>(&Qp[arow[rt] * LDQ]) + dbyte + 16 * j;
+                        const sf16x8 vah = __builtin_bit_cast(sf16x8, *reinterpret_cast<const uint4*>(prow));
+                        const sf16x8 val = __builtin_bit_cast(sf16x8, *reinterpret_cast<const uint4*>(prow + 256));
+                        acc[0][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(val, vbh, acc[0][rt], 0, 0, 0);
+                        acc[0][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vah, vbl, acc[0][rt], 0, 0, 0);
+                        acc[0][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vah, vbh, acc[0][rt], 0, 0, 0);
+                    }
+                }
+                const float inv = __builtin_ldexpf(1.0f, 127 - cu - qexp);   // back to true units (this lane's context row)
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) acc[0][rt][k] *= inv;
+            } else
 #pragma unroll
             for (int m = 0; m < NCH; m++) {
                 float4 qv[RT];
