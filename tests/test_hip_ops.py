@@ -736,7 +736,8 @@ def test_k1_forward_fp16_split_scores_any_context_scale():
     """Stage 1 of the D = 128 forward kernels (register-resident for Lr <= 32, LDS-staged above) runs as a two-way fp16 split
     with one power-of-two scale per CONTEXT row; the region rows are normalised inside the kernel.  Context rows of wildly different magnitude (1e-6 .. 1e4,
     nothing normalised them), a zero row and a row with one dominant element: raw scores against fp64 to fp32-class accuracy
-    relative to |context row| (a cosine-like score is bounded by it)."""
+    relative to |context row| (a cosine-like score is bounded by it); and the attended rows A for frames whose raw rows differ
+    by 8 orders of magnitude."""
     from tvqaplus_amd import _lib
     lib = _lib.load()
     g = torch.Generator().manual_seed(77)
@@ -745,7 +746,7 @@ def test_k1_forward_fp16_split_scores_any_context_scale():
         Cn = torch.randn(N, NA, Lqa, D, generator=g) * 10.0 ** (torch.rand(N, NA, Lqa, 1, generator=g) * 10 - 6)
         Cn[0, 0, 3] = 0.0
         Cn[1, 2, 5, 17] = 3e6
-        Q = torch.randn(N, Li, Lr, D, generator=g) * 3.0
+        Q = torch.randn(N, Li, Lr, D, generator=g) * 10.0 ** torch.randint(-4, 5, (N, Li, 1, 1), generator=g).float()   # per-frame magnitude
         cm = torch.ones(N, NA, Lqa); qm = torch.ones(N, Li, Lr)
         dev = "cuda"
         Cd, Qd, cmd, qmd = Cn.to(dev), Q.to(dev), cm.to(dev), qm.to(dev)
@@ -758,6 +759,12 @@ def test_k1_forward_fp16_split_scores_any_context_scale():
         rown = Cn.double().norm(dim=-1)[:, :, None, :, None].clamp_min(1e-30)
         err = ((S.double().cpu() - ref).abs() / rown).max()
         assert bool(torch.isfinite(S).all()) and float(err) < 2e-6, (Lr, float(err))
+        # stage 2 (fp16 split in the LDS-staged kernel: weights x raw rows, one scale per frame): A against the kernel's own
+        # weights times the raw rows in fp64, relative to the frame's largest magnitude
+        refA = torch.einsum("naiwr,nird->naiwd", Sn.double().cpu(), Q.double())
+        fmax = Q.abs().amax(dim=(2, 3))[:, None, :, None, None].double()
+        errA = ((A.double().cpu() - refA).abs() / fmax).max()
+        assert bool(torch.isfinite(A).all()) and float(errA) < 2e-6, (Lr, float(errA))
 
 
 def test_cpp_host_runs_the_c_abi(ops, tmp_path):

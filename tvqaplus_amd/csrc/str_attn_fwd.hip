@@ -43,6 +43,8 @@ int stage_str_attn_fwd_reg_bf16(const float* Cn, const void* Q, const float* c_m
 #ifndef K1_F16
 #define K1_F16 1        // WGF, fp32 storage: stage 1 as a two-way fp16 split on v_mfma_f32_16x16x32_f16 (see str_attn_fwd_reg.hip)
 #endif
+#define QT_ROW 144      // F16L: bytes per d of a transposed plane (64 slots x 2 B + 16 B pad)
+#define QT_PLANE (128 * QT_ROW)
 #define DD 128          // row width
 #define LDQ (DD + 4)    // padded LDS row stride (floats): ds_read_b128 of 16 rows x one chunk is conflict free
 #define NCH 8           // 4-float chunks per lane group (DD / 16)
@@ -66,6 +68,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = tim ? __builtin_readcyclecounter() : 0;
 #define TICK(ph) do { if (tim) { unsigned long long tn = __builtin_readcyclecounter(); tacc[ph] += tn - tlast; tlast = tn; } } while (0)
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr bool F16L = K1_F16 && WGF && std::is_same<TQ, float>::value;   // see below
     // floats per wave: Lr rows + one zero row, rinv[RT*16], qm[RT*16], context mask of the slice [tiles_per_slice*16]
     const int WB = (Lr + 1) * LDQ + 2 * RT * 16 + tiles_per_slice * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
@@ -74,8 +77,12 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
     // WGF: a second copy holds the stage-1 operand READY -- normalised, dropped, scaled by 1/keep -- written once per frame while
     // it is staged, so the tile loop reads it as is (it used to multiply by 1/|row| and expand the dropout bits for every
     // context tile, the hash in each of the 4 waves).  Subtitle shape, training: 451 -> 392 us, the evaluation time; 20 fewer VGPRs
-    float* Qp = Qr + (Lr + 1) * LDQ;
-    float* rinv = Qr + (WGF ? 2 : 1) * (Lr + 1) * LDQ;
+    // F16L: no raw copy -- the prepared fp16 pairs (stage 1) sit in the first row block, followed by the TRANSPOSED fp16 planes
+    // of the raw rows for stage 2: QT[plane][d][slot], 64 region slots (128 B) + 16 B pad per d (16 lanes of consecutive d read
+    // 16 bytes each without bank conflicts), slot order = MFMA operand order (below)
+    float* Qp = F16L ? Qr : Qr + (Lr + 1) * LDQ;
+    char* QT = reinterpret_cast<char*>(Qr + (Lr + 1) * LDQ);
+    float* rinv = F16L ? Qr + (Lr + 1) * LDQ + 2 * QT_PLANE / 4 : Qr + (WGF ? 2 : 1) * (Lr + 1) * LDQ;
     float* qm = rinv + RT * 16;
     float* cms = qm + RT * 16;
     const int CR = NA * Lqa, CT = (CR + 15) >> 4;
@@ -87,7 +94,11 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
     // 3 MFMAs of 16 cycles per 32 d and region tile instead of 8 of 32 cycles.  A lane group owns 8 consecutive chunks
     // (dchunk), so MFMA step j takes the 8 consecutive d of chunks 2j, 2j + 1: one 16-byte LDS read per plane.  The short
     // last tile runs as a padded 16-row tile here (12 MFMAs = 192 cycles; the 4x4x1 blocks of T4 cost 256 and need fp32 rows).
-    constexpr bool F16L = K1_F16 && WGF && std::is_same<TQ, float>::value;
+    // Stage 2 (A^T tile = Q^T . S_^T, contraction over the regions) likewise: 32 regions per MFMA step = region tiles 2s, 2s + 1;
+    // lane group g contributes the 8 weights it holds after stage 1 (rows 4g + k of both tiles), so the region rows are STAGED
+    // in that order -- wave w, row pair srow, j = 0..7 loads region (tile 2 (w >> 1) + (j >> 2), row 4 (2 (w & 1) + srow) + (j & 3)):
+    // a staging lane then holds, for each of its four d, exactly one 8-slot operand fragment and writes it with one 16-byte
+    // LDS store per plane.  Raw rows scaled by one power of two per frame (largest magnitude -> [2^11, 2^12)), weights by 2^11.
     constexpr bool T4 = PERM && KL == 1 && !F16L;
     constexpr int RF = T4 ? RT - 1 : RT;            // full 16-region tiles of stage 1
     // context tiles per step: two independent chains (MFMA, LDS reads, softmax) keep the in-order stream busy, but with
@@ -122,6 +133,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
     const long n_items = WGF ? (long)N * Li : (long)N * Li * slices;
     const long n_waves = (long)gridDim.x * wpb;
     volatile int* const wg_flag = reinterpret_cast<volatile int*>(cms + (WGF ? CT * 16 : 0));   // WGF: [any valid region, next item lo, hi]
+    float* const fmaxs = cms + (WGF ? CT * 16 : 0) + 4;   // F16L: largest raw magnitude seen by each wave while staging
     // dynamic distribution: every wave (WGF: workgroup) starts on its own item, then draws tickets (one relaxed atomic per
     // item), so the last items are picked up by whoever is free -- a static stride leaves 4800 items / 2048 waves at 78 %
     long item = WGF ? (long)blockIdx.x : (long)blockIdx.x * wpb + wave;
@@ -148,6 +160,52 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
         TICK(5);
         // ---- stage the frame: raw rows -> LDS, 1/|row| (x * (1/n) instead of x / n: 1 ulp), region mask ----
         unsigned long long anyb = 0ull;
+        float4 fv[F16L ? 8 : 1];                      // F16L: this lane's 8 raw rows x 4 d, kept for the transposed planes
+        if (F16L) {
+            const int ks = wave >> 1, gq = 2 * (wave & 1) + srow;
+            bool ok[8];
+            float pmv[8];
+            int rr[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int tile = 2 * ks + (j >> 2), k = j & 3;
+                const int r = (PERM && tile == RT - 1) ? base_last + gq + 4 * k : 16 * tile + 4 * gq + k;
+                ok[j] = tile < RT && r < Lr;
+                rr[j] = ok[j] ? r : 0;
+                fv[j] = ok[j] ? ldv4(Q + (frame * Lr + rr[j]) * DD + 4 * sq) : f4zero();
+                pmv[j] = (ok[j] && sq == 0) ? qmask[frame * Lr + rr[j]] : 0.f;
+            }
+            float lmx = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int r = rr[j];
+                const float ss = group_sum(f4hsum(f4mul(fv[j], fv[j])), 32);
+                lmx = h_amax3(h_amax3(lmx, fv[j].x, fv[j].y), fv[j].z, fv[j].w);
+                if (ok[j]) {
+                    float4 pv4 = f4scale(fv[j], (1.0f / fmaxf(sqrtf(ss), 1e-12f)) * (TRAIN ? inv_keep : 1.0f));
+                    if (TRAIN) {   // dropout first (zeros stay zeros), then the fp16 pair of 2^qexp * value
+                        const unsigned kb4 = drop4_bits(seed, (uint64_t)(frame * Lr + r) * D4 + sq, th);
+                        pv4.x = (kb4 & 1u) ? pv4.x : 0.f;
+                        pv4.y = (kb4 & 2u) ? pv4.y : 0.f;
+                        pv4.z = (kb4 & 4u) ? pv4.z : 0.f;
+                        pv4.w = (kb4 & 8u) ? pv4.w : 0.f;
+                    }
+                    unsigned h01, l01, h23, l23;
+                    h_split2(pv4.x, pv4.y, qsc, h01, l01);
+                    h_split2(pv4.z, pv4.w, qsc, h23, l23);
+                    char* prow = reinterpret_cast<char*>(&Qp[r * LDQ]);
+                    *reinterpret_cast<uint2*>(prow + 8 * sq) = make_uint2(h01, h23);
+                    *reinterpret_cast<uint2*>(prow + 256 + 8 * sq) = make_uint2(l01, l23);
+                    if (sq == 0) {
+                        rinv[r] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+                        qm[r] = pmv[j];
+                    }
+                }
+                anyb |= __ballot(pmv[j] != 0.f);
+            }
+            lmx = wave_max(lmx);
+            if (lane == 0) fmaxs[wave] = lmx;
+        } else
         for (int r0 = WGF ? 16 * wave : 0; r0 < Lr; r0 += WGF ? 16 * 4 : 16) {  // 16 rows per batch: all loads of a batch are in flight together
             float4 v[8];
             float pmv[8];
@@ -164,29 +222,14 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
                 if (r < Lr) st4(&Qr[r * LDQ + 4 * sq], v[j]);
                 if (WGF && r < Lr) {
                     float4 pv4 = f4scale(v[j], (1.0f / fmaxf(sqrtf(ss), 1e-12f)) * (TRAIN ? inv_keep : 1.0f));
-                    if (F16L) {   // dropout first (zeros stay zeros), then the fp16 pair of 2^qexp * value
-                        if (TRAIN) {
-                            const unsigned kb4 = drop4_bits(seed, (uint64_t)(frame * Lr + r) * D4 + sq, th);
-                            pv4.x = (kb4 & 1u) ? pv4.x : 0.f;
-                            pv4.y = (kb4 & 2u) ? pv4.y : 0.f;
-                            pv4.z = (kb4 & 4u) ? pv4.z : 0.f;
-                            pv4.w = (kb4 & 8u) ? pv4.w : 0.f;
-                        }
-                        unsigned h01, l01, h23, l23;
-                        h_split2(pv4.x, pv4.y, qsc, h01, l01);
-                        h_split2(pv4.z, pv4.w, qsc, h23, l23);
-                        char* prow = reinterpret_cast<char*>(&Qp[r * LDQ]);
-                        *reinterpret_cast<uint2*>(prow + 8 * sq) = make_uint2(h01, h23);
-                        *reinterpret_cast<uint2*>(prow + 256 + 8 * sq) = make_uint2(l01, l23);
-                    }
-                    if (TRAIN && !F16L) {
+                    if (TRAIN) {
                         const unsigned kb4 = drop4_bits(seed, (uint64_t)(frame * Lr + r) * D4 + sq, th);
                         pv4.x = (kb4 & 1u) ? pv4.x : 0.f;
                         pv4.y = (kb4 & 2u) ? pv4.y : 0.f;
                         pv4.z = (kb4 & 4u) ? pv4.z : 0.f;
                         pv4.w = (kb4 & 8u) ? pv4.w : 0.f;
                     }
-                    if (!F16L) st4(&Qp[r * LDQ + 4 * sq], pv4);
+                    st4(&Qp[r * LDQ + 4 * sq], pv4);
                 }
                 if (r < Lr && sq == 0) {
                     rinv[r] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
@@ -215,6 +258,30 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
             }
             item = next_item;
             continue;
+        }
+        float inv2 = 1.f;
+        if (F16L) {
+            // transposed fp16 planes of the raw rows: one scale per frame
+            const float fmx = fmaxf(fmaxf(fmaxs[0], fmaxs[1]), fmaxf(fmaxs[2], fmaxs[3]));
+            const int qu = h_up_field((int)(__float_as_uint(fmx) >> 23) & 0xff);
+            const float sc2 = __uint_as_float((unsigned)qu << 23);
+            inv2 = __builtin_ldexpf(1.0f, 127 - qu - 11);
+            const int slot16 = (wave >> 1) * 4 + 2 * (wave & 1) + srow;      // (MFMA step, lane group) of this lane's fragment
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float c8[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) c8[j] = e == 0 ? fv[j].x : (e == 1 ? fv[j].y : (e == 2 ? fv[j].z : fv[j].w));
+                uint4 vh, vl;
+                h_split2(c8[0], c8[1], sc2, vh.x, vl.x);
+                h_split2(c8[2], c8[3], sc2, vh.y, vl.y);
+                h_split2(c8[4], c8[5], sc2, vh.z, vl.z);
+                h_split2(c8[6], c8[7], sc2, vh.w, vl.w);
+                char* pq = QT + (4 * sq + e) * QT_ROW + 16 * slot16;
+                *reinterpret_cast<uint4*>(pq) = vh;
+                *reinterpret_cast<uint4*>(pq + QT_PLANE) = vl;
+            }
+            __syncthreads();                          // the planes are complete
         }
         TICK(0);
         float ri[RT], qmk[RT][4];
@@ -400,6 +467,35 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
                 }
             TICK(3);
             // ---- stage 2: A^T tiles: per 16-wide d tile, one accumulator chain per context tile ----
+            if (F16L) {
+                constexpr int NS2 = (RT + 1) / 2;           // 32-region MFMA steps
+                unsigned wh[NS2][4], wl[NS2][4];
+#pragma unroll
+                for (int s2 = 0; s2 < NS2; s2++) {
+                    h_split2(pv[0][2 * s2][0], pv[0][2 * s2][1], 2048.f, wh[s2][0], wl[s2][0]);
+                    h_split2(pv[0][2 * s2][2], pv[0][2 * s2][3], 2048.f, wh[s2][1], wl[s2][1]);
+                    if (2 * s2 + 1 < RT) {
+                        h_split2(pv[0][2 * s2 + 1][0], pv[0][2 * s2 + 1][1], 2048.f, wh[s2][2], wl[s2][2]);
+                        h_split2(pv[0][2 * s2 + 1][2], pv[0][2 * s2 + 1][3], 2048.f, wh[s2][3], wl[s2][3]);
+                    } else wh[s2][2] = wh[s2][3] = wl[s2][2] = wl[s2][3] = 0u;
+                }
+#pragma unroll
+                for (int dt = 0; dt < NCH; dt++) {
+                    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s2 = 0; s2 < NS2; s2++) {
+                        const char* pq = QT + (16 * dt + c15) * QT_ROW + 16 * (4 * s2 + g);
+                        const sf16x8 qh8 = __builtin_bit_cast(sf16x8, *reinterpret_cast<const uint4*>(pq));
+                        const sf16x8 ql8 = __builtin_bit_cast(sf16x8, *reinterpret_cast<const uint4*>(pq + QT_PLANE));
+                        const sf16x8 wh8 = __builtin_bit_cast(sf16x8, make_uint4(wh[s2][0], wh[s2][1], wh[s2][2], wh[s2][3]));
+                        const sf16x8 wl8 = __builtin_bit_cast(sf16x8, make_uint4(wl[s2][0], wl[s2][1], wl[s2][2], wl[s2][3]));
+                        o = __builtin_amdgcn_mfma_f32_16x16x32_f16(ql8, wh8, o, 0, 0, 0);
+                        o = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh8, wl8, o, 0, 0, 0);
+                        o = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh8, wh8, o, 0, 0, 0);
+                    }
+                    stv4(A + orow[0] * DD + dt * 16 + 4 * g, make_float4(o[0] * inv2, o[1] * inv2, o[2] * inv2, o[3] * inv2));
+                }
+            } else
 #pragma unroll
             for (int dt = 0; dt < NCH; dt++) {
                 f32x4 o[NU];
@@ -491,7 +587,10 @@ static int launch_d128_t(const float* Cn, const TQ* Q, const float* cm, const fl
     static const bool no_wgf = getenv("STAGE_K1_NO_WGF") != nullptr;
     if constexpr (RT >= 3) if (!no_wgf) {
         // one frame copy per 4-wave workgroup (kernel comment); two workgroups per CU by registers
-        const size_t lds = ((size_t)2 * (Lr + 1) * LDQ + 2 * RT * 16 + (size_t)CT * 16 + 4) * sizeof(float);   // raw + prepared copy
+        constexpr bool f16l = K1_F16 && std::is_same<TQ, float>::value;
+        // fp32 storage: prepared fp16 pairs + transposed fp16 planes; bf16 storage: raw + prepared fp32 copy
+        const size_t lds = ((f16l ? (size_t)(Lr + 1) * LDQ + 2 * QT_PLANE / 4 : (size_t)2 * (Lr + 1) * LDQ) + 2 * RT * 16 +
+                            (size_t)CT * 16 + 8) * sizeof(float);
         auto kern = str_attn_fwd_d128_kernel<RT, KL, PERM, TRAIN, VEC_S, true, TQ>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         long wg_per_cu = (long)((160 * 1024) / ((lds + 511) / 512 * 512));
