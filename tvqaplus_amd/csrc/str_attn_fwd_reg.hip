@@ -59,6 +59,13 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
     // the context rows get one power-of-two scale per row from their largest magnitude), the contraction index of a
     // 32-wide MFMA step j is d = 16 (2j + c) + 4 g + e (c = 0, 1: the two float4 a lane already holds) for BOTH operands.
     constexpr bool F16S1 = K1_F16 && RF > 0 && std::is_same<TQ, float>::value && !(K1_ABL & 8);
+    // Stage 2 likewise (fp32 storage): the <= 8 contraction slots of a lane group (NK2 regions) are ONE 32-wide MFMA step.
+    // Weights (softmax output, <= 1) scaled by 2^11, the raw region rows by one power of two per frame (undone on the outputs).
+    // The 16 operand fragments of the frame (8 d tiles x hi / lo) do not fit next to the stage-1 operands, so every lane parks
+    // them in a private 256-byte column of LDS (written once per item, read back per tile as aligned 4-register tuples; a lane
+    // only ever reads what it wrote: no barrier) -- the fp32 operands they replace held 40 registers.
+    constexpr bool F16S2 = K1_F16 && std::is_same<TQ, float>::value && !(K1_ABL & 4);
+    extern __shared__ __attribute__((aligned(16))) uint4 qpark[];      // F16S2: [wave][16 fragments][64 lanes]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int c15 = lane & 15, g = lane >> 4;
     const int CR = NA * Lqa, CT = (CR + 15) >> 4;
@@ -209,6 +216,40 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
                     h_split2(u.z, u.w, qsc, qh[rt][j][1], ql[rt][j][1]);
                     h_split2(w.x, w.y, qsc, qh[rt][j][2], ql[rt][j][2]);
                     h_split2(w.z, w.w, qsc, qh[rt][j][3], ql[rt][j][3]);
+                }
+        }
+
+        uint4* const myq = qpark + (size_t)wave * 16 * 64 + lane;
+        float inv2 = 1.f;
+        if (F16S2) {
+            float qmx = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NK2; ks++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) qmx = h_amax3(h_amax3(qmx, q2[ks][b].x, q2[ks][b].y), q2[ks][b].z, q2[ks][b].w);
+            qmx = wave_max(qmx);
+            const int qu = h_up_field((int)(__float_as_uint(qmx) >> 23) & 0xff);
+            const float sc2 = __uint_as_float((unsigned)qu << 23);
+            inv2 = __builtin_ldexpf(1.0f, 127 - qu - 11);
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float c8[8];
+#pragma unroll
+                    for (int ks = 0; ks < 8; ks++) {
+                        if (ks < NK2) {
+                            const float4 q = q2[ks][b];
+                            c8[ks] = e == 0 ? q.x : (e == 1 ? q.y : (e == 2 ? q.z : q.w));
+                        } else c8[ks] = 0.f;
+                    }
+                    uint4 vh = make_uint4(0u, 0u, 0u, 0u), vl = make_uint4(0u, 0u, 0u, 0u);
+                    h_split2(c8[0], c8[1], sc2, vh.x, vl.x);
+                    if (NK2 > 2) h_split2(c8[2], c8[3], sc2, vh.y, vl.y);
+                    if (NK2 > 4) h_split2(c8[4], c8[5], sc2, vh.z, vl.z);
+                    if (NK2 > 6) h_split2(c8[6], c8[7], sc2, vh.w, vl.w);
+                    myq[((b * 4 + e) * 2 + 0) * 64] = vh;
+                    myq[((b * 4 + e) * 2 + 1) * 64] = vl;
                 }
         }
 
@@ -370,13 +411,38 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
 #pragma unroll
             for (int reg = 0; reg < 4; reg++)   // rows past the end alias the last valid row
                 arow4[reg] = (size_t)out_row(min(t * 16 + 4 * g + reg, CR - 1)) * RD + 4 * c15;
+            uint4 wh4 = make_uint4(0u, 0u, 0u, 0u), wl4 = make_uint4(0u, 0u, 0u, 0u);
+            if (F16S2) {   // weights in slot order ks = 4 rt + k (masked / padded slots are exactly 0)
+                float w8[8];
+#pragma unroll
+                for (int ks = 0; ks < 8; ks++) w8[ks] = ks < NK2 ? pv[ks >> 2][ks & 3] : 0.f;
+                h_split2(w8[0], w8[1], 2048.f, wh4.x, wl4.x);
+                if (NK2 > 2) h_split2(w8[2], w8[3], 2048.f, wh4.y, wl4.y);
+                if (NK2 > 4) h_split2(w8[4], w8[5], 2048.f, wh4.z, wl4.z);
+                if (NK2 > 6) h_split2(w8[6], w8[7], 2048.f, wh4.w, wl4.w);
+            }
 #pragma unroll
             for (int b = 0; b < 2; b++) {
                 f32x4 o[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) o[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (F16S2) {
+                    const sf16x8 wh8 = __builtin_bit_cast(sf16x8, wh4), wl8 = __builtin_bit_cast(sf16x8, wl4);
 #pragma unroll
-                for (int rt = 0; rt < RT; rt++)
+                    for (int e = 0; e < 4; e++) {
+                        const sf16x8 qh8 = __builtin_bit_cast(sf16x8, myq[((b * 4 + e) * 2 + 0) * 64]);
+                        const sf16x8 ql8 = __builtin_bit_cast(sf16x8, myq[((b * 4 + e) * 2 + 1) * 64]);
+                        o[e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh8, ql8, o[e], 0, 0, 0);
+                        o[e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl8, qh8, o[e], 0, 0, 0);
+                        o[e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh8, qh8, o[e], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+#pragma unroll
+                        for (int reg = 0; reg < 4; reg++) o[e][reg] *= inv2;
+                }
+#pragma unroll
+                for (int rt = 0; rt < (F16S2 ? 0 : RT); rt++)
 #pragma unroll
                     for (int k = 0; k < ((K1_ABL & 4) ? (rt == 0 ? 1 : 0) : ((rt == RT - 1) ? KL : 4)); k++) {
                         if (T4 && rt == RT - 1 && !tail_any) continue;   // all weights of this k-step are exactly 0
@@ -430,7 +496,8 @@ static int launch_reg_t(const float* Cn, const TQ* Q, const float* cm, const flo
     const long draws = items - (long)(static_rounds - 1) * entering;
     const StageTicket tk = stage_next_ticket((unsigned int)draws);
     if (!tk.word) return (int)hipErrorOutOfMemory;
-    hipLaunchKernelGGL((str_attn_fwd_reg_kernel<RT, KL, PERM, TRAIN, VEC_S, TQ>), dim3((unsigned)blocks), dim3(256), 0, st, Cn, Q,
+    const size_t park = (K1_F16 && std::is_same<TQ, float>::value) ? (size_t)4 * 16 * 64 * sizeof(uint4) : 0;   // 64 KB per workgroup
+    hipLaunchKernelGGL((str_attn_fwd_reg_kernel<RT, KL, PERM, TRAIN, VEC_S, TQ>), dim3((unsigned)blocks), dim3(256), park, st, Cn, Q,
                        cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, slices, tps, (uint64_t)seed, th, ik, tk.word, tk.base,
                        static_rounds);
     STAGE_LAUNCH_CHECK_TICKET(tk);
