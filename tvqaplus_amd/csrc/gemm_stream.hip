@@ -573,7 +573,11 @@ int stage_gemm_nt_stream(const float* X, const void* gate, int gate_kind, const 
     }
     const bool vec = (K % 4 == 0) && K >= 4 && (((uintptr_t)X & 15) == 0) && (((uintptr_t)W & 15) == 0) &&
                      (gate_kind != 1 || ((uintptr_t)gate & 15) == 0);
-    if (!vec || M < 4096 || K < 64 || M * (long long)K * 4 >= (1ll << 31)) return 1;   // buffer addressing: < 2 GiB
+    // rows: from 4096; from 1024 for K <= 384, where a handful of workgroups with one 32-row tile per wave still beat the
+    // tiled kernel's 128 x 128 tiles (M = 3200: 20 -> 12 us at K = 128, 35 -> 26 us at K = 384, but 64 -> 80 us at K = 768)
+    static const long long min_m_env = getenv("STAGE_GEMM_STREAM_MIN_M") ? atoll(getenv("STAGE_GEMM_STREAM_MIN_M")) : 0;
+    const long long min_m_nt = min_m_env ? min_m_env : (K <= 384 ? 1024 : 4096);
+    if (!vec || M < min_m_nt || K < 64 || M * (long long)K * 4 >= (1ll << 31)) return 1;   // buffer addressing: < 2 GiB
     if ((gate_kind == 2 || mask_out) && residual) return 1;                              // combinations nobody needs
     if (mask_out && gate_kind != 0) return 1;
     const int lds = 3 * SPLANE * (int)sizeof(unsigned short) + SBN * (int)sizeof(float);
@@ -1410,7 +1414,10 @@ __global__ __launch_bounds__(64 * TW_WAVES, 2) void gemm_tn_quad_kernel(const fl
 int stage_gemm_tn_stream(const float* dY, const void* gate, int gate_kind, const float* X, float* part, float* part_b,
                          long long M, int N, int K, int* S_io, long* rows_per_split_io, void* stream) {
     // buffer addressing: every operand must be smaller than 2 GiB
-    if (M < 4096 || M * (long long)N * 4 >= (1ll << 31) || M * (long long)K * 4 >= (1ll << 31)) return 1;
+    // rows: from 4096; from 1024 for K <= 128 (M = 3200: 27 -> 21 us; wider K loses to the tiled fp32 kernel there)
+    static const long long min_m_env = getenv("STAGE_GEMM_STREAM_MIN_M") ? atoll(getenv("STAGE_GEMM_STREAM_MIN_M")) : 0;
+    const long long min_m_tn = min_m_env ? min_m_env : (K <= 128 ? 1024 : 4096);
+    if (M < min_m_tn || M * (long long)N * 4 >= (1ll << 31) || M * (long long)K * 4 >= (1ll << 31)) return 1;
     if (!gate) gate_kind = 0;
     const float* G = (const float*)gate;
     int S = *S_io;
