@@ -41,7 +41,7 @@ int stage_str_attn_fwd_reg_bf16(const float* Cn, const void* Q, const float* c_m
                                 unsigned long long seed, void* stream);
 
 #ifndef K1_F16
-#define K1_F16 1        // WGF, fp32 storage: stage 1 as a two-way fp16 split on v_mfma_f32_16x16x32_f16 (see str_attn_fwd_reg.hip)
+#define K1_F16 1        // WGF: both products as two-way fp16 splits on v_mfma_f32_16x16x32_f16 (see str_attn_fwd_reg.hip)
 #endif
 #define QT_ROW 144      // F16L: bytes per d of a transposed plane (64 slots x 2 B + 16 B pad)
 #define QT_PLANE (128 * QT_ROW)
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = tim ? __builtin_readcyclecounter() : 0;
 #define TICK(ph) do { if (tim) { unsigned long long tn = __builtin_readcyclecounter(); tacc[ph] += tn - tlast; tlast = tn; } } while (0)
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr bool F16L = K1_F16 && WGF && std::is_same<TQ, float>::value;   // see below
+    constexpr bool F16L = K1_F16 && WGF;   // see below
     // floats per wave: Lr rows + one zero row, rinv[RT*16], qm[RT*16], context mask of the slice [tiles_per_slice*16]
     const int WB = (Lr + 1) * LDQ + 2 * RT * 16 + tiles_per_slice * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
@@ -587,8 +587,8 @@ static int launch_d128_t(const float* Cn, const TQ* Q, const float* cm, const fl
     static const bool no_wgf = getenv("STAGE_K1_NO_WGF") != nullptr;
     if constexpr (RT >= 3) if (!no_wgf) {
         // one frame copy per 4-wave workgroup (kernel comment); two workgroups per CU by registers
-        constexpr bool f16l = K1_F16 && std::is_same<TQ, float>::value;
-        // fp32 storage: prepared fp16 pairs + transposed fp16 planes; bf16 storage: raw + prepared fp32 copy
+        constexpr bool f16l = K1_F16;
+        // K1_F16: prepared fp16 pairs + transposed fp16 planes; otherwise raw + prepared fp32 copy
         const size_t lds = ((f16l ? (size_t)(Lr + 1) * LDQ + 2 * QT_PLANE / 4 : (size_t)2 * (Lr + 1) * LDQ) + 2 * RT * 16 +
                             (size_t)CT * 16 + 8) * sizeof(float);
         auto kern = str_attn_fwd_d128_kernel<RT, KL, PERM, TRAIN, VEC_S, true, TQ>;

@@ -35,7 +35,7 @@
 __device__ __forceinline__ void st4_out(float* p, float4 v) { ST4_OUT(p, v); }
 __device__ __forceinline__ void st4_out(stage_bf16* p, float4 v) { stv4(p, v); }   // bf16 storage: 8 bytes per lane, 128 per row half
 #ifndef K1_F16
-#define K1_F16 1        // fp32 storage: the full 16-region tiles of stage 1 run as a two-way fp16 split on v_mfma_f32_16x16x32_f16
+#define K1_F16 1        // both products run as two-way fp16 splits on v_mfma_f32_16x16x32_f16 (either storage type: the operands are fp32 in registers)
 #endif                  // (3 instructions of 16 cycles per 32 d instead of 8 of 32 cycles; common.h, DESIGN.md findings 20, 23)
 #define RD 128          // row width (floats)
 #define RNCH 8          // 4-float chunks per lane group
@@ -58,13 +58,13 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
     // Stage 1 of the full tiles on fp16 pairs: both operands are bounded (the region rows are normalised here: |x| <= 1/keep;
     // the context rows get one power-of-two scale per row from their largest magnitude), the contraction index of a
     // 32-wide MFMA step j is d = 16 (2j + c) + 4 g + e (c = 0, 1: the two float4 a lane already holds) for BOTH operands.
-    constexpr bool F16S1 = K1_F16 && RF > 0 && std::is_same<TQ, float>::value && !(K1_ABL & 8);
-    // Stage 2 likewise (fp32 storage): the <= 8 contraction slots of a lane group (NK2 regions) are ONE 32-wide MFMA step.
+    constexpr bool F16S1 = K1_F16 && RF > 0 && !(K1_ABL & 8);
+    // Stage 2 likewise: the <= 8 contraction slots of a lane group (NK2 regions) are ONE 32-wide MFMA step.
     // Weights (softmax output, <= 1) scaled by 2^11, the raw region rows by one power of two per frame (undone on the outputs).
     // The 16 operand fragments of the frame (8 d tiles x hi / lo) do not fit next to the stage-1 operands, so every lane parks
     // them in a private 256-byte column of LDS (written once per item, read back per tile as aligned 4-register tuples; a lane
     // only ever reads what it wrote: no barrier) -- the fp32 operands they replace held 40 registers.
-    constexpr bool F16S2 = K1_F16 && std::is_same<TQ, float>::value && !(K1_ABL & 4);
+    constexpr bool F16S2 = K1_F16 && !(K1_ABL & 4);
     extern __shared__ __attribute__((aligned(16))) uint4 qpark[];      // F16S2: [wave][16 fragments][64 lanes]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int c15 = lane & 15, g = lane >> 4;
@@ -496,7 +496,7 @@ static int launch_reg_t(const float* Cn, const TQ* Q, const float* cm, const flo
     const long draws = items - (long)(static_rounds - 1) * entering;
     const StageTicket tk = stage_next_ticket((unsigned int)draws);
     if (!tk.word) return (int)hipErrorOutOfMemory;
-    const size_t park = (K1_F16 && std::is_same<TQ, float>::value) ? (size_t)4 * 16 * 64 * sizeof(uint4) : 0;   // 64 KB per workgroup
+    const size_t park = K1_F16 ? (size_t)4 * 16 * 64 * sizeof(uint4) : 0;   // 64 KB per workgroup
     hipLaunchKernelGGL((str_attn_fwd_reg_kernel<RT, KL, PERM, TRAIN, VEC_S, TQ>), dim3((unsigned)blocks), dim3(256), park, st, Cn, Q,
                        cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, slices, tps, (uint64_t)seed, th, ik, tk.word, tk.base,
                        static_rounds);
