@@ -183,6 +183,21 @@ int stage_masked_max_fwd(const float* x, const float* mask, const int* window, f
 int stage_masked_max_bwd(const float* dout, const int* argmax, const float* mask, float* dx, long long R, int L, int D,
                          int accumulate, void* stream);
 
+/* ---- LayerNorm whose output only feeds a masked max over the sequence axis, in one pass ---------------------------
+ * The classifier head: final_layer_norm of the cls_encoder (model/encoder.py:52) -> mask_logits + max over the Lqa words
+ * (model/stage.py:503).  x, res (optional, added before the norm; sum_out = x + res is written for the backward) are
+ * (R, L, K); mask (R, L); out (R, K), argmax (R, K) int; mean / rstd (R * L).  The normalised (R, L, K) tensor and, in the
+ * backward, its dense gradient are never materialised.  `stage_ln_masked_max_supported`: K == 128.
+ * Backward: xin = the saved sum (or x when res == NULL); dx (R, L, K) is the gradient of x and of res; workspace as
+ * stage_ln_bwd_ws_bytes(K).                                                                                          */
+int stage_ln_masked_max_supported(int L, int K);
+int stage_ln_masked_max_fwd(const float* x, const float* res, float* sum_out, const float* gamma, const float* beta,
+                            const float* mask, float* out, int* argmax, float* mean, float* rstd, long long R, int L, int K,
+                            float eps, void* stream);
+int stage_ln_masked_max_bwd(const float* dout, const int* argmax, const float* mask, const float* xin, const float* mean,
+                            const float* rstd, const float* gamma, float* dx, float* dgamma, float* dbeta, long long R, int L,
+                            int K, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- bf16 storage mode (BASELINE.json configs[4]: bf16 weights / activations, fp32 softmax and accumulation) ------
  * Same operations and argument meaning as the fp32 entry points of the same name; every pointer typed `void*` is a
  * tensor of bf16 (raw 16-bit words) instead of float.  Statistics, affine parameters, weights, biases, masks, arg-max

@@ -767,6 +767,55 @@ def test_k1_forward_fp16_split_scores_any_context_scale():
         assert bool(torch.isfinite(A).all()) and float(errA) < 2e-6, (Lr, float(errA))
 
 
+@pytest.mark.parametrize("R,L,with_res", [(37, 40, True), (5, 1, True), (64, 7, False), (300, 40, True), (9, 33, False)])
+def test_ln_masked_max_fused(ops, R, L, with_res):
+    """LayerNorm + mask_logits + max over the sequence axis in one pass against the two separate operators of this package
+    and against plain torch (forward and all gradients); groups with every row
+    masked, ties (duplicated rows) and a single valid row included."""
+    K = 128
+    g = torch.Generator().manual_seed(R * 100 + L)
+    x = torch.randn(R, L, K, generator=g)
+    res = torch.randn(R, L, K, generator=g) if with_res else None
+    if L > 2:
+        x[0, 1] = x[0, 0]
+        if with_res: res[0, 1] = res[0, 0]          # rows 0 and 1 of group 0 are identical: the first one must win
+    gamma, beta = torch.randn(K, generator=g), torch.randn(K, generator=g)
+    mask = (torch.rand(R, L, generator=g) > 0.3).float()
+    mask[R - 1] = 0.0                                # a group without a valid row
+    if R > 2: mask[1] = 0.0; mask[1, L - 1] = 1.0    # a group with one valid row
+    gout = torch.randn(R, K, generator=g)
+
+    def run(fused):
+        xs = x.clone().cuda().requires_grad_(True)
+        rs = res.clone().cuda().requires_grad_(True) if with_res else None
+        gm, bt = gamma.clone().cuda().requires_grad_(True), beta.clone().cuda().requires_grad_(True)
+        if fused:
+            out = ops.ln_masked_max(xs, rs, gm, bt, mask.cuda())
+        else:
+            y, _ = ops.layernorm(xs, gm, bt, res=rs)
+            out = ops.masked_max(y, mask.cuda())
+        out.backward(gout.cuda())
+        return [out.detach().cpu(), xs.grad.cpu(), rs.grad.cpu() if with_res else None, gm.grad.cpu(), bt.grad.cpu()]
+    f, u = run(True), run(False)
+    assert float((f[0] - u[0]).abs().max()) <= 1e-5 * (1.0 + float(u[0].abs().max()))   # same arithmetic up to FMA contraction
+    for name, a, b in zip(("dx", "dres", "dgamma", "dbeta"), f[1:], u[1:]):
+        if a is not None:
+            assert float((a - b).abs().max()) <= 2e-5 * (1.0 + float(b.abs().max())), name
+    # plain torch reference
+    xt = x.clone().double().requires_grad_(True)
+    rt = res.clone().double().requires_grad_(True) if with_res else None
+    gt, btt = gamma.clone().double().requires_grad_(True), beta.clone().double().requires_grad_(True)
+    v = xt + rt if with_res else xt
+    y = F.layer_norm(v, (K,), gt, btt, 1e-5)
+    m = mask.double()[:, :, None]
+    ref = (y * m + (1 - m) * (-1e10)).max(dim=1).values
+    ref.backward(gout.double())
+    check("out", f[0], ref.detach().float())
+    check("dx", f[1], xt.grad.float())
+    check("dgamma", f[3], gt.grad.float())
+    check("dbeta", f[4], btt.grad.float())
+
+
 def test_cpp_host_runs_the_c_abi(ops, tmp_path):
     """examples/k1_forward_host.cpp (C++ + HIP runtime, no torch) built here and run: its output sums equal the Python
     binding's on the same deterministic inputs."""

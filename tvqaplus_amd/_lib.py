@@ -56,6 +56,9 @@ SIGNATURES = {
     "stage_mha_core_bwd": (I, [P, P, P, P, P, P, P, P, P, LL, I, I, I, F, U64, P]),
     "stage_masked_max_fwd": (I, [P, P, P, P, P, LL, I, I, P]),
     "stage_masked_max_bwd": (I, [P, P, P, P, LL, I, I, I, P]),
+    "stage_ln_masked_max_supported": (I, [I, I]),
+    "stage_ln_masked_max_fwd": (I, [P, P, P, P, P, P, P, P, P, P, LL, I, I, F, P]),
+    "stage_ln_masked_max_bwd": (I, [P, P, P, P, P, P, P, P, P, P, LL, I, I, P, SZ, P]),
     # bf16 storage mode: same argument lists as the fp32 entry points of the same name
     "stage_str_attn_fwd_bf16": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, U64, P]),
     "stage_str_attn_bwd_fused_bf16": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, SZ, P]),

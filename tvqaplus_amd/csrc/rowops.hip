@@ -331,12 +331,17 @@ __global__ __launch_bounds__(256) void ln_fwd_fast_kernel(RowSrcT<T> src, const 
     }
 }
 
-template <int MODE, bool DROP, int NQ0, typename T = float, typename TDX = T>
+// MM (MODE 0): the incoming gradient is that of a masked max over groups of mm_L consecutive rows (stage_ln_masked_max_*): `dy`
+// is the (rows / mm_L, K) gradient of the maxima and the row gradient dy[row][d] = (mm_idx[grp][d] == l) ? dy[grp][d] * mask[row] : 0
+// is formed while it is loaded -- the dense (rows, K) gradient tensor (491 MB at the classifier head) is never written or read.
+template <int MODE, bool DROP, int NQ0, typename T = float, typename TDX = T, bool MM = false>
 __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(RowSrcT<T> src, const T* __restrict__ dy,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, TDX* __restrict__ dx,
                                                           T* __restrict__ db_out, float* __restrict__ part, long rows,
-                                                          int K, int LPR, uint64_t seed, uint32_t th, float inv_keep) {
+                                                          int K, int LPR, uint64_t seed, uint32_t th, float inv_keep,
+                                                          const int* __restrict__ mm_idx = nullptr,
+                                                          const float* __restrict__ mm_mask = nullptr, int mm_L = 1) {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [wpb*RPW][2][K]
     constexpr int NQ = (MODE == 0) ? NQ0 : 3;
     constexpr int NX = (MODE == 0) ? NQ0 : 2;
@@ -376,8 +381,21 @@ __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(RowSrcT<T> src, const 
                 xv[u][0] = ldv4(src.x + a_row_fast(rc, src.rep, src.inner) * D + 4 * sl);
                 xv[u][1] = ldv4s(src.b + rc * D + 4 * sl);
             }
+            if (MM) {
+                const long grp = rc / mm_L;
+                const int l = (int)(rc - grp * mm_L);
+                const float mk = mm_mask[rc];
 #pragma unroll
-            for (int t = 0; t < NQ; t++) d[u][t] = ldv4s(dy + rc * K + 4 * jc[t]);
+                for (int t = 0; t < NQ; t++) {
+                    const int4 bi = *reinterpret_cast<const int4*>(mm_idx + grp * K + 4 * jc[t]);
+                    const float4 gq = ldv4(dy + grp * K + 4 * jc[t]);
+                    d[u][t] = make_float4(bi.x == l ? gq.x * mk : 0.f, bi.y == l ? gq.y * mk : 0.f, bi.z == l ? gq.z * mk : 0.f,
+                                          bi.w == l ? gq.w * mk : 0.f);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NQ; t++) d[u][t] = ldv4s(dy + rc * K + 4 * jc[t]);
+            }
         }
 #pragma unroll
         for (int u = 0; u < LN_UR; u++) {
@@ -991,6 +1009,124 @@ extern "C" int stage_masked_max_bwd(const float* dout, const int* argmax, const 
     const int grid = stage_grid_for(R * L * (D / 4), 256, GRID_CAP * 8);
     hipLaunchKernelGGL(masked_max_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dout, argmax, mask, dx,
                        (long)R, L, D / 4, accumulate);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm whose output only feeds a masked max over the sequence axis (the classifier head: final_layer_norm of the
+// cls_encoder -> mask_logits + max over the Lqa words, model/stage.py:503, model/encoder.py:52): one pass, the normalised
+// (R, L, K) tensor is never written.  One wave per group of L rows; 32 lanes per row (K = 128), two rows per step, eight rows
+// in flight.  Same arithmetic as ln_fwd_fast_kernel / masked_max_fwd_kernel (first maximum wins).
+//     v = x + res ; sum_out = v ; y = (v - mean) * rstd * gamma + beta ; out[g, d] = max_l ( y * m + (1 - m) * NEG )
+// Backward: ln_bwd_fast_kernel<..., MM = true> (the row gradient is gathered from (dout, argmax) on the fly).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_mm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                        float* __restrict__ sum_out, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ mask,
+                                                        float* __restrict__ out, int* __restrict__ idx,
+                                                        float* __restrict__ mean, float* __restrict__ rstd, long R, int L,
+                                                        float eps) {
+    constexpr int K = 128;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int sub = lane >> 5, sl = lane & 31;
+    const float4 gm = ld4(gamma + 4 * sl), bt = ld4(beta + 4 * sl);
+    for (long grp = (long)blockIdx.x * wpb + wave; grp < R; grp += (long)gridDim.x * wpb) {
+        float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        int4 bi = make_int4(-1, -1, -1, -1);
+        const long row0 = grp * L;
+        for (int l0 = 0; l0 < L; l0 += 8) {
+            float4 v[4], rv[4];
+            float mk[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int l = min(l0 + 2 * u + sub, L - 1);
+                v[u] = ldv4s(x + (row0 + l) * K + 4 * sl);
+                if (res) rv[u] = ldv4s(res + (row0 + l) * K + 4 * sl);
+                mk[u] = mask[row0 + l];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int l = l0 + 2 * u + sub;
+                const bool ok = l < L;
+                if (res) {
+                    v[u] = f4add(v[u], rv[u]);
+                    if (ok) stv4(sum_out + (row0 + l) * K + 4 * sl, v[u]);
+                }
+                const float mu = group_sum(f4hsum(v[u]), 32) * (1.0f / K);
+                const float4 dd = make_float4(v[u].x - mu, v[u].y - mu, v[u].z - mu, v[u].w - mu);
+                const float q = group_sum(f4hsum(f4mul(dd, dd)), 32);
+                const float rs = 1.0f / sqrtf(q * (1.0f / K) + eps);
+                if (ok && sl == 0) {
+                    mean[row0 + l] = mu;
+                    rstd[row0 + l] = rs;
+                }
+                if (ok) {
+                    const float off = (1.0f - mk[u]) * STAGE_NEG;
+                    const float4 w = make_float4(((v[u].x - mu) * rs * gm.x + bt.x) * mk[u] + off, ((v[u].y - mu) * rs * gm.y + bt.y) * mk[u] + off,
+                                                 ((v[u].z - mu) * rs * gm.z + bt.z) * mk[u] + off, ((v[u].w - mu) * rs * gm.w + bt.w) * mk[u] + off);
+                    if (w.x > best.x) { best.x = w.x; bi.x = l; }
+                    if (w.y > best.y) { best.y = w.y; bi.y = l; }
+                    if (w.z > best.z) { best.z = w.z; bi.z = l; }
+                    if (w.w > best.w) { best.w = w.w; bi.w = l; }
+                }
+            }
+        }
+        // the two row parities: larger value wins, on a tie the smaller row (= the first maximum in row order)
+#define LN_MM_MERGE(C)                                                                                                  \
+    {                                                                                                                   \
+        const float ov = __shfl_xor(best.C, 32);                                                                        \
+        const int oi = __shfl_xor(bi.C, 32);                                                                            \
+        if (oi >= 0 && (bi.C < 0 || ov > best.C || (ov == best.C && oi < bi.C))) { best.C = ov; bi.C = oi; }            \
+    }
+        LN_MM_MERGE(x) LN_MM_MERGE(y) LN_MM_MERGE(z) LN_MM_MERGE(w)
+#undef LN_MM_MERGE
+        if (sub == 0) {
+            st4(out + grp * K + 4 * sl, best);
+            *reinterpret_cast<int4*>(idx + grp * K + 4 * sl) = bi;
+        }
+    }
+}
+
+extern "C" int stage_ln_masked_max_supported(int L, int K) { return (K == 128 && L >= 1) ? 1 : 0; }
+
+extern "C" int stage_ln_masked_max_fwd(const float* x, const float* res, float* sum_out, const float* gamma, const float* beta,
+                                       const float* mask, float* out, int* argmax, float* mean, float* rstd, long long R, int L,
+                                       int K, float eps, void* stream) {
+    if (R <= 0) return 0;
+    if (!stage_ln_masked_max_supported(L, K) || (res && !sum_out)) return STAGE_ERR_SHAPE;
+    const int grid = stage_grid_for(R, 4, GRID_CAP * 8);
+    hipLaunchKernelGGL(ln_mm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, res, sum_out, gamma, beta, mask, out,
+                       argmax, mean, rstd, (long)R, L, eps);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+// xin = x + res as saved by the forward; dx is the gradient of both x and res
+extern "C" int stage_ln_masked_max_bwd(const float* dout, const int* argmax, const float* mask, const float* xin,
+                                       const float* mean, const float* rstd, const float* gamma, float* dx, float* dgamma,
+                                       float* dbeta, long long R, int L, int K, void* ws, size_t ws_bytes, void* stream) {
+    if (!stage_ln_masked_max_supported(L, K)) return STAGE_ERR_SHAPE;
+    if (ws_bytes < stage_ln_bwd_ws_bytes(K)) return STAGE_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const long long rows = R * L;
+    if (rows <= 0) {
+        (void)hipMemsetAsync(dgamma, 0, sizeof(float) * K, st);
+        (void)hipMemsetAsync(dbeta, 0, sizeof(float) * K, st);
+        return 0;
+    }
+    if (rows >= (1ll << 31)) return STAGE_ERR_SHAPE;
+    const int LPR = ln_lpr(K / 4);
+    const int rows_per_block = 4 * (64 / LPR);
+    const int grid = stage_grid_for(rows, rows_per_block * 8, PART_CAP);
+    const size_t lds = (size_t)rows_per_block * 2 * K * sizeof(float);
+    float* part = (float*)ws;
+    RowSrc src{xin, nullptr, 0, 1, 0, nullptr};
+    if ((K / 4 + LPR - 1) / LPR != 1) return STAGE_ERR_SHAPE;
+    hipLaunchKernelGGL((ln_bwd_fast_kernel<0, false, 1, float, float, true>), dim3(grid), dim3(256), lds, st, src, dout, mean, rstd,
+                       gamma, dx, (float*)nullptr, part, (long)rows, K, LPR, (uint64_t)0, 0u, 1.0f, argmax, mask, L);
+    STAGE_LAUNCH_CHECK();
+    stage_colreduce(part, dgamma, dbeta, grid, (long)2 * K, 2 * K, K, 1, st);
     STAGE_LAUNCH_CHECK();
     return 0;
 }

@@ -194,6 +194,7 @@ class STAGE(nn.Module):
                                                relu=False)
         # developer switch: False (or STAGE_NO_FUSE_LN_DWCONV=1) = separate LayerNorm and depthwise-conv kernels
         self.fuse_ln_dwconv = os.environ.get("STAGE_NO_FUSE_LN_DWCONV") is None
+        self.fuse_ln_max = os.environ.get("STAGE_NO_FUSE_LN_MAX") is None
         # storage type of the activations between kernels: fp32 (the reference's), or bf16 with ``opt.storage_dtype = "bf16"``
         # (BASELINE.json configs[4]: bf16 weights / activations, fp32 softmax / statistics / accumulation; parameters stay
         # fp32 master copies, a weight is rounded to bf16 when a GEMM stages it; scores, losses and logits are fp32)
@@ -228,8 +229,10 @@ class STAGE(nn.Module):
         return ops.layernorm(x, ln.weight, ln.bias, p=self._p() if drop else 0.0, seed=self._seed() if drop else 0,
                              res=res, res_period=res_period)
 
-    def _encoder_block(self, x, mask, blk: _EncoderBlockParams):
-        """model/encoder.py:29-52.  x (M, L, D).  Residual adds are deferred into the next LayerNorm's prologue."""
+    def _encoder_block(self, x, mask, blk: _EncoderBlockParams, pool_mask=None):
+        """model/encoder.py:29-52.  x (M, L, D).  Residual adds are deferred into the next LayerNorm's prologue.
+        ``pool_mask`` (M, L): the caller only needs the masked max of the block's output over L (the classifier head,
+        model/stage.py:503) -- the final LayerNorm and the max run as one pass and (M, D) is returned."""
         M, L, D = x.shape
         pending, cur, period = x, blk.position_encoding.rows(L), L  # first LN sees x + pe[:L]
         for i in range(blk.n_conv):
@@ -256,12 +259,20 @@ class STAGE(nn.Module):
             p_attn = p_attn if self.training else 0.0
             a = ops.mha_core(q, k, v, mask, mha.nh, p=p_attn, seed=self._seed() if p_attn > 0 else 0)
             pending = ops.linear(a, mha.linears[3].weight, mha.linears[3].bias)
+        if pool_mask is not None:
+            if self.fuse_ln_max and period == 0 and ops.ln_masked_max_supported(pending, L, D):
+                return ops.ln_masked_max(pending, cur, blk.final_layer_norm.weight, blk.final_layer_norm.bias, pool_mask)
+            y, _ = self._ln(pending, blk.final_layer_norm, res=cur, res_period=period)
+            return ops.masked_max(y, pool_mask)
         y, _ = self._ln(pending, blk.final_layer_norm, res=cur, res_period=period)
         return y
 
-    def _stacked_encoder(self, x, mask, enc: _StackedEncoderParams):
-        for blk in enc.stacked_encoderBlocks:
-            x = self._encoder_block(x, mask, blk)
+    def _stacked_encoder(self, x, mask, enc: _StackedEncoderParams, pool_mask=None):
+        blocks = list(enc.stacked_encoderBlocks)
+        if pool_mask is not None and not blocks:
+            return ops.masked_max(x, pool_mask)
+        for j, blk in enumerate(blocks):
+            x = self._encoder_block(x, mask, blk, pool_mask=pool_mask if j == len(blocks) - 1 else None)
         return x
 
     def base_encoder(self, data, data_mask, init_encoder, downsize_encoder, input_encoder, l2_normalize=False):
@@ -372,8 +383,7 @@ class STAGE(nn.Module):
         D = statement.shape[-1]
         x = statement.reshape(N * NA * Li, Lqa, D)
         m = statement_mask.reshape(N * NA * Li, Lqa).contiguous()
-        x = self._stacked_encoder(x, m, self.cls_encoder)
-        mx = ops.masked_max(x, m)                                                       # :503
+        mx = self._stacked_encoder(x, m, self.cls_encoder, pool_mask=m)                # encoder + :503 (max over the words)
         mx_mask = (m.sum(1) != 0).float().view(N, NA, Li, 1)                             # :504
         enc = mx.view(N * NA * Li, D)
         # residual_temporal_predictor, layer 0 (:469-482).  Layers >= 1 (t_iter > 0) never reach any output or
