@@ -34,6 +34,8 @@ _OPS = {
                              lambda C, Q, c_mask, q_mask, scale, p=0.0, seed_c=0, seed_q=0:
                              ops.structured_attention(C, Q, c_mask, q_mask, scale, p, seed_c, seed_q)),
     "masked_max": ("(Tensor x, Tensor mask, Tensor? window=None) -> Tensor", lambda x, mask, window=None: ops.masked_max(x, mask, window)),
+    "ln_masked_max": ("(Tensor x, Tensor? res, Tensor gamma, Tensor beta, Tensor mask) -> Tensor",
+                      lambda x, res, gamma, beta, mask: ops.ln_masked_max(x, res, gamma, beta, mask)),
     "mha_core": ("(Tensor q, Tensor k, Tensor v, Tensor mask, int nh, float p=0.0, int seed=0) -> Tensor",
                  lambda q, k, v, mask, nh, p=0.0, seed=0: ops.mha_core(q, k, v, mask, nh, p, seed)),
 }
