@@ -269,6 +269,12 @@ int stage_masked_max_fwd_bf16(const void* x, const float* mask, const int* windo
                               int L, int D, void* stream);
 int stage_masked_max_bwd_bf16(const void* dout, const int* argmax, const float* mask, void* dx, long long R, int L, int D,
                               int accumulate, void* stream);
+int stage_ln_masked_max_fwd_bf16(const void* x, const void* res, void* sum_out, const float* gamma, const float* beta,
+                                 const float* mask, void* out, int* argmax, float* mean, float* rstd, long long R, int L,
+                                 int K, float eps, void* stream);
+int stage_ln_masked_max_bwd_bf16(const void* dout, const int* argmax, const float* mask, const void* xin, const float* mean,
+                                 const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta, long long R,
+                                 int L, int K, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -209,6 +209,38 @@ def test_l2norm_and_masked_max_bf16(ops):
         check("dmax", vd.grad, vc.grad, ULP2)
 
 
+@pytest.mark.parametrize("R,L", [(37, 40), (6, 7)])
+def test_ln_masked_max_bf16(ops, R, L):
+    """Fused LayerNorm + masked max on bf16 activations against fp32 torch on the rounded inputs.  (The two separate bf16
+    operators are NOT the reference here: they take the max of the ROUNDED normalised values, where rows tie that differ
+    below bf16 resolution; the fused kernel compares the unrounded fp32 values, as the fp32 reference does.)"""
+    K = 128
+    g = torch.Generator().manual_seed(R + L)
+    x, res = rb(torch.randn(R, L, K, generator=g)), rb(torch.randn(R, L, K, generator=g))
+    gamma, beta = torch.randn(K, generator=g), torch.randn(K, generator=g)
+    mask = (torch.rand(R, L, generator=g) > 0.3).float()
+    mask[R - 1] = 0.0
+    gout = rb(torch.randn(R, K, generator=g))
+    xs, rs = devb(x, True), devb(res, True)
+    gm, bt = dev(gamma, True), dev(beta, True)
+    out = ops.ln_masked_max(xs, rs, gm, bt, mask.cuda())
+    assert out.dtype == BF
+    out.backward(gout.to(BF).cuda())
+    xt, rt = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    gt, btt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = F.layer_norm(xt + rt, (K,), gt, btt, 1e-5)
+    m = mask[:, :, None]
+    ref = (y * m + (1 - m) * (-1e10)).max(dim=1).values
+    ref.backward(gout)
+    ok = ref.detach() > -1e9
+    check("out", out.float().cpu()[ok], ref.detach()[ok], ULP2)
+    # the backward normalises the sum as it was STORED (bf16): x_hat carries one rounding of the saved activation
+    check("dx", xs.grad, xt.grad, 2e-2)
+    assert torch.equal(xs.grad, rs.grad)
+    check("dgamma", gm.grad.cpu(), gt.grad, 6e-2)     # few selected rows per column: sums of a handful of rounded x_hat terms
+    check("dbeta", bt.grad.cpu(), btt.grad, PTOL)
+
+
 @pytest.mark.parametrize("N,Li,Lr,Lqa,ext", [(2, 7, 20, 40, False), (2, 5, 50, 40, True), (1, 4, 36, 23, False), (2, 6, 8, 12, True)])
 def test_k1_fast_kernels_bf16(ops, N, Li, Lr, Lqa, ext):
     """StructuredAttention at D = 128 on bf16 Q / A / dA: the register-resident and LDS-staged forward kernels and the fused

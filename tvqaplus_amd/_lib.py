@@ -81,6 +81,8 @@ SIGNATURES = {
     "stage_mha_core_bwd_bf16": (I, [P, P, P, P, P, P, P, P, LL, I, I, I, F, U64, P]),
     "stage_masked_max_fwd_bf16": (I, [P, P, P, P, P, LL, I, I, P]),
     "stage_masked_max_bwd_bf16": (I, [P, P, P, P, LL, I, I, I, P]),
+    "stage_ln_masked_max_fwd_bf16": (I, [P, P, P, P, P, P, P, P, P, P, LL, I, I, F, P]),
+    "stage_ln_masked_max_bwd_bf16": (I, [P, P, P, P, P, P, P, P, P, P, LL, I, I, P, SZ, P]),
 }
 
 _lib = None

@@ -1021,10 +1021,11 @@ extern "C" int stage_masked_max_bwd(const float* dout, const int* argmax, const 
 //     v = x + res ; sum_out = v ; y = (v - mean) * rstd * gamma + beta ; out[g, d] = max_l ( y * m + (1 - m) * NEG )
 // Backward: ln_bwd_fast_kernel<..., MM = true> (the row gradient is gathered from (dout, argmax) on the fly).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ln_mm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
-                                                        float* __restrict__ sum_out, const float* __restrict__ gamma,
+template <typename T>
+__global__ __launch_bounds__(256) void ln_mm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                        T* __restrict__ sum_out, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ mask,
-                                                        float* __restrict__ out, int* __restrict__ idx,
+                                                        T* __restrict__ out, int* __restrict__ idx,
                                                         float* __restrict__ mean, float* __restrict__ rstd, long R, int L,
                                                         float eps) {
     constexpr int K = 128;
@@ -1053,7 +1054,7 @@ __global__ __launch_bounds__(256) void ln_mm_fwd_kernel(const float* __restrict_
                     v[u] = f4add(v[u], rv[u]);
                     if (ok) stv4(sum_out + (row0 + l) * K + 4 * sl, v[u]);
                 }
-                const float mu = group_sum(f4hsum(v[u]), 32) * (1.0f / K);
+                const float mu = group_sum(f4hsum(v[u]), 32) * (1.0f / K);   // (16-bit storage: statistics of the unrounded sum, as in ln_fwd_fast_kernel)
                 const float4 dd = make_float4(v[u].x - mu, v[u].y - mu, v[u].z - mu, v[u].w - mu);
                 const float q = group_sum(f4hsum(f4mul(dd, dd)), 32);
                 const float rs = 1.0f / sqrtf(q * (1.0f / K) + eps);
@@ -1082,7 +1083,7 @@ __global__ __launch_bounds__(256) void ln_mm_fwd_kernel(const float* __restrict_
         LN_MM_MERGE(x) LN_MM_MERGE(y) LN_MM_MERGE(z) LN_MM_MERGE(w)
 #undef LN_MM_MERGE
         if (sub == 0) {
-            st4(out + grp * K + 4 * sl, best);
+            stv4(out + grp * K + 4 * sl, best);
             *reinterpret_cast<int4*>(idx + grp * K + 4 * sl) = bi;
         }
     }
@@ -1096,16 +1097,17 @@ extern "C" int stage_ln_masked_max_fwd(const float* x, const float* res, float* 
     if (R <= 0) return 0;
     if (!stage_ln_masked_max_supported(L, K) || (res && !sum_out)) return STAGE_ERR_SHAPE;
     const int grid = stage_grid_for(R, 4, GRID_CAP * 8);
-    hipLaunchKernelGGL(ln_mm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, res, sum_out, gamma, beta, mask, out,
+    hipLaunchKernelGGL(ln_mm_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, res, sum_out, gamma, beta, mask, out,
                        argmax, mean, rstd, (long)R, L, eps);
     STAGE_LAUNCH_CHECK();
     return 0;
 }
 
 // xin = x + res as saved by the forward; dx is the gradient of both x and res
-extern "C" int stage_ln_masked_max_bwd(const float* dout, const int* argmax, const float* mask, const float* xin,
-                                       const float* mean, const float* rstd, const float* gamma, float* dx, float* dgamma,
-                                       float* dbeta, long long R, int L, int K, void* ws, size_t ws_bytes, void* stream) {
+template <typename T>
+static int ln_masked_max_bwd_t(const T* dout, const int* argmax, const float* mask, const T* xin, const float* mean,
+                               const float* rstd, const float* gamma, T* dx, float* dgamma, float* dbeta, long long R, int L, int K,
+                               void* ws, size_t ws_bytes, void* stream) {
     if (!stage_ln_masked_max_supported(L, K)) return STAGE_ERR_SHAPE;
     if (ws_bytes < stage_ln_bwd_ws_bytes(K)) return STAGE_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -1121,14 +1123,19 @@ extern "C" int stage_ln_masked_max_bwd(const float* dout, const int* argmax, con
     const int grid = stage_grid_for(rows, rows_per_block * 8, PART_CAP);
     const size_t lds = (size_t)rows_per_block * 2 * K * sizeof(float);
     float* part = (float*)ws;
-    RowSrc src{xin, nullptr, 0, 1, 0, nullptr};
+    RowSrcT<T> src{xin, nullptr, 0, 1, 0, nullptr};
     if ((K / 4 + LPR - 1) / LPR != 1) return STAGE_ERR_SHAPE;
-    hipLaunchKernelGGL((ln_bwd_fast_kernel<0, false, 1, float, float, true>), dim3(grid), dim3(256), lds, st, src, dout, mean, rstd,
-                       gamma, dx, (float*)nullptr, part, (long)rows, K, LPR, (uint64_t)0, 0u, 1.0f, argmax, mask, L);
+    hipLaunchKernelGGL((ln_bwd_fast_kernel<0, false, 1, T, T, true>), dim3(grid), dim3(256), lds, st, src, dout, mean, rstd,
+                       gamma, dx, (T*)nullptr, part, (long)rows, K, LPR, (uint64_t)0, 0u, 1.0f, argmax, mask, L);
     STAGE_LAUNCH_CHECK();
     stage_colreduce(part, dgamma, dbeta, grid, (long)2 * K, 2 * K, K, 1, st);
     STAGE_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int stage_ln_masked_max_bwd(const float* dout, const int* argmax, const float* mask, const float* xin,
+                                       const float* mean, const float* rstd, const float* gamma, float* dx, float* dgamma,
+                                       float* dbeta, long long R, int L, int K, void* ws, size_t ws_bytes, void* stream) {
+    return ln_masked_max_bwd_t<float>(dout, argmax, mask, xin, mean, rstd, gamma, dx, dgamma, dbeta, R, L, K, ws, ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1262,4 +1269,22 @@ extern "C" int stage_l2norm_bwd_mixed_bf16(const float* dy, const void* x, const
                            (long)rows, K, eps, LPR, (uint64_t)0, 0u, 1.0f, 0, add);
     STAGE_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int stage_ln_masked_max_fwd_bf16(const void* x, const void* res, void* sum_out, const float* gamma, const float* beta,
+                                            const float* mask, void* out, int* argmax, float* mean, float* rstd, long long R,
+                                            int L, int K, float eps, void* stream) {
+    if (R <= 0) return 0;
+    if (!stage_ln_masked_max_supported(L, K) || (res && !sum_out)) return STAGE_ERR_SHAPE;
+    const int grid = stage_grid_for(R, 4, GRID_CAP * 8);
+    hipLaunchKernelGGL(ln_mm_fwd_kernel<B16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const B16*)x, (const B16*)res,
+                       (B16*)sum_out, gamma, beta, mask, (B16*)out, argmax, mean, rstd, (long)R, L, eps);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int stage_ln_masked_max_bwd_bf16(const void* dout, const int* argmax, const float* mask, const void* xin,
+                                            const float* mean, const float* rstd, const float* gamma, void* dx, float* dgamma,
+                                            float* dbeta, long long R, int L, int K, void* ws, size_t ws_bytes, void* stream) {
+    return ln_masked_max_bwd_t<B16>((const B16*)dout, argmax, mask, (const B16*)xin, mean, rstd, gamma, (B16*)dx, dgamma, dbeta, R, L,
+                                    K, ws, ws_bytes, stream);
 }

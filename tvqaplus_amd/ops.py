@@ -669,16 +669,16 @@ class _LnMaskedMax(torch.autograd.Function):
     """max over the sequence axis of mask_logits(LayerNorm(x + res)) in one pass (csrc/rowops.hip: ln_mm_fwd_kernel)."""
     @_on_device
     def forward(ctx, x, res, gamma, beta, mask):
-        x, mask = _chk(x, "x"), _chk(mask, "mask")          # (R, L, K), (R, L)
+        x, mask = _act(x, "x"), _chk(mask, "mask")          # (R, L, K), (R, L)
         R, L, K = x.shape
-        res_c = None if res is None else _chk(res, "res")
+        res_c = None if res is None else _act(res, "res", x)
         gamma, beta = _chk(gamma, "gamma"), _chk(beta, "beta")
         out = torch.empty(R, K, dtype=x.dtype, device=x.device)
         idx = torch.empty(R, K, dtype=torch.int32, device=x.device)
         mean = torch.empty(R * L, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
         s = torch.empty_like(x) if res_c is not None else None
-        _call("stage_ln_masked_max_fwd", _ptr(x), _ptr(res_c), _ptr(s), _ptr(gamma), _ptr(beta), _ptr(mask), _ptr(out), _ptr(idx),
+        _call("stage_ln_masked_max_fwd" + _sfx(x), _ptr(x), _ptr(res_c), _ptr(s), _ptr(gamma), _ptr(beta), _ptr(mask), _ptr(out), _ptr(idx),
               _ptr(mean), _ptr(rstd), R, L, K, EPS_LN, _stream())
         ctx.save_for_backward(s if res_c is not None else x, mean, rstd, gamma, idx, mask)
         ctx.shape = (R, L, K)
@@ -689,19 +689,19 @@ class _LnMaskedMax(torch.autograd.Function):
     def backward(ctx, dout):
         xin, mean, rstd, gamma, idx, mask = ctx.saved_tensors
         R, L, K = ctx.shape
-        dout = _chk(dout, "dout")
+        dout = _act(dout, "dout", xin)
         dx = torch.empty_like(xin)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         lib = _lib.load()
         wsb = lib.stage_ln_bwd_ws_bytes(K)
         ws = _workspace(wsb, xin.device)
-        _call("stage_ln_masked_max_bwd", _ptr(dout), _ptr(idx), _ptr(mask), _ptr(xin), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dx),
+        _call("stage_ln_masked_max_bwd" + _sfx(xin), _ptr(dout), _ptr(idx), _ptr(mask), _ptr(xin), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dx),
               _ptr(dgamma), _ptr(dbeta), R, L, K, _ptr(ws), wsb, _stream())
         return (dx if ctx.needs_input_grad[0] else None), (dx if (ctx.has_res and ctx.needs_input_grad[1]) else None), dgamma, dbeta, None
 
 
 def ln_masked_max_supported(x, L: int, K: int) -> bool:
-    return x.dtype == torch.float32 and bool(_lib.load().stage_ln_masked_max_supported(int(L), int(K)))
+    return bool(_lib.load().stage_ln_masked_max_supported(int(L), int(K)))
 
 
 def ln_masked_max(x, res, gamma, beta, mask):
