@@ -140,6 +140,19 @@ int stage_ln_dwconv_bwd(const float* dh, const float* xin, const float* mean, co
  * `gate` (M,K) fuses a ReLU backward on the input operand (dX = (dY .* [Y>0]) . W with W passed transposed).       */
 int stage_gemm_nt(const float* X, const float* gate, const float* W, const float* bias, const float* residual, float* Y,
                   long long M, int N, int K, int relu, void* stream);
+/* LayerNorm gain / bias gradients straight from the dX product of the Linear behind it, for a LayerNorm whose INPUT needs no
+ * gradient (first layer of the input MLPs: LayerNorm -> Dropout -> Linear -> ReLU, model/stage.py:85-91, 98-104):
+ *   dgamma[n] = sum_m G[m,n] x_hat[m,n] , dbeta[n] = sum_m G[m,n] ,  G = ((dY .* relu mask) . Wt^T) .* keep / (1 - p)
+ * dY (M, K), gate_mask = the ReLU bit mask of the forward (stage_gemm_nt_mask) or NULL, Wt (N, K) = the weight transposed,
+ * x / mean / rstd = the LayerNorm input and statistics, keep_mask = stage_dropout_keepmask of its dropout stream (NULL when
+ * p_drop == 0).  The (M, N) gradient is reduced inside the GEMM epilogue and never written.                              */
+int stage_gemm_nt_lnparam_supported(long long M, int N, int K);
+size_t stage_gemm_nt_lnparam_ws_bytes(long long M, int N);
+int stage_gemm_nt_lnparam(const float* dY, const unsigned* gate_mask, const float* Wt, const float* x, const float* mean,
+                          const float* rstd, const unsigned* keep_mask, float p_drop, float* dgamma, float* dbeta, long long M,
+                          int N, int K, void* ws, size_t ws_bytes, void* stream);
+/* keep bits of the dropout stream stage_layernorm_fwd(p_drop, seed) applied to a (rows, K) output: [ceil(K/32)][rows] words */
+int stage_dropout_keepmask(float p_drop, unsigned long long seed, unsigned* mask, long long rows, int K, void* stream);
 /* dW[N,K] = sum_m (dY .* [gate>0])[m,n] X[m,k] ; db[N] = column sums (db may be NULL)                              */
 size_t stage_gemm_tn_ws_bytes(long long M, int N, int K);
 int stage_gemm_tn(const float* dY, const float* gate, const float* X, float* dW, float* db, long long M, int N, int K,

@@ -816,6 +816,36 @@ def test_ln_masked_max_fused(ops, R, L, with_res):
     check("dbeta", f[4], btt.grad.float())
 
 
+@pytest.mark.parametrize("M,K,N,p", [(4200, 768, 300, 0.1), (5000, 300, 300, 0.0), (9000, 128, 72, 0.25), (4100, 260, 128, 0.1)])
+def test_input_ln_linear_fused_backward(ops, M, K, N, p):
+    """First layer of the input MLPs (LayerNorm -> Dropout -> Linear -> ReLU on features that need no gradient): the LayerNorm's
+    gain / bias gradients reduced inside the dX GEMM's epilogue (stage_gemm_nt_lnparam + stage_dropout_keepmask) against the two
+    separate operators with the same dropout seed -- same output, same parameter gradients."""
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g).cuda()
+    gamma, beta = torch.randn(K, generator=g), torch.randn(K, generator=g)
+    w, b = torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    gout = torch.randn(M, N, generator=g).cuda()
+    seed = 1234567
+    assert ops.input_ln_linear_supported(x, w)
+
+    def run(fused):
+        gm, bt = gamma.clone().cuda().requires_grad_(True), beta.clone().cuda().requires_grad_(True)
+        ww, bb = w.clone().cuda().requires_grad_(True), b.clone().cuda().requires_grad_(True)
+        if fused:
+            h = ops.input_ln_linear(x, gm, bt, ww, bb, p=p, seed=seed)
+        else:
+            y, _ = ops.layernorm(x, gm, bt, p=p, seed=seed)
+            h = ops.linear(y, ww, bb, relu=True)
+        h.backward(gout)
+        return [h.detach(), gm.grad, bt.grad, ww.grad, bb.grad]
+    f, u = run(True), run(False)
+    assert torch.equal(f[0], u[0])
+    for name, a, c in zip(("dgamma", "dbeta", "dw", "db"), f[1:], u[1:]):
+        err = float((a - c).abs().max()) / (1e-6 + float(c.abs().max()))
+        assert err < 2e-5, (name, err)
+
+
 def test_cpp_host_runs_the_c_abi(ops, tmp_path):
     """examples/k1_forward_host.cpp (C++ + HIP runtime, no torch) built here and run: its output sums equal the Python
     binding's on the same deterministic inputs."""

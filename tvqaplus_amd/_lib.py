@@ -57,6 +57,10 @@ SIGNATURES = {
     "stage_masked_max_fwd": (I, [P, P, P, P, P, LL, I, I, P]),
     "stage_masked_max_bwd": (I, [P, P, P, P, LL, I, I, I, P]),
     "stage_ln_masked_max_supported": (I, [I, I]),
+    "stage_gemm_nt_lnparam_supported": (I, [LL, I, I]),
+    "stage_gemm_nt_lnparam_ws_bytes": (SZ, [LL, I]),
+    "stage_gemm_nt_lnparam": (I, [P, P, P, P, P, P, P, F, P, P, LL, I, I, P, SZ, P]),
+    "stage_dropout_keepmask": (I, [F, U64, P, LL, I, P]),
     "stage_ln_masked_max_fwd": (I, [P, P, P, P, P, P, P, P, P, P, LL, I, I, F, P]),
     "stage_ln_masked_max_bwd": (I, [P, P, P, P, P, P, P, P, P, P, LL, I, I, P, SZ, P]),
     # bf16 storage mode: same argument lists as the fp32 entry points of the same name

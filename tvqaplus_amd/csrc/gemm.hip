@@ -363,6 +363,28 @@ extern "C" int stage_gemm_mask_supported(long long M, int N, int K) {
     return fwd && dx ? 1 : 0;
 }
 
+// LayerNorm gain / bias gradients straight from the dX product of the Linear behind it (gemm_stream.hip: COLSUM): for a
+// LayerNorm whose INPUT needs no gradient (the first layer of the input MLPs, model/stage.py:85-91, 98-104) the (M, N) gradient
+// of its output is reduced over the rows inside the GEMM epilogue instead of being written and read back.
+size_t stage_gemm_nt_lnparam_ws(long long M, int N);
+int stage_gemm_nt_stream_lnparam(const float* dY, const unsigned* gate_mask, const float* Wt, const float* x, const float* mean,
+                                 const float* rstd, const unsigned* keep_mask, float p_drop, float* dgamma, float* dbeta,
+                                 long long M, int N, int K, void* ws, size_t ws_bytes, void* stream);
+extern "C" int stage_gemm_nt_lnparam_supported(long long M, int N, int K) {
+    if (gemm_exact_f32() || getenv("STAGE_GEMM_TILED") || getenv("STAGE_GEMM_NO_LNPARAM")) return 0;
+    return (K % 4 == 0 && K >= 64 && N % 4 == 0 && M >= 4096 && M * (long long)K * 4 < (1ll << 31) &&
+            M * (long long)N * 4 < (1ll << 31)) ? 1 : 0;
+}
+extern "C" size_t stage_gemm_nt_lnparam_ws_bytes(long long M, int N) { return stage_gemm_nt_lnparam_ws(M, N); }
+extern "C" int stage_gemm_nt_lnparam(const float* dY, const unsigned* gate_mask, const float* Wt, const float* x, const float* mean,
+                                     const float* rstd, const unsigned* keep_mask, float p_drop, float* dgamma, float* dbeta,
+                                     long long M, int N, int K, void* ws, size_t ws_bytes, void* stream) {
+    if (!stage_gemm_nt_lnparam_supported(M, N, K)) return STAGE_ERR_SHAPE;
+    const int rc = stage_gemm_nt_stream_lnparam(dY, gate_mask, Wt, x, mean, rstd, keep_mask, p_drop, dgamma, dbeta, M, N, K, ws,
+                                                ws_bytes, stream);
+    return rc == 1 ? STAGE_ERR_SHAPE : rc;
+}
+
 extern "C" int stage_gemm_nt_mask(const float* X, const unsigned* gate_mask, const float* W, const float* bias, float* Y,
                                   unsigned* relu_mask_out, long long M, int N, int K, int relu, void* stream) {
     if (M <= 0 || N <= 0) return 0;

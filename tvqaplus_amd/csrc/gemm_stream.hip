@@ -140,14 +140,27 @@ __device__ __forceinline__ float4 s_gate4(float4 v, float4 g) {
 // GATE: 0 none, 1 fp32 tensor (x kept where gate > 0), 2 bit mask (uint32 [ceil(K/32)][M] word-major, bit b of word w <=>
 // column 32w + b kept).  MASK_OUT: also emit the ReLU bit mask of Y (uint32 [ceil(N/32)][M]) for the two backward GEMMs -- they
 // then read 1/32 of the bytes the fp32 gate costs.
-template <int GATE, bool HAS_RES, bool WPRE, bool MASK_OUT>
+// COLSUM: the product is the gradient of a LayerNorm OUTPUT whose input needs no gradient (the first layer of the input MLPs:
+// LN(768) -> dropout -> Linear(768 -> 300), model/stage.py:85-91): only the LayerNorm's gain / bias gradients are wanted,
+//     dgamma[n] = sum_m Y[m,n] * keep[m,n] / (1-p) * x_hat[m,n]      dbeta[n] = sum_m Y[m,n] * keep[m,n] / (1-p)
+// so the tile is reduced over its rows in the epilogue and never stored (737 MB written and read back by a LayerNorm backward
+// for 2 x 768 numbers, at the subtitle stream).  R = the LayerNorm input x (M, N), cs = {mean, rstd (M each), keep bits}; per wave and
+// column the partial sums go to cs_part[(row group * 8 + wave)][2][N], finished by the column reduction of the LayerNorm backward.
+struct StageColsum {
+    const float* mean;
+    const float* rstd;
+    float* part;
+    const unsigned* keep;   // dropout keep bits of the LayerNorm output, [ceil(N/32)][M] words (NULL: no dropout); hashing them
+    float inv_keep;         // here (64-bit multiplies) spilled 600 registers, a 23 MB bit mask from a 30 us pre-pass does not
+};
+template <int GATE, bool HAS_RES, bool WPRE, bool MASK_OUT, bool COLSUM = false>
 __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const float* __restrict__ X,
                                                                         const float* __restrict__ G,
                                                                         const float* __restrict__ W,
                                                                         const float* __restrict__ bias,
                                                                         const float* __restrict__ R, float* __restrict__ Y,
                                                                         unsigned* __restrict__ mask_out, long M, int N,
-                                                                        int K, int relu, int xcd_gx) {
+                                                                        int K, int relu, int xcd_gx, StageColsum cs = StageColsum()) {
     constexpr bool HAS_GATE = GATE == 1;
     extern __shared__ __attribute__((aligned(16))) unsigned short Wp[];   // [3][SBN][SWS] bf16, k permuted per 16-group
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -305,11 +318,24 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
     // the current one has been consumed (straight-line code: asm results defined inside a branch get merged by register
     // copies, and a copy of a register whose load is still in flight copies garbage).  When the next unit is a new tile,
     // that request therefore precedes the 64 stores of the current tile ("steady": the waits then use vmcnt(63)).
-    const bool full_cols = n0 + SBN <= N;                 // this workgroup stores all 4 column tiles: 64 stores per tile
+    const bool full_cols = !COLSUM && n0 + SBN <= N;      // this workgroup stores all 4 column tiles: 64 stores per tile (COLSUM: none)
     bool w_loaded = false, first = true, after_stores = false;
     if (multi) w_issue(0);
     fetch(0, ((long)bx * SWAVES + wave) * 32 + l31, 0);
     fetch(1, ((long)bx * SWAVES + wave) * 32 + l31, 32);
+    // COLSUM: running column sums of this wave, kept in LDS (lane-private slots [wave][h][dgamma | dbeta][128 columns]: eight more
+    // live registers spill next to the loads in flight)
+    float* cs_acc = reinterpret_cast<float*>(Wp + 3 * SPLANE) + SBN + (wave * 2 + h) * 2 * SBN;
+    const int NWN_cs = (N + 31) >> 5;
+    const __amdgpu_buffer_rsrc_t cs_rx = __builtin_amdgcn_make_buffer_rsrc((void*)(COLSUM ? R : X), 0, (int)(M * (COLSUM ? N : K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t cs_rm = __builtin_amdgcn_make_buffer_rsrc((void*)(COLSUM ? cs.mean : X), 0, (int)(M * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t cs_rr = __builtin_amdgcn_make_buffer_rsrc((void*)(COLSUM ? cs.rstd : X), 0, (int)(M * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t cs_rk = __builtin_amdgcn_make_buffer_rsrc((void*)((COLSUM && cs.keep) ? (const void*)cs.keep : (const void*)X), 0,
+                                                                           (int)(M * NWN_cs * 4), 0x00020000);
+    if (COLSUM) {
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) cs_acc[nt * 32 + l31] = cs_acc[SBN + nt * 32 + l31] = 0.f;
+    }
     for (long bt = bx; bt < n_bt; bt += gx) {
         const long t = bt * SWAVES + wave;               // this wave's tile (may be past the end: then it only syncs)
         const bool live = t < MT;
@@ -504,6 +530,39 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
                 for (int nt = 0; nt < 4; nt++) acc[nt][r] = __builtin_ldexpf(acc[nt][r], dr);
             }
         }
+        if (COLSUM) {
+            // rows of this lane: t*32 + 4h + dm(r); column n0 + nt*32 + l31 = bit l31 of keep word (n0 >> 5) + nt of the row
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                if (n0 + nt * 32 >= N) continue;          // whole column tile past N (uniform)
+                const int n = n0 + nt * 32 + l31;
+                const bool nok = n < N;
+                const int ncl = nok ? n : N - 1;
+                float sg = 0.f, sb = 0.f;
+                // buffer loads: descriptors in SGPRs, one 32-bit lane offset per group, the row step as a scalar offset (64-bit
+                // per-load addresses cost two VGPRs each and spilled).  Rows past the end of a tensor read 0: rstd = 0 removes them.
+#pragma unroll
+                for (int rq = 0; rq < 4; rq++) {          // rows 8 rq + 4h + 0..3 of the tile
+                    const int m0 = (int)(t * 32) + 4 * h + 8 * rq;
+                    const int vx = (m0 * N + ncl) * 4, vm = m0 * 4;
+                    const int vk = (((n0 >> 5) + nt) * (int)M + m0) * 4;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const float xv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(cs_rx, vx, j * N * 4, 0));
+                        const float mu = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(cs_rm, vm, j * 4, 0));
+                        const float rsd = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(cs_rr, vm, j * 4, 0));
+                        const unsigned kw = cs.keep ? __builtin_amdgcn_raw_buffer_load_b32(cs_rk, vk, j * 4, 0) : 0xFFFFFFFFu;
+                        const bool keep = nok && m0 + j < M && ((kw >> l31) & 1u);
+                        const float gq = keep ? acc[nt][4 * rq + j] * cs.inv_keep : 0.f;
+                        sb += gq;
+                        sg += gq * ((xv - mu) * rsd);
+                    }
+                }
+                cs_acc[nt * 32 + l31] += sg;
+                cs_acc[SBN + nt * 32 + l31] += sb;
+            }
+            continue;
+        }
 #pragma unroll
         for (int nt = 0; nt < 4; nt++) {
             if (n0 + nt * 32 >= N) continue;              // whole column tile past N (uniform)
@@ -551,6 +610,19 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
                     const int dm = (r & 3) + 8 * (r >> 2);
                     if (nok && t * 32 + 4 * h + dm < M) yp[(long)dm * N] = acc[nt][r];
                 }
+            }
+        }
+    }
+    if (COLSUM) {   // the two lane halves hold different rows of the same columns; one partial row per (row group, wave)
+        float* prow = cs.part + ((long)bx * SWAVES + wave) * 2 * N;
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+            const float g1 = cs_acc[nt * 32 + l31], b1 = cs_acc[SBN + nt * 32 + l31];
+            const float sg = xsum32(g1, g1), sb = xsum32(b1, b1);
+            const int n = n0 + nt * 32 + l31;
+            if (h == 0 && n < N) {
+                prow[n] = sg;
+                prow[N + n] = sb;
             }
         }
     }
@@ -611,6 +683,70 @@ int stage_gemm_nt_stream(const float* X, const void* gate, int gate_kind, const 
     else if (gate_kind == 1) { if (residual) LAUNCH_ST(1, true, false); else LAUNCH_ST(1, false, false); }
     else { if (residual) LAUNCH_ST(0, true, false); else LAUNCH_ST(0, false, false); }
 #undef LAUNCH_ST
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+// LayerNorm gain / bias gradients straight from the dX product (kernel comment at StageColsum).  dY (M, K) [gated by the ReLU bit
+// mask], Wt (N, K) = the Linear's weight transposed, x / mean / rstd = the LayerNorm's input and statistics, keep_mask = the keep
+// bits of its dropout ([ceil(N/32)][M] words, stage_dropout_keepmask; NULL when p_drop == 0).  Workspace: stage_gemm_nt_lnparam_ws_bytes.  Returns 1 when the shape is not handled (caller: dX + LayerNorm backward).
+static long colsum_rows(long long M, int N) {
+    const long MT = (M + 31) / 32, n_bt = (MT + SWAVES - 1) / SWAVES;
+    const int n_tiles = (N + SBN - 1) / SBN;
+    long gx = 256 / n_tiles;
+    if (gx < 1) gx = 1;
+    if (gx > n_bt) gx = n_bt;
+    if (n_tiles > 1 && gx >= 8) gx = gx / 8 * 8;
+    return gx * SWAVES;
+}
+size_t stage_gemm_nt_lnparam_ws(long long M, int N) { return (size_t)colsum_rows(M, N) * 2 * (size_t)N * sizeof(float); }
+int stage_gemm_nt_stream_lnparam(const float* dY, const unsigned* gate_mask, const float* Wt, const float* x, const float* mean,
+                                 const float* rstd, const unsigned* keep_mask, float p_drop, float* dgamma, float* dbeta,
+                                 long long M, int N, int K, void* ws, size_t ws_bytes, void* stream) {
+    const bool vec = (K % 4 == 0) && K >= 4 && (((uintptr_t)dY & 15) == 0) && (((uintptr_t)Wt & 15) == 0);
+    if (!STAGE_GEMM_NT_F16 || !vec || M < 4096 || K < 64 || N % 4 != 0 || M * (long long)K * 4 >= (1ll << 31) ||
+        M * (long long)N * 4 >= (1ll << 31))
+        return 1;
+    if (ws_bytes < stage_gemm_nt_lnparam_ws(M, N)) return STAGE_ERR_WORKSPACE;
+    const int lds = 3 * SPLANE * (int)sizeof(unsigned short) + SBN * (int)sizeof(float) + SWAVES * 2 * 2 * SBN * (int)sizeof(float);
+    const long MT = (M + 31) / 32, n_bt = (MT + SWAVES - 1) / SWAVES;
+    const int n_tiles = (N + SBN - 1) / SBN;
+    long gx = 256 / n_tiles;
+    if (gx < 1) gx = 1;
+    if (gx > n_bt) gx = n_bt;
+    int xcd_gx = 0;
+    if (n_tiles > 1 && gx >= 8) {
+        gx = gx / 8 * 8;
+        xcd_gx = (int)gx;
+    }
+    dim3 grid(xcd_gx ? (unsigned)(gx * n_tiles) : (unsigned)gx, xcd_gx ? 1u : (unsigned)n_tiles), block(64 * SWAVES);
+    StageColsum cs;
+    cs.mean = mean;
+    cs.rstd = rstd;
+    cs.part = (float*)ws;
+    const bool dr = p_drop > 0.f;
+    if (dr && !keep_mask) return STAGE_ERR_SHAPE;
+    cs.keep = dr ? keep_mask : nullptr;
+    cs.inv_keep = dr ? 1.0f / (1.0f - p_drop) : 1.0f;
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_CS(GT)                                                                                                  \
+    do {                                                                                                               \
+        static bool attr_done = false;                                                                                 \
+        if (!attr_done) {                                                                                              \
+            (void)hipFuncSetAttribute((const void*)gemm_nt_stream_kernel<GT, false, false, false, true>,               \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                \
+            attr_done = true;                                                                                          \
+        }                                                                                                              \
+        hipLaunchKernelGGL((gemm_nt_stream_kernel<GT, false, false, false, true>), grid, block, lds, st, dY,            \
+                           (const float*)gate_mask, Wt, (const float*)nullptr, x, (float*)nullptr, (unsigned*)nullptr, \
+                           (long)M, N, K, 0, xcd_gx, cs);                                                              \
+    } while (0)
+    if (gate_mask) LAUNCH_CS(2);
+    else LAUNCH_CS(0);
+#undef LAUNCH_CS
+    STAGE_LAUNCH_CHECK();
+    // column c = t*N + n of the [2][N] partial rows goes to dgamma[n] (t = 0) or dbeta[n] (t = 1)
+    stage_colreduce(cs.part, dgamma, dbeta, (int)colsum_rows(M, N), (long)2 * N, 2 * N, N, 1, st);
     STAGE_LAUNCH_CHECK();
     return 0;
 }

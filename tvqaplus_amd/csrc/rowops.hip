@@ -1089,6 +1089,34 @@ __global__ __launch_bounds__(256) void ln_mm_fwd_kernel(const T* __restrict__ x,
     }
 }
 
+// keep bits of the dropout stream that stage_layernorm_fwd (p_drop, seed) applied to a (rows, K) output: word-major
+// [ceil(K/32)][rows], bit b of word w <=> element 32 w + b kept (the format of the ReLU masks of the GEMMs)
+__global__ __launch_bounds__(256) void dropout_keepmask_kernel(unsigned* __restrict__ mask, long rows, int K, uint64_t seed, uint32_t th) {
+    const int K4 = K >> 2, NW = (K + 31) >> 5;
+    const long total = rows * NW;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int w = (int)(e / rows);
+        const long row = e - (long)w * rows;
+        unsigned bits = 0u;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int jq = 8 * w + q;
+            if (jq < K4) bits |= drop4_bits(seed, (uint64_t)row * K4 + jq, th) << (4 * q);
+        }
+        mask[e] = bits;
+    }
+}
+extern "C" int stage_dropout_keepmask(float p_drop, unsigned long long seed, unsigned* mask, long long rows, int K, void* stream) {
+    if (rows <= 0) return 0;
+    if (K % 4 != 0 || !(p_drop > 0.f)) return STAGE_ERR_SHAPE;
+    const long total = rows * ((K + 31) / 32);
+    const int grid = stage_grid_for(total, 256, GRID_CAP * 8);
+    hipLaunchKernelGGL(dropout_keepmask_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, mask, (long)rows, K, (uint64_t)seed,
+                       drop_thresh16(p_drop));
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int stage_ln_masked_max_supported(int L, int K) { return (K == 128 && L >= 1) ? 1 : 0; }
 
 extern "C" int stage_ln_masked_max_fwd(const float* x, const float* res, float* sum_out, const float* gamma, const float* beta,

@@ -370,6 +370,69 @@ def linear(x, w, bias=None, relu: bool = False):
     return _Linear.apply(x, w, bias, relu)
 
 
+class _InputLnLinear(torch.autograd.Function):
+    """relu(linear(drop(LN(x)))) for an input that needs NO gradient (first layer of the input MLPs): forward = the LayerNorm and
+    the Linear kernels; backward = weight gradient + the LayerNorm's gain / bias gradients reduced inside the dX GEMM's epilogue
+    (stage_gemm_nt_lnparam) -- the (M, K) gradient of the LayerNorm output is never written."""
+    @_on_device
+    def forward(ctx, x, gamma, beta, w, bias, p: float, seed: int):
+        x = _chk(x, "x")
+        K = x.shape[-1]
+        M = x.numel() // K
+        gamma, beta = _chk(gamma, "gamma"), _chk(beta, "beta")
+        w2, bias_c = _chk(w, "w").reshape(w.shape[0], -1), _chk(bias, "bias")
+        N = w2.shape[0]
+        y = torch.empty_like(x)
+        mean = torch.empty(M, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        _call("stage_layernorm_fwd", _ptr(x), None, 0, None, _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), M, K, EPS_LN,
+              float(p), int(seed), _stream())
+        h = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+        mask = torch.empty((N + 31) // 32, M, dtype=torch.int32, device=x.device)
+        _call("stage_gemm_nt_mask", _ptr(y), None, _ptr(w2), _ptr(bias_c), _ptr(h), _ptr(mask), M, N, K, 1, _stream())
+        ctx.save_for_backward(x, mean, rstd, y, w2, mask)
+        ctx.p, ctx.seed, ctx.wshape, ctx.w_obj = float(p), int(seed), w.shape, w
+        return h
+
+    @_on_device
+    def backward(ctx, dh):
+        x, mean, rstd, y, w2, mask = ctx.saved_tensors
+        N, K = w2.shape
+        M = x.numel() // K
+        dh = _chk(dh, "dh")
+        lib = _lib.load()
+        dw, db = torch.empty_like(w2), torch.empty(N, dtype=torch.float32, device=x.device)
+        wsb = lib.stage_gemm_tn_ws_bytes(M, N, K)
+        ws = _workspace(wsb, x.device)
+        _call("stage_gemm_tn_mask", _ptr(dh), _ptr(mask), _ptr(y), _ptr(dw), _ptr(db), M, N, K, _ptr(ws), wsb, _stream())
+        keep = None
+        if ctx.p > 0.0:
+            keep = torch.empty((K + 31) // 32, M, dtype=torch.int32, device=x.device)
+            _call("stage_dropout_keepmask", ctx.p, ctx.seed, _ptr(keep), M, K, _stream())
+        wt = _transposed_weight(ctx.w_obj, w2)          # (K, N)
+        dgamma, dbeta = torch.empty(K, dtype=torch.float32, device=x.device), torch.empty(K, dtype=torch.float32, device=x.device)
+        wsb2 = lib.stage_gemm_nt_lnparam_ws_bytes(M, K)
+        ws2 = _workspace(wsb2, x.device)
+        _call("stage_gemm_nt_lnparam", _ptr(dh), _ptr(mask), _ptr(wt), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(keep), ctx.p, _ptr(dgamma),
+              _ptr(dbeta), M, K, N, _ptr(ws2), wsb2, _stream())
+        return None, dgamma, dbeta, dw.view(ctx.wshape), db, None, None
+
+
+def input_ln_linear_supported(x, w) -> bool:
+    """The fused backward of ``input_ln_linear`` applies: fp32 storage, x needs no gradient, shapes the streaming kernels take."""
+    if x.dtype != torch.float32 or x.requires_grad or not torch.is_grad_enabled():
+        return False
+    K = x.shape[-1]
+    M, N = x.numel() // K, w.shape[0]
+    lib = _lib.load()
+    return bool(lib.stage_gemm_mask_supported(M, N, K)) and bool(lib.stage_gemm_nt_lnparam_supported(M, K, N)) and x.data_ptr() % 16 == 0
+
+
+def input_ln_linear(x, gamma, beta, w, bias, p: float = 0.0, seed: int = 0):
+    """relu(linear(drop(LayerNorm(x)))) for a feature tensor that needs no gradient (see _InputLnLinear)."""
+    return _InputLnLinear.apply(x, gamma, beta, w, bias, p, seed)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # depthwise Conv1d along L
 # ---------------------------------------------------------------------------------------------------------------

@@ -195,6 +195,9 @@ class STAGE(nn.Module):
         # developer switch: False (or STAGE_NO_FUSE_LN_DWCONV=1) = separate LayerNorm and depthwise-conv kernels
         self.fuse_ln_dwconv = os.environ.get("STAGE_NO_FUSE_LN_DWCONV") is None
         self.fuse_ln_max = os.environ.get("STAGE_NO_FUSE_LN_MAX") is None
+        # opt-in: correct, but 0.6 ms SLOWER per step as built (DESIGN.md finding 25) -- the register budget forces the variant
+        # without the weight-chunk prefetch
+        self.fuse_input_ln = os.environ.get("STAGE_FUSE_INPUT_LN") is not None
         # storage type of the activations between kernels: fp32 (the reference's), or bf16 with ``opt.storage_dtype = "bf16"``
         # (BASELINE.json configs[4]: bf16 weights / activations, fp32 softmax / statistics / accumulation; parameters stay
         # fp32 master copies, a weight is rounded to bf16 when a GEMM stages it; scores, losses and logits are fp32)
@@ -282,8 +285,13 @@ class STAGE(nn.Module):
             data = data.to(self.storage)      # bf16 storage: features are rounded once on entry
         if l2_normalize:
             data = ops.l2norm(data)
-        y, _ = self._ln(data, init_encoder[0], drop=True)
-        y = ops.linear(y, init_encoder[2].weight, init_encoder[2].bias, relu=True)
+        if self.fuse_input_ln and ops.input_ln_linear_supported(data, init_encoder[2].weight):
+            # features need no gradient: the first LayerNorm's gain / bias gradients come out of the dX GEMM's epilogue
+            y = ops.input_ln_linear(data, init_encoder[0].weight, init_encoder[0].bias, init_encoder[2].weight, init_encoder[2].bias,
+                                    p=self._p(), seed=self._seed())
+        else:
+            y, _ = self._ln(data, init_encoder[0], drop=True)
+            y = ops.linear(y, init_encoder[2].weight, init_encoder[2].bias, relu=True)
         y, _ = self._ln(y, init_encoder[4], drop=True)            # LN(300) then input_embedding's Dropout
         y = ops.linear(y, downsize_encoder[1].weight, downsize_encoder[1].bias, relu=True)
         y, _ = self._ln(y, downsize_encoder[3])
