@@ -4,15 +4,15 @@
 TAG=${1:-r02}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-python bench.py > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench.err
-python bench.py --no_cpu_baseline --dense > gpurun_out/${TAG}_bench_line_dense.json 2>> gpurun_out/${TAG}_bench.err
-bash tools/trace_bench.sh ${TAG}_bench > /dev/null 2>&1
+timeout 600 python bench.py > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench.err
+timeout 300 python bench.py --no_cpu_baseline --dense > gpurun_out/${TAG}_bench_line_dense.json 2>> gpurun_out/${TAG}_bench.err
+timeout 300 bash tools/trace_bench.sh ${TAG}_bench > /dev/null 2>&1
 # K1 forward PMC: bench.py --only_roofline launches the video shape then the subtitle shape
-bash tools/pmc_run.sh ${TAG}_k1_fwd str_attn_fwd python bench.py --only_roofline > /dev/null 2>&1
-bash tools/pmc_run.sh ${TAG}_k1_bwd_vid str_attn_bwd_fused python tools/k1_bwd_times.py > /dev/null 2>&1
-LR=50 bash tools/pmc_run.sh ${TAG}_k1_bwd_sub str_attn_bwd_fused python tools/k1_bwd_times.py > /dev/null 2>&1
-bash tools/pmc_run.sh ${TAG}_gemm_nt gemm_nt_stream python tools/gemm_one.py 960000 128 384 nt > /dev/null 2>&1
-bash tools/pmc_run.sh ${TAG}_gemm_tn gemm_tn_quad python tools/gemm_one.py 960000 128 384 tn > /dev/null 2>&1
-python tools/k1_bwd_times.py > gpurun_out/${TAG}_k1_bwd_times_vid.txt 2>&1
-LR=50 python tools/k1_bwd_times.py > gpurun_out/${TAG}_k1_bwd_times_sub.txt 2>&1
+timeout 400 bash tools/pmc_run.sh ${TAG}_k1_fwd str_attn_fwd python bench.py --only_roofline > /dev/null 2>&1
+timeout 400 bash tools/pmc_run.sh ${TAG}_k1_bwd_vid str_attn_bwd_fused python tools/k1_bwd_times.py > /dev/null 2>&1
+LR=50 timeout 400 bash tools/pmc_run.sh ${TAG}_k1_bwd_sub str_attn_bwd_fused python tools/k1_bwd_times.py > /dev/null 2>&1
+timeout 400 bash tools/pmc_run.sh ${TAG}_gemm_nt gemm_nt_stream python tools/gemm_one.py 960000 128 384 nt > /dev/null 2>&1
+timeout 400 bash tools/pmc_run.sh ${TAG}_gemm_tn gemm_tn_quad python tools/gemm_one.py 960000 128 384 tn > /dev/null 2>&1
+timeout 200 python tools/k1_bwd_times.py > gpurun_out/${TAG}_k1_bwd_times_vid.txt 2>&1
+LR=50 timeout 200 python tools/k1_bwd_times.py > gpurun_out/${TAG}_k1_bwd_times_sub.txt 2>&1
 ls gpurun_out | grep ${TAG}
