@@ -22,7 +22,7 @@
                         // 16 weight fragments read from LDS for one of the four column tiles only; TN share kernel: 1, 2, 4 alike,
                         // 32 no barrier
 #ifndef STAGE_GEMM_TERMS
-#define STAGE_GEMM_TERMS 3      // bf16 terms per fp32 operand: 3 = exact split (six products kept, 3e-7 vs fp64);
+#define STAGE_GEMM_TERMS 3      // bf16 mode only (STAGE_GEMM_NT_F16 / _TN_F16 = 0): bf16 terms per fp32 operand: 3 = exact split (six products, 3e-7 vs fp64);
 #endif                          // 2 = hi + mid only (three products kept: every product carries a relative error <= ~2^-17,
                                 // measured ~1e-5 of the result's scale; half the matrix-core work) -- `make TERMS=2`
 #define SBN 128                 // output columns per workgroup
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64 * SWAVES, 2) void gemm_nt_stream_kernel(const fl
                                                                         unsigned* __restrict__ mask_out, long M, int N,
                                                                         int K, int relu, int xcd_gx, StageColsum cs = StageColsum()) {
     constexpr bool HAS_GATE = GATE == 1;
-    extern __shared__ __attribute__((aligned(16))) unsigned short Wp[];   // [3][SBN][SWS] bf16, k permuted per 16-group
+    extern __shared__ __attribute__((aligned(16))) unsigned short Wp[];   // [2 fp16 planes (3 bf16 planes)][SBN][SWS], k permuted per 16-group
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     // Workgroup -> (row group bx, column tile by).  Workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own
@@ -760,7 +760,7 @@ int stage_gemm_nt_stream_lnparam(const float* dY, const unsigned* gate_mask, con
 // lines, 4x more VMEM instructions than dwordx4 but no LDS, no barrier, no transpose.  The loads are buffer loads
 // (resource + wave-uniform row offset in an SGPR + constant 32-bit lane offset): no 64-bit per-lane address arithmetic
 // in the loop, and rows past the end of the tensor read as 0.  Each wave owns a 64 x 64 patch of the 128 x 128 output tile
-// of its workgroup (2 x 2 MFMA tiles, exact 3-way bf16 split on v_mfma_f32_32x32x16_bf16) and walks the rows of its slab
+// of its workgroup (2 x 2 MFMA tiles; this variant without operand sharing still runs the 3-way bf16 split) and walks the rows of its slab
 // 16 at a time with the next step's 32 (48 with gate) loads in flight.
 // =====================================================================================================================
 __device__ __forceinline__ float s_buf_load(__amdgpu_buffer_rsrc_t r, int voff_bytes, int soff_bytes) {
