@@ -1361,21 +1361,24 @@ __global__ __launch_bounds__(64 * TW_WAVES, 2) void gemm_tn_wide_kernel(const fl
 // kernels above (a shared exponent for the four columns of a lane would save 30 VALU instructions per double step, but a
 // weak column next to a strong one would lose its relative accuracy -- and Adam normalises every weight's gradient).
 // ---------------------------------------------------------------------------------------------------------------------
-#define TQ_TILES 16     // operand tiles per workgroup: 4 of dY (one quad), 12 of X (three quads)
-template <int GATE>     // 0 none, 2 bit mask
-__global__ __launch_bounds__(64 * TW_WAVES, 2) void gemm_tn_quad_kernel(const float* __restrict__ dY, const unsigned* __restrict__ G,
+// NXQ = X quads per workgroup: 3 (K > 128: 128 x 384 tile, 8 waves, wave patch 64 x 96) or 1 (K <= 128: 128 x 128 tile, 4 waves,
+// wave patch 64 x 64, two workgroups per CU)
+template <int GATE, int NXQ>     // GATE: 0 none, 2 bit mask
+__global__ __launch_bounds__(128 * (1 + NXQ), 2) void gemm_tn_quad_kernel(const float* __restrict__ dY, const unsigned* __restrict__ G,
                                                                         const float* __restrict__ X, float* __restrict__ part,
                                                                         float* __restrict__ part_b, long M, int N, int K,
                                                                         long rows_per_split) {
-    // [2 buffers][2 MFMA steps][16 tiles][2 planes][64 lanes] uint4 (128 KB), then [2 buffers][16 tiles][32] exponent changes
+    // [2 buffers][2 MFMA steps][TQ_TILES][2 planes][64 lanes] uint4 (128 / 64 KB), then [2 buffers][TQ_TILES][32] exponent changes
+    constexpr int TQ_TILES = 4 * (1 + NXQ);           // operand tiles per workgroup: 4 of dY (one quad), 4 per X quad
+    constexpr int TJ = NXQ == 3 ? 3 : 2;              // X tiles per consumer wave
     extern __shared__ __attribute__((aligned(16))) uint4 exq[];
     int* exd = reinterpret_cast<int*>(exq + 2 * 2 * TQ_TILES * 2 * 64);
     // the wave index decides descriptor and leading dimension of the loads: as an SGPR value (the compiler cannot prove
     // threadIdx.x >> 6 uniform and would wrap every buffer load into a waterfall loop)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, h = lane >> 5;
-    const int pn = wave >> 2, pk = wave & 3;              // consumer role: rows pn (2 dY tiles), columns pk (3 X tiles)
-    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 384;
+    const int pn = NXQ == 3 ? wave >> 2 : wave >> 1, pk = NXQ == 3 ? wave & 3 : wave & 1;   // consumer role: rows pn (2 dY tiles), columns pk (TJ X tiles)
+    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128 * NXQ;
     const int split = blockIdx.z;
     const long mbeg = (long)split * rows_per_split;
     const long mend = min(M, mbeg + rows_per_split);
@@ -1395,16 +1398,16 @@ __global__ __launch_bounds__(64 * TW_WAVES, 2) void gemm_tn_quad_kernel(const fl
     const int gcol = min(n0 + 4 * pl, N - 4);
     const int gbit = gcol & 31;                           // bits gbit .. gbit + 3 of the mask word belong to this group
     const int moff = (int)(((long)(gcol >> 5) * M + 16 * ps + 8 * ph) * 4);   // [word][row] mask
-    f32x16 acc[2][3];
+    f32x16 acc[2][TJ];
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 3; j++)
+        for (int j = 0; j < TJ; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
     int eb[4] = {0, 0, 0, 0};                             // running exponents of the four columns this lane prepares
-    int upA[2] = {254, 254}, upB[3] = {254, 254, 254};    // scale fields in force for the tiles this wave consumes
+    int upA[2] = {254, 254}, upB[3] = {254, 254, 254};    // (TJ of upB used)    // scale fields in force for the tiles this wave consumes
     const bool want_b = part_b != nullptr && blockIdx.y == 0 && is_y;
 
     typedef unsigned tq_u4 __attribute__((ext_vector_type(4)));
@@ -1464,24 +1467,24 @@ __global__ __launch_bounds__(64 * TW_WAVES, 2) void gemm_tn_quad_kernel(const fl
         }
     };
     auto consume = [&](int xb) {
-        int dA[2], dB[3];
+        int dA[2], dB[3] = {0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 2; i++) dA[i] = exd[(xb * TQ_TILES + pn * 2 + i) * 32 + l31];
 #pragma unroll
-        for (int j = 0; j < 3; j++) dB[j] = exd[(xb * TQ_TILES + 4 + pk * 3 + j) * 32 + l31];
-        if (__any((dA[0] | dA[1] | dB[0] | dB[1] | dB[2]) != 0)) {   // a column's scale moved: bring the accumulators along
+        for (int j = 0; j < TJ; j++) dB[j] = exd[(xb * TQ_TILES + 4 + pk * TJ + j) * 32 + l31];
+        if (__any((dA[0] | dA[1] | dB[0] | dB[1] | dB[2]) != 0)) {   // (dB[2] stays 0 for TJ == 2)   // a column's scale moved: bring the accumulators along
 #pragma unroll
             for (int i = 0; i < 2; i++) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int dr = __builtin_amdgcn_ds_bpermute(4 * h_row_of(r, h), dA[i]);
 #pragma unroll
-                    for (int j = 0; j < 3; j++) acc[i][j][r] = __builtin_ldexpf(acc[i][j][r], dr + dB[j]);
+                    for (int j = 0; j < TJ; j++) acc[i][j][r] = __builtin_ldexpf(acc[i][j][r], dr + dB[j]);
                 }
                 upA[i] += dA[i];
             }
 #pragma unroll
-            for (int j = 0; j < 3; j++) upB[j] += dB[j];
+            for (int j = 0; j < TJ; j++) upB[j] += dB[j];
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; s2++) {
@@ -1492,10 +1495,10 @@ __global__ __launch_bounds__(64 * TW_WAVES, 2) void gemm_tn_quad_kernel(const fl
 #pragma unroll
                 for (int p2 = 0; p2 < 2; p2++) a[i][p2] = __builtin_bit_cast(sf16x8, exb[((pn * 2 + i) * 2 + p2) * 64]);
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
+            for (int j = 0; j < TJ; j++) {
                 sf16x8 b[2];
 #pragma unroll
-                for (int p2 = 0; p2 < 2; p2++) b[p2] = __builtin_bit_cast(sf16x8, exb[((4 + pk * 3 + j) * 2 + p2) * 64]);
+                for (int p2 = 0; p2 < 2; p2++) b[p2] = __builtin_bit_cast(sf16x8, exb[((4 + pk * TJ + j) * 2 + p2) * 64]);
 #pragma unroll
                 for (int i = 0; i < 2; i++) acc[i][j] = h_mfma_terms(a[i], b, acc[i][j]);
             }
@@ -1520,14 +1523,14 @@ __global__ __launch_bounds__(64 * TW_WAVES, 2) void gemm_tn_quad_kernel(const fl
         for (int r = 0; r < 16; r++) {
             const int ua = __builtin_amdgcn_ds_bpermute(4 * h_row_of(r, h), upA[i]);
 #pragma unroll
-            for (int j = 0; j < 3; j++) acc[i][j][r] = __builtin_ldexpf(acc[i][j][r], 254 - ua - upB[j]);
+            for (int j = 0; j < TJ; j++) acc[i][j][r] = __builtin_ldexpf(acc[i][j][r], 254 - ua - upB[j]);
         }
     float* po = part + (size_t)split * N * K;
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const int idx = pk * 3 + j;
+        for (int j = 0; j < TJ; j++) {
+            const int idx = pk * TJ + j;
             const int k = k0 + 128 * (idx >> 2) + 4 * l31 + (idx & 3);
             if (k >= K) continue;
 #pragma unroll
@@ -1579,15 +1582,15 @@ int stage_gemm_tn_stream(const float* dY, const void* gate, int gate_kind, const
         static const bool no_quad = getenv("STAGE_GEMM_TN_NOQUAD") != nullptr;
         if (STAGE_GEMM_TN_F16 && !no_quad && gate_kind != 1 && N % 4 == 0 && K % 4 == 0 && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0 &&
             (gate_kind != 2 || (M % 4 == 0 && ((uintptr_t)gate & 15) == 0 && rows_per_split % 16 == 0))) {
-            const int ldsq = 2 * 2 * TQ_TILES * 2 * 64 * (int)sizeof(uint4) + 2 * TQ_TILES * 32 * (int)sizeof(int);
+            const int ldsq = 2 * 2 * 16 * 2 * 64 * (int)sizeof(uint4) + 2 * 16 * 32 * (int)sizeof(int);
 #define LAUNCH_TNQ(GT)                                                                                                 \
     do {                                                                                                               \
         static bool attr_done = false;                                                                                 \
         if (!attr_done) {                                                                                              \
-            (void)hipFuncSetAttribute((const void*)gemm_tn_quad_kernel<GT>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsq); \
+            (void)hipFuncSetAttribute((const void*)gemm_tn_quad_kernel<GT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsq); \
             attr_done = true;                                                                                          \
         }                                                                                                              \
-        hipLaunchKernelGGL(gemm_tn_quad_kernel<GT>, gridw, dim3(64 * TW_WAVES), ldsq, (hipStream_t)stream, dY,         \
+        hipLaunchKernelGGL((gemm_tn_quad_kernel<GT, 3>), gridw, dim3(64 * TW_WAVES), ldsq, (hipStream_t)stream, dY,    \
                            (const unsigned*)gate, X, part, part_b, (long)M, N, K, rows_per_split);                     \
     } while (0)
             if (gate_kind == 2) LAUNCH_TNQ(2);
@@ -1615,6 +1618,28 @@ int stage_gemm_tn_stream(const float* dY, const void* gate, int gate_kind, const
         return 0;
     }
     dim3 grid((N + 127) / 128, (K + 127) / 128, S);
+    {   // K <= 128: the quad kernel with ONE X quad (row-wise 16-byte loads; same conditions as above)
+        static const bool no_quad1 = getenv("STAGE_GEMM_TN_NOQUAD") != nullptr;
+        if (STAGE_GEMM_TN_F16 && !no_quad1 && gate_kind != 1 && N % 4 == 0 && K % 4 == 0 && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0 &&
+            (gate_kind != 2 || (M % 4 == 0 && ((uintptr_t)gate & 15) == 0 && rows_per_split % 16 == 0))) {
+            const int ldsq1 = 2 * 2 * 8 * 2 * 64 * (int)sizeof(uint4) + 2 * 8 * 32 * (int)sizeof(int);
+#define LAUNCH_TNQ1(GT)                                                                                                \
+    do {                                                                                                               \
+        static bool attr_done = false;                                                                                 \
+        if (!attr_done) {                                                                                              \
+            (void)hipFuncSetAttribute((const void*)gemm_tn_quad_kernel<GT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsq1); \
+            attr_done = true;                                                                                          \
+        }                                                                                                              \
+        hipLaunchKernelGGL((gemm_tn_quad_kernel<GT, 1>), grid, dim3(256), ldsq1, (hipStream_t)stream, dY,              \
+                           (const unsigned*)gate, X, part, part_b, (long)M, N, K, rows_per_split);                     \
+    } while (0)
+            if (gate_kind == 2) LAUNCH_TNQ1(2);
+            else LAUNCH_TNQ1(0);
+#undef LAUNCH_TNQ1
+            STAGE_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     static const bool no_share = getenv("STAGE_GEMM_TN_NOSHARE") != nullptr;
 #define LAUNCH_TNS(GT)                                                                                                 \
     do {                                                                                                               \
