@@ -174,3 +174,17 @@ def test_cpp_host_example_builds_against_the_c_abi(tmp_path):
                            os.path.join(root, "examples", "k1_forward_host.cpp"), "-L", os.path.join(root, "tvqaplus_amd"),
                            "-lstage_hip", "-o", exe])
     assert os.path.getsize(exe) > 0
+
+
+def test_model_stage_import_shim():
+    """The reference drivers' own import line (main.py:13, inference.py:7: ``from model.stage import STAGE``) resolves to the
+    HIP class when ``<repo>/shim`` leads PYTHONPATH -- in a fresh interpreter, as a driver process would see it."""
+    import subprocess
+    import sys
+    code = ("from model.stage import STAGE; import tvqaplus_amd.stage as S; assert STAGE is S.STAGE; "
+            "from tvqaplus_amd.synth import make_opt; import contextlib, io\n"
+            "with contextlib.redirect_stdout(io.StringIO()): m = STAGE(make_opt(hsz=16, embedding_size=8, vfeat_size=8))\n"
+            "assert m.num_a == 5 and m.bridge_hsz == 300 and m.inference_mode is False; print('shim ok')")
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "shim"))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd="/tmp")
+    assert out.returncode == 0 and "shim ok" in out.stdout, out.stderr

@@ -29,6 +29,32 @@ def _model_from(fx, device):
     return model.to(device)
 
 
+def _centred_oracle_grads(fx):
+    """Parameter gradients of the fixture's training loss from the fp32 oracle with LayerNorm written in the CENTRED form
+    (xc = x - mean; xhat = xc * rsqrt(mean(xc^2) + eps)) and differentiated by autograd through those ops.  On a constant row
+    (a valid frame whose regions are all masked pools to -1e10 everywhere) xc is exactly zero, so the backward is the well
+    defined limit -- d gamma = 0, dx = rstd * (g - mean g) -- instead of the rounding noise torch's fused CPU kernel returns
+    with |x| = 1e10 operands.  fp64 is no yardstick here: x * m + (1 - m) * -1e10 absorbs x only in fp32, and that absorption
+    is part of the function the reference computes."""
+    def ln(x, P, key):
+        w, b = P[key + ".weight"], P[key + ".bias"]
+        xc = x - x.mean(-1, keepdim=True)
+        return xc * torch.rsqrt((xc * xc).mean(-1, keepdim=True) + 1e-5) * w + b
+    batch = fx.batch()
+    P = {k: (v.clone().requires_grad_(not k.endswith(".pe")) if v.is_floating_point() else v.clone())
+         for k, v in fx.group("param").items()}
+    opt = fx.opt
+    opt.mha_dropout = 0.0
+    keep = O._ln
+    O._ln = ln
+    try:
+        ref = O.stage_forward(P, opt, batch, training=True)
+        O.training_loss(ref, n_examples=len(batch.qid)).backward()
+    finally:
+        O._ln = keep
+    return {k: v.grad for k, v in P.items() if v.grad is not None}
+
+
 @pytest.mark.parametrize("name", MODEL_CASES)
 def test_golden_whole_model(hip_device, name):
     fx = Fixture(name)
@@ -53,9 +79,13 @@ def test_golden_whole_model(hip_device, name):
         assert rel_err(loss, exp["loss"]) < TOL
         G = fx.group("grad")
         worst, errs = ("", 0.0), {}
+        GC = _centred_oracle_grads(fx) if UNDEFINED_GRADS.get(name) else {}
         for k, p in model.named_parameters():
             if k in UNDEFINED_GRADS.get(name, ()):
+                # the reference's fp32 CPU value is rounding noise here (conftest.UNDEFINED_GRADS); the centred-form oracle is
+                # the well-defined limit and is what the product has to match
                 assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+                assert rel_err(p.grad, GC[k]) < GTOL, (k, rel_err(p.grad, GC[k]))
                 continue
             got = p.grad if p.grad is not None else torch.zeros_like(p)
             e = errs[k] = rel_err(got, G[k])
@@ -441,3 +471,24 @@ def test_stress_config_long_subtitles_d256(hip_device):
         g = P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])
         got = p.grad if p.grad is not None else torch.zeros_like(p)
         assert rel_err(got, g) < 4e-3, k
+
+
+@pytest.mark.parametrize("name", ["mid_train", "small_local_train", "small_supatt_train"])
+def test_gradients_against_fp64(hip_device, name):
+    """The assertion behind GTOL (promoted from tools/fp64_gradient_check.py): against an fp64 evaluation of the same graph
+    the HIP path's parameter gradients are within 4e-3 of (1 + |g|) -- and no further from it than 1.5x the reference's own
+    fp32 gradients are (tests/test_oracle_golden.py pins that those are several 1e-3 off)."""
+    from test_oracle_golden import fp64_gradients
+    fx = Fixture(name)
+    if fx.opt.use_sup_att:
+        pytest.skip("fp64 yardstick is built without the attention-loss term")
+    G, G64 = fx.group("grad"), fp64_gradients(fx)
+    model = _model_from(fx, hip_device).train()
+    batch = fx.batch().to(hip_device)
+    (out, targets), _, _, t_loss, _, _ = model.forward_main(batch)
+    (F.cross_entropy(out, targets, reduction="sum") * (len(batch.qid) / len(targets)) + 0.5 * t_loss).backward()
+    e_ref = max(rel_err(G[k].double(), G64[k]) for k in G64)
+    e_hip = max(rel_err((p.grad if p.grad is not None else torch.zeros_like(p)).double(), G64[k])
+                for k, p in model.named_parameters())
+    assert e_hip < 4e-3, (e_hip, e_ref)
+    assert e_hip < max(1.5 * e_ref, 1e-3), (e_hip, e_ref)

@@ -95,3 +95,28 @@ def test_position_table_beyond_500():
     tab = O.position_table({}, "none", 600, 32)
     ref = O.position_table({}, "none", 500, 32)
     assert torch.equal(tab[:500], ref)
+
+
+def fp64_gradients(fx):
+    """Parameter gradients of a train fixture's loss from the oracle evaluated in fp64 (the well-conditioned yardstick)."""
+    opt = fx.opt
+    opt.mha_dropout = 0.0
+    P64 = {k: (v.double().requires_grad_(not k.endswith(".pe")) if v.is_floating_point() else v)
+           for k, v in fx.group("param").items()}
+    b = fx.batch()
+    b64 = type(b)({k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in b.items()})
+    ref = O.stage_forward(P64, opt, b64, training=True)
+    O.training_loss(ref, n_examples=b.target.shape[0]).backward()
+    return {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in P64.items() if v.requires_grad}
+
+
+def test_reference_fp32_gradients_are_off_fp64_by_more_than_the_output_tolerance():
+    """Why parameter gradients are held to 6e-3 and not to the outputs' 1e-3 (tests/test_hip_stage.py: GTOL): the
+    REFERENCE's own fp32 gradients of the mid fixture deviate from an fp64 evaluation of the same graph by several 1e-3 of
+    (1 + |g|) -- LayerNorms over padded / near-constant rows amplify rounding by rstd ~ 316.  A tolerance below that spread
+    would test the summation order of torch's CPU kernels, not the arithmetic.  The HIP path is held to 4e-3 against the SAME
+    fp64 yardstick in tests/test_hip_stage.py::test_gradients_against_fp64."""
+    fx = Fixture("mid_train")
+    G, G64 = fx.group("grad"), fp64_gradients(fx)
+    worst = max(rel_err(G[k].double(), G64[k]) for k in G64)
+    assert 1.5e-3 < worst < 6e-3, worst

@@ -112,12 +112,39 @@ def build_att_pairs(model, batch, scores: Optional[torch.Tensor] = None, n_local
     return pos, neg
 
 
+class PinnedStage:
+    """Two pinned host buffers for the per-step index upload, each guarded by the event of the copy that last read it: the host
+    may only rewrite a buffer once the asynchronous host-to-device copy issued from it has run (a single unguarded buffer was a
+    race whenever nothing else synchronised the step -- add_local off, or a loop with no per-step host read)."""
+
+    def __init__(self):
+        self.bufs = [None, None]
+        self.events = [None, None]
+        self.turn = 0
+
+    def upload(self, t: torch.Tensor, device) -> torch.Tensor:
+        i = self.turn
+        self.turn ^= 1
+        if self.events[i] is not None:
+            self.events[i].synchronize()           # the copy that read this buffer two steps ago has finished
+        n = t.numel()
+        if self.bufs[i] is None or self.bufs[i].numel() < n:
+            self.bufs[i] = torch.empty(max(2 * n, 4096), dtype=t.dtype, pin_memory=True)
+        self.bufs[i][:n].copy_(t)
+        with torch.cuda.device(device):
+            dev = self.bufs[i][:n].to(device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))
+        self.events[i] = ev
+        return dev
+
+
 class AttPairs:
     """Flat indices into a contiguous (N, NA, Li, Lqa, Lr) score tensor for the M positive rows followed by the M negative
-    rows, resident on the device.  ``stage`` = pinned host buffer reused across steps (``pin_memory()`` per call registers
+    rows, resident on the device.  ``stage`` = a ``PinnedStage`` reused across steps (``pin_memory()`` per call registers
     a fresh page-locked allocation every time: ~0.5 ms of host time on the launch path)."""
 
-    def __init__(self, pos: np.ndarray, neg: np.ndarray, shape, device, stage: Optional[torch.Tensor] = None):
+    def __init__(self, pos: np.ndarray, neg: np.ndarray, shape, device, stage: Optional[PinnedStage] = None):
         both = np.concatenate([pos, neg], axis=0)
         _, NA, Li, Lqa, Lr = shape
         flat = (((both[:, 0] * NA + both[:, 1]) * Li + both[:, 2]) * Lqa + both[:, 3]) * Lr + both[:, 4]
@@ -125,10 +152,9 @@ class AttPairs:
         self.shape = tuple(shape)
         t = torch.from_numpy(flat)
         if torch.device(device).type == "cuda":
-            if stage is None or stage.numel() < t.numel():
-                stage = torch.empty(max(2 * t.numel(), 4096), dtype=torch.int64, pin_memory=True)
-            stage[: t.numel()].copy_(t)
-            self.flat = stage[: t.numel()].to(device, non_blocking=True)
+            if stage is None:
+                stage = PinnedStage()
+            self.flat = stage.upload(t, device)
         else:
             self.flat = t
         self.stage = stage

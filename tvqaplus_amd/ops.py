@@ -262,24 +262,38 @@ def cat3_layernorm(a, b, gamma, beta, rep: int = 1, inner: int = 1, p: float = 0
 # ---------------------------------------------------------------------------------------------------------------
 # Linear (+bias, +ReLU) on the matrix cores
 # ---------------------------------------------------------------------------------------------------------------
-_WT_CACHE = {}   # id(weight) -> (data_ptr, version, transposed copy); entries die with their weight (weakref callback)
+_WT_CACHE = {}   # id(weight) -> (data_ptr, version, transposed copy, weakref, epoch); entries die with their weight
+_WT_EPOCH = 0
+
+
+def new_step() -> None:
+    """Called by STAGE.forward_main at the top of every forward: transposed-weight copies made during earlier steps are no
+    longer trusted.  (The version counter alone misses in-place writes through ``p.data`` -- ``dist.broadcast(p.data)``,
+    manual EMA, some third-party optimizers -- so a copy is only reused inside the forward/backward pair it was made in,
+    where a shared module (the input encoder: QA, subtitle and video streams) asks for the same transpose several times.)"""
+    global _WT_EPOCH
+    _WT_EPOCH += 1
+
+
+def invalidate_weight_cache() -> None:
+    """Drop every cached transposed weight (for callers that rewrite weights between a forward and its backward)."""
+    _WT_CACHE.clear()
 
 
 def _transposed_weight(w, w2):
-    """(K, N) copy of the (N, K) weight for the dX GEMM.  A module used several times per step (the shared encoders: video,
-    subtitle and QA streams) would transpose the same weight once per use; the copy is cached per weight object and
-    remade when the weight was written to (optimizer step, load_state_dict: the version counter) or re-pointed."""
+    """(K, N) copy of the (N, K) weight for the dX GEMM, cached per weight object for the current step (see ``new_step``)."""
     import weakref
     key = id(w)
     hit = _WT_CACHE.get(key)
-    if hit is not None and hit[0] == w2.data_ptr() and hit[1] == w._version and hit[2].shape == (w2.shape[1], w2.shape[0]):
+    if (hit is not None and hit[4] == _WT_EPOCH and hit[0] == w2.data_ptr() and hit[1] == w._version
+            and hit[2].shape == (w2.shape[1], w2.shape[0])):
         return hit[2]
     wt = w2.t().contiguous()
     try:
         ref = weakref.ref(w, lambda _r, k=key: _WT_CACHE.pop(k, None))
     except TypeError:
         return wt
-    _WT_CACHE[key] = (w2.data_ptr(), w._version, wt, ref)
+    _WT_CACHE[key] = (w2.data_ptr(), w._version, wt, ref, _WT_EPOCH)
     return wt
 
 
@@ -555,6 +569,17 @@ import os as _os
 _K1_BWD_UNFUSED = _os.environ.get("STAGE_K1_BWD_UNFUSED") is not None   # developer switch (cross-check in the tests)
 
 
+def _fold_dsn(dS, dSn, Sn, scale):
+    """A gradient that arrives on the NORMALISED scores (the model never sends one; the public operator may be used that way,
+    model/context_query_attention.py:61 is differentiable in the reference): S_ = softmax(scale * S) * mask, so it reaches the
+    raw scores as scale * S_ * (dS_ - <dS_, S_>) on the unmasked entries (masked entries have S_ = 0 and a zero gradient, fully
+    masked rows are zeroed by the mask).  A few plumbing-sized ATen ops on a path the training step does not take."""
+    if dSn is None:
+        return dS
+    g = scale * Sn * (dSn - (dSn * Sn).sum(-1, keepdim=True))
+    return g if dS is None else dS + g
+
+
 class _StrAttn(torch.autograd.Function):
     """The fast kernels (D = 128, Lr <= 64).  fp32, or bf16 storage: Q, A and dA are bf16 and are converted as the kernels load
     / store them; the context side (N*NA*Lqa rows: small) is normalised in fp32, the score maps are fp32."""
@@ -577,16 +602,16 @@ class _StrAttn(torch.autograd.Function):
               Lqa, Lr, D, float(scale), float(p), int(seed_q), _stream())
         ctx.save_for_backward(Cf, Q, Cn, Sn, q_mask)
         ctx.cfg = (float(scale), float(p), int(seed_c), int(seed_q))
-        ctx.mark_non_differentiable(Sn)
         # raw S only receives a gradient when the supervised attention loss is on: without this autograd hands the
         # backward a materialised zero tensor (a 77 / 192 MB fill plus one more read in the dS kernel)
         ctx.set_materialize_grads(False)
         return A, S, Sn
 
     @_on_device
-    def backward(ctx, dA, dS, _dSn):
+    def backward(ctx, dA, dS, dSn):
         Cf, Q, Cn, Sn, q_mask = ctx.saved_tensors
         scale, p, seed_c, seed_q = ctx.cfg
+        dS = _fold_dsn(dS, dSn, Sn, scale)
         bf = Q.dtype == _BF16
         N, NA, Lqa, D = Cf.shape
         _, Li, Lr, _ = Q.shape
@@ -653,14 +678,14 @@ class _StrAttnLong(torch.autograd.Function):
               N, NA, Li, Lqa, Lr, D, float(scale), int(dt == torch.bfloat16), _stream())
         ctx.save_for_backward(C, Q, Cn, Qn, Sn, A)
         ctx.cfg = (float(scale), float(p), int(seed_c), int(seed_q))
-        ctx.mark_non_differentiable(Sn)
         ctx.set_materialize_grads(False)
         return A, S, Sn
 
     @_on_device
-    def backward(ctx, dA, dS, _dSn):
+    def backward(ctx, dA, dS, dSn):
         C, Q, Cn, Qn, Sn, A = ctx.saved_tensors
         scale, p, seed_c, seed_q = ctx.cfg
+        dS = _fold_dsn(dS, dSn, Sn, scale)
         dt = C.dtype
         N, NA, Lqa, D = C.shape
         _, Li, Lr, _ = Q.shape

@@ -114,6 +114,12 @@ class FlatGradBucket:
         for p in self.params:
             p.grad = None
 
+    def reset_absent(self) -> None:
+        """Forget which parameters were agreed to be structurally without gradient (call on EVERY rank after enabling or
+        disabling a model branch mid-run); the next ``all_reduce`` agrees again."""
+        self._absent = None
+        self._absent_basis = None
+
     def pack(self) -> None:
         """Copy the current gradients into the flat buffer and make every ``p.grad`` a view of it.  Parameters without a
         gradient contribute zeros to the buffer; whether such a parameter receives ``p.grad`` afterwards is decided by
@@ -131,12 +137,24 @@ class FlatGradBucket:
 
     def _drop_absent(self) -> None:
         """Parameters that have no gradient on ANY rank keep ``grad = None``.  Which ones is a property of the model
-        structure, so it is agreed once (one small all-reduce + host read at the first step) and cached."""
+        structure, so it is agreed once (one small all-reduce + host read at the first step) and cached together with the
+        LOCAL presence vector it was derived from.  When that vector changes later (a branch enabled after warm-up, a first
+        step that skipped a path) the cached decision would silently drop a real gradient: with one rank the decision is
+        simply remade (host-only comparison, no device read); with several ranks a one-sided extra collective would
+        desynchronise them, so the change raises and the caller re-agrees with ``reset_absent()`` on every rank."""
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        if getattr(self, "_absent", None) is not None and self._present_local != self._absent_basis:
+            if world > 1:
+                raise RuntimeError("FlatGradBucket: the set of parameters that receive a gradient changed on rank %d after the "
+                                   "first step; call bucket.reset_absent() on every rank when enabling / disabling a model "
+                                   "branch" % dist.get_rank())
+            self._absent = None
         if getattr(self, "_absent", None) is None:
             flags = torch.tensor([1.0 if f else 0.0 for f in self._present_local], device=self.flat.device)
-            if dist.is_initialized() and dist.get_world_size() > 1:
+            if world > 1:
                 dist.all_reduce(flags, op=dist.ReduceOp.SUM)
             self._absent = [f == 0.0 for f in flags.tolist()]
+            self._absent_basis = list(self._present_local)
         for absent, p in zip(self._absent, self.params):
             if absent:
                 p.grad = None
@@ -169,6 +187,7 @@ def global_loss_scale(n_examples_local: int, n_targets_local: int, device=None, 
 # candidate x batch layout (more ranks than examples)
 # ---------------------------------------------------------------------------------------------------------------
 NUM_CANDIDATES = 5   # model/stage.py:79
+_GROUP_CACHE = {}    # (E, C, world) -> the candidate groups of the default process group (communicators are never rebuilt)
 
 
 class _GroupCE(torch.autograd.Function):
@@ -201,13 +220,17 @@ class CandidateLayout:
     ``shard(batch)`` returns the local batch: the example slice, ``qas_bert`` / ``qas_mask`` / ``qas`` restricted to the
     local candidates, ``target`` kept GLOBAL, plus ``cand_offset`` (global index of local candidate 0) and ``gt_scores_fn``
     which the model calls in add_local training to obtain the ground-truth candidate's temporal scores
-    (tvqaplus_amd.stage.STAGE.get_proposals)."""
+    (tvqaplus_amd.stage.STAGE.get_proposals), and ``dropout_rank`` (the example block: the replicated context encoders of a
+    group share one dropout stream, as the five candidates of an example share one context mask in the reference).
+    ``global_loss_scale`` costs one blocking host read per step (the data-dependent proposal count of add_local)."""
 
     def __init__(self, n_examples: int, rank: Optional[int] = None, world: Optional[int] = None):
         if rank is None:
             rank = dist.get_rank() if dist.is_initialized() else 0
         if world is None:
             world = dist.get_world_size() if dist.is_initialized() else 1
+        if n_examples <= 0:
+            raise ValueError("CandidateLayout needs at least one example (got n_examples=%d)" % n_examples)
         self.rank, self.world, self.n_examples = rank, world, n_examples
         self.E = min(n_examples, world)
         self.C = max(1, min(NUM_CANDIDATES, world // self.E))
@@ -219,11 +242,15 @@ class CandidateLayout:
         self.group = None
         self.group_ranks = list(range(self.block * self.C, (self.block + 1) * self.C)) if self.active else []
         if dist.is_initialized() and world > 1 and self.C > 1:
-            # new_group is collective over the world: every rank creates every block's group
-            for b in range(self.E):
-                g = dist.new_group(ranks=list(range(b * self.C, (b + 1) * self.C)))
-                if b == self.block:
-                    self.group = g
+            # new_group is collective over the world: every rank creates every block's group -- ONCE per (E, C) shape of the
+            # process group (a layout built per batch, e.g. for a smaller last batch, reuses the communicators)
+            key = (self.E, self.C, world)
+            groups = _GROUP_CACHE.get(key)
+            if groups is None:
+                groups = [dist.new_group(ranks=list(range(b * self.C, (b + 1) * self.C))) for b in range(self.E)]
+                _GROUP_CACHE[key] = groups
+            if self.active:
+                self.group = groups[self.block]
 
     # ---- data --------------------------------------------------------------------------------------------------
     def shard(self, batch):
@@ -243,6 +270,9 @@ class CandidateLayout:
                 out[k] = v
         out["cand_offset"] = k0
         out["gt_scores_fn"] = self.gt_scores
+        # dropout stream of the example block: the ranks of a candidate group replicate the same context encoders and must
+        # drop the same units there (STAGE._seed); the QA side holds different candidates per rank, so sharing is harmless
+        out["dropout_rank"] = self.block
         return out
 
     # ---- collectives inside the group ----------------------------------------------------------------------------

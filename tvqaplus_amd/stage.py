@@ -211,6 +211,7 @@ class STAGE(nn.Module):
         # process rank (identical seeds on every data-parallel rank would drop the same units everywhere).  The stream
         # position is not part of state_dict(): like the reference, a resumed run does not replay the masks.
         self._seed_state: Optional[int] = None
+        self._dropout_rank: Optional[int] = None
         self.mha_dropout_override: Optional[float] = None  # tests: the reference's fixed 0.1 can be zeroed
 
     # ---- dropout bookkeeping ---------------------------------------------------------------------------------
@@ -222,7 +223,9 @@ class STAGE(nn.Module):
             # the seed of torch's default generator as of NOW (the latest torch.manual_seed), read without consuming a draw:
             # the reference's negative sampling (get_att_loss) draws from that generator and must see the same sequence
             draw = int(torch.initial_seed())
-            rank = int(os.environ.get("RANK", "0"))
+            # ranks of one candidate group (parallel.CandidateLayout) replicate the context encoders of the SAME examples: they
+            # share the stream of their example block (batch.dropout_rank), so the replicated work drops the same units
+            rank = int(os.environ.get("RANK", "0")) if self._dropout_rank is None else int(self._dropout_rank)
             self._seed_state = (draw * 0x9E3779B97F4A7C15 + 0x1234567 + rank * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
         self._seed_state = (self._seed_state * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
         return self._seed_state >> 1
@@ -445,11 +448,14 @@ class STAGE(nn.Module):
 
     def forward_main(self, batch):
         """model/stage.py:199-348."""
+        ops.new_step()
         self.bsz = len(batch.qid)
         N, D = self.bsz, self.hsz
         NA = batch.qas_bert.shape[1]          # 5 (self.num_a), or the local candidates of a candidate-sharded batch
         cand_offset = int(_opt(batch, "cand_offset", 0) or 0)
         gt_scores_fn = _opt(batch, "gt_scores_fn", None)
+        if self._seed_state is None and _opt(batch, "dropout_rank", None) is not None:
+            self._dropout_rank = int(_opt(batch, "dropout_rank"))
         qas_mask = batch.qas_mask.view(N, NA, -1).float()
         a_embed = self.base_encoder(batch.qas_bert.view(N * NA, -1, self.wd_size), qas_mask.view(N * NA, -1),
                                     self.bert_word_encoding_fc, self.input_embedding, self.input_encoder)
