@@ -46,6 +46,34 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, local, world
 
 
+def _host_staged(t: torch.Tensor) -> bool:
+    """Device tensors on a ``gloo`` process group (single-GPU tests of the multi-rank path: several ranks share cuda:0 and the
+    collectives run over gloo) are staged through host memory; on ``nccl`` (= RCCL) they are reduced in place over xGMI."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _all_reduce_sum(t: torch.Tensor, group=None) -> None:
+    if _host_staged(t):
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def _all_gather(t: torch.Tensor, n: int, group=None) -> List[torch.Tensor]:
+    """n equally shaped tensors, one per rank of the group."""
+    t = t.contiguous()
+    if _host_staged(t):
+        h = t.detach().cpu()
+        out = [torch.empty_like(h) for _ in range(n)]
+        dist.all_gather(out, h, group=group)
+        return [o.to(t.device) for o in out]
+    out = [torch.empty_like(t) for _ in range(n)]
+    dist.all_gather(out, t, group=group)
+    return out
+
+
 def shard_range(n_examples: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous example-major shard [lo, hi) of a global batch (sizes differ by at most one)."""
     base, rem = divmod(n_examples, world)
@@ -80,14 +108,11 @@ def all_gather_outputs(local: torch.Tensor, counts: Optional[Sequence[int]] = No
         return local
     world = dist.get_world_size()
     if counts is None or len(set(counts)) == 1:
-        out = [torch.empty_like(local) for _ in range(world)]
-        dist.all_gather(out, local.contiguous())
-        return torch.cat(out, dim=0)
+        return torch.cat(_all_gather(local, world), dim=0)
     mx = max(counts)
     pad = local.new_zeros((mx,) + tuple(local.shape[1:]))
     pad[: local.shape[0]] = local
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad)
+    out = _all_gather(pad, world)
     return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
 
 
@@ -152,7 +177,7 @@ class FlatGradBucket:
         if getattr(self, "_absent", None) is None:
             flags = torch.tensor([1.0 if f else 0.0 for f in self._present_local], device=self.flat.device)
             if world > 1:
-                dist.all_reduce(flags, op=dist.ReduceOp.SUM)
+                _all_reduce_sum(flags)
             self._absent = [f == 0.0 for f in flags.tolist()]
             self._absent_basis = list(self._present_local)
         for absent, p in zip(self._absent, self.params):
@@ -163,7 +188,7 @@ class FlatGradBucket:
         """Pack (always: ``flat`` is valid with one rank too), sum over ranks, drop the structurally absent gradients."""
         self.pack()
         if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            _all_reduce_sum(self.flat)
         self._drop_absent()
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -179,7 +204,7 @@ def global_loss_scale(n_examples_local: int, n_targets_local: int, device=None, 
     v = torch.tensor([float(n_examples_local), float(n_targets_local)], dtype=torch.float64, device=device)
     if not count_this_rank:
         v.zero_()
-    dist.all_reduce(v, op=dist.ReduceOp.SUM)
+    _all_reduce_sum(v)
     return float(v[0].item() / v[1].item())
 
 
@@ -283,8 +308,7 @@ class CandidateLayout:
         kmax = max(shard_range(NUM_CANDIDATES, p, self.C)[1] - shard_range(NUM_CANDIDATES, p, self.C)[0] for p in range(self.C))
         pad = local.new_zeros((local.shape[0], kmax) + tuple(local.shape[2:]))
         pad[:, : local.shape[1]] = local
-        parts = [torch.empty_like(pad) for _ in range(self.C)]
-        dist.all_gather(parts, pad.contiguous(), group=self.group)
+        parts = _all_gather(pad, self.C, group=self.group)
         cols = []
         for p, t in enumerate(parts):
             a, b = shard_range(NUM_CANDIDATES, p, self.C)
@@ -312,6 +336,5 @@ class CandidateLayout:
         mx = max(counts)
         pad = full.new_zeros((mx, NUM_CANDIDATES))
         pad[: full.shape[0]] = full
-        out = [torch.empty_like(pad) for _ in range(self.world)]
-        dist.all_gather(out, pad)
+        out = _all_gather(pad, self.world)
         return torch.cat([out[b * self.C][: counts[b]] for b in range(self.E)], dim=0)
