@@ -289,6 +289,73 @@ int stage_ln_masked_max_bwd_bf16(const void* dout, const int* argmax, const floa
                                  const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta, long long R,
                                  int L, int K, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- K-groups: launch sequencing on the C side (one forward and one backward symbol per fused-op group) --
+ * Each group runs the kernels above in the order tvqaplus_amd/ops.py would, as ONE call (csrc/groups.hip); fp32 storage.
+ * Memory protocol: `arena` (stage_grp_*_arena_bytes) = what the forward keeps for the backward, carved deterministically;
+ * `tmp` (stage_grp_*_bwd_tmp_bytes) = backward-only scratch; `flags` = host ints written by the forward and handed back to the
+ * backward (which optional kernel paths ran; 16 ints are enough for every group); `params` / `grads` = HOST arrays of device
+ * pointers in the order each group documents; `seeds` = host array, one entry per dropout site in forward order.
+ * STAGE_ERR_SHAPE is returned before anything is launched when a group does not take the shape (use the per-op entry points). */
+/* G1 input MLP (model/stage.py:350-362, :85-91, :98-104, :115-120; l2 != 0: F.normalize of :256 first):
+ * [l2norm] -> LN(K0)+drop -> Linear(K0->H)+ReLU -> LN(H)+drop -> Linear(H->D)+ReLU -> LN(D).  x (M, K0) -> out (M, D).
+ * params / grads: g0 b0 W1 c1 g1 b1 W2 c2 g2 b2; seeds[2].  The features receive no gradient.                            */
+size_t stage_grp_input_mlp_arena_bytes(long long M, int K0, int H, int D, int l2);
+int stage_grp_input_mlp_fwd(const float* x, const float* const* params, float* out, void* arena, size_t arena_bytes, int* flags,
+                            long long M, int K0, int H, int D, int l2, float p_drop, const unsigned long long* seeds,
+                            void* stream);
+size_t stage_grp_input_mlp_bwd_tmp_bytes(long long M, int K0, int H, int D);
+int stage_grp_input_mlp_bwd(const float* dout, const float* x, const float* const* params, float* const* grads,
+                            const void* arena, size_t arena_bytes, const int* flags, void* tmp, size_t tmp_bytes, long long M,
+                            int K0, int H, int D, int l2, float p_drop, const unsigned long long* seeds, void* stream);
+/* G2 encoder block without self-attention (model/encoder.py:29-52, model/cnn.py:37-47, model/position_encoding.py:38-43):
+ * x (M, L, D), pe (>= L, D).  pool_mask (M, L) != NULL: out = masked max over L of the block's output (model/stage.py:503),
+ * (M, D); otherwise out (M, L, D).  params / grads: per conv i (ln_g ln_b dw_w dw_b pw_w pw_b), then final_g final_b;
+ * seeds: one per even conv index.  dx may be NULL.                                                                        */
+size_t stage_grp_encoder_arena_bytes(long long M, int L, int D, int n_conv, int pooled);
+int stage_grp_encoder_fwd(const float* x, const float* pe, const float* pool_mask, const float* const* params, float* out,
+                          void* arena, size_t arena_bytes, int* flags, long long M, int L, int D, int n_conv, int k, float p_drop,
+                          const unsigned long long* seeds, void* stream);
+size_t stage_grp_encoder_bwd_tmp_bytes(long long M, int L, int D, int k, int pooled);
+int stage_grp_encoder_bwd(const float* dout, const float* x, const float* pool_mask, const float* const* params,
+                          float* const* grads, float* dx, const void* arena, size_t arena_bytes, const int* flags, void* tmp,
+                          size_t tmp_bytes, long long M, int L, int D, int n_conv, int k, float p_drop,
+                          const unsigned long long* seeds, void* stream);
+/* G3 QA <-> context attention + down-projection (model/stage.py:365-387): qa (N,NA,Lqa,D), ctx (N,Li,Lr,D) ->
+ * mixed (N,NA,Li,Lqa,D), S_raw / S_norm (N,NA,Li,Lqa,Lr).  params / grads: ln_g ln_b W c; seeds[3] = context-side, region-side,
+ * LayerNorm dropout.  Backward: dS_ext = gradient on S_raw or NULL; d_qa sums both uses of the QA embedding.              */
+size_t stage_grp_qa_ctx_arena_bytes(int N, int NA, int Li, int Lqa, int D);
+int stage_grp_qa_ctx_fwd(const float* qa, const float* ctx, const float* qa_mask, const float* ctx_mask,
+                         const float* const* params, float* mixed, float* S_raw, float* S_norm, void* arena, size_t arena_bytes,
+                         int* flags, int N, int NA, int Li, int Lqa, int Lr, int D, float scale, float p_drop,
+                         const unsigned long long* seeds, void* stream);
+size_t stage_grp_qa_ctx_bwd_tmp_bytes(int N, int NA, int Li, int Lqa, int Lr, int D);
+int stage_grp_qa_ctx_bwd(const float* d_mixed, const float* dS_ext, const float* qa, const float* ctx, const float* ctx_mask,
+                         const float* mixed, const float* S_norm, const float* const* params, float* const* grads, float* d_qa,
+                         float* d_ctx, const void* arena, size_t arena_bytes, const int* flags, void* tmp, size_t tmp_bytes, int N,
+                         int NA, int Li, int Lqa, int Lr, int D, float scale, float p_drop, const unsigned long long* seeds,
+                         void* stream);
+/* G4 two-stream fusion (model/stage.py:276-279, :106-113): s, v (U, D) -> out (U, D).  params / grads: ln3_g ln3_b W c ln_g ln_b;
+ * seeds[1].                                                                                                                */
+size_t stage_grp_concat_fc_arena_bytes(long long U, int D);
+int stage_grp_concat_fc_fwd(const float* s, const float* v, const float* const* params, float* out, void* arena,
+                            size_t arena_bytes, int* flags, long long U, int D, float p_drop, const unsigned long long* seeds,
+                            void* stream);
+size_t stage_grp_concat_fc_bwd_tmp_bytes(long long U, int D);
+int stage_grp_concat_fc_bwd(const float* dout, const float* s, const float* v, const float* const* params, float* const* grads,
+                            float* ds, float* dv, const void* arena, size_t arena_bytes, const int* flags, void* tmp,
+                            size_t tmp_bytes, long long U, int D, float p_drop, const unsigned long long* seeds, void* stream);
+/* G5 temporal head, layer 0 (model/stage.py:469-482, LinearWrapper :15-32): enc (R, D) -> first = enc + h (R, D), t_st, t_ed (R).
+ * params / grads: lnp_g lnp_b Wp cp lns_g lns_b Ws cs lne_g lne_b We ce; seeds[3].  d_first may be NULL.                  */
+size_t stage_grp_temporal_head_arena_bytes(long long R, int D);
+int stage_grp_temporal_head_fwd(const float* enc, const float* const* params, float* first, float* t_st, float* t_ed,
+                                void* arena, size_t arena_bytes, int* flags, long long R, int D, float p_drop,
+                                const unsigned long long* seeds, void* stream);
+size_t stage_grp_temporal_head_bwd_tmp_bytes(long long R, int D);
+int stage_grp_temporal_head_bwd(const float* d_first, const float* d_st, const float* d_ed, const float* enc, const float* first,
+                                const float* const* params, float* const* grads, float* d_enc, const void* arena,
+                                size_t arena_bytes, const int* flags, void* tmp, size_t tmp_bytes, long long R, int D,
+                                float p_drop, const unsigned long long* seeds, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,6 +87,28 @@ SIGNATURES = {
     "stage_masked_max_bwd_bf16": (I, [P, P, P, P, LL, I, I, I, P]),
     "stage_ln_masked_max_fwd_bf16": (I, [P, P, P, P, P, P, P, P, P, P, LL, I, I, F, P]),
     "stage_ln_masked_max_bwd_bf16": (I, [P, P, P, P, P, P, P, P, P, P, LL, I, I, P, SZ, P]),
+    # K-groups (csrc/groups.hip): one forward and one backward symbol per fused-op group; params / grads / seeds / flags are
+    # HOST arrays (pointers to them travel as void*)
+    "stage_grp_input_mlp_arena_bytes": (SZ, [LL, I, I, I, I]),
+    "stage_grp_input_mlp_fwd": (I, [P, P, P, P, SZ, P, LL, I, I, I, I, F, P, P]),
+    "stage_grp_input_mlp_bwd_tmp_bytes": (SZ, [LL, I, I, I]),
+    "stage_grp_input_mlp_bwd": (I, [P, P, P, P, P, SZ, P, P, SZ, LL, I, I, I, I, F, P, P]),
+    "stage_grp_encoder_arena_bytes": (SZ, [LL, I, I, I, I]),
+    "stage_grp_encoder_fwd": (I, [P, P, P, P, P, P, SZ, P, LL, I, I, I, I, F, P, P]),
+    "stage_grp_encoder_bwd_tmp_bytes": (SZ, [LL, I, I, I, I]),
+    "stage_grp_encoder_bwd": (I, [P, P, P, P, P, P, P, SZ, P, P, SZ, LL, I, I, I, I, F, P, P]),
+    "stage_grp_qa_ctx_arena_bytes": (SZ, [I, I, I, I, I]),
+    "stage_grp_qa_ctx_fwd": (I, [P, P, P, P, P, P, P, P, P, SZ, P, I, I, I, I, I, I, F, F, P, P]),
+    "stage_grp_qa_ctx_bwd_tmp_bytes": (SZ, [I, I, I, I, I, I]),
+    "stage_grp_qa_ctx_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, SZ, P, P, SZ, I, I, I, I, I, I, F, F, P, P]),
+    "stage_grp_concat_fc_arena_bytes": (SZ, [LL, I]),
+    "stage_grp_concat_fc_fwd": (I, [P, P, P, P, P, SZ, P, LL, I, F, P, P]),
+    "stage_grp_concat_fc_bwd_tmp_bytes": (SZ, [LL, I]),
+    "stage_grp_concat_fc_bwd": (I, [P, P, P, P, P, P, P, P, SZ, P, P, SZ, LL, I, F, P, P]),
+    "stage_grp_temporal_head_arena_bytes": (SZ, [LL, I]),
+    "stage_grp_temporal_head_fwd": (I, [P, P, P, P, P, P, SZ, P, LL, I, F, P, P]),
+    "stage_grp_temporal_head_bwd_tmp_bytes": (SZ, [LL, I]),
+    "stage_grp_temporal_head_bwd": (I, [P, P, P, P, P, P, P, P, P, SZ, P, P, SZ, LL, I, F, P, P]),
 }
 
 _lib = None

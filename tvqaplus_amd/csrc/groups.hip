@@ -1,0 +1,586 @@
+// K-group entry points: launch sequencing of STAGE's fused-op groups on the C side (last bullet:
+// "one fwd and one bwd symbol per K-group").  Each group runs the same kernels, in the same order and with the same
+// arguments, as the per-op path of tvqaplus_amd/ops.py -- but as ONE call from the host language: the Python thread sees
+// ~25 calls per training step instead of ~360, so the step no longer depends on how fast the host interpreter can issue
+// launches (the driver-timed step was host-bound).  fp32 storage; shapes a group does not take return
+// STAGE_ERR_SHAPE before anything is launched (the caller then uses the per-op entry points).
+//
+// Memory protocol (all device memory belongs to the caller):
+//   arena  what the forward keeps for the backward (normalised operands, GEMM outputs, ReLU bit masks, statistics), carved
+//          deterministically from one caller buffer of stage_grp_*_arena_bytes(); the backward carves the same layout
+//   tmp    backward-only scratch (gradients in flight, transposed weights, kernel workspaces), stage_grp_*_bwd_tmp_bytes()
+//   flags  host ints written by the forward and handed back to the backward (which optional kernel paths were taken)
+//   params / grads  host arrays of device pointers in the order each group documents; seeds: host array, one per dropout site
+#include "common.h"
+#include "../../include/stage_hip.h"
+
+namespace {
+
+struct Bump {
+    char* base;
+    size_t off;
+    template <class T>
+    T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? (T*)(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+inline size_t umax(size_t a, size_t b) { return a > b ? a : b; }
+inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+#define TRY(call)                     \
+    do {                              \
+        const int rc__ = (call);      \
+        if (rc__ != 0) return rc__;   \
+    } while (0)
+
+constexpr float EPS_LN = 1e-5f, EPS_L2 = 1e-12f;
+
+__global__ void grp_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int N, int K) {
+    // wt[k][n] = w[n][k]; weights are at most a few hundred KB: one element per thread, reads coalesced
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * K) return;
+    const int n = (int)(i / K), k = (int)(i % K);
+    wt[(size_t)k * N + n] = w[i];
+}
+int transpose(const float* w, float* wt, int N, int K, void* st) {
+    const long total = (long)N * K;
+    hipLaunchKernelGGL(grp_transpose_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)st, w, wt, N, K);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- Linear (+bias, +ReLU): tvqaplus_amd/ops.py::_Linear ----------------------------------------------------------
+bool lin_wants_mask(const float* x, const float* W, long long M, int N, int K, int relu) {
+    return relu && stage_gemm_mask_supported(M, N, K) && al16(x) && al16(W);
+}
+size_t lin_mask_words(long long M, int N) { return (size_t)((N + 31) / 32) * (size_t)M; }
+// forward; *has_mask = 1 when the ReLU bit mask was written (mask may be NULL: never try)
+int lin_fwd(const float* x, const float* W, const float* b, float* y, unsigned* mask, int* has_mask, long long M, int N, int K,
+            int relu, void* st) {
+    *has_mask = 0;
+    if (mask && lin_wants_mask(x, W, M, N, K, relu)) {
+        const int rc = stage_gemm_nt_mask(x, nullptr, W, b, y, mask, M, N, K, 1, st);
+        if (rc == 0) { *has_mask = 1; return 0; }
+        if (rc != STAGE_ERR_SHAPE) return rc;
+    }
+    return stage_gemm_nt(x, nullptr, W, b, nullptr, y, M, N, K, relu, st);
+}
+size_t lin_bwd_ws(long long M, int N, int K) { return umax(stage_gemm_tn_ws_bytes(M, N, K), 256); }
+// backward: dx (M,K) [may be NULL], dW (N,K), db (N) [may be NULL]; wt = scratch for the (K,N) transposed weight
+int lin_bwd(const float* dy, const float* x, const float* y, const unsigned* mask, int has_mask, int relu, const float* W, float* wt,
+            float* dx, float* dW, float* db, long long M, int N, int K, void* ws, size_t wsb, void* st) {
+    const float* gate = relu ? y : nullptr;
+    const bool use_mask = has_mask && al16(dy);
+    if (dx) {
+        TRY(transpose(W, wt, N, K, st));
+        bool done = false;
+        if (use_mask) {
+            const int rc = stage_gemm_nt_mask(dy, mask, wt, nullptr, dx, nullptr, M, K, N, 0, st);
+            if (rc == 0) done = true;
+            else if (rc != STAGE_ERR_SHAPE) return rc;
+        }
+        if (!done) TRY(stage_gemm_nt(dy, gate, wt, nullptr, nullptr, dx, M, K, N, 0, st));
+    }
+    // every kernel gets exactly the workspace size its own query names (some size their partial-sum grids by it: the per-op path
+    // and this one then reduce in the same order and agree bit for bit)
+    const size_t need = stage_gemm_tn_ws_bytes(M, N, K);
+    if (wsb < need) return STAGE_ERR_WORKSPACE;
+    if (use_mask) {
+        const int rc = stage_gemm_tn_mask(dy, mask, x, dW, db, M, N, K, ws, need, st);
+        if (rc == 0) return 0;
+        if (rc != STAGE_ERR_SHAPE) return rc;
+    }
+    return stage_gemm_tn(dy, gate, x, dW, db, M, N, K, ws, need, st);
+}
+
+bool ln_dwconv_ok(int D, int k) {
+    const int d4 = D / 4;
+    return D % 4 == 0 && d4 >= 4 && d4 <= 64 && (d4 & (d4 - 1)) == 0 && k >= 1 && k <= 9 && (k % 2) == 1;
+}
+bool cat3_reduced_ok(int D, int rep, int inner) {
+    const int d4 = D / 4;
+    return rep > 1 && D % 4 == 0 && d4 >= 4 && d4 <= 64 && (d4 & (d4 - 1)) == 0 && inner <= 64;
+}
+
+// =====================================================================================================================
+// G1  input MLP (model/stage.py:350-362 base_encoder up to the encoder; :85-91 / :98-104 bridge, :115-120 input_embedding;
+//     l2 != 0: the F.normalize of :256 first):  [l2norm] -> LN(K0)+drop -> Linear(K0->H)+ReLU -> LN(H)+drop -> Linear(H->D)+ReLU -> LN(D)
+//     params: g0 b0 W1 c1 g1 b1 W2 c2 g2 b2 ; seeds: [LN0 dropout, LN1 dropout] ; flags: [mask1, mask2]
+// =====================================================================================================================
+struct MlpArena {
+    float *xn, *y0, *mean0, *rstd0, *h1, *y1, *mean1, *rstd1, *h2, *mean2, *rstd2;
+    unsigned *mask1, *mask2;
+    size_t bytes;
+};
+MlpArena mlp_layout(void* base, long long M, int K0, int H, int D, int l2) {
+    Bump b{(char*)base, 0};
+    MlpArena a;
+    a.xn = l2 ? b.take<float>((size_t)M * K0) : nullptr;
+    a.y0 = b.take<float>((size_t)M * K0);
+    a.mean0 = b.take<float>((size_t)M);
+    a.rstd0 = b.take<float>((size_t)M);
+    a.h1 = b.take<float>((size_t)M * H);
+    a.mask1 = b.take<unsigned>(lin_mask_words(M, H));
+    a.y1 = b.take<float>((size_t)M * H);
+    a.mean1 = b.take<float>((size_t)M);
+    a.rstd1 = b.take<float>((size_t)M);
+    a.h2 = b.take<float>((size_t)M * D);
+    a.mask2 = b.take<unsigned>(lin_mask_words(M, D));
+    a.mean2 = b.take<float>((size_t)M);
+    a.rstd2 = b.take<float>((size_t)M);
+    a.bytes = b.off;
+    return a;
+}
+
+}  // namespace
+
+extern "C" size_t stage_grp_input_mlp_arena_bytes(long long M, int K0, int H, int D, int l2) {
+    return mlp_layout(nullptr, M, K0, H, D, l2).bytes;
+}
+
+extern "C" int stage_grp_input_mlp_fwd(const float* x, const float* const* P, float* out, void* arena, size_t arena_bytes,
+                                       int* flags, long long M, int K0, int H, int D, int l2, float p,
+                                       const unsigned long long* seeds, void* st) {
+    if (M <= 0 || K0 % 4 || H % 4 || D % 4 || K0 > 1024 || H > 1024 || D > 1024) return STAGE_ERR_SHAPE;
+    MlpArena a = mlp_layout(arena, M, K0, H, D, l2);
+    if (arena_bytes < a.bytes) return STAGE_ERR_WORKSPACE;
+    const float* xin = x;
+    if (l2) {
+        TRY(stage_l2norm_fwd(x, a.xn, nullptr, M, K0, EPS_L2, 0.f, 0ull, st));
+        xin = a.xn;
+    }
+    TRY(stage_layernorm_fwd(xin, nullptr, 0, nullptr, P[0], P[1], a.y0, a.mean0, a.rstd0, M, K0, EPS_LN, p, seeds[0], st));
+    TRY(lin_fwd(a.y0, P[2], P[3], a.h1, a.mask1, &flags[0], M, H, K0, 1, st));
+    TRY(stage_layernorm_fwd(a.h1, nullptr, 0, nullptr, P[4], P[5], a.y1, a.mean1, a.rstd1, M, H, EPS_LN, p, seeds[1], st));
+    TRY(lin_fwd(a.y1, P[6], P[7], a.h2, a.mask2, &flags[1], M, D, H, 1, st));
+    TRY(stage_layernorm_fwd(a.h2, nullptr, 0, nullptr, P[8], P[9], out, a.mean2, a.rstd2, M, D, EPS_LN, 0.f, 0ull, st));
+    return 0;
+}
+
+namespace {
+struct MlpTmp { float *dh2, *dy1, *dh1, *dy0, *wt; void* ws; size_t wsb, bytes; };
+MlpTmp mlp_tmp(void* base, long long M, int K0, int H, int D) {
+    Bump b{(char*)base, 0};
+    MlpTmp t;
+    t.dh2 = b.take<float>((size_t)M * D);
+    t.dy1 = b.take<float>((size_t)M * H);
+    t.dh1 = b.take<float>((size_t)M * H);
+    t.dy0 = b.take<float>((size_t)M * K0);
+    t.wt = b.take<float>((size_t)umax((size_t)H * K0, (size_t)D * H));
+    t.wsb = umax(umax(stage_ln_bwd_ws_bytes(K0), stage_ln_bwd_ws_bytes(H)), stage_ln_bwd_ws_bytes(D));
+    t.wsb = umax(t.wsb, umax(lin_bwd_ws(M, H, K0), lin_bwd_ws(M, D, H)));
+    t.ws = b.take<char>(t.wsb);
+    t.bytes = b.off;
+    return t;
+}
+}  // namespace
+
+extern "C" size_t stage_grp_input_mlp_bwd_tmp_bytes(long long M, int K0, int H, int D) { return mlp_tmp(nullptr, M, K0, H, D).bytes; }
+
+// grads: same order as params (dg0 db0 dW1 dc1 dg1 db1 dW2 dc2 dg2 db2).  The features need no gradient (they are data).
+extern "C" int stage_grp_input_mlp_bwd(const float* dout, const float* x, const float* const* P, float* const* G, const void* arena,
+                                       size_t arena_bytes, const int* flags, void* tmp, size_t tmp_bytes, long long M, int K0,
+                                       int H, int D, int l2, float p, const unsigned long long* seeds, void* st) {
+    MlpArena a = mlp_layout((void*)arena, M, K0, H, D, l2);
+    MlpTmp t = mlp_tmp(tmp, M, K0, H, D);
+    if (arena_bytes < a.bytes || tmp_bytes < t.bytes) return STAGE_ERR_WORKSPACE;
+    const float* xin = l2 ? a.xn : x;
+    TRY(stage_layernorm_bwd(dout, a.h2, a.mean2, a.rstd2, P[8], t.dh2, nullptr, G[8], G[9], M, D, 0.f, 0ull, t.ws, stage_ln_bwd_ws_bytes(D), st));
+    TRY(lin_bwd(t.dh2, a.y1, a.h2, a.mask2, flags[1], 1, P[6], t.wt, t.dy1, G[6], G[7], M, D, H, t.ws, t.wsb, st));
+    TRY(stage_layernorm_bwd(t.dy1, a.h1, a.mean1, a.rstd1, P[4], t.dh1, nullptr, G[4], G[5], M, H, p, seeds[1], t.ws, stage_ln_bwd_ws_bytes(H), st));
+    TRY(lin_bwd(t.dh1, a.y0, a.h1, a.mask1, flags[0], 1, P[2], t.wt, t.dy0, G[2], G[3], M, H, K0, t.ws, t.wsb, st));
+    TRY(stage_layernorm_bwd(t.dy0, xin, a.mean0, a.rstd0, P[0], nullptr, nullptr, G[0], G[1], M, K0, p, seeds[0], t.ws, stage_ln_bwd_ws_bytes(K0), st));
+    return 0;
+}
+
+// =====================================================================================================================
+// G2  encoder block without self-attention (model/encoder.py:29-52, model/cnn.py:37-47, model/position_encoding.py:38-43):
+//     x + pe -> n_conv x [LN (+dropout on even i) -> depthwise conv -> 1x1 conv + ReLU -> + residual] -> final LN
+//     pooled != 0: the caller only needs the masked max over L of the output (model/stage.py:503) -> out (M, D)
+//     params: per conv i: ln_g ln_b dw_w dw_b pw_w pw_b ; then final_g final_b.  seeds: one per even conv index.
+//     flags: [pw mask of conv i] for i < n_conv ; flags[n_conv] = 1 when LayerNorm + max ran fused
+//     Residual adds are deferred into the next LayerNorm's prologue (exported sums), as in STAGE._encoder_block.
+// =====================================================================================================================
+namespace {
+constexpr int ENC_MAX_CONV = 8;
+struct EncArena {
+    float *h[ENC_MAX_CONV], *s[ENC_MAX_CONV], *mean[ENC_MAX_CONV], *rstd[ENC_MAX_CONV], *g[ENC_MAX_CONV];
+    unsigned* mask[ENC_MAX_CONV];
+    float *sf, *meanf, *rstdf, *yf;
+    int* idx;
+    size_t bytes;
+};
+EncArena enc_layout(void* base, long long M, int L, int D, int n_conv, int pooled) {
+    Bump b{(char*)base, 0};
+    EncArena a;
+    const size_t R = (size_t)M * L;
+    for (int i = 0; i < n_conv; i++) {
+        a.h[i] = b.take<float>(R * D);
+        a.s[i] = b.take<float>(R * D);
+        a.mean[i] = b.take<float>(R);
+        a.rstd[i] = b.take<float>(R);
+        a.g[i] = b.take<float>(R * D);
+        a.mask[i] = b.take<unsigned>(lin_mask_words((long long)R, D));
+    }
+    a.sf = b.take<float>(R * D);
+    a.meanf = b.take<float>(R);
+    a.rstdf = b.take<float>(R);
+    a.yf = pooled ? b.take<float>(R * D) : nullptr;          // only used when LayerNorm + max do not run fused
+    a.idx = pooled ? b.take<int>((size_t)M * D) : nullptr;
+    a.bytes = b.off;
+    return a;
+}
+}  // namespace
+
+extern "C" size_t stage_grp_encoder_arena_bytes(long long M, int L, int D, int n_conv, int pooled) {
+    if (n_conv > ENC_MAX_CONV) return 0;
+    return enc_layout(nullptr, M, L, D, n_conv, pooled).bytes;
+}
+
+extern "C" int stage_grp_encoder_fwd(const float* x, const float* pe, const float* pool_mask, const float* const* P, float* out,
+                                     void* arena, size_t arena_bytes, int* flags, long long M, int L, int D, int n_conv, int k,
+                                     float p, const unsigned long long* seeds, void* st) {
+    if (M <= 0 || L <= 0 || n_conv < 0 || n_conv > ENC_MAX_CONV || !ln_dwconv_ok(D, k) || D > 1024) return STAGE_ERR_SHAPE;
+    const int pooled = pool_mask != nullptr;
+    EncArena a = enc_layout(arena, M, L, D, n_conv, pooled);
+    if (arena_bytes < a.bytes) return STAGE_ERR_WORKSPACE;
+    const long long R = M * L;
+    const float* pending = x;
+    const float* cur = pe;
+    int period = L;
+    for (int i = 0; i < n_conv; i++) {
+        const float* const* Q = P + 6 * i;
+        const bool drop = (i % 2) == 0;
+        const unsigned long long seed = drop ? seeds[i / 2] : 0ull;
+        TRY(stage_ln_dwconv_fwd(pending, cur, period, a.s[i], Q[0], Q[1], Q[2], Q[3], a.h[i], a.mean[i], a.rstd[i], M, L, D, k, EPS_LN,
+                                drop ? p : 0.f, seed, st));
+        cur = a.s[i];
+        period = 0;
+        TRY(lin_fwd(a.h[i], Q[4], Q[5], a.g[i], a.mask[i], &flags[i], R, D, D, 1, st));
+        pending = a.g[i];
+    }
+    const float* const* F = P + 6 * n_conv;
+    flags[n_conv] = 0;
+    if (pooled && period == 0 && stage_ln_masked_max_supported(L, D)) {
+        flags[n_conv] = 1;
+        return stage_ln_masked_max_fwd(pending, cur, a.sf, F[0], F[1], pool_mask, out, a.idx, a.meanf, a.rstdf, M, L, D, EPS_LN, st);
+    }
+    float* y = pooled ? a.yf : out;
+    TRY(stage_layernorm_fwd(pending, cur, period, a.sf, F[0], F[1], y, a.meanf, a.rstdf, R, D, EPS_LN, 0.f, 0ull, st));
+    if (pooled) TRY(stage_masked_max_fwd(y, pool_mask, nullptr, out, a.idx, M, L, D, st));
+    return 0;
+}
+
+namespace {
+struct EncTmp { float *Ga, *Gb, *dh, *dyf, *wt; void* ws; size_t wsb, bytes; };
+EncTmp enc_tmp(void* base, long long M, int L, int D, int k, int pooled) {
+    Bump b{(char*)base, 0};
+    EncTmp t;
+    const size_t R = (size_t)M * L;
+    t.Ga = b.take<float>(R * D);
+    t.Gb = b.take<float>(R * D);
+    t.dh = b.take<float>(R * D);
+    t.dyf = pooled ? b.take<float>(R * D) : nullptr;
+    t.wt = b.take<float>((size_t)D * D);
+    t.wsb = umax(umax(stage_ln_bwd_ws_bytes(D), stage_ln_dwconv_bwd_ws_bytes(D, k)), lin_bwd_ws((long long)R, D, D));
+    t.ws = b.take<char>(t.wsb);
+    t.bytes = b.off;
+    return t;
+}
+}  // namespace
+
+extern "C" size_t stage_grp_encoder_bwd_tmp_bytes(long long M, int L, int D, int k, int pooled) {
+    return enc_tmp(nullptr, M, L, D, k, pooled).bytes;
+}
+
+// dout: (M, L, D), or (M, D) when pooled.  dx (M, L, D) receives the gradient of x (may be NULL).  grads in params order.
+extern "C" int stage_grp_encoder_bwd(const float* dout, const float* x, const float* pool_mask, const float* const* P,
+                                     float* const* Gr, float* dx, const void* arena, size_t arena_bytes, const int* flags,
+                                     void* tmp, size_t tmp_bytes, long long M, int L, int D, int n_conv, int k, float p,
+                                     const unsigned long long* seeds, void* st) {
+    (void)x;
+    const int pooled = pool_mask != nullptr;
+    if (n_conv < 0 || n_conv > ENC_MAX_CONV) return STAGE_ERR_SHAPE;
+    EncArena a = enc_layout((void*)arena, M, L, D, n_conv, pooled);
+    EncTmp t = enc_tmp(tmp, M, L, D, k, pooled);
+    if (arena_bytes < a.bytes || tmp_bytes < t.bytes) return STAGE_ERR_WORKSPACE;
+    const long long R = M * L;
+    const float* const* F = P + 6 * n_conv;
+    float* const* GF = Gr + 6 * n_conv;
+    // G = gradient of the last exported sum (pending + cur): it feeds the last 1x1 conv's output AND the previous sum
+    float* G = (n_conv == 0 && dx) ? dx : t.Ga;
+    if (pooled && flags[n_conv]) {
+        TRY(stage_ln_masked_max_bwd(dout, a.idx, pool_mask, a.sf, a.meanf, a.rstdf, F[0], G, GF[0], GF[1], M, L, D, t.ws, stage_ln_bwd_ws_bytes(D), st));
+    } else {
+        const float* dy = dout;
+        if (pooled) {
+            TRY(stage_masked_max_bwd(dout, a.idx, pool_mask, t.dyf, M, L, D, 0, st));
+            dy = t.dyf;
+        }
+        TRY(stage_layernorm_bwd(dy, a.sf, a.meanf, a.rstdf, F[0], G, nullptr, GF[0], GF[1], R, D, 0.f, 0ull, t.ws, stage_ln_bwd_ws_bytes(D), st));
+    }
+    for (int i = n_conv - 1; i >= 0; i--) {
+        const float* const* Q = P + 6 * i;
+        float* const* GQ = Gr + 6 * i;
+        const bool drop = (i % 2) == 0;
+        const unsigned long long seed = drop ? seeds[i / 2] : 0ull;
+        // 1x1 conv + ReLU: G is the gradient of its output; its input was the depthwise conv's output h[i]
+        TRY(lin_bwd(G, a.h[i], a.g[i], a.mask[i], flags[i], 1, Q[4], t.wt, t.dh, GQ[4], GQ[5], R, D, D, t.ws, t.wsb, st));
+        // LayerNorm -> depthwise conv: gradient of the sum s[i] = LN-path gradient + what reached the sum directly (G)
+        float* Gn = (i == 0 && dx) ? dx : (G == t.Ga ? t.Gb : t.Ga);
+        TRY(stage_ln_dwconv_bwd(t.dh, a.s[i], a.mean[i], a.rstd[i], Q[0], Q[1], Q[2], Gn, G, GQ[0], GQ[1], GQ[2], GQ[3], M, L, D, k,
+                                drop ? p : 0.f, seed, t.ws, stage_ln_dwconv_bwd_ws_bytes(D, k), st));
+        G = Gn;
+    }
+    return 0;
+}
+
+// =====================================================================================================================
+// G3  QA <-> context attention + down-projection (model/stage.py:365-387, model/context_query_attention.py:35-101):
+//     Cn = drop(normalize(qa)) ; (A, S_raw, S_norm) = StructuredAttention(Cn, ctx) ; z = drop(LN_3D([qa, A, qa*A])) ;
+//     mixed = ReLU(Linear_3D->D(z)).  Fast attention kernels only (Lr <= 64; longer rows: STAGE_ERR_SHAPE -> per-op path).
+//     params: ln_g ln_b W c ; seeds: [context-side dropout, region-side dropout, LayerNorm dropout] ; flags: [mask]
+// =====================================================================================================================
+namespace {
+struct QaArena { float *Cn, *A, *z, *mean, *rstd; unsigned* mask; size_t bytes; };
+QaArena qa_layout(void* base, int N, int NA, int Li, int Lqa, int D) {
+    Bump b{(char*)base, 0};
+    QaArena a;
+    const size_t U = (size_t)N * NA * Li * Lqa;
+    a.Cn = b.take<float>((size_t)N * NA * Lqa * D);
+    a.A = b.take<float>(U * D);
+    a.z = b.take<float>(U * 3 * D);
+    a.mean = b.take<float>(U);
+    a.rstd = b.take<float>(U);
+    a.mask = b.take<unsigned>(lin_mask_words((long long)U, D));
+    a.bytes = b.off;
+    return a;
+}
+struct QaTmp { float *dz, *dA, *Qn, *dQn, *dCn, *dS, *da_full, *wt; void* ws; size_t wsb, bytes; };
+QaTmp qa_tmp(void* base, int N, int NA, int Li, int Lqa, int Lr, int D) {
+    Bump b{(char*)base, 0};
+    QaTmp t;
+    const size_t U = (size_t)N * NA * Li * Lqa, Qe = (size_t)N * Li * Lr * D;
+    t.dz = b.take<float>(U * 3 * D);
+    t.dA = b.take<float>(U * D);
+    t.Qn = b.take<float>(Qe);
+    t.dQn = b.take<float>(Qe);
+    t.dCn = b.take<float>((size_t)N * NA * Lqa * D);
+    t.wt = b.take<float>((size_t)3 * D * D);
+    // the kernels that only run for shapes the fused ones reject share one region (they never run together with dz's consumers)
+    t.dS = nullptr;
+    t.da_full = nullptr;
+    t.wsb = umax(lin_bwd_ws((long long)U, D, 3 * D), stage_ln_bwd_ws_bytes(3 * D));
+    t.wsb = umax(t.wsb, stage_cat3_layernorm_bwd_reduced_ws_bytes((long long)U, D, Li, Lqa));
+    t.wsb = umax(t.wsb, umax(stage_str_attn_bwd_fused_ws_bytes(N, NA, Li, Lqa, D), stage_str_attn_bwd_ws_bytes(N, NA, Lqa, D)));
+    t.ws = b.take<char>(t.wsb);
+    t.bytes = b.off;
+    return t;
+}
+}  // namespace
+
+extern "C" size_t stage_grp_qa_ctx_arena_bytes(int N, int NA, int Li, int Lqa, int D) { return qa_layout(nullptr, N, NA, Li, Lqa, D).bytes; }
+
+extern "C" int stage_grp_qa_ctx_fwd(const float* qa, const float* ctx, const float* qa_mask, const float* ctx_mask,
+                                    const float* const* P, float* mixed, float* S_raw, float* S_norm, void* arena,
+                                    size_t arena_bytes, int* flags, int N, int NA, int Li, int Lqa, int Lr, int D, float scale,
+                                    float p, const unsigned long long* seeds, void* st) {
+    if (N <= 0 || Lr > 64 || D % 16 || D > 256 || NA * Lqa > 256) return STAGE_ERR_SHAPE;
+    QaArena a = qa_layout(arena, N, NA, Li, Lqa, D);
+    if (arena_bytes < a.bytes) return STAGE_ERR_WORKSPACE;
+    const long long U = (long long)N * NA * Li * Lqa;
+    TRY(stage_l2norm_fwd(qa, a.Cn, nullptr, (long long)N * NA * Lqa, D, EPS_L2, p, seeds[0], st));
+    TRY(stage_str_attn_fwd(a.Cn, ctx, qa_mask, ctx_mask, a.A, S_raw, S_norm, N, NA, Li, Lqa, Lr, D, scale, p, seeds[1], st));
+    TRY(stage_cat3_layernorm_fwd(qa, a.A, P[0], P[1], a.z, a.mean, a.rstd, U, D, Li, Lqa, EPS_LN, p, seeds[2], st));
+    return lin_fwd(a.z, P[2], P[3], mixed, a.mask, &flags[0], U, D, 3 * D, 1, st);
+}
+
+extern "C" size_t stage_grp_qa_ctx_bwd_tmp_bytes(int N, int NA, int Li, int Lqa, int Lr, int D) {
+    size_t b = qa_tmp(nullptr, N, NA, Li, Lqa, Lr, D).bytes;
+    // fallback kernels (shapes the fused ones reject): unreduced [a]-gradient rows / the materialised score gradient
+    const size_t U = (size_t)N * NA * Li * Lqa;
+    return b + 512 + umax(U * D, U * Lr) * sizeof(float);
+}
+
+// d_mixed (U, D); dS_ext: gradient on S_raw (supervised attention loss) or NULL.  Outputs: d_qa (N,NA,Lqa,D) = both uses of the QA
+// embedding (attention context + the [a, b, a*b] operand), d_ctx (N,Li,Lr,D).  grads: dln_g dln_b dW dc.
+extern "C" int stage_grp_qa_ctx_bwd(const float* d_mixed, const float* dS_ext, const float* qa, const float* ctx,
+                                    const float* ctx_mask, const float* mixed, const float* S_norm, const float* const* P,
+                                    float* const* G, float* d_qa, float* d_ctx, const void* arena, size_t arena_bytes,
+                                    const int* flags, void* tmp, size_t tmp_bytes, int N, int NA, int Li, int Lqa, int Lr, int D,
+                                    float scale, float p, const unsigned long long* seeds, void* st) {
+    QaArena a = qa_layout((void*)arena, N, NA, Li, Lqa, D);
+    QaTmp t = qa_tmp(tmp, N, NA, Li, Lqa, Lr, D);
+    if (arena_bytes < a.bytes || tmp_bytes < stage_grp_qa_ctx_bwd_tmp_bytes(N, NA, Li, Lqa, Lr, D)) return STAGE_ERR_WORKSPACE;
+    float* extra = (float*)((char*)tmp + ((t.bytes + 255) & ~(size_t)255));
+    const long long U = (long long)N * NA * Li * Lqa, Crows = (long long)N * NA * Lqa, Qrows = (long long)N * Li * Lr;
+    // Linear(3D -> D) + ReLU
+    TRY(lin_bwd(d_mixed, a.z, mixed, a.mask, flags[0], 1, P[2], t.wt, t.dz, G[2], G[3], U, D, 3 * D, t.ws, t.wsb, st));
+    // LayerNorm over [a, b, a*b]; the gradient of the broadcast operand a is summed over the frames inside the kernel
+    bool reduced = false;
+    if (cat3_reduced_ok(D, Li, Lqa)) {
+        const int rc = stage_cat3_layernorm_bwd_reduced(t.dz, qa, a.A, a.mean, a.rstd, P[0], d_qa, t.dA, G[0], G[1], U, D, Li, Lqa, p,
+                                                        seeds[2], t.ws, stage_cat3_layernorm_bwd_reduced_ws_bytes(U, D, Li, Lqa), st);
+        if (rc == 0) reduced = true;
+        else if (rc != STAGE_ERR_SHAPE) return rc;
+    }
+    if (!reduced) {
+        TRY(stage_cat3_layernorm_bwd(t.dz, qa, a.A, a.mean, a.rstd, P[0], extra, t.dA, G[0], G[1], U, D, Li, Lqa, p, seeds[2], t.ws,
+                                     stage_ln_bwd_ws_bytes(3 * D), st));
+        if (Li > 1) TRY(stage_reduce_rep(extra, d_qa, (long long)N * NA, Li, (long long)Lqa * D, st));
+        else TRY((int)hipMemcpyAsync(d_qa, extra, (size_t)Crows * D * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)st));
+    }
+    // StructuredAttention backward
+    TRY(stage_l2norm_fwd(ctx, t.Qn, nullptr, Qrows, D, EPS_L2, p, seeds[1], st));
+    int rc = stage_str_attn_bwd_fused(t.dA, dS_ext, a.Cn, ctx, t.Qn, S_norm, ctx_mask, d_ctx, t.dQn, t.dCn, N, NA, Li, Lqa, Lr, D,
+                                      scale, t.ws, stage_str_attn_bwd_fused_ws_bytes(N, NA, Li, Lqa, D), st);
+    if (rc == STAGE_ERR_SHAPE)
+        rc = stage_str_attn_bwd(t.dA, dS_ext, a.Cn, ctx, t.Qn, S_norm, extra, d_ctx, t.dQn, t.dCn, N, NA, Li, Lqa, Lr, D, scale, t.ws,
+                                stage_str_attn_bwd_ws_bytes(N, NA, Lqa, D), st);
+    if (rc != 0) return rc;
+    // the two normalisations: gradients accumulate onto what is already in d_qa (the [a,b,a*b] path) / d_ctx (the value path)
+    TRY(stage_l2norm_bwd(t.dCn, qa, d_qa, Crows, D, EPS_L2, p, seeds[0], 1, st));
+    return stage_l2norm_bwd(t.dQn, ctx, d_ctx, Qrows, D, EPS_L2, p, seeds[1], 1, st);
+}
+
+// =====================================================================================================================
+// G4  two-stream fusion concat_fc (model/stage.py:276-279, :106-113): LN_3D([s, v, s*v]) + drop -> Linear(3D->D) + ReLU -> LN(D)
+//     params: ln3_g ln3_b W c ln_g ln_b ; seeds: [LayerNorm dropout] ; flags: [mask]
+// =====================================================================================================================
+namespace {
+struct FcArena { float *z, *mean3, *rstd3, *h, *mean, *rstd; unsigned* mask; size_t bytes; };
+FcArena fc_layout(void* base, long long U, int D) {
+    Bump b{(char*)base, 0};
+    FcArena a;
+    a.z = b.take<float>((size_t)U * 3 * D);
+    a.mean3 = b.take<float>((size_t)U);
+    a.rstd3 = b.take<float>((size_t)U);
+    a.h = b.take<float>((size_t)U * D);
+    a.mask = b.take<unsigned>(lin_mask_words(U, D));
+    a.mean = b.take<float>((size_t)U);
+    a.rstd = b.take<float>((size_t)U);
+    a.bytes = b.off;
+    return a;
+}
+struct FcTmp { float *dh, *dz, *wt; void* ws; size_t wsb, bytes; };
+FcTmp fc_tmp(void* base, long long U, int D) {
+    Bump b{(char*)base, 0};
+    FcTmp t;
+    t.dh = b.take<float>((size_t)U * D);
+    t.dz = b.take<float>((size_t)U * 3 * D);
+    t.wt = b.take<float>((size_t)3 * D * D);
+    t.wsb = umax(umax(lin_bwd_ws(U, D, 3 * D), stage_ln_bwd_ws_bytes(3 * D)), stage_ln_bwd_ws_bytes(D));
+    t.ws = b.take<char>(t.wsb);
+    t.bytes = b.off;
+    return t;
+}
+}  // namespace
+
+extern "C" size_t stage_grp_concat_fc_arena_bytes(long long U, int D) { return fc_layout(nullptr, U, D).bytes; }
+extern "C" size_t stage_grp_concat_fc_bwd_tmp_bytes(long long U, int D) { return fc_tmp(nullptr, U, D).bytes; }
+
+extern "C" int stage_grp_concat_fc_fwd(const float* s, const float* v, const float* const* P, float* out, void* arena,
+                                       size_t arena_bytes, int* flags, long long U, int D, float p,
+                                       const unsigned long long* seeds, void* st) {
+    if (U <= 0 || D % 4 || D > 256) return STAGE_ERR_SHAPE;
+    FcArena a = fc_layout(arena, U, D);
+    if (arena_bytes < a.bytes) return STAGE_ERR_WORKSPACE;
+    TRY(stage_cat3_layernorm_fwd(s, v, P[0], P[1], a.z, a.mean3, a.rstd3, U, D, 1, 1, EPS_LN, p, seeds[0], st));
+    TRY(lin_fwd(a.z, P[2], P[3], a.h, a.mask, &flags[0], U, D, 3 * D, 1, st));
+    return stage_layernorm_fwd(a.h, nullptr, 0, nullptr, P[4], P[5], out, a.mean, a.rstd, U, D, EPS_LN, 0.f, 0ull, st);
+}
+
+// ds, dv (U, D) ; grads: dln3_g dln3_b dW dc dln_g dln_b
+extern "C" int stage_grp_concat_fc_bwd(const float* dout, const float* s, const float* v, const float* const* P, float* const* G,
+                                       float* ds, float* dv, const void* arena, size_t arena_bytes, const int* flags, void* tmp,
+                                       size_t tmp_bytes, long long U, int D, float p, const unsigned long long* seeds, void* st) {
+    FcArena a = fc_layout((void*)arena, U, D);
+    FcTmp t = fc_tmp(tmp, U, D);
+    if (arena_bytes < a.bytes || tmp_bytes < t.bytes) return STAGE_ERR_WORKSPACE;
+    TRY(stage_layernorm_bwd(dout, a.h, a.mean, a.rstd, P[4], t.dh, nullptr, G[4], G[5], U, D, 0.f, 0ull, t.ws, stage_ln_bwd_ws_bytes(D), st));
+    TRY(lin_bwd(t.dh, a.z, a.h, a.mask, flags[0], 1, P[2], t.wt, t.dz, G[2], G[3], U, D, 3 * D, t.ws, t.wsb, st));
+    return stage_cat3_layernorm_bwd(t.dz, s, v, a.mean3, a.rstd3, P[0], ds, dv, G[0], G[1], U, D, 1, 1, p, seeds[0], t.ws,
+                                    stage_ln_bwd_ws_bytes(3 * D), st);
+}
+
+// =====================================================================================================================
+// G5  temporal head, layer 0 (model/stage.py:469-482 residual_temporal_predictor, LinearWrapper :15-32):
+//     h = ReLU(Linear(drop(LN_p(enc)))) ; first = enc + h ; t_st = Linear_st(drop(LN_st(first))) ; t_ed = Linear_ed(drop(LN_ed(first)))
+//     params: lnp_g lnp_b Wp cp lns_g lns_b Ws cs lne_g lne_b We ce ; seeds: [LN_p, LN_st, LN_ed dropout] ; flags: [mask_p]
+//     outputs: first (R, D), t_st (R), t_ed (R)
+// =====================================================================================================================
+namespace {
+struct ThArena { float *yp, *meanp, *rstdp, *h, *ys, *means, *rstds, *ye, *meane, *rstde; unsigned* mask; size_t bytes; };
+ThArena th_layout(void* base, long long R, int D) {
+    Bump b{(char*)base, 0};
+    ThArena a;
+    a.yp = b.take<float>((size_t)R * D);
+    a.meanp = b.take<float>((size_t)R);
+    a.rstdp = b.take<float>((size_t)R);
+    a.h = b.take<float>((size_t)R * D);
+    a.mask = b.take<unsigned>(lin_mask_words(R, D));
+    a.ys = b.take<float>((size_t)R * D);
+    a.means = b.take<float>((size_t)R);
+    a.rstds = b.take<float>((size_t)R);
+    a.ye = b.take<float>((size_t)R * D);
+    a.meane = b.take<float>((size_t)R);
+    a.rstde = b.take<float>((size_t)R);
+    a.bytes = b.off;
+    return a;
+}
+struct ThTmp { float *dye, *dfirst, *dys, *G, *dyp, *wt; void* ws; size_t wsb, bytes; };
+ThTmp th_tmp(void* base, long long R, int D) {
+    Bump b{(char*)base, 0};
+    ThTmp t;
+    t.dye = b.take<float>((size_t)R * D);
+    t.dfirst = b.take<float>((size_t)R * D);
+    t.dys = b.take<float>((size_t)R * D);
+    t.G = b.take<float>((size_t)R * D);
+    t.dyp = b.take<float>((size_t)R * D);
+    t.wt = b.take<float>((size_t)D * D);
+    t.wsb = umax(umax(lin_bwd_ws(R, D, D), lin_bwd_ws(R, 1, D)), stage_ln_bwd_ws_bytes(D));
+    t.ws = b.take<char>(t.wsb);
+    t.bytes = b.off;
+    return t;
+}
+}  // namespace
+
+extern "C" size_t stage_grp_temporal_head_arena_bytes(long long R, int D) { return th_layout(nullptr, R, D).bytes; }
+extern "C" size_t stage_grp_temporal_head_bwd_tmp_bytes(long long R, int D) { return th_tmp(nullptr, R, D).bytes; }
+
+extern "C" int stage_grp_temporal_head_fwd(const float* enc, const float* const* P, float* first, float* t_st, float* t_ed,
+                                           void* arena, size_t arena_bytes, int* flags, long long R, int D, float p,
+                                           const unsigned long long* seeds, void* st) {
+    if (R <= 0 || D % 4 || D > 1024) return STAGE_ERR_SHAPE;
+    ThArena a = th_layout(arena, R, D);
+    if (arena_bytes < a.bytes) return STAGE_ERR_WORKSPACE;
+    int none = 0;
+    TRY(stage_layernorm_fwd(enc, nullptr, 0, nullptr, P[0], P[1], a.yp, a.meanp, a.rstdp, R, D, EPS_LN, p, seeds[0], st));
+    TRY(lin_fwd(a.yp, P[2], P[3], a.h, a.mask, &flags[0], R, D, D, 1, st));
+    TRY(stage_layernorm_fwd(a.h, enc, 0, first, P[4], P[5], a.ys, a.means, a.rstds, R, D, EPS_LN, p, seeds[1], st));
+    TRY(lin_fwd(a.ys, P[6], P[7], t_st, nullptr, &none, R, 1, D, 0, st));
+    TRY(stage_layernorm_fwd(first, nullptr, 0, nullptr, P[8], P[9], a.ye, a.meane, a.rstde, R, D, EPS_LN, p, seeds[2], st));
+    return lin_fwd(a.ye, P[10], P[11], t_ed, nullptr, &none, R, 1, D, 0, st);
+}
+
+// d_first may be NULL (no gradient arrived on the exported sum).  d_enc (R, D).  grads in params order.
+extern "C" int stage_grp_temporal_head_bwd(const float* d_first, const float* d_st, const float* d_ed, const float* enc,
+                                           const float* first, const float* const* P, float* const* G, float* d_enc,
+                                           const void* arena, size_t arena_bytes, const int* flags, void* tmp, size_t tmp_bytes,
+                                           long long R, int D, float p, const unsigned long long* seeds, void* st) {
+    ThArena a = th_layout((void*)arena, R, D);
+    ThTmp t = th_tmp(tmp, R, D);
+    if (arena_bytes < a.bytes || tmp_bytes < t.bytes) return STAGE_ERR_WORKSPACE;
+    // end scorer: Linear(D -> 1), LayerNorm of `first`; its input gradient joins what arrived on `first` from the pooling path
+    TRY(lin_bwd(d_ed, a.ye, nullptr, nullptr, 0, 0, P[10], t.wt, t.dye, G[10], G[11], R, 1, D, t.ws, t.wsb, st));
+    TRY(stage_layernorm_bwd(t.dye, first, a.meane, a.rstde, P[8], t.dfirst, d_first, G[8], G[9], R, D, p, seeds[2], t.ws, stage_ln_bwd_ws_bytes(D), st));
+    // start scorer: LayerNorm of (h + enc) with the exported sum `first`: total gradient of the sum = own path + t.dfirst
+    TRY(lin_bwd(d_st, a.ys, nullptr, nullptr, 0, 0, P[6], t.wt, t.dys, G[6], G[7], R, 1, D, t.ws, t.wsb, st));
+    TRY(stage_layernorm_bwd(t.dys, first, a.means, a.rstds, P[4], t.G, t.dfirst, G[4], G[5], R, D, p, seeds[1], t.ws, stage_ln_bwd_ws_bytes(D), st));
+    // projection: t.G is the gradient of h (and, as the residual, of enc)
+    TRY(lin_bwd(t.G, a.yp, a.h, a.mask, flags[0], 1, P[2], t.wt, t.dyp, G[2], G[3], R, D, D, t.ws, t.wsb, st));
+    return stage_layernorm_bwd(t.dyp, enc, a.meanp, a.rstdp, P[0], d_enc, t.G, G[0], G[1], R, D, p, seeds[0], t.ws, stage_ln_bwd_ws_bytes(D), st);
+}

@@ -1,0 +1,306 @@
+"""K-groups: one ``torch.autograd.Function`` per fused-op GROUP of STAGE, each backed by one forward and one backward entry point of
+``libstage_hip.so`` that sequences the group's kernels on the C side (csrc/groups.hip; SURVEY.md section 8b, last bullet).
+
+The per-op path (``tvqaplus_amd.ops``: one Function and ~4 ``torch.empty`` per kernel) issues ~360 launches per training step from
+Python; here the interpreter sees one call per group -- input MLP, encoder block, QA<->context attention + down-projection,
+two-stream fusion, temporal head -- i.e. ~12 forward and ~12 backward calls.  The kernels, their order and their arguments are
+the per-op path's (``tests/test_hip_groups.py`` holds the two paths equal, dropout on), so this is sequencing only: what changes
+is that the step no longer depends on how fast the host can issue launches.
+
+Memory: the caller (this module) owns everything.  ``arena`` = one buffer per group call that the C side carves into what the
+backward needs; ``tmp`` = backward-only scratch, freed when the backward returns (stream-ordered, like every torch temporary).
+A group that does not take a shape raises ``Unsupported`` BEFORE launching anything; STAGE then runs that group per-op.
+fp32 storage only (the bf16 storage mode stays on the per-op path).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from .ops import _chk, _on_device, _stream
+
+_U8 = torch.uint8
+
+
+class Unsupported(Exception):
+    """The C side declined the shape (STAGE_ERR_SHAPE) before launching anything."""
+
+
+def _ptrs(ts: Sequence[Optional[torch.Tensor]]):
+    return (ctypes.c_void_p * max(1, len(ts)))(*[None if t is None else t.data_ptr() for t in ts])
+
+
+def _u64(seeds: Sequence[int]):
+    return (ctypes.c_ulonglong * max(1, len(seeds)))(*[int(s) for s in seeds])
+
+
+def _flags():
+    return (ctypes.c_int * 16)()
+
+
+def _rc(rc: int, what: str):
+    if rc == _lib.STAGE_ERR_SHAPE:
+        raise Unsupported(what)
+    if rc != 0:
+        _lib.check(rc, what)
+
+
+_SIZES = {}
+
+
+def _size(fn_name: str, *dims) -> int:
+    """Arena / scratch sizes depend on the dimensions only: one C call per distinct shape."""
+    key = (fn_name,) + dims
+    v = _SIZES.get(key)
+    if v is None:
+        v = _SIZES[key] = int(getattr(_lib.load(), fn_name)(*dims))
+    return v
+
+
+def _buf(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=_U8, device=device)
+
+
+def _grad_views(params: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+    """One allocation for all parameter gradients of a group call; 256-byte aligned slices shaped like the parameters."""
+    offs, total = [], 0
+    for w in params:
+        offs.append(total)
+        total += (w.numel() + 63) // 64 * 64
+    flat = torch.empty(total, dtype=torch.float32, device=params[0].device)
+    return [flat[o: o + w.numel()].view(w.shape) for o, w in zip(offs, params)]
+
+
+def _params(params) -> List[torch.Tensor]:
+    return [_chk(w, "param") for w in params]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# G1 input MLP
+# ---------------------------------------------------------------------------------------------------------------
+class _InputMLP(torch.autograd.Function):
+    @_on_device
+    def forward(ctx, x, l2: int, p: float, seeds, *params):
+        x = _chk(x, "x")
+        params = _params(params)
+        K0, H, D = x.shape[-1], params[2].shape[0], params[6].shape[0]
+        M = x.numel() // K0
+        lib = _lib.load()
+        ab = _size("stage_grp_input_mlp_arena_bytes", M, K0, H, D, int(l2))
+        arena = _buf(ab, x.device)
+        out = torch.empty(x.shape[:-1] + (D,), dtype=torch.float32, device=x.device)
+        flags = _flags()
+        _rc(lib.stage_grp_input_mlp_fwd(x.data_ptr(), _ptrs(params), out.data_ptr(), arena.data_ptr(), ab, flags, M, K0, H, D, int(l2),
+                                        float(p), _u64(seeds), _stream()), "stage_grp_input_mlp_fwd")
+        ctx.save_for_backward(x, arena, *params)
+        ctx.cfg = (M, K0, H, D, int(l2), float(p), tuple(seeds), flags, ab)
+        return out
+
+    @_on_device
+    def backward(ctx, dout):
+        x, arena, *params = ctx.saved_tensors
+        M, K0, H, D, l2, p, seeds, flags, ab = ctx.cfg
+        dout = _chk(dout, "dout")
+        lib = _lib.load()
+        grads = _grad_views(params)
+        tb = _size("stage_grp_input_mlp_bwd_tmp_bytes", M, K0, H, D)
+        tmp = _buf(tb, x.device)
+        _rc(lib.stage_grp_input_mlp_bwd(dout.data_ptr(), x.data_ptr(), _ptrs(params), _ptrs(grads), arena.data_ptr(), ab, flags,
+                                        tmp.data_ptr(), tb, M, K0, H, D, l2, p, _u64(seeds), _stream()), "stage_grp_input_mlp_bwd")
+        return (None, None, None, None) + tuple(grads)
+
+
+def input_mlp(x, l2: bool, p: float, seeds, params):
+    """x (..., K0) features -> (..., D).  params: ln0.w ln0.b fc1.w fc1.b ln1.w ln1.b fc2.w fc2.b ln2.w ln2.b."""
+    return _InputMLP.apply(x, int(bool(l2)), p, tuple(seeds), *params)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# G2 encoder block (no self-attention)
+# ---------------------------------------------------------------------------------------------------------------
+class _Encoder(torch.autograd.Function):
+    @_on_device
+    def forward(ctx, x, pe, pool_mask, k: int, p: float, seeds, *params):
+        x = _chk(x, "x")                       # (M, L, D)
+        pe = _chk(pe, "pe")
+        params = _params(params)
+        M, L, D = x.shape
+        n_conv = (len(params) - 2) // 6
+        pooled = pool_mask is not None
+        pm = _chk(pool_mask, "pool_mask") if pooled else None
+        lib = _lib.load()
+        ab = _size("stage_grp_encoder_arena_bytes", M, L, D, n_conv, int(pooled))
+        arena = _buf(ab, x.device)
+        out = torch.empty((M, D) if pooled else (M, L, D), dtype=torch.float32, device=x.device)
+        flags = _flags()
+        _rc(lib.stage_grp_encoder_fwd(x.data_ptr(), pe.data_ptr(), None if pm is None else pm.data_ptr(), _ptrs(params), out.data_ptr(),
+                                      arena.data_ptr(), ab, flags, M, L, D, n_conv, int(k), float(p), _u64(seeds), _stream()),
+            "stage_grp_encoder_fwd")
+        ctx.save_for_backward(x, pm, arena, *params)
+        ctx.cfg = (M, L, D, n_conv, int(k), float(p), tuple(seeds), flags, ab, pooled)
+        return out
+
+    @_on_device
+    def backward(ctx, dout):
+        x, pm, arena, *params = ctx.saved_tensors
+        M, L, D, n_conv, k, p, seeds, flags, ab, pooled = ctx.cfg
+        dout = _chk(dout, "dout")
+        lib = _lib.load()
+        grads = _grad_views(params)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        tb = _size("stage_grp_encoder_bwd_tmp_bytes", M, L, D, k, int(pooled))
+        tmp = _buf(tb, x.device)
+        _rc(lib.stage_grp_encoder_bwd(dout.data_ptr(), x.data_ptr(), None if pm is None else pm.data_ptr(), _ptrs(params), _ptrs(grads),
+                                      None if dx is None else dx.data_ptr(), arena.data_ptr(), ab, flags, tmp.data_ptr(), tb, M, L, D,
+                                      n_conv, k, p, _u64(seeds), _stream()), "stage_grp_encoder_bwd")
+        return (dx, None, None, None, None, None) + tuple(grads)
+
+
+def encoder_block(x, pe, pool_mask, k: int, p: float, seeds, params):
+    """x (M, L, D) -> (M, L, D), or (M, D) = masked max over L when ``pool_mask`` (M, L) is given.
+    params: per conv (ln.w ln.b dw.w dw.b pw.w pw.b), then final_ln.w final_ln.b."""
+    return _Encoder.apply(x, pe, pool_mask, k, p, tuple(seeds), *params)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# G3 QA <-> context attention + down-projection
+# ---------------------------------------------------------------------------------------------------------------
+class _QaCtx(torch.autograd.Function):
+    @_on_device
+    def forward(ctx, qa, cx, qa_mask, cx_mask, scale: float, p: float, seeds, *params):
+        qa, cx = _chk(qa, "qa"), _chk(cx, "ctx")                # (N, NA, Lqa, D), (N, Li, Lr, D)
+        qa_mask, cx_mask = _chk(qa_mask, "qa_mask"), _chk(cx_mask, "ctx_mask")
+        params = _params(params)
+        N, NA, Lqa, D = qa.shape
+        _, Li, Lr, _ = cx.shape
+        lib = _lib.load()
+        ab = _size("stage_grp_qa_ctx_arena_bytes", N, NA, Li, Lqa, D)
+        arena = _buf(ab, qa.device)
+        mixed = torch.empty(N, NA, Li, Lqa, D, dtype=torch.float32, device=qa.device)
+        S = torch.empty(N, NA, Li, Lqa, Lr, dtype=torch.float32, device=qa.device)
+        Sn = torch.empty_like(S)
+        flags = _flags()
+        _rc(lib.stage_grp_qa_ctx_fwd(qa.data_ptr(), cx.data_ptr(), qa_mask.data_ptr(), cx_mask.data_ptr(), _ptrs(params), mixed.data_ptr(),
+                                     S.data_ptr(), Sn.data_ptr(), arena.data_ptr(), ab, flags, N, NA, Li, Lqa, Lr, D, float(scale), float(p),
+                                     _u64(seeds), _stream()), "stage_grp_qa_ctx_fwd")
+        ctx.save_for_backward(qa, cx, cx_mask, mixed, Sn, arena, *params)
+        ctx.cfg = (N, NA, Li, Lqa, Lr, D, float(scale), float(p), tuple(seeds), flags, ab)
+        ctx.set_materialize_grads(False)      # raw S only receives a gradient with the supervised attention loss
+        return mixed, S, Sn
+
+    @_on_device
+    def backward(ctx, d_mixed, dS, dSn):
+        from .ops import _fold_dsn
+        qa, cx, cx_mask, mixed, Sn, arena, *params = ctx.saved_tensors
+        N, NA, Li, Lqa, Lr, D, scale, p, seeds, flags, ab = ctx.cfg
+        dS = _fold_dsn(dS, dSn, Sn, scale)
+        d_mixed = _chk(d_mixed, "d_mixed") if d_mixed is not None else torch.zeros_like(mixed)
+        dS = _chk(dS, "dS") if dS is not None else None
+        lib = _lib.load()
+        grads = _grad_views(params)
+        d_qa, d_cx = torch.empty_like(qa), torch.empty_like(cx)
+        tb = _size("stage_grp_qa_ctx_bwd_tmp_bytes", N, NA, Li, Lqa, Lr, D)
+        tmp = _buf(tb, qa.device)
+        _rc(lib.stage_grp_qa_ctx_bwd(d_mixed.data_ptr(), None if dS is None else dS.data_ptr(), qa.data_ptr(), cx.data_ptr(),
+                                     cx_mask.data_ptr(), mixed.data_ptr(), Sn.data_ptr(), _ptrs(params), _ptrs(grads), d_qa.data_ptr(),
+                                     d_cx.data_ptr(), arena.data_ptr(), ab, flags, tmp.data_ptr(), tb, N, NA, Li, Lqa, Lr, D, scale, p,
+                                     _u64(seeds), _stream()), "stage_grp_qa_ctx_bwd")
+        return (d_qa, d_cx, None, None, None, None, None) + tuple(grads)
+
+
+def qa_ctx(qa, cx, qa_mask, cx_mask, scale: float, p: float, seeds, params):
+    """-> mixed (N,NA,Li,Lqa,D), raw scores, normalised scores (N,NA,Li,Lqa,Lr).  params: ln.w ln.b fc.w fc.b."""
+    return _QaCtx.apply(qa, cx, qa_mask, cx_mask, scale, p, tuple(seeds), *params)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# G4 two-stream fusion
+# ---------------------------------------------------------------------------------------------------------------
+class _ConcatFc(torch.autograd.Function):
+    @_on_device
+    def forward(ctx, s, v, p: float, seeds, *params):
+        s, v = _chk(s, "s"), _chk(v, "v")
+        params = _params(params)
+        D = s.shape[-1]
+        U = s.numel() // D
+        lib = _lib.load()
+        ab = _size("stage_grp_concat_fc_arena_bytes", U, D)
+        arena = _buf(ab, s.device)
+        out = torch.empty_like(s)
+        flags = _flags()
+        _rc(lib.stage_grp_concat_fc_fwd(s.data_ptr(), v.data_ptr(), _ptrs(params), out.data_ptr(), arena.data_ptr(), ab, flags, U, D,
+                                        float(p), _u64(seeds), _stream()), "stage_grp_concat_fc_fwd")
+        ctx.save_for_backward(s, v, arena, *params)
+        ctx.cfg = (U, D, float(p), tuple(seeds), flags, ab)
+        return out
+
+    @_on_device
+    def backward(ctx, dout):
+        s, v, arena, *params = ctx.saved_tensors
+        U, D, p, seeds, flags, ab = ctx.cfg
+        dout = _chk(dout, "dout")
+        lib = _lib.load()
+        grads = _grad_views(params)
+        ds, dv = torch.empty_like(s), torch.empty_like(v)
+        tb = _size("stage_grp_concat_fc_bwd_tmp_bytes", U, D)
+        tmp = _buf(tb, s.device)
+        _rc(lib.stage_grp_concat_fc_bwd(dout.data_ptr(), s.data_ptr(), v.data_ptr(), _ptrs(params), _ptrs(grads), ds.data_ptr(),
+                                        dv.data_ptr(), arena.data_ptr(), ab, flags, tmp.data_ptr(), tb, U, D, p, _u64(seeds), _stream()),
+            "stage_grp_concat_fc_bwd")
+        return (ds, dv, None, None) + tuple(grads)
+
+
+def concat_fc(s, v, p: float, seeds, params):
+    """params: ln3.w ln3.b fc.w fc.b ln.w ln.b."""
+    return _ConcatFc.apply(s, v, p, tuple(seeds), *params)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# G5 temporal head (layer 0)
+# ---------------------------------------------------------------------------------------------------------------
+class _TemporalHead(torch.autograd.Function):
+    @_on_device
+    def forward(ctx, enc, p: float, seeds, *params):
+        enc = _chk(enc, "enc")                        # (R, D)
+        params = _params(params)
+        R, D = enc.shape
+        lib = _lib.load()
+        ab = _size("stage_grp_temporal_head_arena_bytes", R, D)
+        arena = _buf(ab, enc.device)
+        first = torch.empty_like(enc)
+        t_st = torch.empty(R, 1, dtype=torch.float32, device=enc.device)
+        t_ed = torch.empty_like(t_st)
+        flags = _flags()
+        _rc(lib.stage_grp_temporal_head_fwd(enc.data_ptr(), _ptrs(params), first.data_ptr(), t_st.data_ptr(), t_ed.data_ptr(),
+                                            arena.data_ptr(), ab, flags, R, D, float(p), _u64(seeds), _stream()),
+            "stage_grp_temporal_head_fwd")
+        ctx.save_for_backward(enc, first, arena, *params)
+        ctx.cfg = (R, D, float(p), tuple(seeds), flags, ab)
+        ctx.set_materialize_grads(False)
+        return first, t_st, t_ed
+
+    @_on_device
+    def backward(ctx, d_first, d_st, d_ed):
+        enc, first, arena, *params = ctx.saved_tensors
+        R, D, p, seeds, flags, ab = ctx.cfg
+        d_st = _chk(d_st, "d_st") if d_st is not None else torch.zeros(R, 1, dtype=torch.float32, device=enc.device)
+        d_ed = _chk(d_ed, "d_ed") if d_ed is not None else torch.zeros(R, 1, dtype=torch.float32, device=enc.device)
+        d_first = _chk(d_first, "d_first") if d_first is not None else None
+        lib = _lib.load()
+        grads = _grad_views(params)
+        d_enc = torch.empty_like(enc)
+        tb = _size("stage_grp_temporal_head_bwd_tmp_bytes", R, D)
+        tmp = _buf(tb, enc.device)
+        _rc(lib.stage_grp_temporal_head_bwd(None if d_first is None else d_first.data_ptr(), d_st.data_ptr(), d_ed.data_ptr(), enc.data_ptr(),
+                                            first.data_ptr(), _ptrs(params), _ptrs(grads), d_enc.data_ptr(), arena.data_ptr(), ab, flags,
+                                            tmp.data_ptr(), tb, R, D, p, _u64(seeds), _stream()), "stage_grp_temporal_head_bwd")
+        return (d_enc, None, None) + tuple(grads)
+
+
+def temporal_head(enc, p: float, seeds, params):
+    """enc (R, D) -> first = enc + h (R, D), start / end scores (R, 1) each.
+    params: proj(ln.w ln.b fc.w fc.b) st(ln.w ln.b fc.w fc.b) ed(ln.w ln.b fc.w fc.b)."""
+    return _TemporalHead.apply(enc, p, tuple(seeds), *params)

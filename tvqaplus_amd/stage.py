@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import groups, ops
 
 NEG = -1e10
 
@@ -198,6 +198,11 @@ class STAGE(nn.Module):
         # opt-in: correct, but 0.6 ms SLOWER per step as built (DESIGN.md finding 25) -- the register budget forces the variant
         # without the weight-chunk prefetch
         self.fuse_input_ln = os.environ.get("STAGE_FUSE_INPUT_LN") is not None
+        # launch sequencing: True = one C call per fused-op GROUP (tvqaplus_amd/groups.py, csrc/groups.hip: ~25 host calls per
+        # training step); False (or STAGE_NO_GROUPS=1) = one call per kernel (tvqaplus_amd/ops.py, ~360).  Same kernels, same order,
+        # same dropout streams: tests/test_hip_groups.py holds the two equal.  Groups cover fp32 storage and encoder blocks
+        # without self-attention; everything else falls back to the per-op path group by group.
+        self.use_groups = os.environ.get("STAGE_NO_GROUPS") is None
         # storage type of the activations between kernels: fp32 (the reference's), or bf16 with ``opt.storage_dtype = "bf16"``
         # (BASELINE.json configs[4]: bf16 weights / activations, fp32 softmax / statistics / accumulation; parameters stay
         # fp32 master copies, a weight is rounded to bf16 when a GEMM stages it; scores, losses and logits are fp32)
@@ -230,6 +235,23 @@ class STAGE(nn.Module):
         self._seed_state = (self._seed_state * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
         return self._seed_state >> 1
 
+    def _seeds(self, n: int) -> List[int]:
+        return [self._seed() for _ in range(n)]
+
+    def _grouped(self) -> bool:
+        return self.use_groups and self.storage == torch.float32
+
+    def _try_group(self, fn, n_seeds: int, *args):
+        """Run one K-group; ``None`` when the C side declines the shape (nothing was launched; the dropout stream is rewound
+        so that the per-op path draws the same seeds)."""
+        state = self._seed_state
+        seeds = self._seeds(n_seeds)
+        try:
+            return fn(seeds, *args)
+        except groups.Unsupported:
+            self._seed_state = state
+            return None
+
     # ---- building blocks ---------------------------------------------------------------------------------------
     def _ln(self, x, ln: nn.LayerNorm, drop: bool = False, res=None, res_period: int = 0):
         return ops.layernorm(x, ln.weight, ln.bias, p=self._p() if drop else 0.0, seed=self._seed() if drop else 0,
@@ -240,6 +262,19 @@ class STAGE(nn.Module):
         ``pool_mask`` (M, L): the caller only needs the masked max of the block's output over L (the classifier head,
         model/stage.py:503) -- the final LayerNorm and the max run as one pass and (M, D) is returned."""
         M, L, D = x.shape
+        if (self._grouped() and blk.num_heads == 0 and blk.n_conv >= 1 and x.dtype == torch.float32 and self.fuse_ln_dwconv
+                and self.fuse_ln_max):
+            k = blk.conv[0].depthwise_conv.weight.shape[-1]
+            params = []
+            for i in range(blk.n_conv):
+                c = blk.conv[i]
+                params += [blk.layer_norm[i].weight, blk.layer_norm[i].bias, c.depthwise_conv.weight, c.depthwise_conv.bias,
+                           c.pointwise_conv.weight, c.pointwise_conv.bias]
+            params += [blk.final_layer_norm.weight, blk.final_layer_norm.bias]
+            y = self._try_group(lambda seeds: groups.encoder_block(x, blk.position_encoding.rows(L), pool_mask, k, self._p(), seeds,
+                                                                   params), (blk.n_conv + 1) // 2)
+            if y is not None:
+                return y
         pending, cur, period = x, blk.position_encoding.rows(L), L  # first LN sees x + pe[:L]
         for i in range(blk.n_conv):
             c = blk.conv[i]
@@ -286,6 +321,13 @@ class STAGE(nn.Module):
         M, L, _ = data.shape
         if data.dtype != self.storage:
             data = data.to(self.storage)      # bf16 storage: features are rounded once on entry
+        if self._grouped() and not self.fuse_input_ln and data.dtype == torch.float32:
+            params = [init_encoder[0].weight, init_encoder[0].bias, init_encoder[2].weight, init_encoder[2].bias,
+                      init_encoder[4].weight, init_encoder[4].bias, downsize_encoder[1].weight, downsize_encoder[1].bias,
+                      downsize_encoder[3].weight, downsize_encoder[3].bias]
+            y = self._try_group(lambda seeds: groups.input_mlp(data, l2_normalize, self._p(), seeds, params), 2)
+            if y is not None:
+                return self._stacked_encoder(y.view(M, L, -1), data_mask, input_encoder)
         if l2_normalize:
             data = ops.l2norm(data)
         if self.fuse_input_ln and ops.input_ln_linear_supported(data, init_encoder[2].weight):
@@ -305,14 +347,20 @@ class STAGE(nn.Module):
         N, NA, Lqa, D = qa_embed.shape
         Li = ctx_embed.shape[1]
         p = self._p()
+        # (s_mask.sum(-1) != 0) with s_mask = qa_mask (x) ctx_mask
+        mixed_mask = ((qa_mask != 0).view(N, NA, 1, Lqa) & (ctx_mask.sum(-1) != 0).view(N, 1, Li, 1)).float()
+        if self._grouped() and qa_embed.dtype == torch.float32 and ctx_embed.shape[2] <= 64:
+            proj = self.c2q_down_projection
+            res = self._try_group(lambda seeds: groups.qa_ctx(qa_embed, ctx_embed, qa_mask, ctx_mask, self.scale, p, seeds,
+                                                              [proj[0].weight, proj[0].bias, proj[2].weight, proj[2].bias]), 3)
+            if res is not None:
+                return res[0], mixed_mask, res[1], res[2]
         u_a, raw_s, s_norm = ops.structured_attention(qa_embed, ctx_embed, qa_mask, ctx_mask, self.scale, p=p,
                                                       seed_c=self._seed(), seed_q=self._seed())
         proj = self.c2q_down_projection
         z = ops.cat3_layernorm(qa_embed.reshape(N * NA * Lqa, D), u_a.view(-1, D), proj[0].weight, proj[0].bias,
                                rep=Li, inner=Lqa, p=p, seed=self._seed())
         mixed = ops.linear(z, proj[2].weight, proj[2].bias, relu=True).view(N, NA, Li, Lqa, D)
-        # (s_mask.sum(-1) != 0) with s_mask = qa_mask (x) ctx_mask
-        mixed_mask = ((qa_mask != 0).view(N, NA, 1, Lqa) & (ctx_mask.sum(-1) != 0).view(N, 1, Li, 1)).float()
         return mixed, mixed_mask, raw_s, s_norm
 
     # ---- span proposals (model/stage.py:389-467, model/model_utils.py:37-123) ----------------------------------
@@ -399,10 +447,20 @@ class STAGE(nn.Module):
         enc = mx.view(N * NA * Li, D)
         # residual_temporal_predictor, layer 0 (:469-482).  Layers >= 1 (t_iter > 0) never reach any output or
         # gradient because of the `[:1]` slice at :516 (0.5*(t0 + mean([t0])) == t0 exactly), so they are skipped.
-        h, _ = self._linear_wrapper(enc, self.cls_projection_layers[0])
         st_lw, ed_lw = self.temporal_scoring_st_layers[0], self.temporal_scoring_ed_layers[0]
-        t_st, first = self._linear_wrapper(h, st_lw, res=enc)                            # first = enc + h
-        t_ed, _ = self._linear_wrapper(first, ed_lw)
+        res = None
+        if self._grouped() and enc.dtype == torch.float32:
+            pj = self.cls_projection_layers[0]
+            res = self._try_group(lambda seeds: groups.temporal_head(
+                enc, self._p(), seeds, [pj.conv[0].weight, pj.conv[0].bias, pj.conv[2].weight, pj.conv[2].bias,
+                                        st_lw.conv[0].weight, st_lw.conv[0].bias, st_lw.conv[2].weight, st_lw.conv[2].bias,
+                                        ed_lw.conv[0].weight, ed_lw.conv[0].bias, ed_lw.conv[2].weight, ed_lw.conv[2].bias]), 3)
+        if res is not None:
+            first, t_st, t_ed = res
+        else:
+            h, _ = self._linear_wrapper(enc, self.cls_projection_layers[0])
+            t_st, first = self._linear_wrapper(h, st_lw, res=enc)                        # first = enc + h
+            t_ed, _ = self._linear_wrapper(first, ed_lw)
         t_scores = torch.cat([t_st, t_ed], dim=-1).view(N, NA, Li, 2).float()   # scores / losses are fp32 in every storage mode
         tm = ts_labels_mask.view(N, 1, Li, 1)
         t_scores = t_scores * tm + (1 - tm) * NEG                                        # :521 mask_logits
@@ -480,10 +538,16 @@ class STAGE(nn.Module):
             other_outputs["vid_normalized_s"], other_outputs["vid_raw_s"] = norm, raw
         if self.flag_cnt == 2:
             fc = self.concat_fc
-            z = ops.cat3_layernorm(attended_sub.view(-1, D), attended_vid.view(-1, D), fc[0].weight, fc[0].bias,
-                                   p=self._p(), seed=self._seed())
-            z = ops.linear(z, fc[2].weight, fc[2].bias, relu=True)
-            z, _ = self._ln(z, fc[4])
+            z = None
+            if self._grouped() and attended_sub.dtype == torch.float32:
+                z = self._try_group(lambda seeds: groups.concat_fc(
+                    attended_sub.view(-1, D), attended_vid.view(-1, D), self._p(), seeds,
+                    [fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias, fc[4].weight, fc[4].bias]), 1)
+            if z is None:
+                z = ops.cat3_layernorm(attended_sub.view(-1, D), attended_vid.view(-1, D), fc[0].weight, fc[0].bias,
+                                       p=self._p(), seed=self._seed())
+                z = ops.linear(z, fc[2].weight, fc[2].bias, relu=True)
+                z, _ = self._ln(z, fc[4])
             statement, statement_mask = z.view(attended_vid.shape), attended_vid_mask
         elif self.sub_flag:
             statement, statement_mask = attended_sub, attended_sub_mask
