@@ -356,6 +356,41 @@ int stage_grp_temporal_head_bwd(const float* d_first, const float* d_st, const f
                                 size_t arena_bytes, const int* flags, void* tmp, size_t tmp_bytes, long long R, int D,
                                 float p_drop, const unsigned long long* seeds, void* stream);
 
+/* ---- head glue (model/stage.py:389-467, 484-555, 613-746): the small tensor algebra around the temporal scores, the span
+ * proposals, the pooling, the classifier and the two auxiliary losses as a handful of kernels (csrc/groups.hip) ----------- */
+/* t_scores (N, NA, Li, 2) = mask_logits(cat(t_st, t_ed), frame mask (N, Li))   (model/stage.py:515-521) and its backward */
+int stage_tscores_fwd(const float* t_st, const float* t_ed, const float* tm, float* out, int N, int NA, int Li, void* stream);
+int stage_tscores_bwd(const float* dout, const float* tm, float* d_st, float* d_ed, int N, int NA, int Li, void* stream);
+/* span proposal of the ground-truth candidate (training, model/stage.py:408-418, model/model_utils.py:92-123): softmax over the
+ * frames, arg max of the upper-triangular products (first maximal pair).  target / labels: int64 (N).  spans (6, N) float:
+ * predicted start, end, confidence, label start, label end, answer index (so that ONE device-to-host copy carries everything
+ * the proposal bookkeeping needs).  Li <= 2048.                                                                               */
+int stage_gt_spans(const float* t_scores, const long long* target, const long long* lab_st, const long long* lab_ed,
+                   float* spans, int N, int NA, int Li, void* stream);
+/* temporal loss (model/stage.py:539-555) and d loss / d t_scores in one pass; scratch: N floats; cand_offset: global index of
+ * local candidate 0 (candidate-sharded batches: examples whose ground truth is not local contribute nothing)               */
+int stage_ts_loss(const float* t_scores, const long long* target, const long long* lab_st, const long long* lab_ed, float* loss,
+                  float* grad, float* scratch, int N, int NA, int Li, int cand_offset, void* stream);
+/* supervised attention loss (model/stage.py:738-745) over M (positive, negative) pairs: flat = 2M int64 indices into scores
+ * (positives, then negatives); hinge != 0: max(0, margin + s_neg - s_pos), else log1p(exp(alpha (s_neg - s_pos))).  coef (M) is
+ * kept for the backward, which zero-fills dS (n_scores floats) and scatters gout[0] * coef into it.                          */
+int stage_att_loss_fwd(const float* scores, const long long* flat, long long M, int hinge, float alpha, float margin, float* coef,
+                       float* loss, void* stream);
+int stage_att_loss_bwd(const long long* flat, const float* coef, const float* gout, long long M, float* dS, long long n_scores,
+                       void* stream);
+/* G6 proposal pooling + answer classifier (model/stage.py:420-467, 526-536): first (N*NA, Li, D), mask (N*NA, Li), glob / idx_g =
+ * stage_masked_max_fwd(first, mask) computed ahead; meta (device int32) = src[P] | win[2P] | inv[2N] (proposal -> example, frame
+ * window [st, ed), example -> its <= 2 proposals or -1).  logits (P*NA).  params / grads: ln_g ln_b W c (2D wide); seeds[1].
+ * d_first (N*NA, Li, D) receives both pooling paths.                                                                          */
+size_t stage_grp_pool_cls_arena_bytes(long long P, int NA, int D);
+int stage_grp_pool_cls_fwd(const float* first, const float* mask, const float* glob, const int* meta, const float* const* params,
+                           float* logits, void* arena, size_t arena_bytes, int N, int NA, int Li, int D, long long P, float p_drop,
+                           const unsigned long long* seeds, void* stream);
+size_t stage_grp_pool_cls_bwd_tmp_bytes(long long P, int NA, int D);
+int stage_grp_pool_cls_bwd(const float* d_logits, const float* mask, const int* idx_g, const int* meta, const float* const* params,
+                           float* const* grads, float* d_first, const void* arena, size_t arena_bytes, void* tmp, size_t tmp_bytes,
+                           int N, int NA, int Li, int D, long long P, float p_drop, const unsigned long long* seeds, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,7 +69,7 @@ def test_group_path_equals_per_op_path(hip_device, case):
     assert torch.equal(o1, o2) and torch.equal(t1, t2), (float((o1 - o2).abs().max()), float((t1 - t2).abs().max()))
     for k in m1:
         assert torch.equal(m1[k], m2[k]), k
-    assert l1 == l2
+    assert abs(l1 - l2) <= 2e-6 * (1 + abs(l1)), (l1, l2)       # the fused loss kernels sum in their own (fixed) order
     exact, inexact = 0, []
     for k in g1:
         assert (g1[k] is None) == (g2[k] is None), k
@@ -99,7 +99,8 @@ def test_group_path_eval_and_inference_equal_per_op_path(hip_device):
         with torch.no_grad():
             out, _, _, t_loss, t_prob, other = model.forward_main(batch)
         outs.append((out.clone(), t_prob.clone(), float(t_loss)))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert abs(outs[0][2] - outs[1][2]) <= 2e-6 * (1 + abs(outs[0][2]))
 
 
 def test_group_path_issues_few_host_calls(hip_device):
@@ -134,4 +135,4 @@ def test_group_path_issues_few_host_calls(hip_device):
             ops._FN.clear()
         return n[0]
     counts["per_op"], counts["groups"] = run(False), run(True)
-    assert counts["groups"] <= 60 and counts["groups"] * 4 <= counts["per_op"], counts
+    assert counts["groups"] <= 45 and counts["groups"] * 4 <= counts["per_op"], counts

@@ -109,6 +109,17 @@ SIGNATURES = {
     "stage_grp_temporal_head_fwd": (I, [P, P, P, P, P, P, SZ, P, LL, I, F, P, P]),
     "stage_grp_temporal_head_bwd_tmp_bytes": (SZ, [LL, I]),
     "stage_grp_temporal_head_bwd": (I, [P, P, P, P, P, P, P, P, P, SZ, P, P, SZ, LL, I, F, P, P]),
+    # head glue: temporal scores, span proposal, pooling + classifier, auxiliary losses
+    "stage_tscores_fwd": (I, [P, P, P, P, I, I, I, P]),
+    "stage_tscores_bwd": (I, [P, P, P, P, I, I, I, P]),
+    "stage_gt_spans": (I, [P, P, P, P, P, I, I, I, P]),
+    "stage_ts_loss": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
+    "stage_att_loss_fwd": (I, [P, P, LL, I, F, F, P, P, P]),
+    "stage_att_loss_bwd": (I, [P, P, P, LL, P, LL, P]),
+    "stage_grp_pool_cls_arena_bytes": (SZ, [LL, I, I]),
+    "stage_grp_pool_cls_fwd": (I, [P, P, P, P, P, P, P, SZ, I, I, I, I, LL, F, P, P]),
+    "stage_grp_pool_cls_bwd_tmp_bytes": (SZ, [LL, I, I]),
+    "stage_grp_pool_cls_bwd": (I, [P, P, P, P, P, P, P, P, SZ, P, SZ, I, I, I, I, LL, F, P, P]),
 }
 
 _lib = None

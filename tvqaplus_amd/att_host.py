@@ -175,6 +175,11 @@ def get_att_loss(model, scores: torch.Tensor, batch, pairs=None):
             return scores.sum() * 0.0, None
         pairs = AttPairs(pos, neg, scores.shape, scores.device)
     assert pairs.shape == tuple(scores.shape), (pairs.shape, tuple(scores.shape))
+    grouped = getattr(model, "_grouped", None)
+    if grouped is not None and grouped() and scores.is_cuda and scores.dtype == torch.float32:
+        # gather + loss + per-pair gradient coefficients in one kernel; the backward zero-fills and scatters (csrc/groups.hip)
+        from . import groups
+        return groups.att_loss(scores.contiguous(), pairs.flat, pairs.m, model.att_loss_type, model.alpha, model.margin), None
     # ONE flat gather: the gradient reaches raw_s as a sparse scatter
     vals = scores.contiguous().reshape(-1).index_select(0, pairs.flat)
     s_pos, s_neg = vals[: pairs.m], vals[pairs.m:]

@@ -584,3 +584,396 @@ extern "C" int stage_grp_temporal_head_bwd(const float* d_first, const float* d_
     TRY(lin_bwd(t.G, a.yp, a.h, a.mask, flags[0], 1, P[2], t.wt, t.dyp, G[2], G[3], R, D, D, t.ws, t.wsb, st));
     return stage_layernorm_bwd(t.dyp, enc, a.meanp, a.rstdp, P[0], d_enc, t.G, G[0], G[1], R, D, p, seeds[0], t.ws, stage_ln_bwd_ws_bytes(D), st);
 }
+
+// =====================================================================================================================
+// Head glue: the small tensor algebra around the temporal scores, span proposals, pooling, classifier and the two auxiliary
+// losses (model/stage.py:389-467, 484-555, 613-746).  In the per-op path this is ~100 tiny ATen / HIP launches issued right
+// after the step's only host synchronisation (the proposal read-back), i.e. while the device has nothing else queued.
+// =====================================================================================================================
+namespace {
+
+// t_scores[n, a, i, c] = t_c[(n*NA + a)*Li + i] * tm[n, i] + (1 - tm[n, i]) * (-1e10)     (model/stage.py:520-521, mask_logits)
+__global__ void tscores_fwd_kernel(const float* __restrict__ t_st, const float* __restrict__ t_ed, const float* __restrict__ tm,
+                                   float* __restrict__ out, long R, int NA, int Li) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const long n = r / ((long)NA * Li);
+    const int i = (int)(r % Li);
+    const float m = tm[n * Li + i], off = (1.0f - m) * STAGE_NEG;
+    reinterpret_cast<float2*>(out)[r] = make_float2(t_st[r] * m + off, t_ed[r] * m + off);
+}
+__global__ void tscores_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ tm, float* __restrict__ d_st,
+                                   float* __restrict__ d_ed, long R, int NA, int Li) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const long n = r / ((long)NA * Li);
+    const float m = tm[n * Li + (int)(r % Li)];
+    const float2 g = reinterpret_cast<const float2*>(dout)[r];
+    d_st[r] = g.x * m;
+    d_ed[r] = g.y * m;
+}
+
+// block-wide reductions in a fixed order (256 threads)
+__device__ __forceinline__ float block_max256(float v, float* sh) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+__device__ __forceinline__ float block_sum256(float v, float* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// Span proposal of the ground-truth candidate (training; model/stage.py:408-418, model/model_utils.py:92-123): softmax over the
+// frames of its start / end scores, arg max of the upper-triangular products p_st[i] * p_ed[j] (i <= j; the first maximal pair in
+// row-major order).  One workgroup per example.  spans (6, N): st, ed, confidence, label start, label end, answer index.
+#define SPAN_MAX_LI 2048
+__global__ __launch_bounds__(256) void span_kernel(const float* __restrict__ t_scores, const long long* __restrict__ target,
+                                                   const long long* __restrict__ lab_st, const long long* __restrict__ lab_ed,
+                                                   float* __restrict__ spans, int N, int NA, int Li) {
+    __shared__ float ps[SPAN_MAX_LI], pe[SPAN_MAX_LI], sh[4];
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const float* x = t_scores + ((long)n * NA + (int)target[n]) * Li * 2;
+    float m0 = -INFINITY, m1 = -INFINITY;
+    for (int i = tid; i < Li; i += 256) {
+        const float2 v = reinterpret_cast<const float2*>(x)[i];
+        m0 = fmaxf(m0, v.x);
+        m1 = fmaxf(m1, v.y);
+    }
+    m0 = block_max256(m0, sh);
+    m1 = block_max256(m1, sh);
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = tid; i < Li; i += 256) {
+        const float2 v = reinterpret_cast<const float2*>(x)[i];
+        const float e0 = expf(v.x - m0), e1 = expf(v.y - m1);
+        ps[i] = e0;
+        pe[i] = e1;
+        s0 += e0;
+        s1 += e1;
+    }
+    s0 = block_sum256(s0, sh);
+    s1 = block_sum256(s1, sh);
+    for (int i = tid; i < Li; i += 256) {
+        ps[i] = ps[i] / s0;
+        pe[i] = pe[i] / s1;
+    }
+    __syncthreads();
+    // rows i = tid, tid + 256, ...: best j >= i
+    float best = -1.f;
+    int bidx = 0x7fffffff;
+    for (int i = tid; i < Li; i += 256) {
+        const float a = ps[i];
+        for (int j = i; j < Li; j++) {
+            const float v = a * pe[j];
+            if (v > best) { best = v; bidx = i * Li + j; }       // ascending (i, j): strict > keeps the first maximum of this thread
+        }
+    }
+    bv[tid] = best;
+    bi[tid] = bidx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            const float v2 = bv[tid + o];
+            const int i2 = bi[tid + o];
+            if (v2 > bv[tid] || (v2 == bv[tid] && i2 < bi[tid])) { bv[tid] = v2; bi[tid] = i2; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int idx = bi[0] == 0x7fffffff ? 0 : bi[0];
+        spans[0 * N + n] = (float)(idx / Li);
+        spans[1 * N + n] = (float)(idx % Li);
+        spans[2 * N + n] = fmaxf(bv[0], 0.f);
+        spans[3 * N + n] = (float)lab_st[n];
+        spans[4 * N + n] = (float)lab_ed[n];
+        spans[5 * N + n] = (float)target[n];
+    }
+}
+
+// Local (windowed) + global pooling of the proposals (model/stage.py:420-467): output row r = (proposal p, candidate a) reads the
+// frames of source row src[p]*NA + a.  pooled[r, 0:D] = masked max over the window, pooled[r, D:2D] = glob[source row].
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ m,
+                                                       const float* __restrict__ glob, const int* __restrict__ src,
+                                                       const int* __restrict__ win, float* __restrict__ pooled,
+                                                       int* __restrict__ idx, long Rn, int NA, int L, int D4) {
+    const long total = Rn * D4;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long r = e / D4;
+        const int q = (int)(e % D4);
+        const long p = r / NA;
+        const long sr = (long)src[p] * NA + (r % NA);
+        const int st = max(0, win[2 * p]), ed = min(L, win[2 * p + 1]);
+        float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        int4 bi = make_int4(-1, -1, -1, -1);
+        const float* px = x + (sr * L) * (long)D4 * 4 + 4 * q;
+        for (int l = st; l < ed; l++) {                         // ascending, strict >: the first maximum (torch.max)
+            const float4 v = ld4(px + (long)l * D4 * 4);
+            const float mk = m[sr * L + l], off = (1.0f - mk) * STAGE_NEG;
+            const float4 w = make_float4(v.x * mk + off, v.y * mk + off, v.z * mk + off, v.w * mk + off);
+            if (w.x > best.x) { best.x = w.x; bi.x = l; }
+            if (w.y > best.y) { best.y = w.y; bi.y = l; }
+            if (w.z > best.z) { best.z = w.z; bi.z = l; }
+            if (w.w > best.w) { best.w = w.w; bi.w = l; }
+        }
+        float* po = pooled + r * (long)D4 * 8 + 4 * q;
+        *reinterpret_cast<float4*>(po) = best;
+        *reinterpret_cast<float4*>(po + D4 * 4) = ld4(glob + sr * (long)D4 * 4 + 4 * q);
+        *reinterpret_cast<int4*>(idx + e * 4) = bi;
+    }
+}
+// dx[source row, l, d] = m[l] * ( sum_j [idx[r_j, d] == l] dpooled[r_j, d]  +  [idx_g[d] == l] sum_j dpooled[r_j, D + d] ),
+// r_j = the (at most two) proposals of the example: inv (N, 2), -1 = none.  The whole dx is written.
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dpooled, const int* __restrict__ idx,
+                                                       const int* __restrict__ idx_g, const float* __restrict__ m,
+                                                       const int* __restrict__ inv, float* __restrict__ dx, long Rs, int NA, int L,
+                                                       int D4) {
+    const long total = Rs * L * D4;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(e % D4);
+        const long rl = e / D4;
+        const int l = (int)(rl % L);
+        const long sr = rl / L;
+        const long n = sr / NA;
+        const int a = (int)(sr % NA);
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f), gg = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int p = inv[2 * n + j];
+            if (p < 0) continue;
+            const long r = (long)p * NA + a;
+            const int4 bi = *reinterpret_cast<const int4*>(idx + (r * D4 + q) * 4);
+            const float4 g = ld4(dpooled + r * (long)D4 * 8 + 4 * q);
+            o.x += bi.x == l ? g.x : 0.f;
+            o.y += bi.y == l ? g.y : 0.f;
+            o.z += bi.z == l ? g.z : 0.f;
+            o.w += bi.w == l ? g.w : 0.f;
+            gg = f4add(gg, ld4(dpooled + r * (long)D4 * 8 + D4 * 4 + 4 * q));
+        }
+        const int4 big = *reinterpret_cast<const int4*>(idx_g + (sr * D4 + q) * 4);
+        const float mk = m[rl];
+        o.x = (o.x + (big.x == l ? gg.x : 0.f)) * mk;
+        o.y = (o.y + (big.y == l ? gg.y : 0.f)) * mk;
+        o.z = (o.z + (big.z == l ? gg.z : 0.f)) * mk;
+        o.w = (o.w + (big.w == l ? gg.w : 0.f)) * mk;
+        *reinterpret_cast<float4*>(dx + e * 4) = o;
+    }
+}
+
+// Temporal loss (model/stage.py:539-555): 0.5 * (CE_sum(start scores of the ground-truth candidate, st) + CE_sum(end scores, ed)),
+// and its gradient w.r.t. t_scores in the same pass.  One workgroup per (example, local candidate); examples whose ground-truth
+// candidate is not local (candidate-sharded batches, cand_offset) contribute nothing here.
+__global__ __launch_bounds__(256) void ts_loss_kernel(const float* __restrict__ t, const long long* __restrict__ target,
+                                                      const long long* __restrict__ lab_st, const long long* __restrict__ lab_ed,
+                                                      float* __restrict__ grad, float* __restrict__ part, int NA, int Li,
+                                                      int cand_offset) {
+    __shared__ float sh[4];
+    const int n = blockIdx.x / NA, a = blockIdx.x % NA, tid = threadIdx.x;
+    const float* x = t + (long)blockIdx.x * Li * 2;
+    float* g = grad + (long)blockIdx.x * Li * 2;
+    const int local = (int)target[n] - cand_offset;
+    if (a != local) {
+        for (int i = tid; i < Li; i += 256) reinterpret_cast<float2*>(g)[i] = make_float2(0.f, 0.f);
+        if (tid == 0 && a == 0 && (local < 0 || local >= NA)) part[n] = 0.f;
+        return;
+    }
+    float m0 = -INFINITY, m1 = -INFINITY;
+    for (int i = tid; i < Li; i += 256) {
+        const float2 v = reinterpret_cast<const float2*>(x)[i];
+        m0 = fmaxf(m0, v.x);
+        m1 = fmaxf(m1, v.y);
+    }
+    m0 = block_max256(m0, sh);
+    m1 = block_max256(m1, sh);
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = tid; i < Li; i += 256) {
+        const float2 v = reinterpret_cast<const float2*>(x)[i];
+        s0 += expf(v.x - m0);
+        s1 += expf(v.y - m1);
+    }
+    s0 = block_sum256(s0, sh);
+    s1 = block_sum256(s1, sh);
+    const float l0 = logf(s0), l1 = logf(s1);
+    const int st = (int)lab_st[n], ed = (int)lab_ed[n];
+    for (int i = tid; i < Li; i += 256) {
+        const float2 v = reinterpret_cast<const float2*>(x)[i];
+        const float p0 = expf(v.x - m0 - l0), p1 = expf(v.y - m1 - l1);
+        reinterpret_cast<float2*>(g)[i] = make_float2(0.5f * (p0 - (i == st ? 1.f : 0.f)), 0.5f * (p1 - (i == ed ? 1.f : 0.f)));
+    }
+    if (tid == 0) {
+        const float lp0 = x[2 * st] - m0 - l0, lp1 = x[2 * ed + 1] - m1 - l1;
+        part[n] = -0.5f * (lp0 + lp1);
+    }
+}
+__global__ void sum_small_kernel(const float* __restrict__ in, int n, float* __restrict__ out) {
+    // one wave, fixed order: lane-strided partial sums, then the wave reduction
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) s += in[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+// Supervised attention loss (model/stage.py:738-745) on gathered (positive, negative) score pairs: lse: log1p(exp(alpha (s_neg - s_pos)));
+// hinge: max(0, margin + s_neg - s_pos).  coef[p] = d loss / d (s_neg - s_pos).  One workgroup, fixed summation order.
+__global__ __launch_bounds__(256) void att_loss_kernel(const float* __restrict__ scores, const long long* __restrict__ flat, long M,
+                                                       int hinge, float alpha, float margin, float* __restrict__ coef,
+                                                       float* __restrict__ loss) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (long p = threadIdx.x; p < M; p += 256) {
+        const float sp = scores[flat[p]], sn = scores[flat[M + p]];
+        if (hinge) {
+            const float v = margin + sn - sp;
+            s += fmaxf(v, 0.f);
+            coef[p] = v > 0.f ? 1.f : 0.f;
+        } else {
+            const float e = expf(alpha * (sn - sp));
+            s += log1pf(e);
+            coef[p] = isinf(e) ? alpha : alpha * (e / (1.f + e));
+        }
+    }
+    s = block_sum256(s, sh);
+    if (threadIdx.x == 0) loss[0] = s;
+}
+__global__ void att_scatter_kernel(const long long* __restrict__ flat, const float* __restrict__ coef, const float* __restrict__ gout,
+                                   long M, float* __restrict__ dS) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= M) return;
+    const float c = coef[p] * gout[0];
+    atomicAdd(dS + flat[p], -c);
+    atomicAdd(dS + flat[M + p], c);
+}
+
+inline unsigned blocks_for(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+inline unsigned capped_grid(long n, int bs) {
+    long g = (n + bs - 1) / bs;
+    return (unsigned)(g > 65536 * 4 ? 65536 * 4 : (g < 1 ? 1 : g));
+}
+}  // namespace
+
+// t_st, t_ed (N*NA*Li) + frame mask (N, Li) -> masked scores (N, NA, Li, 2)   (model/stage.py:515-521)
+extern "C" int stage_tscores_fwd(const float* t_st, const float* t_ed, const float* tm, float* out, int N, int NA, int Li, void* st) {
+    const long R = (long)N * NA * Li;
+    if (R <= 0) return 0;
+    hipLaunchKernelGGL(tscores_fwd_kernel, dim3(blocks_for(R, 256)), dim3(256), 0, (hipStream_t)st, t_st, t_ed, tm, out, R, NA, Li);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int stage_tscores_bwd(const float* dout, const float* tm, float* d_st, float* d_ed, int N, int NA, int Li, void* st) {
+    const long R = (long)N * NA * Li;
+    if (R <= 0) return 0;
+    hipLaunchKernelGGL(tscores_bwd_kernel, dim3(blocks_for(R, 256)), dim3(256), 0, (hipStream_t)st, dout, tm, d_st, d_ed, R, NA, Li);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+// spans (6, N) float: predicted start, end, confidence of the ground-truth candidate, the label's start / end, the answer index
+extern "C" int stage_gt_spans(const float* t_scores, const long long* target, const long long* lab_st, const long long* lab_ed,
+                              float* spans, int N, int NA, int Li, void* st) {
+    if (N <= 0) return 0;
+    if (Li > SPAN_MAX_LI || Li < 1) return STAGE_ERR_SHAPE;
+    hipLaunchKernelGGL(span_kernel, dim3(N), dim3(256), 0, (hipStream_t)st, t_scores, target, lab_st, lab_ed, spans, N, NA, Li);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+// loss (1), grad (N, NA, Li, 2) = d loss / d t_scores; scratch: N floats
+extern "C" int stage_ts_loss(const float* t_scores, const long long* target, const long long* lab_st, const long long* lab_ed,
+                             float* loss, float* grad, float* scratch, int N, int NA, int Li, int cand_offset, void* st) {
+    if (N <= 0 || NA <= 0 || Li <= 0) return STAGE_ERR_SHAPE;
+    hipLaunchKernelGGL(ts_loss_kernel, dim3(N * NA), dim3(256), 0, (hipStream_t)st, t_scores, target, lab_st, lab_ed, grad, scratch, NA,
+                       Li, cand_offset);
+    hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(64), 0, (hipStream_t)st, scratch, N, loss);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+// flat: 2M int64 indices into `scores` (M positives, then M negatives); coef (M) is kept for the backward
+extern "C" int stage_att_loss_fwd(const float* scores, const long long* flat, long long M, int hinge, float alpha, float margin,
+                                  float* coef, float* loss, void* st) {
+    if (M <= 0) return STAGE_ERR_SHAPE;
+    hipLaunchKernelGGL(att_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)st, scores, flat, (long)M, hinge, alpha, margin, coef, loss);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+// dS (n_scores, zero-filled here) += gout[0] * coef scattered to the pair indices
+extern "C" int stage_att_loss_bwd(const long long* flat, const float* coef, const float* gout, long long M, float* dS,
+                                  long long n_scores, void* st) {
+    TRY((int)hipMemsetAsync(dS, 0, (size_t)n_scores * sizeof(float), (hipStream_t)st));
+    hipLaunchKernelGGL(att_scatter_kernel, dim3(blocks_for((long)M, 256)), dim3(256), 0, (hipStream_t)st, flat, coef, gout, (long)M, dS);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- G6  proposal pooling + answer classifier (model/stage.py:420-467, 526-536; LinearWrapper :15-32) -----------------------
+//     first (N*NA, Li, D), mask (N*NA, Li), glob / idx_g = its global masked max (stage_masked_max_fwd, computed before the
+//     proposal read-back), meta (int32, device): src[P] | win[2P] | inv[2N].  logits (P*NA).  params: ln_g ln_b W c (2D wide);
+//     seeds[1]; no flags.  Backward: d_first (N*NA, Li, D) receives BOTH pooling paths (local windows and the global max).
+namespace {
+struct PcArena { float *pooled, *y, *mean, *rstd; int* idx; size_t bytes; };
+PcArena pc_layout(void* base, long Rn, int D) {
+    Bump b{(char*)base, 0};
+    PcArena a;
+    a.pooled = b.take<float>((size_t)Rn * 2 * D);
+    a.idx = b.take<int>((size_t)Rn * D);
+    a.y = b.take<float>((size_t)Rn * 2 * D);
+    a.mean = b.take<float>((size_t)Rn);
+    a.rstd = b.take<float>((size_t)Rn);
+    a.bytes = b.off;
+    return a;
+}
+struct PcTmp { float *dy, *dpooled, *wt; void* ws; size_t wsb, bytes; };
+PcTmp pc_tmp(void* base, long Rn, int D) {
+    Bump b{(char*)base, 0};
+    PcTmp t;
+    t.dy = b.take<float>((size_t)Rn * 2 * D);
+    t.dpooled = b.take<float>((size_t)Rn * 2 * D);
+    t.wt = b.take<float>((size_t)2 * D);
+    t.wsb = umax(lin_bwd_ws(Rn, 1, 2 * D), stage_ln_bwd_ws_bytes(2 * D));
+    t.ws = b.take<char>(t.wsb);
+    t.bytes = b.off;
+    return t;
+}
+}  // namespace
+
+extern "C" size_t stage_grp_pool_cls_arena_bytes(long long P, int NA, int D) { return pc_layout(nullptr, (long)P * NA, D).bytes; }
+extern "C" size_t stage_grp_pool_cls_bwd_tmp_bytes(long long P, int NA, int D) { return pc_tmp(nullptr, (long)P * NA, D).bytes; }
+
+extern "C" int stage_grp_pool_cls_fwd(const float* first, const float* mask, const float* glob, const int* meta,
+                                      const float* const* P, float* logits, void* arena, size_t arena_bytes, int N, int NA, int Li,
+                                      int D, long long Pn, float p, const unsigned long long* seeds, void* st) {
+    if (N <= 0 || Pn <= 0 || D % 4 || 2 * D > 1024) return STAGE_ERR_SHAPE;
+    const long Rn = (long)Pn * NA;
+    PcArena a = pc_layout(arena, Rn, D);
+    if (arena_bytes < a.bytes) return STAGE_ERR_WORKSPACE;
+    const int* src = meta;
+    const int* win = meta + Pn;
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(capped_grid(Rn * (D / 4), 256)), dim3(256), 0, (hipStream_t)st, first, mask, glob, src, win,
+                       a.pooled, a.idx, Rn, NA, Li, D / 4);
+    STAGE_LAUNCH_CHECK();
+    TRY(stage_layernorm_fwd(a.pooled, nullptr, 0, nullptr, P[0], P[1], a.y, a.mean, a.rstd, Rn, 2 * D, EPS_LN, p, seeds[0], st));
+    int none = 0;
+    return lin_fwd(a.y, P[2], P[3], logits, nullptr, &none, Rn, 1, 2 * D, 0, st);
+}
+
+extern "C" int stage_grp_pool_cls_bwd(const float* d_logits, const float* mask, const int* idx_g, const int* meta,
+                                      const float* const* P, float* const* G, float* d_first, const void* arena, size_t arena_bytes,
+                                      void* tmp, size_t tmp_bytes, int N, int NA, int Li, int D, long long Pn, float p,
+                                      const unsigned long long* seeds, void* st) {
+    const long Rn = (long)Pn * NA;
+    PcArena a = pc_layout((void*)arena, Rn, D);
+    PcTmp t = pc_tmp(tmp, Rn, D);
+    if (arena_bytes < a.bytes || tmp_bytes < t.bytes) return STAGE_ERR_WORKSPACE;
+    TRY(lin_bwd(d_logits, a.y, nullptr, nullptr, 0, 0, P[2], t.wt, t.dy, G[2], G[3], Rn, 1, 2 * D, t.ws, t.wsb, st));
+    TRY(stage_layernorm_bwd(t.dy, a.pooled, a.mean, a.rstd, P[0], t.dpooled, nullptr, G[0], G[1], Rn, 2 * D, p, seeds[0], t.ws,
+                            stage_ln_bwd_ws_bytes(2 * D), st));
+    const int* inv = meta + 3 * Pn;
+    const long Rs = (long)N * NA;
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(capped_grid(Rs * Li * (D / 4), 256)), dim3(256), 0, (hipStream_t)st, t.dpooled, a.idx, idx_g,
+                       mask, inv, d_first, Rs, NA, Li, D / 4);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}

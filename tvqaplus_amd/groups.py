@@ -304,3 +304,154 @@ def temporal_head(enc, p: float, seeds, params):
     """enc (R, D) -> first = enc + h (R, D), start / end scores (R, 1) each.
     params: proj(ln.w ln.b fc.w fc.b) st(ln.w ln.b fc.w fc.b) ed(ln.w ln.b fc.w fc.b)."""
     return _TemporalHead.apply(enc, p, tuple(seeds), *params)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Head glue: temporal scores, span proposal, pooling + classifier, auxiliary losses (csrc/groups.hip, "head glue")
+# ---------------------------------------------------------------------------------------------------------------
+class _TScores(torch.autograd.Function):
+    @_on_device
+    def forward(ctx, t_st, t_ed, tm, N: int, NA: int, Li: int):
+        t_st, t_ed, tm = _chk(t_st, "t_st"), _chk(t_ed, "t_ed"), _chk(tm, "frame mask")
+        out = torch.empty(N, NA, Li, 2, dtype=torch.float32, device=t_st.device)
+        _rc(_lib.load().stage_tscores_fwd(t_st.data_ptr(), t_ed.data_ptr(), tm.data_ptr(), out.data_ptr(), N, NA, Li, _stream()),
+            "stage_tscores_fwd")
+        ctx.save_for_backward(tm)
+        ctx.cfg = (N, NA, Li, t_st.shape, t_ed.shape)
+        return out
+
+    @_on_device
+    def backward(ctx, dout):
+        (tm,) = ctx.saved_tensors
+        N, NA, Li, s1, s2 = ctx.cfg
+        dout = _chk(dout, "dout")
+        d_st = torch.empty(s1, dtype=torch.float32, device=dout.device)
+        d_ed = torch.empty(s2, dtype=torch.float32, device=dout.device)
+        _rc(_lib.load().stage_tscores_bwd(dout.data_ptr(), tm.data_ptr(), d_st.data_ptr(), d_ed.data_ptr(), N, NA, Li, _stream()),
+            "stage_tscores_bwd")
+        return d_st, d_ed, None, None, None, None
+
+
+def tscores(t_st, t_ed, frame_mask, N: int, NA: int, Li: int):
+    """mask_logits(cat(t_st, t_ed), frame mask) -> (N, NA, Li, 2)   (model/stage.py:515-521)."""
+    return _TScores.apply(t_st, t_ed, frame_mask, N, NA, Li)
+
+
+def gt_spans(t_scores, target, lab_st, lab_ed):
+    """(6, N) device floats: predicted start, end, confidence of the ground-truth candidate's span, the label's start, end and the
+    answer index (model/stage.py:408-418; no gradient)."""
+    t = _chk(t_scores.detach(), "t_scores")
+    N, NA, Li, _ = t.shape
+    target, lab_st, lab_ed = (_chk(v, "labels", torch.int64) for v in (target, lab_st, lab_ed))
+    spans = torch.empty(6, N, dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        _rc(_lib.load().stage_gt_spans(t.data_ptr(), target.data_ptr(), lab_st.data_ptr(), lab_ed.data_ptr(), spans.data_ptr(), N, NA, Li,
+                                       _stream()), "stage_gt_spans")
+    return spans
+
+
+def masked_max_raw(x, mask):
+    """(R, L, D), (R, L) -> max (R, D), argmax (R, D) int32; no autograd node (the pooling group owns this gradient)."""
+    x, mask = _chk(x.detach(), "x"), _chk(mask, "mask")
+    R, L, D = x.shape
+    out = torch.empty(R, D, dtype=torch.float32, device=x.device)
+    idx = torch.empty(R, D, dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device):
+        _rc(_lib.load().stage_masked_max_fwd(x.data_ptr(), mask.data_ptr(), None, out.data_ptr(), idx.data_ptr(), R, L, D, _stream()),
+            "stage_masked_max_fwd")
+    return out, idx
+
+
+class _PoolCls(torch.autograd.Function):
+    @_on_device
+    def forward(ctx, first, mask, glob, idx_g, meta, dims, p: float, seeds, *params):
+        first, mask, glob = _chk(first, "first"), _chk(mask, "mask"), _chk(glob, "glob")
+        idx_g, meta = _chk(idx_g, "idx_g", torch.int32), _chk(meta, "meta", torch.int32)
+        params = _params(params)
+        N, NA, Li, D, P = dims
+        lib = _lib.load()
+        ab = _size("stage_grp_pool_cls_arena_bytes", P, NA, D)
+        arena = _buf(ab, first.device)
+        logits = torch.empty(P * NA, 1, dtype=torch.float32, device=first.device)
+        _rc(lib.stage_grp_pool_cls_fwd(first.data_ptr(), mask.data_ptr(), glob.data_ptr(), meta.data_ptr(), _ptrs(params), logits.data_ptr(),
+                                       arena.data_ptr(), ab, N, NA, Li, D, P, float(p), _u64(seeds), _stream()), "stage_grp_pool_cls_fwd")
+        ctx.save_for_backward(first, mask, idx_g, meta, arena, *params)
+        ctx.cfg = (dims, float(p), tuple(seeds), ab)
+        return logits
+
+    @_on_device
+    def backward(ctx, d_logits):
+        first, mask, idx_g, meta, arena, *params = ctx.saved_tensors
+        (N, NA, Li, D, P), p, seeds, ab = ctx.cfg
+        d_logits = _chk(d_logits, "d_logits")
+        lib = _lib.load()
+        grads = _grad_views(params)
+        d_first = torch.empty_like(first)
+        tb = _size("stage_grp_pool_cls_bwd_tmp_bytes", P, NA, D)
+        tmp = _buf(tb, first.device)
+        _rc(lib.stage_grp_pool_cls_bwd(d_logits.data_ptr(), mask.data_ptr(), idx_g.data_ptr(), meta.data_ptr(), _ptrs(params), _ptrs(grads),
+                                       d_first.data_ptr(), arena.data_ptr(), ab, tmp.data_ptr(), tb, N, NA, Li, D, P, p, _u64(seeds),
+                                       _stream()), "stage_grp_pool_cls_bwd")
+        return (d_first, None, None, None, None, None, None, None) + tuple(grads)
+
+
+def pool_classifier(first, mask, glob, idx_g, meta, dims, p: float, seeds, params):
+    """first (N*NA, Li, D) -> logits (P*NA, 1): local window max + global max of every proposal, LayerNorm(2D) + dropout,
+    Linear(2D -> 1).  meta (device int32): src[P] | win[2P] | inv[2N].  params: ln.w ln.b fc.w fc.b."""
+    return _PoolCls.apply(first, mask, glob, idx_g, meta, tuple(dims), p, tuple(seeds), *params)
+
+
+class _TsLoss(torch.autograd.Function):
+    @_on_device
+    def forward(ctx, t_scores, target, lab_st, lab_ed, cand_offset: int):
+        t = _chk(t_scores, "t_scores")
+        N, NA, Li, _ = t.shape
+        target, lab_st, lab_ed = (_chk(v, "labels", torch.int64) for v in (target, lab_st, lab_ed))
+        loss = torch.empty((), dtype=torch.float32, device=t.device)
+        grad = torch.empty_like(t)
+        scratch = torch.empty(N, dtype=torch.float32, device=t.device)
+        _rc(_lib.load().stage_ts_loss(t.data_ptr(), target.data_ptr(), lab_st.data_ptr(), lab_ed.data_ptr(), loss.data_ptr(), grad.data_ptr(),
+                                      scratch.data_ptr(), N, NA, Li, int(cand_offset), _stream()), "stage_ts_loss")
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None, None
+
+
+def ts_loss(t_scores, target, lab_st, lab_ed, cand_offset: int = 0):
+    """0.5 * (CE_sum(start scores of the ground-truth candidate, st) + CE_sum(end scores, ed))   (model/stage.py:539-555)."""
+    return _TsLoss.apply(t_scores, target, lab_st, lab_ed, cand_offset)
+
+
+class _AttLoss(torch.autograd.Function):
+    @_on_device
+    def forward(ctx, scores, flat, M: int, hinge: bool, alpha: float, margin: float):
+        scores = _chk(scores, "scores")
+        flat = _chk(flat, "pair indices", torch.int64)
+        coef = torch.empty(M, dtype=torch.float32, device=scores.device)
+        loss = torch.empty((), dtype=torch.float32, device=scores.device)
+        _rc(_lib.load().stage_att_loss_fwd(scores.data_ptr(), flat.data_ptr(), M, int(bool(hinge)), float(alpha), float(margin),
+                                           coef.data_ptr(), loss.data_ptr(), _stream()), "stage_att_loss_fwd")
+        ctx.save_for_backward(flat, coef)
+        ctx.cfg = (M, scores.shape)
+        return loss
+
+    @_on_device
+    def backward(ctx, g):
+        flat, coef = ctx.saved_tensors
+        M, shape = ctx.cfg
+        g = _chk(g.reshape(1), "g")
+        dS = torch.empty(shape, dtype=torch.float32, device=coef.device)
+        _rc(_lib.load().stage_att_loss_bwd(flat.data_ptr(), coef.data_ptr(), g.data_ptr(), M, dS.data_ptr(), dS.numel(), _stream()),
+            "stage_att_loss_bwd")
+        return dS, None, None, None, None, None
+
+
+def att_loss(scores, flat, M: int, loss_type: str, alpha: float, margin: float):
+    """Supervised attention loss over M (positive, negative) pairs of a contiguous score tensor (model/stage.py:738-745)."""
+    if loss_type not in ("lse", "hinge"):
+        raise NotImplementedError("Only support hinge and lse")
+    return _AttLoss.apply(scores, flat, M, loss_type == "hinge", alpha, margin)

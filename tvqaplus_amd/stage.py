@@ -211,6 +211,7 @@ class STAGE(nn.Module):
             raise ValueError("opt.storage_dtype must be 'fp32' or 'bf16', got %r" % sd)
         self.storage = torch.bfloat16 if sd in ("bf16", "bfloat16") else torch.float32
         self._span_host = None      # pinned landing buffer of the per-step proposal spans (get_proposals)
+        self._meta_stage = None     # pinned staging of the per-step proposal bookkeeping (_proposals_grouped)
         # counter-based dropout stream (csrc/common.h): seeded lazily from the seed of torch's default generator at the first
         # use (so torch.manual_seed() before training takes effect, as for the reference's nn.Dropout) and mixed with the
         # process rank (identical seeds on every data-parallel rank would drop the same units everywhere).  The stream
@@ -436,14 +437,20 @@ class STAGE(nn.Module):
         return ops.linear(y, lw.conv[2].weight, lw.conv[2].bias, relu=lw.relu), s
 
     def classfier_head_multi_proposal(self, statement, statement_mask, targets, ts_labels, ts_labels_mask,
-                                      extra_span_length=3, gt_scores_fn=None):
+                                      extra_span_length=3, gt_scores_fn=None, pool_mask_factors=None):
         """model/stage.py:484-537."""
         N, NA, Li, Lqa = statement_mask.shape
         D = statement.shape[-1]
         x = statement.reshape(N * NA * Li, Lqa, D)
         m = statement_mask.reshape(N * NA * Li, Lqa).contiguous()
         mx = self._stacked_encoder(x, m, self.cls_encoder, pool_mask=m)                # encoder + :503 (max over the words)
-        mx_mask = (m.sum(1) != 0).float().view(N, NA, Li, 1)                             # :504
+        if pool_mask_factors is not None:
+            # :504 from the factors of the statement mask (qa word mask x frame validity): any word valid AND the frame valid --
+            # two reductions over KBs instead of one over the 154 MB (N, 5, Li, Lqa) mask
+            qa_any, frame_any = pool_mask_factors
+            mx_mask = (qa_any.view(N, NA, 1) & frame_any.view(N, 1, Li)).float().view(N, NA, Li, 1)
+        else:
+            mx_mask = (m.sum(1) != 0).float().view(N, NA, Li, 1)                         # :504
         enc = mx.view(N * NA * Li, D)
         # residual_temporal_predictor, layer 0 (:469-482).  Layers >= 1 (t_iter > 0) never reach any output or
         # gradient because of the `[:1]` slice at :516 (0.5*(t0 + mean([t0])) == t0 exactly), so they are skipped.
@@ -461,10 +468,18 @@ class STAGE(nn.Module):
             h, _ = self._linear_wrapper(enc, self.cls_projection_layers[0])
             t_st, first = self._linear_wrapper(h, st_lw, res=enc)                        # first = enc + h
             t_ed, _ = self._linear_wrapper(first, ed_lw)
-        t_scores = torch.cat([t_st, t_ed], dim=-1).view(N, NA, Li, 2).float()   # scores / losses are fp32 in every storage mode
-        tm = ts_labels_mask.view(N, 1, Li, 1)
-        t_scores = t_scores * tm + (1 - tm) * NEG                                        # :521 mask_logits
+        grouped_tail = res is not None
+        if grouped_tail:
+            t_scores = groups.tscores(t_st, t_ed, ts_labels_mask.reshape(N, Li), N, NA, Li)  # cat + :521 mask_logits, one kernel
+        else:
+            t_scores = torch.cat([t_st, t_ed], dim=-1).view(N, NA, Li, 2).float()   # scores / losses are fp32 in every storage mode
+            tm = ts_labels_mask.view(N, 1, Li, 1)
+            t_scores = t_scores * tm + (1 - tm) * NEG                                    # :521 mask_logits
         first = first.view(N, NA, Li, D)
+        if (grouped_tail and self.add_local and self.training and gt_scores_fn is None and NA == self.num_a
+                and first.is_cuda):
+            logits, targets = self._proposals_grouped(first, mx_mask, t_scores, targets, ts_labels, extra_span_length)
+            return logits.view(-1, NA), targets, t_scores
         if self.add_local:
             pooled, targets = self.get_proposals(first, mx_mask, t_scores, targets, ts_labels,
                                                  extra_span_length=extra_span_length, gt_scores_fn=gt_scores_fn)
@@ -473,12 +488,62 @@ class STAGE(nn.Module):
         logits, _ = self._linear_wrapper(pooled.reshape(-1, pooled.shape[-1]), self.classifier)
         return logits.view(-1, NA).float(), targets, t_scores
 
+    def _proposals_grouped(self, first, mx_mask, t_scores, targets, ts_labels, extra_span_length,
+                           iou_thd=0.5, ce_prob_thd=0.01):
+        """get_proposals (training, model/stage.py:406-438) + classifier (:536) on the K-group path: one span kernel before the
+        per-step read-back, ONE pooling + classifier group after it (csrc/groups.hip, G6), the proposal bookkeeping
+        (source example, frame window, inverse map) uploaded as one int32 tensor through pinned staging."""
+        from .att_host import PinnedStage
+        N, NA, Li, D = first.shape
+        dev = first.device
+        spans = groups.gt_spans(t_scores, targets, ts_labels["st"], ts_labels["ed"])         # (6, N) device floats
+        if self._span_host is None or self._span_host.shape != spans.shape:
+            self._span_host = torch.empty(spans.shape, dtype=torch.float32, pin_memory=True)
+        x = first.reshape(N * NA, Li, D)
+        m = mx_mask.reshape(N * NA, Li)
+        with torch.cuda.device(dev):
+            self._span_host.copy_(spans, non_blocking=True)
+            arrived = torch.cuda.Event()
+            arrived.record(torch.cuda.current_stream(dev))
+            glob, idx_g = groups.masked_max_raw(x, m)       # queued behind the copy: runs while the host reads the spans
+            arrived.synchronize()
+        host = self._span_host.tolist()
+        src, wins, inv = [], [], [-1] * (2 * N)
+        for n in range(N):
+            gs, ge = int(host[3][n]), int(host[4][n]) + 1
+            cand = [(gs, ge)]
+            if host[2][n] >= ce_prob_thd:
+                ps, pe = int(host[0][n]), int(host[1][n]) + 1
+                inter = max(0, min(pe, ge) - max(ps, gs))
+                union = max(pe, ge) - min(ps, gs)
+                if union != 0 and inter / union >= iou_thd:
+                    cand.append((ps, pe))
+            for j, (s0, e0) in enumerate(cand):
+                inv[2 * n + j] = len(src)
+                src.append(n)
+                wins += [max(0, s0 - extra_span_length), e0 + extra_span_length]
+        P = len(src)
+        if self._meta_stage is None:
+            self._meta_stage = PinnedStage()
+        # the repeated targets travel with the bookkeeping (ATen's index_select switches kernels at 16 indices: the first step
+        # with a 17th proposal paid ~9 ms of lazy kernel loading inside the training loop)
+        tgt = [int(host[5][n]) for n in src]
+        meta = self._meta_stage.upload(torch.tensor(src + wins + inv + tgt, dtype=torch.int32), dev)
+        cl = self.classifier
+        seeds = self._seeds(1)
+        logits = groups.pool_classifier(x, m, glob, idx_g, meta, (N, NA, Li, D, P), self._p(), seeds,
+                                        [cl.conv[0].weight, cl.conv[0].bias, cl.conv[2].weight, cl.conv[2].bias])
+        return logits, meta[3 * P + 2 * N:].long()
+
     def get_ts_loss(self, temporal_scores, ts_labels, answer_indices, cand_offset: int = 0):
         """model/stage.py:539-555.  ``cand_offset``: global index of local candidate 0 when the candidates of an example
         are spread over ranks -- only examples whose ground-truth candidate is local contribute here (the sum over the
         ranks of the group is the full loss)."""
         bsz = len(answer_indices)
         NA_loc, Li = temporal_scores.shape[1:3]
+        if self._grouped() and temporal_scores.is_cuda and temporal_scores.dtype == torch.float32:
+            # loss and its gradient in one pass (csrc/groups.hip: ts_loss_kernel) instead of gather + 2 x (log-softmax, nll) + add
+            return groups.ts_loss(temporal_scores, answer_indices, ts_labels["st"], ts_labels["ed"], cand_offset)
         local = answer_indices - cand_offset
         if cand_offset == 0 and NA_loc == self.num_a:
             ca = temporal_scores.gather(1, local.view(bsz, 1, 1, 1).expand(bsz, 1, Li, 2)).squeeze(1)   # [n, target_n]
@@ -570,9 +635,11 @@ class STAGE(nn.Module):
                 att_pairs = AttPairs(pos, neg, (N, NA, Li_v, batch.qas_mask.shape[-1], Lr_v), batch.vid.device,
                                      getattr(self, "_att_stage", None))
                 self._att_stage = att_pairs.stage
+        ctx_m = vid_mask if self.vfeat_flag else sub_mask       # the statement mask's context side (model/stage.py:386)
+        factors = ((qas_mask != 0).any(-1), ctx_m.sum(-1) != 0)
         out, target, t_scores = self.classfier_head_multi_proposal(
             statement, statement_mask, batch.target, batch.ts_label, batch.ts_label_mask.float(),
-            extra_span_length=self.extra_span_length, gt_scores_fn=gt_scores_fn)
+            extra_span_length=self.extra_span_length, gt_scores_fn=gt_scores_fn, pool_mask_factors=factors)
         assert len(out) == len(target)
         other_outputs["temporal_scores"] = t_scores
 
