@@ -289,6 +289,20 @@ int stage_ln_masked_max_bwd_bf16(const void* dout, const int* argmax, const floa
                                  const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta, long long R,
                                  int L, int K, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- backward of  y = ReLU(drop(LN_3D([a, b, a*b])) W^T + c)  without the 3D-wide gradient (csrc/cat3_fused.hip) -----------------
+ * (model/stage.py:381-385 c2q_down_projection, :276-279 concat_fc.)  The Linear's input gradient (dy .* relu') W, 1.47 GB at the
+ * full configuration, is neither written nor read back: one workgroup owns complete 3D-wide rows, the product stays in matrix-core
+ * accumulators and the LayerNorm backward runs on them.  dy (rows, D) = gradient of the Linear's output BEFORE the ReLU gate;
+ * relu_mask = the forward's ReLU bit mask ([D/32][rows], stage_gemm_nt_mask); W (D, 3D); a, b, mean, rstd, gamma, p_drop, seed as
+ * for stage_cat3_layernorm_bwd*.  Outputs: rep > 1: da (rows / rep, D) summed over the frames (as ..._bwd_reduced), rep == 1:
+ * da (rows, D); db (rows, D); dgamma, dbeta (3D).  D == 128, rows >= 4096 (STAGE_ERR_SHAPE otherwise).                         */
+int stage_cat3_dx_ln_bwd_supported(long long rows, int D, int rep, int inner);
+size_t stage_cat3_dx_ln_bwd_ws_bytes(long long rows, int D, int rep, int inner);
+int stage_cat3_dx_ln_bwd(const float* dy, const unsigned* relu_mask, const float* W, const float* a, const float* b,
+                         const float* mean, const float* rstd, const float* gamma, float* da, float* db, float* dgamma,
+                         float* dbeta, long long rows, int D, int rep, int inner, float p_drop, unsigned long long seed, void* ws,
+                         size_t ws_bytes, void* stream);
+
 /* ---- K-groups: launch sequencing on the C side (one forward and one backward symbol per fused-op group) --
  * Each group runs the kernels above in the order tvqaplus_amd/ops.py would, as ONE call (csrc/groups.hip); fp32 storage.
  * Memory protocol: `arena` (stage_grp_*_arena_bytes) = what the forward keeps for the backward, carved deterministically;

@@ -136,3 +136,69 @@ def test_group_path_issues_few_host_calls(hip_device):
         return n[0]
     counts["per_op"], counts["groups"] = run(False), run(True)
     assert counts["groups"] <= 45 and counts["groups"] * 4 <= counts["per_op"], counts
+
+
+@pytest.mark.parametrize("which,dims,p", [
+    ("qa_ctx", dict(N=2, NA=5, Li=12, Lqa=40, Lr=20), 0.1),      # broadcast `a` (rep = Li): LDS image + slab sum
+    ("qa_ctx", dict(N=1, NA=5, Li=31, Lqa=29, Lr=10), 0.0),      # inner <= 32: one padded tile per frame, no dropout
+    ("qa_ctx", dict(N=1, NA=5, Li=29, Lqa=29, Lr=10), 0.2),      # ... with dropout; a chunk of frames that is not a multiple of four
+    ("qa_ctx", dict(N=3, NA=5, Li=7, Lqa=40, Lr=12), 0.1),       # inner = 40, 7 frames: the last group of four is ragged
+    ("concat_fc", dict(U=4096 + 77), 0.1),                        # rep = 1, last tile partly filled
+    ("concat_fc", dict(U=9000), 0.0),
+])
+def test_fused_cat3_backward_equals_gemm_plus_layernorm_backward(hip_device, which, dims, p):
+    """csrc/cat3_fused.hip (the Linear's input gradient never leaves the compute unit) against the two-kernel path it replaces
+    (dX GEMM -> 3D-wide tensor -> LayerNorm backward): same gradients to fp32 rounding (both products are the two-way fp16 split;
+    the summation orders differ)."""
+    import os
+    from tvqaplus_amd import groups
+    g = torch.Generator().manual_seed(7)
+    D = 128
+    dev = hip_device
+
+    def rnd(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g) * scale).to(dev)
+    ln_w, ln_b = (1.0 + 0.1 * torch.randn(3 * D, generator=g)).to(dev).requires_grad_(), rnd(3 * D, scale=0.1).requires_grad_()
+    W, c = rnd(D, 3 * D, scale=0.08).requires_grad_(), rnd(D, scale=0.1).requires_grad_()
+    seeds = [11, 12, 13]
+    results = []
+    for fused in (False, True):
+        if fused:
+            os.environ.pop("STAGE_NO_CAT3_FUSED", None)
+        else:
+            os.environ["STAGE_NO_CAT3_FUSED"] = "1"
+        try:
+            gg = torch.Generator().manual_seed(3)
+            if which == "qa_ctx":
+                N, NA, Li, Lqa, Lr = (dims[k] for k in ("N", "NA", "Li", "Lqa", "Lr"))
+                qa = (torch.randn(N, NA, Lqa, D, generator=gg)).to(dev).requires_grad_()
+                cx = (torch.randn(N, Li, Lr, D, generator=gg)).to(dev).requires_grad_()
+                qm = (torch.rand(N, NA, Lqa, generator=gg) > 0.2).float().to(dev)
+                cm = (torch.rand(N, Li, Lr, generator=gg) > 0.2).float().to(dev)
+                mixed, S, Sn = groups.qa_ctx(qa, cx, qm, cm, 10.0, p, seeds, [ln_w, ln_b, W, c])
+                go = torch.randn(mixed.shape, generator=gg).to(dev)
+                (mixed * go).sum().backward()
+                outs = [qa.grad, cx.grad]
+            else:
+                U = dims["U"]
+                s = torch.randn(U, D, generator=gg).to(dev).requires_grad_()
+                v = torch.randn(U, D, generator=gg).to(dev).requires_grad_()
+                l2w, l2b = torch.ones(D, device=dev, requires_grad=True), torch.zeros(D, device=dev, requires_grad=True)
+                out = groups.concat_fc(s, v, p, seeds[:1], [ln_w, ln_b, W, c, l2w, l2b])
+                go = torch.randn(out.shape, generator=gg).to(dev)
+                (out * go).sum().backward()
+                outs = [s.grad, v.grad]
+            torch.cuda.synchronize()
+            results.append([t.clone() for t in outs] + [ln_w.grad.clone(), ln_b.grad.clone(), W.grad.clone(), c.grad.clone()])
+        finally:
+            os.environ.pop("STAGE_NO_CAT3_FUSED", None)
+            for t in (ln_w, ln_b, W, c):
+                t.grad = None
+    names = ["d_a", "d_b", "d_gamma", "d_beta", "dW", "dc"]
+    for nm, x, y in zip(names, results[0], results[1]):
+        scale = float(x.abs().max()) + 1e-12
+        err = float((x - y).abs().max())
+        assert err <= 2e-5 * scale, (nm, err, scale)
+    assert torch.equal(results[0][4], results[1][4]) and torch.equal(results[0][5], results[1][5])   # the weight gradient is the same kernel
+    # the two paths sum in different orders: bit-identical input gradients would mean the fused kernel did not run
+    assert not torch.equal(results[0][1], results[1][1])

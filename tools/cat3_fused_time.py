@@ -1,0 +1,66 @@
+"""The fused backward of LayerNorm([a, b, a*b]) -> dropout -> Linear -> ReLU (csrc/cat3_fused.hip) against the two kernels it
+replaces (dX GEMM + LayerNorm backward) at the bench shapes: per-launch times (events) and max differences.
+REP=300 (c2q: `a` broadcast over the frames) or REP=1 (concat_fc); P=0.1 dropout."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tvqaplus_amd import _lib
+if os.environ.get("LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["LIB"])
+lib = _lib.load()
+dev = "cuda"
+D = 128
+rep = int(os.environ.get("REP", 300)); inner = 40 if rep > 1 else 1
+G = int(os.environ.get("G", 80))
+U = G * rep * inner if rep > 1 else int(os.environ.get("U", 960000))
+p = float(os.environ.get("P", 0.1)); seed = 1234
+g = torch.Generator().manual_seed(1)
+a = torch.randn((U // rep) if rep > 1 else U, D, generator=g).to(dev)
+b = torch.randn(U, D, generator=g).to(dev)
+gamma = (1 + 0.1 * torch.randn(3 * D, generator=g)).to(dev); beta = (0.1 * torch.randn(3 * D, generator=g)).to(dev)
+W = (0.08 * torch.randn(D, 3 * D, generator=g)).to(dev); bias = torch.zeros(D, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+z = torch.empty(U, 3 * D, device=dev); mean = torch.empty(U, device=dev); rstd = torch.empty(U, device=dev)
+_lib.check(lib.stage_cat3_layernorm_fwd(a.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), U, D, rep, inner, 1e-5, p, seed, st), "fwd")
+y = torch.empty(U, D, device=dev); mask = torch.empty(D // 32, U, dtype=torch.int32, device=dev)
+_lib.check(lib.stage_gemm_nt_mask(z.data_ptr(), None, W.data_ptr(), bias.data_ptr(), y.data_ptr(), mask.data_ptr(), U, D, 3 * D, 1, st), "gemm fwd")
+dy = torch.randn(U, D, generator=g).to(dev)
+Wt = W.t().contiguous()
+dz = torch.empty(U, 3 * D, device=dev)
+da1 = torch.empty_like(a); db1 = torch.empty_like(b); dg1 = torch.empty(3 * D, device=dev); dbt1 = torch.empty(3 * D, device=dev)
+da2 = torch.empty_like(a); db2 = torch.empty_like(b); dg2 = torch.empty(3 * D, device=dev); dbt2 = torch.empty(3 * D, device=dev)
+wsb = max(lib.stage_cat3_layernorm_bwd_reduced_ws_bytes(U, D, rep, inner) if rep > 1 else 0, lib.stage_ln_bwd_ws_bytes(3 * D),
+          lib.stage_cat3_dx_ln_bwd_ws_bytes(U, D, rep, inner))
+ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+def unfused():
+    _lib.check(lib.stage_gemm_nt_mask(dy.data_ptr(), mask.data_ptr(), Wt.data_ptr(), None, dz.data_ptr(), None, U, 3 * D, D, 0, st), "dx")
+    if rep > 1:
+        _lib.check(lib.stage_cat3_layernorm_bwd_reduced(dz.data_ptr(), a.data_ptr(), b.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                   da1.data_ptr(), db1.data_ptr(), dg1.data_ptr(), dbt1.data_ptr(), U, D, rep, inner, p, seed, ws.data_ptr(), wsb, st), "ln bwd")
+    else:
+        _lib.check(lib.stage_cat3_layernorm_bwd(dz.data_ptr(), a.data_ptr(), b.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                   da1.data_ptr(), db1.data_ptr(), dg1.data_ptr(), dbt1.data_ptr(), U, D, rep, inner, p, seed, ws.data_ptr(), wsb, st), "ln bwd")
+def fused():
+    _lib.check(lib.stage_cat3_dx_ln_bwd(dy.data_ptr(), mask.data_ptr(), W.data_ptr(), a.data_ptr(), b.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+               gamma.data_ptr(), da2.data_ptr(), db2.data_ptr(), dg2.data_ptr(), dbt2.data_ptr(), U, D, rep, inner, p, seed, ws.data_ptr(), wsb, st), "fused")
+unfused(); fused(); torch.cuda.synchronize()
+# independent check of d beta (torch): sum over rows of dz * keep / (1 - p), keep = where the forward's z is non-zero
+keep = (z != 0).float() / (1.0 - p) if p > 0 else torch.ones_like(z)
+dz_t = torch.matmul(dy * (y > 0).float(), W) * keep
+ref_b = dz_t.double().sum(0)
+print("dbeta vs torch: unfused %.3e fused %.3e (scale %.3e)" % (float((dbt1.double() - ref_b).abs().max()), float((dbt2.double() - ref_b).abs().max()), float(ref_b.abs().max())))
+dd = (dbt2.double() - ref_b).abs()
+bad = (dd > 1e-2 * float(ref_b.abs().max())).nonzero().flatten().tolist()
+print("columns with a wrong d beta:", len(bad), bad[:48])
+del keep, dz_t
+for nm, x, y2 in (("da", da1, da2), ("db", db1, db2), ("dgamma", dg1, dg2), ("dbeta", dbt1, dbt2)):
+    print("%-7s max|diff| %.3e  of scale %.3e" % (nm, float((x - y2).abs().max()), float(x.abs().max())))
+def timeit(fn, name, reps=10):
+    for _ in range(2): fn()
+    cs = torch.cuda.current_stream()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for s, e in ev:
+        s.record(cs); fn(); e.record(cs)
+    torch.cuda.synchronize()
+    t = [s.elapsed_time(e) * 1e3 for s, e in ev]
+    print("%s: avg %.1f min %.1f us" % (name, sum(t) / len(t), min(t)))
+timeit(unfused, "dX GEMM + LayerNorm backward"); timeit(fused, "fused")

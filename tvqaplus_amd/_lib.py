@@ -87,6 +87,9 @@ SIGNATURES = {
     "stage_masked_max_bwd_bf16": (I, [P, P, P, P, LL, I, I, I, P]),
     "stage_ln_masked_max_fwd_bf16": (I, [P, P, P, P, P, P, P, P, P, P, LL, I, I, F, P]),
     "stage_ln_masked_max_bwd_bf16": (I, [P, P, P, P, P, P, P, P, P, P, LL, I, I, P, SZ, P]),
+    "stage_cat3_dx_ln_bwd_supported": (I, [LL, I, I, I]),
+    "stage_cat3_dx_ln_bwd_ws_bytes": (SZ, [LL, I, I, I]),
+    "stage_cat3_dx_ln_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, U64, P, SZ, P]),
     # K-groups (csrc/groups.hip): one forward and one backward symbol per fused-op group; params / grads / seeds / flags are
     # HOST arrays (pointers to them travel as void*)
     "stage_grp_input_mlp_arena_bytes": (SZ, [LL, I, I, I, I]),

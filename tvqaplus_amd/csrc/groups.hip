@@ -376,6 +376,7 @@ QaTmp qa_tmp(void* base, int N, int NA, int Li, int Lqa, int Lr, int D) {
     t.wsb = umax(lin_bwd_ws((long long)U, D, 3 * D), stage_ln_bwd_ws_bytes(3 * D));
     t.wsb = umax(t.wsb, stage_cat3_layernorm_bwd_reduced_ws_bytes((long long)U, D, Li, Lqa));
     t.wsb = umax(t.wsb, umax(stage_str_attn_bwd_fused_ws_bytes(N, NA, Li, Lqa, D), stage_str_attn_bwd_ws_bytes(N, NA, Lqa, D)));
+    t.wsb = umax(t.wsb, stage_cat3_dx_ln_bwd_ws_bytes((long long)U, D, Li, Lqa));
     t.ws = b.take<char>(t.wsb);
     t.bytes = b.off;
     return t;
@@ -417,11 +418,18 @@ extern "C" int stage_grp_qa_ctx_bwd(const float* d_mixed, const float* dS_ext, c
     if (arena_bytes < a.bytes || tmp_bytes < stage_grp_qa_ctx_bwd_tmp_bytes(N, NA, Li, Lqa, Lr, D)) return STAGE_ERR_WORKSPACE;
     float* extra = (float*)((char*)tmp + ((t.bytes + 255) & ~(size_t)255));
     const long long U = (long long)N * NA * Li * Lqa, Crows = (long long)N * NA * Lqa, Qrows = (long long)N * Li * Lr;
-    // Linear(3D -> D) + ReLU
-    TRY(lin_bwd(d_mixed, a.z, mixed, a.mask, flags[0], 1, P[2], t.wt, t.dz, G[2], G[3], U, D, 3 * D, t.ws, t.wsb, st));
-    // LayerNorm over [a, b, a*b]; the gradient of the broadcast operand a is summed over the frames inside the kernel
-    bool reduced = false;
-    if (cat3_reduced_ok(D, Li, Lqa)) {
+    // Linear(3D -> D) + ReLU, LayerNorm over [a, b, a*b].  With the ReLU bit mask at hand the Linear's input gradient never
+    // exists as a tensor (csrc/cat3_fused.hip); otherwise: dX GEMM, then the LayerNorm backward with the broadcast reduction
+    bool reduced = false, fused = false;
+    if (flags[0] && al16(d_mixed) && stage_cat3_dx_ln_bwd_supported(U, D, Li, Lqa)) {
+        TRY(lin_bwd(d_mixed, a.z, mixed, a.mask, flags[0], 1, P[2], t.wt, nullptr, G[2], G[3], U, D, 3 * D, t.ws, t.wsb, st));
+        const int rc = stage_cat3_dx_ln_bwd(d_mixed, a.mask, P[2], qa, a.A, a.mean, a.rstd, P[0], d_qa, t.dA, G[0], G[1], U, D, Li, Lqa, p,
+                                            seeds[2], t.ws, stage_cat3_dx_ln_bwd_ws_bytes(U, D, Li, Lqa), st);
+        if (rc == 0) fused = reduced = true;
+        else if (rc != STAGE_ERR_SHAPE) return rc;
+    }
+    if (!fused) TRY(lin_bwd(d_mixed, a.z, mixed, a.mask, flags[0], 1, P[2], t.wt, t.dz, G[2], G[3], U, D, 3 * D, t.ws, t.wsb, st));
+    if (!fused && cat3_reduced_ok(D, Li, Lqa)) {
         const int rc = stage_cat3_layernorm_bwd_reduced(t.dz, qa, a.A, a.mean, a.rstd, P[0], d_qa, t.dA, G[0], G[1], U, D, Li, Lqa, p,
                                                         seeds[2], t.ws, stage_cat3_layernorm_bwd_reduced_ws_bytes(U, D, Li, Lqa), st);
         if (rc == 0) reduced = true;
@@ -473,6 +481,7 @@ FcTmp fc_tmp(void* base, long long U, int D) {
     t.dz = b.take<float>((size_t)U * 3 * D);
     t.wt = b.take<float>((size_t)3 * D * D);
     t.wsb = umax(umax(lin_bwd_ws(U, D, 3 * D), stage_ln_bwd_ws_bytes(3 * D)), stage_ln_bwd_ws_bytes(D));
+    t.wsb = umax(t.wsb, stage_cat3_dx_ln_bwd_ws_bytes(U, D, 1, 1));
     t.ws = b.take<char>(t.wsb);
     t.bytes = b.off;
     return t;
@@ -501,6 +510,12 @@ extern "C" int stage_grp_concat_fc_bwd(const float* dout, const float* s, const 
     FcTmp t = fc_tmp(tmp, U, D);
     if (arena_bytes < a.bytes || tmp_bytes < t.bytes) return STAGE_ERR_WORKSPACE;
     TRY(stage_layernorm_bwd(dout, a.h, a.mean, a.rstd, P[4], t.dh, nullptr, G[4], G[5], U, D, 0.f, 0ull, t.ws, stage_ln_bwd_ws_bytes(D), st));
+    if (flags[0] && stage_cat3_dx_ln_bwd_supported(U, D, 1, 1)) {      // no 3D-wide gradient tensor (csrc/cat3_fused.hip)
+        TRY(lin_bwd(t.dh, a.z, a.h, a.mask, flags[0], 1, P[2], t.wt, nullptr, G[2], G[3], U, D, 3 * D, t.ws, t.wsb, st));
+        const int rc = stage_cat3_dx_ln_bwd(t.dh, a.mask, P[2], s, v, a.mean3, a.rstd3, P[0], ds, dv, G[0], G[1], U, D, 1, 1, p, seeds[0],
+                                            t.ws, stage_cat3_dx_ln_bwd_ws_bytes(U, D, 1, 1), st);
+        if (rc != STAGE_ERR_SHAPE) return rc;
+    }
     TRY(lin_bwd(t.dh, a.z, a.h, a.mask, flags[0], 1, P[2], t.wt, t.dz, G[2], G[3], U, D, 3 * D, t.ws, t.wsb, st));
     return stage_cat3_layernorm_bwd(t.dz, s, v, a.mean3, a.rstd3, P[0], ds, dv, G[0], G[1], U, D, 1, 1, p, seeds[0], t.ws,
                                     stage_ln_bwd_ws_bytes(3 * D), st);
