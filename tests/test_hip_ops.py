@@ -648,6 +648,41 @@ def test_dropout_statistics_and_backward_mask(ops):
     assert float(x.grad.abs().max()) == 0.0
 
 
+def test_dropout_stream_is_uniform_and_uncorrelated(ops):
+    """The counter-based dropout stream (csrc/common.h: two 32-bit finalisers per group of four elements): keep rates per column,
+    per row and overall; no correlation between neighbours (inside a hash group, across groups, across rows), between the thirds
+    of a 3D-wide row, or between the masks of different seeds (neighbouring integers and successive states of STAGE's seed
+    sequence).  Thresholds are ~5 sigma of the binomial noise."""
+    rows, K, p = 8192, 384, 0.1
+    x = torch.randn(rows, K).cuda()
+    w, b = torch.ones(K).cuda(), torch.zeros(K).cuda()
+
+    def mask(seed):
+        y, _ = ops.layernorm(x, w, b, p=p, seed=seed)
+        return (y != 0).float()
+    s0 = 0x1234567890ABCDEF >> 1
+    m = mask(s0)
+    n = rows * K
+    assert abs(float(m.mean()) - (1 - p)) < 5 * (p * (1 - p) / n) ** 0.5 + 1e-4
+    assert float((m.mean(0) - (1 - p)).abs().max()) < 5 * (p * (1 - p) / rows) ** 0.5
+    assert float((m.mean(1) - (1 - p)).abs().max()) < 5.5 * (p * (1 - p) / K) ** 0.5
+    c = m - m.mean()
+    var = float((c * c).mean())
+
+    def corr(u, v):
+        return abs(float((u * v).mean())) / var
+    tol = 5.0 / (n ** 0.5)
+    for lag in (1, 2, 3, 4, 5, 8, 32, 128):                 # along a row: inside a group of four, across groups, across the thirds
+        assert corr(c[:, :-lag], c[:, lag:]) < tol * 1.1, lag
+    for lag in (1, 2, 7):                                    # down the rows
+        assert corr(c[:-lag], c[lag:]) < tol * 1.1, lag
+    nxt = (s0 * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF     # STAGE._seed's next state
+    for other in (s0 + 1, s0 ^ 1, s0 + (1 << 32), nxt >> 1, (nxt * 6364136223846793005 + 1442695040888963407 & 0xFFFFFFFFFFFFFFFF) >> 1):
+        m2 = mask(other)
+        assert not torch.equal(m, m2)
+        assert corr(c, m2 - m2.mean()) < tol * 1.1, hex(other)
+
+
 def test_torch_ops_namespace_runs_the_hip_kernels(ops):
     """torch.ops.stage_hip.structured_attention / .linear / .layernorm: same results and gradients as the wrappers (they ARE
     the wrappers behind the dispatcher), autograd included."""
