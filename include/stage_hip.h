@@ -302,6 +302,14 @@ int stage_cat3_dx_ln_bwd(const float* dy, const unsigned* relu_mask, const float
                          const float* mean, const float* rstd, const float* gamma, float* da, float* db, float* dgamma,
                          float* dbeta, long long rows, int D, int rep, int inner, float p_drop, unsigned long long seed, void* ws,
                          size_t ws_bytes, void* stream);
+/* Forward twin: z = drop(LN_3D([a, b, a*b])) and y = ReLU(z W^T + bias) in one pass over a and b (z is written once for the
+ * backward's weight-gradient GEMM, never read back here).  z, mean, rstd are bit-identical to stage_cat3_layernorm_fwd; y and
+ * relu_mask_out ([D/32][rows]) as stage_gemm_nt_mask on that z.  D == 128, rows >= 4096; ws: stage_cat3_ln_gemm_fwd_ws_bytes(). */
+int stage_cat3_ln_gemm_fwd_supported(long long rows, int D, int rep, int inner);
+size_t stage_cat3_ln_gemm_fwd_ws_bytes(void);
+int stage_cat3_ln_gemm_fwd(const float* a, const float* b, const float* gamma, const float* beta, const float* W, const float* bias,
+                           float* z, float* mean, float* rstd, float* y, unsigned* relu_mask_out, long long rows, int D, int rep,
+                           int inner, float eps, float p_drop, unsigned long long seed, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- K-groups: launch sequencing on the C side (one forward and one backward symbol per fused-op group) --
  * Each group runs the kernels above in the order tvqaplus_amd/ops.py would, as ONE call (csrc/groups.hip); fp32 storage.

@@ -64,3 +64,15 @@ def timeit(fn, name, reps=10):
     t = [s.elapsed_time(e) * 1e3 for s, e in ev]
     print("%s: avg %.1f min %.1f us" % (name, sum(t) / len(t), min(t)))
 timeit(unfused, "dX GEMM + LayerNorm backward"); timeit(fused, "fused")
+# ---- forward: LayerNorm + dropout + Linear + ReLU in one pass against the two kernels it replaces ----
+z2 = torch.empty_like(z); mean2 = torch.empty_like(mean); rstd2 = torch.empty_like(rstd); y2 = torch.empty_like(y); mask2 = torch.empty_like(mask)
+fwsb = lib.stage_cat3_ln_gemm_fwd_ws_bytes(); fws = torch.empty(fwsb, dtype=torch.uint8, device=dev)
+def fwd_unfused():
+    _lib.check(lib.stage_cat3_layernorm_fwd(a.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), U, D, rep, inner, 1e-5, p, seed, st), "fwd")
+    _lib.check(lib.stage_gemm_nt_mask(z.data_ptr(), None, W.data_ptr(), bias.data_ptr(), y.data_ptr(), mask.data_ptr(), U, D, 3 * D, 1, st), "gemm fwd")
+def fwd_fused():
+    _lib.check(lib.stage_cat3_ln_gemm_fwd(a.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), W.data_ptr(), bias.data_ptr(), z2.data_ptr(), mean2.data_ptr(),
+               rstd2.data_ptr(), y2.data_ptr(), mask2.data_ptr(), U, D, rep, inner, 1e-5, p, seed, fws.data_ptr(), fwsb, st), "fused fwd")
+fwd_unfused(); fwd_fused(); torch.cuda.synchronize()
+print("forward: max|y - y'| %.3e of %.3e, z equal up to %.3e" % (float((y - y2).abs().max()), float(y.abs().max()), float((z - z2).abs().max())))
+timeit(fwd_unfused, "LayerNorm forward + GEMM"); timeit(fwd_fused, "fused forward")

@@ -90,6 +90,9 @@ SIGNATURES = {
     "stage_cat3_dx_ln_bwd_supported": (I, [LL, I, I, I]),
     "stage_cat3_dx_ln_bwd_ws_bytes": (SZ, [LL, I, I, I]),
     "stage_cat3_dx_ln_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, U64, P, SZ, P]),
+    "stage_cat3_ln_gemm_fwd_supported": (I, [LL, I, I, I]),
+    "stage_cat3_ln_gemm_fwd_ws_bytes": (SZ, []),
+    "stage_cat3_ln_gemm_fwd": (I, [P, P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, F, U64, P, SZ, P]),
     # K-groups (csrc/groups.hip): one forward and one backward symbol per fused-op group; params / grads / seeds / flags are
     # HOST arrays (pointers to them travel as void*)
     "stage_grp_input_mlp_arena_bytes": (SZ, [LL, I, I, I, I]),

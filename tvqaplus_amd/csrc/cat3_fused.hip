@@ -482,3 +482,257 @@ extern "C" int stage_cat3_dx_ln_bwd(const float* dy, const unsigned* relu_mask, 
     if (rep > 1) return stage_reduce_rep(da_out, da, groups, CH, (long long)inner * CF_D, st);
     return 0;
 }
+
+// =====================================================================================================================
+// Forward twin:  z = drop(LN_3D([a, b, a*b])) ;  y = ReLU(z W^T + c)  in ONE pass over a and b.
+// The two kernels it replaces (stage_cat3_layernorm_fwd -> 1.47 GB tensor -> stage_gemm_nt_mask) write z and read it back; here the
+// normalised tile is built in registers, written once (the weight-gradient GEMM of the backward still contracts over it) and
+// handed to the matrix cores through LDS: HBM traffic per row 512 B (b) [+ 512 B a] read, 1536 B (z) + 512 B (y) written, instead
+// of + 1536 B read.  Same arithmetic and summation order as ln_fwd_fast_kernel<1> (rowops.hip) for the LayerNorm -- z, mean and
+// rstd are bit-identical -- and the two-way fp16 split of gemm_nt_stream_kernel for the product (one power-of-two scale per row of
+// z, one for the weight).  A workgroup (4 waves) walks 32-row tiles; wave w owns output columns 32 w .. 32 w + 31; its weight
+// fragments (24 k-steps x 2 planes, 48 KB) stream from a pre-split image in global memory (L2 resident).
+// =====================================================================================================================
+namespace {
+constexpr int CFF_KS = 3 * CF_D / 16;             // 24 k-steps of the 32x32x16 MFMA
+constexpr int CFF_WFRAG = 2 * 4 * CFF_KS * 64;    // uint4 fragments of the forward weight image
+
+// Wimg[plane][wave w][k-step ks][lane] = the 8 fp16 of B-operand lane (col n = 32 w + (lane & 31), k = 16 ks + 8 (lane >> 5) + e) of
+// W[n][k]  (W = the Linear's (D, 3D) weight)
+__global__ __launch_bounds__(1024) void cff_prep_w_kernel(const float* __restrict__ W, uint4* __restrict__ img, int* __restrict__ w_up_out) {
+    __shared__ float red[16];
+    const int tid = threadIdx.x;
+    float m = 0.f;
+    for (int e = tid; e < CF_D * 3 * CF_D; e += 1024) m = fmaxf(m, fabsf(W[e]));
+    m = wave_max(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = red[0];
+#pragma unroll
+    for (int i = 1; i < 16; i++) m = fmaxf(m, red[i]);
+    const int w_up = h_up_field((int)(__float_as_uint(m) >> 23) & 0xff);
+    const float sc = __uint_as_float((unsigned)w_up << 23);
+    if (tid == 0) w_up_out[0] = w_up;
+    for (int f = tid; f < 4 * CFF_KS * 64; f += 1024) {
+        const int lane = f & 63, ks = (f >> 6) % CFF_KS, w = f / (64 * CFF_KS);
+        const float* src = W + (long)(32 * w + (lane & 31)) * (3 * CF_D) + 16 * ks + 8 * (lane >> 5);
+        const float4 v0 = ld4(src), v1 = ld4(src + 4);
+        uint4 hi, lo;
+        h_split2(v0.x, v0.y, sc, hi.x, lo.x);
+        h_split2(v0.z, v0.w, sc, hi.y, lo.y);
+        h_split2(v1.x, v1.y, sc, hi.z, lo.z);
+        h_split2(v1.z, v1.w, sc, hi.w, lo.w);
+        img[f] = hi;
+        img[4 * CFF_KS * 64 + f] = lo;
+    }
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(256, 3) void cff_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const uint4* __restrict__ wimg, const int* __restrict__ w_up_p,
+                                                         const float* __restrict__ bias, float* __restrict__ z,
+                                                         float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ y,
+                                                         unsigned* __restrict__ mask_out, long M, int rep, int inner, float eps,
+                                                         uint64_t seed, uint32_t th, float inv_keep) {
+    // LDS: A planes [ks][plane][lane] uint4 (48 KB) | row scale exponent fields [32]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4* Ap = reinterpret_cast<uint4*>(smem_raw);
+    int* row_up = reinterpret_cast<int*>(smem_raw + CFF_KS * 2 * 64 * 16);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int w_up = w_up_p[0];
+    constexpr int K3 = 3 * CF_D, K4 = K3 / 4, D4 = CF_D / 4;
+    const float invK = 1.0f / (float)K3;
+    const long GR = (long)rep * inner;
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)b, 0, (int)(M * CF_D * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a, 0, (int)((M / rep) * CF_D * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc((void*)z, 0, (int)(M * K3 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)(M * CF_D * 4), 0x00020000);
+    const int sj = tid >> 5, sl = tid & 31;               // staging: row inside a pass, float4 index inside each third
+    float4 gm[3], bt[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        gm[t] = ld4(gamma + 4 * (t * D4 + sl));
+        bt[t] = ld4(beta + 4 * (t * D4 + sl));
+    }
+    const int n = 32 * wave + l31;                        // this lane's output column
+    const float bsv = bias ? bias[n] : 0.f;
+    uint2* st_dst = reinterpret_cast<uint2*>(Ap + (sl >> 2) * 2 * 64 + sj + 32 * ((sl >> 1) & 1)) + (sl & 1);
+    const long n_tiles = (M + 31) / 32;
+
+    for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long t0 = tile * 32;
+        __syncthreads();                                  // the previous tile's A planes are free
+        // ---- normalise 32 rows: 32 lanes per row (one float4 of each third), 8 rows per pass; loads of the tile first ----
+        typedef unsigned cf_u4 __attribute__((ext_vector_type(4)));
+        cf_u4 ra[4], rb[4];
+        // broadcast operand: row -> (row / (rep * inner)) * inner + row % inner.  Uniform part once per tile, per row an add and
+        // at most three conditional subtractions (inner >= 11)
+        const long g0 = rep > 1 ? t0 / GR : 0;
+        const int r0 = rep > 1 ? (int)(t0 - g0 * GR) : 0, p0 = rep > 1 ? r0 % inner : 0;
+#pragma unroll
+        for (int pass = 0; pass < 4; pass++) {
+            const int rl = 8 * pass + sj;
+            int ao;
+            if (rep > 1) {
+                int pos = p0 + rl;
+                pos -= pos >= inner ? inner : 0;
+                pos -= pos >= inner ? inner : 0;
+                pos -= pos >= inner ? inner : 0;
+                const long arow = (g0 + ((long)r0 + rl >= GR ? 1 : 0)) * inner + pos;
+                ao = (int)(arow * CF_D * 4) + 16 * sl;
+            } else ao = (int)((t0 + rl) * CF_D * 4) + 16 * sl;
+            ra[pass] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, ao, 0, 0);
+            rb[pass] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (sj * CF_D + 4 * sl) * 4, (int)((t0 + 8 * pass) * CF_D * 4), 0);
+        }
+#pragma unroll
+        for (int pass = 0; pass < 4; pass++) {
+            const int rl = 8 * pass + sj;
+            const long row = t0 + rl;
+            const bool ok = row < M;
+            float4 v[3];
+            v[0] = make_float4(__uint_as_float(ra[pass][0]), __uint_as_float(ra[pass][1]), __uint_as_float(ra[pass][2]), __uint_as_float(ra[pass][3]));
+            v[1] = make_float4(__uint_as_float(rb[pass][0]), __uint_as_float(rb[pass][1]), __uint_as_float(rb[pass][2]), __uint_as_float(rb[pass][3]));
+            v[2] = f4mul(v[0], v[1]);
+            // (the arithmetic of ln_fwd_fast_kernel<1>: same operations, same order)
+            float s = f4hsum(v[0]) + f4hsum(v[1]) + f4hsum(v[2]);
+            s = group_sum(s, 32);
+            const float mu = s * invK;
+            float q = 0.f;
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const float4 d = make_float4(v[t].x - mu, v[t].y - mu, v[t].z - mu, v[t].w - mu);
+                q += f4hsum(f4mul(d, d));
+            }
+            q = group_sum(q, 32);
+            const float rs = 1.0f / sqrtf(q * invK + eps);
+            if (ok && sl == 0) {
+                mean[row] = mu;
+                rstd[row] = rs;
+            }
+            float4 o[3];
+            float m = 0.f;
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                o[t].x = (v[t].x - mu) * rs * gm[t].x + bt[t].x;
+                o[t].y = (v[t].y - mu) * rs * gm[t].y + bt[t].y;
+                o[t].z = (v[t].z - mu) * rs * gm[t].z + bt[t].z;
+                o[t].w = (v[t].w - mu) * rs * gm[t].w + bt[t].w;
+                if (DROP) o[t] = f4mul(o[t], drop4(seed, (uint64_t)row * K4 + (uint64_t)(t * D4 + sl), th, inv_keep));
+                if (!ok) o[t] = f4zero();
+                // z is written once: the weight-gradient GEMM of the backward contracts over it (rows past the end: dropped by bounds)
+                __builtin_amdgcn_raw_buffer_store_b128((cf_u4){__float_as_uint(o[t].x), __float_as_uint(o[t].y), __float_as_uint(o[t].z), __float_as_uint(o[t].w)},
+                                                       rs_z, (sj * K3 + t * CF_D + 4 * sl) * 4, (int)((t0 + 8 * pass) * K3 * 4), 0);
+                m = h_amax3(h_amax3(m, o[t].x, o[t].y), o[t].z, o[t].w);
+            }
+            m = group_max(m, 32);
+            const int up = h_up_field((int)(__float_as_uint(m) >> 23) & 0xff);
+            const float sc = __uint_as_float((unsigned)up << 23);
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                unsigned h01, l01, h23, l23;
+                h_split2(o[t].x, o[t].y, sc, h01, l01);
+                h_split2(o[t].z, o[t].w, sc, h23, l23);
+                // element (row rl, k = 128 t + 4 sl + e): k-step 8 t + (sl >> 2), operand lane rl + 32 ((sl >> 1) & 1), position 4 (sl & 1) + e
+                uint2* dst = st_dst + ((8 * t) * 2 * 64 + 8 * pass) * 2;
+                dst[0] = make_uint2(h01, h23);
+                dst[2 * 64] = make_uint2(l01, l23);
+            }
+            if (sl == 0) row_up[rl] = up;
+        }
+        __syncthreads();
+        // ---- the product: acc = z tile (32 x 384) . W[32 w .. 32 w + 31, :]^T ----
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        const uint4* wp = wimg + (size_t)wave * CFF_KS * 64 + lane;
+        auto load_b = [&](sf16x8 (&bf)[4][2], int kg) {       // four k-steps
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int p2 = 0; p2 < 2; p2++) bf[k][p2] = __builtin_bit_cast(sf16x8, wp[(size_t)p2 * 4 * CFF_KS * 64 + (4 * kg + k) * 64]);
+        };
+        auto mul_b = [&](const sf16x8 (&bf)[4][2], int kg) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                sf16x8 af[2];
+#pragma unroll
+                for (int p2 = 0; p2 < 2; p2++) af[p2] = __builtin_bit_cast(sf16x8, Ap[((4 * kg + k) * 2 + p2) * 64 + lane]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bf[k][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[k][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[k][0], acc, 0, 0, 0);
+            }
+        };
+        {
+            sf16x8 bfa[4][2], bfb[4][2];
+            load_b(bfa, 0);
+#pragma unroll 1
+            for (int kg = 0; kg < CFF_KS / 4; kg += 2) {
+                load_b(bfb, kg + 1);
+                mul_b(bfa, kg);
+                load_b(bfa, kg + 2 < CFF_KS / 4 ? kg + 2 : 0);
+                mul_b(bfb, kg + 1);
+            }
+        }
+        // ---- epilogue: true units, bias, ReLU, ReLU bit mask, store.  C/D layout: column l31, row (r & 3) + 8 (r >> 2) + 4 h ----
+        const int* up_h = row_up + 4 * h;
+        unsigned myw = 0u;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int rl = (r & 3) + 8 * (r >> 2);
+            float v = acc[r] * __builtin_ldexpf(1.0f, 254 - up_h[rl] - w_up) + bsv;
+            v = fmaxf(v, 0.f);
+            acc[r] = v;
+            // one ballot per register = the 32 columns of two rows (lane halves); lane (l31 = r, h) keeps the word of its half
+            const unsigned long long bal = __ballot(v > 0.f);
+            const unsigned wsel = h ? (unsigned)(bal >> 32) : (unsigned)bal;
+            if (l31 == r) myw = wsel;
+        }
+        const long mrow = t0 + 4 * h + (l31 & 3) + 8 * ((l31 & 15) >> 2);
+        if (l31 < 16 && mrow < M) mask_out[(long)wave * M + mrow] = myw;      // [word][row]
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), rs_y, (4 * h * CF_D + n) * 4,
+                                                  (int)((t0 + (r & 3) + 8 * (r >> 2)) * CF_D * 4), 0);
+    }
+}
+}  // namespace
+
+extern "C" int stage_cat3_ln_gemm_fwd_supported(long long rows, int D, int rep, int inner) {
+    if (getenv("STAGE_NO_CAT3_FUSED") || getenv("STAGE_NO_CAT3_FUSED_FWD")) return 0;
+    return (D == CF_D && rows >= 4096 && rows * 3ll * D * 4 < (1ll << 31) && rep >= 1 && inner >= 1 && (rep == 1 || inner >= 11) &&
+            rows % ((long long)rep * inner) == 0) ? 1 : 0;
+}
+extern "C" size_t stage_cat3_ln_gemm_fwd_ws_bytes(void) { return cf_align((size_t)CFF_WFRAG * sizeof(uint4)) + 256; }
+
+// z (rows, 3D), mean / rstd (rows), y (rows, D) = ReLU(z W^T + bias), relu_mask_out [D/32][rows] (as stage_gemm_nt_mask).  W (D, 3D).
+extern "C" int stage_cat3_ln_gemm_fwd(const float* a, const float* b, const float* gamma, const float* beta, const float* W,
+                                      const float* bias, float* z, float* mean, float* rstd, float* y, unsigned* relu_mask_out,
+                                      long long rows, int D, int rep, int inner, float eps, float p_drop, unsigned long long seed,
+                                      void* ws, size_t ws_bytes, void* stream) {
+    if (!stage_cat3_ln_gemm_fwd_supported(rows, D, rep, inner)) return STAGE_ERR_SHAPE;
+    if (ws_bytes < stage_cat3_ln_gemm_fwd_ws_bytes()) return STAGE_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    uint4* img = (uint4*)ws;
+    int* w_up = (int*)((char*)ws + cf_align((size_t)CFF_WFRAG * sizeof(uint4)));
+    hipLaunchKernelGGL(cff_prep_w_kernel, dim3(1), dim3(1024), 0, st, W, img, w_up);
+    const uint32_t th = drop_thresh16(p_drop);
+    const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const size_t lds = (size_t)CFF_KS * 2 * 64 * 16 + 32 * 4;
+    const long tiles = (long)((rows + 31) / 32);
+    const int grid = (int)(tiles < 3072 ? tiles : 3072);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)cff_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void*)cff_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_done = true;
+    }
+    if (p_drop > 0.f)
+        hipLaunchKernelGGL(cff_fwd_kernel<true>, dim3(grid), dim3(256), lds, st, a, b, gamma, beta, img, w_up, bias, z, mean, rstd, y,
+                           relu_mask_out, (long)rows, rep, inner, eps, (uint64_t)seed, th, inv_keep);
+    else
+        hipLaunchKernelGGL(cff_fwd_kernel<false>, dim3(grid), dim3(256), lds, st, a, b, gamma, beta, img, w_up, bias, z, mean, rstd, y,
+                           relu_mask_out, (long)rows, rep, inner, eps, (uint64_t)seed, th, inv_keep);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}

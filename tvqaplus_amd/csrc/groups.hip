@@ -345,7 +345,7 @@ extern "C" int stage_grp_encoder_bwd(const float* dout, const float* x, const fl
 //     params: ln_g ln_b W c ; seeds: [context-side dropout, region-side dropout, LayerNorm dropout] ; flags: [mask]
 // =====================================================================================================================
 namespace {
-struct QaArena { float *Cn, *A, *z, *mean, *rstd; unsigned* mask; size_t bytes; };
+struct QaArena { float *Cn, *A, *z, *mean, *rstd; unsigned* mask; void* fwd_ws; size_t bytes; };
 QaArena qa_layout(void* base, int N, int NA, int Li, int Lqa, int D) {
     Bump b{(char*)base, 0};
     QaArena a;
@@ -356,6 +356,7 @@ QaArena qa_layout(void* base, int N, int NA, int Li, int Lqa, int D) {
     a.mean = b.take<float>(U);
     a.rstd = b.take<float>(U);
     a.mask = b.take<unsigned>(lin_mask_words((long long)U, D));
+    a.fwd_ws = b.take<char>(stage_cat3_ln_gemm_fwd_ws_bytes());     // pre-split weight image of the fused forward (scratch)
     a.bytes = b.off;
     return a;
 }
@@ -395,6 +396,13 @@ extern "C" int stage_grp_qa_ctx_fwd(const float* qa, const float* ctx, const flo
     const long long U = (long long)N * NA * Li * Lqa;
     TRY(stage_l2norm_fwd(qa, a.Cn, nullptr, (long long)N * NA * Lqa, D, EPS_L2, p, seeds[0], st));
     TRY(stage_str_attn_fwd(a.Cn, ctx, qa_mask, ctx_mask, a.A, S_raw, S_norm, N, NA, Li, Lqa, Lr, D, scale, p, seeds[1], st));
+    if (stage_cat3_ln_gemm_fwd_supported(U, D, Li, Lqa) && lin_wants_mask(a.z, P[2], U, D, 3 * D, 1)) {
+        // LayerNorm + dropout + Linear + ReLU in one pass (csrc/cat3_fused.hip); fwd_ws: scratch for its pre-split weight image
+        const int rc = stage_cat3_ln_gemm_fwd(qa, a.A, P[0], P[1], P[2], P[3], a.z, a.mean, a.rstd, mixed, a.mask, U, D, Li, Lqa, EPS_LN, p,
+                                              seeds[2], a.fwd_ws, stage_cat3_ln_gemm_fwd_ws_bytes(), st);
+        if (rc == 0) { flags[0] = 1; return 0; }
+        if (rc != STAGE_ERR_SHAPE) return rc;
+    }
     TRY(stage_cat3_layernorm_fwd(qa, a.A, P[0], P[1], a.z, a.mean, a.rstd, U, D, Li, Lqa, EPS_LN, p, seeds[2], st));
     return lin_fwd(a.z, P[2], P[3], mixed, a.mask, &flags[0], U, D, 3 * D, 1, st);
 }
@@ -459,7 +467,7 @@ extern "C" int stage_grp_qa_ctx_bwd(const float* d_mixed, const float* dS_ext, c
 //     params: ln3_g ln3_b W c ln_g ln_b ; seeds: [LayerNorm dropout] ; flags: [mask]
 // =====================================================================================================================
 namespace {
-struct FcArena { float *z, *mean3, *rstd3, *h, *mean, *rstd; unsigned* mask; size_t bytes; };
+struct FcArena { float *z, *mean3, *rstd3, *h, *mean, *rstd; unsigned* mask; void* fwd_ws; size_t bytes; };
 FcArena fc_layout(void* base, long long U, int D) {
     Bump b{(char*)base, 0};
     FcArena a;
@@ -470,6 +478,7 @@ FcArena fc_layout(void* base, long long U, int D) {
     a.mask = b.take<unsigned>(lin_mask_words(U, D));
     a.mean = b.take<float>((size_t)U);
     a.rstd = b.take<float>((size_t)U);
+    a.fwd_ws = b.take<char>(stage_cat3_ln_gemm_fwd_ws_bytes());
     a.bytes = b.off;
     return a;
 }
@@ -497,8 +506,17 @@ extern "C" int stage_grp_concat_fc_fwd(const float* s, const float* v, const flo
     if (U <= 0 || D % 4 || D > 256) return STAGE_ERR_SHAPE;
     FcArena a = fc_layout(arena, U, D);
     if (arena_bytes < a.bytes) return STAGE_ERR_WORKSPACE;
-    TRY(stage_cat3_layernorm_fwd(s, v, P[0], P[1], a.z, a.mean3, a.rstd3, U, D, 1, 1, EPS_LN, p, seeds[0], st));
-    TRY(lin_fwd(a.z, P[2], P[3], a.h, a.mask, &flags[0], U, D, 3 * D, 1, st));
+    bool fused = false;
+    if (stage_cat3_ln_gemm_fwd_supported(U, D, 1, 1) && lin_wants_mask(a.z, P[2], U, D, 3 * D, 1)) {
+        const int rc = stage_cat3_ln_gemm_fwd(s, v, P[0], P[1], P[2], P[3], a.z, a.mean3, a.rstd3, a.h, a.mask, U, D, 1, 1, EPS_LN, p, seeds[0],
+                                              a.fwd_ws, stage_cat3_ln_gemm_fwd_ws_bytes(), st);
+        if (rc == 0) { flags[0] = 1; fused = true; }
+        else if (rc != STAGE_ERR_SHAPE) return rc;
+    }
+    if (!fused) {
+        TRY(stage_cat3_layernorm_fwd(s, v, P[0], P[1], a.z, a.mean3, a.rstd3, U, D, 1, 1, EPS_LN, p, seeds[0], st));
+        TRY(lin_fwd(a.z, P[2], P[3], a.h, a.mask, &flags[0], U, D, 3 * D, 1, st));
+    }
     return stage_layernorm_fwd(a.h, nullptr, 0, nullptr, P[4], P[5], out, a.mean, a.rstd, U, D, EPS_LN, 0.f, 0ull, st);
 }
 
