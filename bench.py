@@ -49,6 +49,10 @@ def parse():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--storage", choices=["fp32", "bf16"], default="fp32",
                     help="bf16: the bf16 storage mode (BASELINE configs[4]); the headline line is the fp32 default")
+    ap.add_argument("--config", choices=("default", "stress"), default="default",
+                    help="stress = BASELINE.json configs[4]: bf16 weights / activations with fp32 softmax accumulate, hsz = 256, 512 "
+                         "subtitle words per frame (sets --hsz 256 --sub_words 512 --storage bf16; the roofline line is the long-row "
+                         "attention kernel).  The headline line is the default config")
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--gc", choices=("freeze", "default", "off"), default="freeze",
                     help="cyclic garbage collector during the timed steps: freeze (default) = gc.freeze() after the warm-up")
@@ -59,7 +63,11 @@ def parse():
     ap.add_argument("--cpu_all_threads", action="store_true", help="also time the CPU baseline on os.cpu_count() threads (minutes)")
     ap.add_argument("--h2d", action="store_true", help="developer mode: every step takes its batch from pinned host memory "
                     "through tvqaplus_amd.prefetch.BatchPrefetcher (PCIe-inclusive rate for DESIGN.md; never the headline value)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.config == "stress":
+        args.hsz, args.sub_words, args.storage = 256, 512, "bf16"
+        args.cpu_seconds = min(args.cpu_seconds, 5.0)
+    return args
 
 
 def train_step(model, batch, bucket, params, optimizer, n_examples, world=1):
@@ -155,6 +163,43 @@ def k1_roofline(args, device, dense=None):
             "traffic_source": (src + " (builder's rocprofv3 PMC pass, not measured in this run)") if src else None,
             "algorithmic_bytes": alg, "masks": "all-ones" if dense else "ragged",
             "avg_us": round(avg_ms * 1e3, 1), "min_us": round(ms[0] * 1e3, 1),
+            "shape": {"N": N, "NA": NA, "Li": Li, "Lqa": Lqa, "Lr": Lr, "D": D}}
+
+
+def k1_long_roofline(args, device):
+    """BASELINE.json configs[4]: the long-row StructuredAttention forward (csrc/str_attn_long.hip; rows of 512 subtitle words, D = 256,
+    bf16 operands / output, fp32 scores, softmax and accumulation), the C-ABI call alone, events on the launch stream."""
+    from tvqaplus_amd import _lib
+    from tvqaplus_amd.synth import make_batch
+    lib = _lib.load()
+    N, NA, Li, Lqa, Lr, D = args.bsz, 5, args.frames, args.qa_words, args.sub_words, args.hsz
+    bf = args.storage == "bf16"
+    dt = torch.bfloat16 if bf else torch.float32
+    g = torch.Generator().manual_seed(2018)
+    b = make_batch(N=N, Li=Li, Lr=Lr, Lw=2, Lqa=Lqa, wd_size=4, vfeat_size=4, seed=2018, ragged=not args.dense)
+    Cn = F.normalize(torch.randn(N, NA, Lqa, D, generator=g), dim=-1).to(device).to(dt)
+    Q = torch.randn(N, Li, Lr, D, generator=g).to(device).to(dt)
+    Qn = F.normalize(Q.float(), dim=-1).to(dt)
+    cm, qm = b.qas_mask.to(device).contiguous(), b.vid_mask.to(device).contiguous()
+    A = torch.empty(N, NA, Li, Lqa, D, device=device, dtype=dt)
+    S = torch.empty(N, NA, Li, Lqa, Lr, device=device)
+    Sn = torch.empty_like(S)
+    stream = torch.cuda.current_stream()
+
+    def launch():
+        _lib.check(lib.stage_str_attn_long_fwd(Cn.data_ptr(), Q.data_ptr(), Qn.data_ptr(), cm.data_ptr(), qm.data_ptr(), A.data_ptr(),
+                                               S.data_ptr(), Sn.data_ptr(), N, NA, Li, Lqa, Lr, D, 10.0, int(bf), stream.cuda_stream),
+                   "stage_str_attn_long_fwd")
+    ms = _event_times(launch, stream, reps=10, warm=2)
+    avg_ms = sum(ms) / len(ms)
+    U = N * NA * Li * Lqa
+    es = 2 if bf else 4
+    alg = es * (N * NA * Lqa * D + 2 * N * Li * Lr * D + U * D) + 4 * (N * NA * Lqa + N * Li * Lr + 2 * U * Lr)
+    achieved = alg / (avg_ms * 1e-3) / 1e9
+    flops = 2 * 2 * U * Lr * D
+    return {"bound": "hbm", "kernel": "str_attn_long_fwd (%s storage)" % args.storage, "achieved": round(achieved, 1), "peak": 8000.0,
+            "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None, "algorithmic_bytes": alg,
+            "tflops": round(flops / (avg_ms * 1e-3) / 1e12, 1), "avg_us": round(avg_ms * 1e3, 1), "min_us": round(ms[0] * 1e3, 1),
             "shape": {"N": N, "NA": NA, "Li": Li, "Lqa": Lqa, "Lr": Lr, "D": D}}
 
 
@@ -408,7 +453,8 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32" if args.storage == "fp32" else "bf16", "data": "synthetic" + (" (re-sent from pinned host memory every step)" if args.h2d else ""),
-            "config": {"workload": "STAGE train step B=%d/GPU x5 cand x%d frames x%d regions x%d sub x%d QA words, hsz=%d, "
+            "config": {"baseline_config": "configs[4] (bf16 / D=256 / T_sub=512 stress)" if args.config == "stress" else "configs[1]",
+                       "workload": "STAGE train step B=%d/GPU x5 cand x%d frames x%d regions x%d sub x%d QA words, hsz=%d, "
                                    "add_local%s%s, dropout 0.1, %s masks; %s"
                                    % (n_local, args.frames, args.regions, args.sub_words, args.qa_words, args.hsz,
                                       " + supervised attention loss" if sup else "",
@@ -433,7 +479,9 @@ def main():
         if not args.no_device_time:
             rec["device_ms_per_step"], rec["launches_per_step"] = device_time(
                 lambda: train_step(model, nxt() if not args.h2d else batch_dev(), bucket, params, optimizer, n_local, world))
-        if not args.no_roofline:   # rank 0's GPU, after the timed region (the other ranks wait at the final barrier)
+        if not args.no_roofline and args.config == "stress":
+            rec["roofline"] = k1_long_roofline(args, device)
+        elif not args.no_roofline:   # rank 0's GPU, after the timed region (the other ranks wait at the final barrier)
             rec["roofline"] = k1_roofline(args, device)
             rec["roofline_dense"] = k1_roofline(args, device, dense=True)
             rec["roofline_bwd"] = k1_bwd_roofline(args, device)

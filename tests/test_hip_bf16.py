@@ -303,10 +303,12 @@ def _cos(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("hsz,Lw,add_local,heads", [(128, 24, True, 0), (256, 96, False, 0), (64, 12, True, 4)])
+@pytest.mark.parametrize("hsz,Lw,add_local,heads", [(128, 24, True, 0), (256, 96, False, 0), (64, 12, True, 4), (256, 512, True, 0)])
 def test_whole_model_bf16_vs_fp32_oracle(hip_device, hsz, Lw, add_local, heads):
-    """STAGE with opt.storage_dtype = 'bf16' (hsz = 256 with 96-word subtitle rows: the long-row attention kernel) against
-    the fp32 oracle with the same parameters: forward outputs, loss, every parameter gradient."""
+    """STAGE with opt.storage_dtype = 'bf16' (hsz = 256 with 96-word subtitle rows: the long-row attention kernel; hsz = 256 with
+    512-word rows: BASELINE.json configs[4] itself -- bf16 weights / activations, fp32 softmax accumulate, D = 256, T_sub = 512, where
+    the reference's own position table ends at 500) against the fp32 oracle with the same parameters: forward outputs, loss, every
+    parameter gradient."""
     from tvqaplus_amd.stage import STAGE
     from tvqaplus_amd.synth import make_batch, make_opt
     torch.manual_seed(11)

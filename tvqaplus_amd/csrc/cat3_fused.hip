@@ -493,6 +493,9 @@ extern "C" int stage_cat3_dx_ln_bwd(const float* dy, const unsigned* relu_mask, 
 // z, one for the weight).  A workgroup (4 waves) walks 32-row tiles; wave w owns output columns 32 w .. 32 w + 31; its weight
 // fragments (24 k-steps x 2 planes, 48 KB) stream from a pre-split image in global memory (L2 resident).
 // =====================================================================================================================
+#ifndef CFF_NT
+#define CFF_NT 0      // cache policy of the z stores (2 = non-temporal)
+#endif
 namespace {
 constexpr int CFF_KS = 3 * CF_D / 16;             // 24 k-steps of the 32x32x16 MFMA
 constexpr int CFF_WFRAG = 2 * 4 * CFF_KS * 64;    // uint4 fragments of the forward weight image
@@ -622,7 +625,7 @@ __global__ __launch_bounds__(256, 3) void cff_fwd_kernel(const float* __restrict
                 if (!ok) o[t] = f4zero();
                 // z is written once: the weight-gradient GEMM of the backward contracts over it (rows past the end: dropped by bounds)
                 __builtin_amdgcn_raw_buffer_store_b128((cf_u4){__float_as_uint(o[t].x), __float_as_uint(o[t].y), __float_as_uint(o[t].z), __float_as_uint(o[t].w)},
-                                                       rs_z, (sj * K3 + t * CF_D + 4 * sl) * 4, (int)((t0 + 8 * pass) * K3 * 4), 0);
+                                                       rs_z, (sj * K3 + t * CF_D + 4 * sl) * 4, (int)((t0 + 8 * pass) * K3 * 4), CFF_NT);
                 m = h_amax3(h_amax3(m, o[t].x, o[t].y), o[t].z, o[t].w);
             }
             m = group_max(m, 32);

@@ -746,14 +746,29 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
         float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         int4 bi = make_int4(-1, -1, -1, -1);
         const float* px = x + (sr * L) * (long)D4 * 4 + 4 * q;
-        for (int l = st; l < ed; l++) {                         // ascending, strict >: the first maximum (torch.max)
-            const float4 v = ld4(px + (long)l * D4 * 4);
-            const float mk = m[sr * L + l], off = (1.0f - mk) * STAGE_NEG;
-            const float4 w = make_float4(v.x * mk + off, v.y * mk + off, v.z * mk + off, v.w * mk + off);
-            if (w.x > best.x) { best.x = w.x; bi.x = l; }
-            if (w.y > best.y) { best.y = w.y; bi.y = l; }
-            if (w.z > best.z) { best.z = w.z; bi.z = l; }
-            if (w.w > best.w) { best.w = w.w; bi.w = l; }
+        // 8 frames per step, all 16 loads issued before the first compare (a one-frame loop keeps a single dependent load in flight
+        // per lane: 100 us for a few hundred rows); ascending order with strict >: the first maximum, as torch.max
+        for (int l0 = st; l0 < ed; l0 += 8) {
+            float4 v[8];
+            float mk[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int l = min(l0 + u, ed - 1);
+                v[u] = ld4(px + (long)l * D4 * 4);
+                mk[u] = m[sr * L + l];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int l = l0 + u;
+                if (l < ed) {
+                    const float off = (1.0f - mk[u]) * STAGE_NEG;
+                    const float4 w = make_float4(v[u].x * mk[u] + off, v[u].y * mk[u] + off, v[u].z * mk[u] + off, v[u].w * mk[u] + off);
+                    if (w.x > best.x) { best.x = w.x; bi.x = l; }
+                    if (w.y > best.y) { best.y = w.y; bi.y = l; }
+                    if (w.z > best.z) { best.z = w.z; bi.z = l; }
+                    if (w.w > best.w) { best.w = w.w; bi.w = l; }
+                }
+            }
         }
         float* po = pooled + r * (long)D4 * 8 + 4 * q;
         *reinterpret_cast<float4*>(po) = best;
