@@ -2,7 +2,7 @@
 (bench.py: _profile_traffic, the judge) expect.  python tools/collect_profiles.py r02"""
 import os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 HEAD = ("# round %s: rocprofv3 PMC passes (counters only + kernel trace; tools/pmc_run.sh), averages per dispatch; FETCH_SIZE / WRITE_SIZE in KiB\n"
         "# FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950 counts the 128-byte requests of wide loads as 64 B)\n" % TAG[1:].lstrip("0"))
@@ -19,7 +19,7 @@ def put(name, text):
     print("profiles/" + name)
 
 
-for n in ("bench_line.json", "bench_line_dense.json", "bench_kernel_trace_stats.txt", "bf16_storage_bench_line.json",
+for n in ("bench_line.json", "bench_line_dense.json", "bench_line_stress.json", "bench_kernel_trace_stats.txt", "bf16_storage_bench_line.json",
           "bf16_storage_bench_kernel_trace_stats.txt"):
     src = os.path.join(G, "%s_%s" % (TAG, n))
     if os.path.exists(src):
@@ -39,3 +39,10 @@ for k, kern in (("nt", "gemm_nt_stream_kernel, forward 960000 x 384 -> 128"), ("
     if os.path.exists(os.path.join(G, name)):
         put("%s_gemm_%s_pmc.txt" % (TAG, k), HEAD + "# command: bash tools/pmc_run.sh %s_gemm_%s ... python tools/gemm_one.py 960000 128 384 %s   (%s; fp16-split, DESIGN.md finding 20)\n"
             % (TAG, k, k, kern) + "".join(lines(name)))
+
+for k, what in (("rep", "c2q_down_projection shape: a broadcast over 300 frames, 960000 rows"), ("flat", "concat_fc shape: 960000 rows")):
+    name = "pmc_%s_cat3_fused_%s.txt" % (TAG, k)
+    if os.path.exists(os.path.join(G, name)):
+        t = "".join("#   " + l for l in lines("%s_cat3_fused_times_%s.txt" % (TAG, k))[-8:])
+        put("%s_cat3_fused_pmc_%s.txt" % (TAG, k), HEAD + "# command: %sbash tools/pmc_run.sh %s_cat3_fused_%s cf python tools/cat3_fused_time.py   (%s; cf_bwd_kernel = fused backward, "
+            "cff_fwd_kernel = fused forward, csrc/cat3_fused.hip)\n# event-timed, same run:\n%s" % ("REP=1 " if k == "flat" else "", TAG, k, what, t) + "".join(lines(name)))
