@@ -639,7 +639,10 @@ static int launch_d128(const float* Cn, const TQ* Q, const float* cm, const floa
                        int N, int NA, int Li, int Lqa, int Lr, float scale, float p_drop, unsigned long long seed,
                        hipStream_t st) {
     const int rem = Lr - 16 * (RT - 1);
-    const bool vec = (Lr & 3) == 0;
+    // 16-byte score stores need rows that start on 8 bytes only (the hardware takes dwordx4 at dword alignment; 8-byte rows measured
+    // as fast as 16-byte ones); odd Lr keeps the scalar stores
+    static const bool no_vec8 = getenv("STAGE_K1_NO_VEC8") != nullptr;
+    const bool vec = (Lr & 3) == 0 || ((Lr & 1) == 0 && !no_vec8);
 #define ARGS Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st
     if (rem == 16) return vec ? launch_d128_t<RT, 4, false, TRAIN, true, TQ>(ARGS) : launch_d128_t<RT, 4, false, TRAIN, false, TQ>(ARGS);
     switch ((rem + 3) / 4) {

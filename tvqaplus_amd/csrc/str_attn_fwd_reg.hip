@@ -509,7 +509,8 @@ static int launch_reg(const float* Cn, const TQ* Q, const float* cm, const float
                       int N, int NA, int Li, int Lqa, int Lr, float scale, float p_drop, unsigned long long seed,
                       hipStream_t st) {
     const int rem = Lr - 16 * (RT - 1);
-    const bool vec = (Lr & 3) == 0;
+    static const bool no_vec8 = getenv("STAGE_K1_NO_VEC8") != nullptr;       // (see str_attn_fwd.hip: 16-byte stores at 8-byte row starts)
+    const bool vec = (Lr & 3) == 0 || ((Lr & 1) == 0 && !no_vec8);
 #define ARGS Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st
     if (rem == 16) return vec ? launch_reg_t<RT, 4, false, TRAIN, true, TQ>(ARGS) : launch_reg_t<RT, 4, false, TRAIN, false, TQ>(ARGS);
     switch ((rem + 3) / 4) {
