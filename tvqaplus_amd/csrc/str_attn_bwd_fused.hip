@@ -635,16 +635,17 @@ __global__ __launch_bounds__(256) void fus_ext_scan_kernel(const float* __restri
 // per CU and equal shares an example with 300 valid frames ran 1.5x longer than one with 200 and the CUs of the short ones
 // idled (~17 % of the kernel at the synthetic TVQA+ length distribution).  Output: sched[b] = (n, chunk, W_n, 0) for
 // workgroup b (n = -1: unused), per_n[n] = (first workgroup, W_n).  Depends on the masks only: run-to-run deterministic.
-__global__ __launch_bounds__(1024) void fus_schedule_kernel(const float* __restrict__ qmask, const unsigned char* __restrict__ fnv, int N,
-                                                           int Li, int Lr, int G, int4* __restrict__ sched, int2* __restrict__ per_n) {
-    extern __shared__ int sh[];        // V[N], W[N]
-    int* V = sh;
-    int* W = sh + N;
-    for (int n = threadIdx.x; n < N; n += blockDim.x) V[n] = 0;
-    __syncthreads();
-    for (long f = threadIdx.x; f < (long)N * Li; f += blockDim.x) {
-        // all Lr mask values of the frame requested at once (Lr is even: 8-byte loads), no early exit: a chain of dependent
-        // loads per frame made this kernel cost ~25 us
+// Schedule, step 1: frames with a valid region per example (one workgroup per example; one thread per frame, all Lr mask values of a
+// frame requested at once -- Lr is even: 8-byte loads).  The count lands in per_n[n].x for step 2.  (One 1024-thread workgroup used to
+// do both steps: 23 us at the video shape, 70 us at the subtitle shape -- 10 % of the backward -- most of it the scan of N Li Lr mask
+// values through one CU and thread 0 writing the G schedule entries one by one.)
+__global__ __launch_bounds__(256) void fus_count_kernel(const float* __restrict__ qmask, const unsigned char* __restrict__ fnv, int Li, int Lr,
+                                                        int2* __restrict__ per_n) {
+    __shared__ int red[4];
+    const int n = blockIdx.x;
+    int cnt = 0;
+    for (int i = threadIdx.x; i < Li; i += 256) {
+        const long f = (long)n * Li + i;
         float nz = 0.f;
         if (fnv) {                      // gradient on raw_s: the per-frame column counts of fus_ext_scan_kernel
             nz = (float)fnv[f];
@@ -653,8 +654,21 @@ __global__ __launch_bounds__(1024) void fus_schedule_kernel(const float* __restr
 #pragma unroll 8
             for (int r = 0; r < (Lr >> 1); r++) { const float2 v = qm[r]; nz += fabsf(v.x) + fabsf(v.y); }
         }
-        if (nz != 0.f) atomicAdd(&V[f / Li], 1);
+        cnt += nz != 0.f ? 1 : 0;
     }
+    cnt = (int)wave_sum((float)cnt);    // (counts <= Li: exact in fp32)
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) per_n[n] = make_int2(red[0] + red[1] + red[2] + red[3], 0);
+}
+
+// Schedule, step 2 (one workgroup): workgroups per example in proportion to its non-empty frames, then the G entries in parallel
+__global__ __launch_bounds__(256) void fus_schedule_kernel(int N, int Li, int G, int4* __restrict__ sched, int2* __restrict__ per_n) {
+    extern __shared__ int sh[];        // V[N], W[N], first[N + 1]
+    int* V = sh;
+    int* W = sh + N;
+    int* first = sh + 2 * N;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) V[n] = per_n[n].x;
     __syncthreads();
     if (threadIdx.x == 0) {
         long total = 0;
@@ -676,14 +690,21 @@ __global__ __launch_bounds__(1024) void fus_schedule_kernel(const float* __restr
             }
             W[best]++;
         }
-        int first = 0;
+        int f0 = 0;
         for (int n = 0; n < N; n++) {
             if (W[n] > Li) W[n] = Li;
-            per_n[n] = make_int2(first, W[n]);
-            for (int b = 0; b < W[n]; b++) sched[first + b] = make_int4(n, b, W[n], 0);
-            first += W[n];
+            first[n] = f0;
+            f0 += W[n];
         }
-        for (int b = first; b < G; b++) sched[b] = make_int4(-1, 0, 1, 0);
+        first[N] = f0;
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += blockDim.x) per_n[n] = make_int2(first[n], W[n]);
+    for (int b = threadIdx.x; b < G; b += blockDim.x) {
+        int n = -1;
+        for (int m = 0; m < N; m++)
+            if (b >= first[m] && b < first[m + 1]) n = m;
+        sched[b] = n >= 0 ? make_int4(n, b - first[n], W[n], 0) : make_int4(-1, 0, 1, 0);
     }
 }
 
@@ -716,8 +737,9 @@ static int fus_launch(const TD* dA, const float* ext, const float* Cn, const TD*
         hipLaunchKernelGGL(fus_ext_scan_kernel, dim3((unsigned)((long)N * Li)), dim3(256), 0, st, qmask, ext, fnv, NA, Li, Lqa, Lr);
         STAGE_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(fus_schedule_kernel, dim3(1), dim3(1024), 2 * N * sizeof(int), st, qmask, ext ? (const unsigned char*)fnv : nullptr,
-                       N, Li, Lr, G, sched, per_n);
+    hipLaunchKernelGGL(fus_count_kernel, dim3(N), dim3(256), 0, st, qmask, ext ? (const unsigned char*)fnv : nullptr, Li, Lr, per_n);
+    STAGE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fus_schedule_kernel, dim3(1), dim3(256), (3 * N + 1) * sizeof(int), st, N, Li, G, sched, per_n);
     STAGE_LAUNCH_CHECK();
     const size_t base = ((size_t)Lr * FLDQ + FusLay<RT>::QT_FLOATS + (size_t)CR * FusLay<RT>::LG) * sizeof(float);
     const size_t with_da = base + (size_t)CR * FD * sizeof(float);
