@@ -45,8 +45,10 @@ __global__ __launch_bounds__(1024) void cf_prep_w_kernel(const float* __restrict
     for (int i = 1; i < 16; i++) m = fmaxf(m, red[i]);
     const int w_up = h_up_field((int)(__float_as_uint(m) >> 23) & 0xff);
     const float sc = __uint_as_float((unsigned)w_up << 23);
-    if (tid == 0) w_up_out[0] = w_up;
-    for (int f = tid; f < 12 * CF_KS * 64; f += 1024) {
+    if (tid == 0 && blockIdx.x == 0) w_up_out[0] = w_up;
+    // (every workgroup finds the largest magnitude itself -- 192 KB from L2 -- and splits its share of the fragments: one workgroup
+    // for the whole image took 19 us)
+    for (int f = blockIdx.x * 1024 + tid; f < 12 * CF_KS * 64; f += gridDim.x * 1024) {
         const int lane = f & 63, ks = (f >> 6) % CF_KS, ct = f / (64 * CF_KS);
         const int col = 32 * ct + (lane & 31), k0 = 16 * ks + 8 * (lane >> 5);
         float v[8];
@@ -449,7 +451,7 @@ extern "C" int stage_cat3_dx_ln_bwd(const float* dy, const unsigned* relu_mask, 
     uint4* img = (uint4*)wsp;
     int* w_up = (int*)(wsp + cf_align((size_t)CF_WFRAG * sizeof(uint4)));
     wsp += cf_align((size_t)CF_WFRAG * sizeof(uint4)) + 256;
-    hipLaunchKernelGGL(cf_prep_w_kernel, dim3(1), dim3(1024), 0, st, W, img, w_up);
+    hipLaunchKernelGGL(cf_prep_w_kernel, dim3(6), dim3(1024), 0, st, W, img, w_up);
     const uint32_t th = drop_thresh16(p_drop);
     const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
     const bool drop = p_drop > 0.f;
@@ -515,8 +517,8 @@ __global__ __launch_bounds__(1024) void cff_prep_w_kernel(const float* __restric
     for (int i = 1; i < 16; i++) m = fmaxf(m, red[i]);
     const int w_up = h_up_field((int)(__float_as_uint(m) >> 23) & 0xff);
     const float sc = __uint_as_float((unsigned)w_up << 23);
-    if (tid == 0) w_up_out[0] = w_up;
-    for (int f = tid; f < 4 * CFF_KS * 64; f += 1024) {
+    if (tid == 0 && blockIdx.x == 0) w_up_out[0] = w_up;
+    for (int f = blockIdx.x * 1024 + tid; f < 4 * CFF_KS * 64; f += gridDim.x * 1024) {
         const int lane = f & 63, ks = (f >> 6) % CFF_KS, w = f / (64 * CFF_KS);
         const float* src = W + (long)(32 * w + (lane & 31)) * (3 * CF_D) + 16 * ks + 8 * (lane >> 5);
         const float4 v0 = ld4(src), v1 = ld4(src + 4);
@@ -718,7 +720,7 @@ extern "C" int stage_cat3_ln_gemm_fwd(const float* a, const float* b, const floa
     hipStream_t st = (hipStream_t)stream;
     uint4* img = (uint4*)ws;
     int* w_up = (int*)((char*)ws + cf_align((size_t)CFF_WFRAG * sizeof(uint4)));
-    hipLaunchKernelGGL(cff_prep_w_kernel, dim3(1), dim3(1024), 0, st, W, img, w_up);
+    hipLaunchKernelGGL(cff_prep_w_kernel, dim3(6), dim3(1024), 0, st, W, img, w_up);
     const uint32_t th = drop_thresh16(p_drop);
     const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
     const size_t lds = (size_t)CFF_KS * 2 * 64 * 16 + 32 * 4;
