@@ -161,35 +161,72 @@ __global__ __launch_bounds__(256) void str_attn_long_fwd_kernel(const T* __restr
     f32x4 o[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; dt++) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // bf16 storage with DT % 8 == 0 (D = 128, 256): the next block's Q rows (raw 16-bit words, converted where they feed the
-    // matrix cores) and scores are requested before the current block is multiplied -- the loop is one chain of memory round
-    // trips otherwise
-    constexpr bool PF = USEB && (DT % 8 == 0);
+    constexpr bool PF = USEB && (DT % 8 == 0);        // bf16 storage, D = 128 / 256
     constexpr int NW4 = PF ? DT / 8 : 1;
-    uint4 qraw[4][NW4], qraw_n[4][NW4];
-    float4 rv_n = make_float4(-1e10f, -1e10f, -1e10f, -1e10f);
-    auto pf_load = [&](uint4 (&dst)[4][NW4], float4& rvd, int rbn) {
+    // PF: the region contraction on the bf16 matrix cores, 32 regions (two blocks) per step.  K-slot (g, e) of the 16x16x32 MFMA =
+    // region (rb + (e >> 2)) * 16 + 4 g + (e & 3): exactly the eight weights lane (c15, g) holds after the softmax of two blocks, so
+    // the B operand needs no shuffle; the weights go in as bf16 pairs hi + lo (error 2^-16 of a weight -- the fp32 softmax survives),
+    // Q is bf16 in HBM, so the product is exact.  A operand of d tile dt: element DT c15 + dt of the lane's eight Q rows, picked out of
+    // the rows' 16-byte words with one v_perm per row pair.  32 MFMAs of ~16 cycles per step instead of 128 fp32 ones of 32.
+    if constexpr (PF) {
+        for (int rb = 0; rb < nb; rb += 2) {
+            uint4 q8[8][NW4];      // (requesting the next step's rows ahead -- 64 more registers -- measured the same)
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+            for (int e = 0; e < 8; e++)
 #pragma unroll
-            for (int q = 0; q < NW4; q++)
-                dst[k][q] = *reinterpret_cast<const uint4*>(qr + (long)min(rbn * 16 + 4 * g + k, Lr - 1) * D + DT * c15 + 8 * q);
-        rvd = make_float4(-1e10f, -1e10f, -1e10f, -1e10f);
-        if (vec4 && cvalid && rbn * 16 + 4 * g < Lr) rvd = ld4(S + orow * Lr + rbn * 16 + 4 * g);
-    };
-    if constexpr (PF) pf_load(qraw_n, rv_n, 0);
+                for (int q = 0; q < NW4; q++)
+                    q8[e][q] = *reinterpret_cast<const uint4*>(qr + (long)min((rb + (e >> 2)) * 16 + 4 * g + (e & 3), Lr - 1) * D + DT * c15 + 8 * q);
+            float p[8];
+#pragma unroll
+            for (int hb = 0; hb < 2; hb++) {
+                const int b0 = (rb + hb) * 16 + 4 * g;
+                const bool blk = b0 < Lr;
+                float4 rv = make_float4(-1e10f, -1e10f, -1e10f, -1e10f);
+                if (vec4 && cvalid && blk) rv = ld4(S + orow * Lr + b0);
+                {
+#pragma clang fp contract(off)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int r = b0 + k, rc = min(r, Lr - 1);
+                        const float msk = (r < Lr) ? cm * qm[rc] : 0.f;
+                        const float raw = vec4 ? (k == 0 ? rv.x : (k == 1 ? rv.y : (k == 2 ? rv.z : rv.w))) : (cvalid ? S[orow * Lr + rc] : -1e10f);
+                        const float x = raw * scale;
+                        p[4 * hb + k] = (r < Lr) ? expf(x - mx) / sum * msk : 0.f;
+                        if (!vec4 && cvalid && r < Lr) Sn[orow * Lr + r] = p[4 * hb + k];
+                    }
+                }
+                if (vec4 && cvalid && blk) st4(Sn + orow * Lr + b0, make_float4(p[4 * hb], p[4 * hb + 1], p[4 * hb + 2], p[4 * hb + 3]));
+            }
+            unsigned bh[4], bl[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                bh[j] = stage_pk_bf16(p[2 * j], p[2 * j + 1]);
+                bl[j] = stage_pk_bf16(p[2 * j] - __uint_as_float(bh[j] << 16), p[2 * j + 1] - __uint_as_float(bh[j] & 0xFFFF0000u));
+            }
+            const lng_bf16x8 vbh = __builtin_bit_cast(lng_bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+            const lng_bf16x8 vbl = __builtin_bit_cast(lng_bf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+#pragma unroll
+            for (int dt = 0; dt < DT; dt++) {
+                unsigned aw[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint4 w0 = q8[2 * j][dt / 8], w1 = q8[2 * j + 1][dt / 8];
+                    const int wi = (dt % 8) / 2;
+                    const unsigned x0 = wi == 0 ? w0.x : (wi == 1 ? w0.y : (wi == 2 ? w0.z : w0.w));
+                    const unsigned x1 = wi == 0 ? w1.x : (wi == 1 ? w1.y : (wi == 2 ? w1.z : w1.w));
+                    aw[j] = __builtin_amdgcn_perm(x1, x0, (dt & 1) ? 0x07060302u : 0x05040100u);
+                }
+                const lng_bf16x8 va = __builtin_bit_cast(lng_bf16x8, make_uint4(aw[0], aw[1], aw[2], aw[3]));
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, vbl, o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, vbh, o[dt], 0, 0, 0);
+            }
+        }
+    } else
     for (int rb = 0; rb < nb; rb++) {
         float p[4];
         const bool blk = rb * 16 + 4 * g < Lr;
         float4 rv = make_float4(-1e10f, -1e10f, -1e10f, -1e10f);
-        if constexpr (PF) {
-            rv = rv_n;
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-#pragma unroll
-                for (int q = 0; q < NW4; q++) qraw[k][q] = qraw_n[k][q];
-            if (rb + 1 < nb) pf_load(qraw_n, rv_n, rb + 1);
-        } else if (vec4 && cvalid && blk) rv = ld4(S + orow * Lr + rb * 16 + 4 * g);
+        if (vec4 && cvalid && blk) rv = ld4(S + orow * Lr + rb * 16 + 4 * g);
         {
 #pragma clang fp contract(off)
 #pragma unroll
@@ -204,17 +241,7 @@ __global__ __launch_bounds__(256) void str_attn_long_fwd_kernel(const T* __restr
             }
             if (vec4 && cvalid && blk) st4(Sn + orow * Lr + rb * 16 + 4 * g, make_float4(p[0], p[1], p[2], p[3]));
         }
-        if constexpr (PF) {
-#pragma unroll
-            for (int dt = 0; dt < DT; dt++)
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint4 w4 = qraw[k][dt / 8];
-                    const unsigned w = (dt % 8) / 2 == 0 ? w4.x : ((dt % 8) / 2 == 1 ? w4.y : ((dt % 8) / 2 == 2 ? w4.z : w4.w));
-                    const float a = (dt & 1) ? __uint_as_float(w & 0xFFFF0000u) : __uint_as_float(w << 16);
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p[k], o[dt], 0, 0, 0);
-                }
-        } else {
+        {
             float qd[4][DT];             // Q[region rb*16 + 4g + k][DT c15 .. DT c15 + DT - 1]: the operands of all DT tiles
 #pragma unroll
             for (int k = 0; k < 4; k++) lng_ldn<DT>(qd[k], qr + (long)min(rb * 16 + 4 * g + k, Lr - 1) * D + DT * c15);   // S_ = 0 past Lr
