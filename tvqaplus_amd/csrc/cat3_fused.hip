@@ -181,7 +181,10 @@ __global__ __launch_bounds__(256, 2) void cf_bwd_kernel(const float* __restrict_
             asm volatile("" : "+v"(tid_i));
             const int sj = tid_i >> 5, sl = tid_i & 31;   // row inside a pass, float4 index inside the row
             const int vo_dy = (sj * CF_D + 4 * sl) * 4, vo_mk = (int)(((long)(sl >> 3) * M + sj) * 4);
-            uint2* st_dst = reinterpret_cast<uint2*>(Ap + (sl >> 2) * 2 * 64 + sj + 32 * ((sl >> 1) & 1)) + (sl & 1);
+            // operand slot inside its [ks][plane] block: (rl + 32 kh) ^ 2 ks ^ kh (see cff_fwd_kernel: spreads the 16 (k-step, k-half)
+            // pairs a wave stores at once over all banks)
+            uint2* st_e = reinterpret_cast<uint2*>(Ap + (sl >> 2) * 2 * 64 + ((sj + 32 * ((sl >> 1) & 1)) ^ (2 * (sl >> 2)) ^ ((sl >> 1) & 1))) + (sl & 1);
+            uint2* st_o = reinterpret_cast<uint2*>(Ap + (sl >> 2) * 2 * 64 + ((sj + 8 + 32 * ((sl >> 1) & 1)) ^ (2 * (sl >> 2)) ^ ((sl >> 1) & 1))) + (sl & 1);
             typedef unsigned cf_u4 __attribute__((ext_vector_type(4)));
             cf_u4 raw[4];
             unsigned wb[4];
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void cf_bwd_kernel(const float* __restrict_
                 h_split2(v.x, v.y, sc, h01, l01);
                 h_split2(v.z, v.w, sc, h23, l23);
                 // element (row rl = 8 pass + sj, k = 4 sl + e): k-step sl >> 2, operand lane rl + 32 ((sl >> 1) & 1), position 4 (sl & 1) + e
-                uint2* dst = st_dst + 8 * pass * 2;
+                uint2* dst = ((pass & 1) ? st_o : st_e) + 16 * (pass >> 1) * 2;
                 dst[0] = make_uint2(h01, h23);
                 dst[2 * 64] = make_uint2(l01, l23);       // plane 1: + 64 uint4 = + 128 uint2
                 if (sl == 0) {                            // LDS writes only: nothing is loaded inside this branch
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void cf_bwd_kernel(const float* __restrict_
         auto mul_b = [&](const sf16x8 (&bf)[3][2], int ks) {
             sf16x8 af[2];
 #pragma unroll
-            for (int p2 = 0; p2 < 2; p2++) af[p2] = __builtin_bit_cast(sf16x8, Ap[(ks * 2 + p2) * 64 + lane]);
+            for (int p2 = 0; p2 < 2; p2++) af[p2] = __builtin_bit_cast(sf16x8, Ap[(ks * 2 + p2) * 64 + (lane ^ (2 * ks) ^ h)]);
 #pragma unroll
             for (int t = 0; t < 3; t++) {
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bf[t][0], acc[t], 0, 0, 0);
@@ -562,7 +565,13 @@ __global__ __launch_bounds__(256, 3) void cff_fwd_kernel(const float* __restrict
     }
     const int n = 32 * wave + l31;                        // this lane's output column
     const float bsv = bias ? bias[n] : 0.f;
-    uint2* st_dst = reinterpret_cast<uint2*>(Ap + (sl >> 2) * 2 * 64 + sj + 32 * ((sl >> 1) & 1)) + (sl & 1);
+    // Operand slot of (row rl, k-step ks, k-half kh) inside its [ks][plane] block of 64: (rl + 32 kh) ^ 2 (ks & 7) ^ kh.  Unswizzled, the
+    // 16 (k-step, k-half) pairs a wave stores at once sit 512 B apart = on the same banks (16-way conflict: 68 % of the kernel's LDS
+    // cycles -- though not of its run time: the stores are off the critical path); the XOR spreads them over all 64 banks and keeps
+    // the matrix phase's 1 KB block reads conflict free (a constant XOR permutes the slots of a 16-lane group among themselves).
+    // Even / odd passes differ in bit 3 of the row: two pointers.
+    uint2* st_e = reinterpret_cast<uint2*>(Ap + (sl >> 2) * 2 * 64 + ((sj + 32 * ((sl >> 1) & 1)) ^ (2 * (sl >> 2)) ^ ((sl >> 1) & 1))) + (sl & 1);
+    uint2* st_o = reinterpret_cast<uint2*>(Ap + (sl >> 2) * 2 * 64 + ((sj + 8 + 32 * ((sl >> 1) & 1)) ^ (2 * (sl >> 2)) ^ ((sl >> 1) & 1))) + (sl & 1);
     const long n_tiles = (M + 31) / 32;
 
     for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -639,7 +648,7 @@ __global__ __launch_bounds__(256, 3) void cff_fwd_kernel(const float* __restrict
                 h_split2(o[t].x, o[t].y, sc, h01, l01);
                 h_split2(o[t].z, o[t].w, sc, h23, l23);
                 // element (row rl, k = 128 t + 4 sl + e): k-step 8 t + (sl >> 2), operand lane rl + 32 ((sl >> 1) & 1), position 4 (sl & 1) + e
-                uint2* dst = st_dst + ((8 * t) * 2 * 64 + 8 * pass) * 2;
+                uint2* dst = ((pass & 1) ? st_o : st_e) + ((8 * t) * 2 * 64 + 16 * (pass >> 1)) * 2;
                 dst[0] = make_uint2(h01, h23);
                 dst[2 * 64] = make_uint2(l01, l23);
             }
@@ -657,12 +666,13 @@ __global__ __launch_bounds__(256, 3) void cff_fwd_kernel(const float* __restrict
 #pragma unroll
                 for (int p2 = 0; p2 < 2; p2++) bf[k][p2] = __builtin_bit_cast(sf16x8, wp[(size_t)p2 * 4 * CFF_KS * 64 + (4 * kg + k) * 64]);
         };
-        auto mul_b = [&](const sf16x8 (&bf)[4][2], int kg) {
+        auto mul_b = [&](const sf16x8 (&bf)[4][2], int kg, int odd) {      // odd = kg & 1, a literal at both call sites
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 sf16x8 af[2];
 #pragma unroll
-                for (int p2 = 0; p2 < 2; p2++) af[p2] = __builtin_bit_cast(sf16x8, Ap[((4 * kg + k) * 2 + p2) * 64 + lane]);
+                for (int p2 = 0; p2 < 2; p2++)
+                    af[p2] = __builtin_bit_cast(sf16x8, Ap[((4 * kg + k) * 2 + p2) * 64 + (lane ^ (2 * (4 * odd + k)) ^ h)]);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bf[k][0], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[k][1], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[k][0], acc, 0, 0, 0);
@@ -674,9 +684,9 @@ __global__ __launch_bounds__(256, 3) void cff_fwd_kernel(const float* __restrict
 #pragma unroll 1
             for (int kg = 0; kg < CFF_KS / 4; kg += 2) {
                 load_b(bfb, kg + 1);
-                mul_b(bfa, kg);
+                mul_b(bfa, kg, 0);
                 load_b(bfa, kg + 2 < CFF_KS / 4 ? kg + 2 : 0);
-                mul_b(bfb, kg + 1);
+                mul_b(bfb, kg + 1, 1);
             }
         }
         // ---- epilogue: true units, bias, ReLU, ReLU bit mask, store.  C/D layout: column l31, row (r & 3) + 8 (r >> 2) + 4 h ----
