@@ -79,12 +79,84 @@ def _params(params) -> List[torch.Tensor]:
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# Shared modules: one gradient per parameter leaves the graph
+# ---------------------------------------------------------------------------------------------------------------
+# The input embedding, the first encoder and the down-projection are applied to two or three streams per step
+# (model/stage.py:226-269).  With one autograd node per application, autograd sums their parameter gradients with one
+# ``add`` kernel per parameter and extra use (31 launches per step).  ``gate(params)`` hands out aliases of the parameters for one
+# step; a group that is called with such an alias puts its gradient into the gate's sink (the first contribution is kept as is, later
+# ones are added with ONE multi-tensor add per group call) and returns None for it; the gate's own backward -- which autograd
+# runs after every consumer, whatever they returned -- hands the totals to the parameters.
+class _Sink:
+    def __init__(self, n: int):
+        self.acc: List[Optional[torch.Tensor]] = [None] * n
+
+    def add(self, idx: Sequence[int], grads: Sequence[torch.Tensor]):
+        accs, news = [], []
+        for i, g in zip(idx, grads):
+            if self.acc[i] is None:
+                self.acc[i] = g
+            else:
+                accs.append(self.acc[i])
+                news.append(g)
+        if accs:
+            torch._foreach_add_(accs, news)
+
+
+class _ParamGate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sink, *params):
+        ctx.sink = sink
+        ctx.set_materialize_grads(False)
+        outs = tuple(w.detach() for w in params)
+        for i, o in enumerate(outs):
+            o._stage_sink = (sink, i)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        res = []
+        for a, g in zip(ctx.sink.acc, gouts):     # g: whatever reached the alias through ordinary autograd (a per-kernel fallback)
+            res.append(a if g is None else (g if a is None else a + g))
+        ctx.sink.acc = [None] * len(res)
+        return (None,) + tuple(res)
+
+
+def gate(params: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+    """Aliases of ``params`` for ONE training step (see above); use them wherever the parameters go into a group call."""
+    return list(_ParamGate.apply(_Sink(len(params)), *params))
+
+
+def _sinks(params) -> list:
+    return [getattr(w, "_stage_sink", None) for w in params]
+
+
+def _deliver(sinks, grads) -> tuple:
+    """Parameter gradients of a group call: into the sinks of gated parameters (returned as None), as they are otherwise."""
+    if not any(sinks):
+        return tuple(grads)
+    out, per = [], {}
+    for sk, g in zip(sinks, grads):
+        if sk is None:
+            out.append(g)
+        else:
+            e = per.setdefault(id(sk[0]), (sk[0], [], []))
+            e[1].append(sk[1])
+            e[2].append(g)
+            out.append(None)
+    for sink, idx, gs in per.values():
+        sink.add(idx, gs)
+    return tuple(out)
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # G1 input MLP
 # ---------------------------------------------------------------------------------------------------------------
 class _InputMLP(torch.autograd.Function):
     @_on_device
     def forward(ctx, x, l2: int, p: float, seeds, *params):
         x = _chk(x, "x")
+        ctx.sinks = _sinks(params)
         params = _params(params)
         K0, H, D = x.shape[-1], params[2].shape[0], params[6].shape[0]
         M = x.numel() // K0
@@ -110,7 +182,7 @@ class _InputMLP(torch.autograd.Function):
         tmp = _buf(tb, x.device)
         _rc(lib.stage_grp_input_mlp_bwd(dout.data_ptr(), x.data_ptr(), _ptrs(params), _ptrs(grads), arena.data_ptr(), ab, flags,
                                         tmp.data_ptr(), tb, M, K0, H, D, l2, p, _u64(seeds), _stream()), "stage_grp_input_mlp_bwd")
-        return (None, None, None, None) + tuple(grads)
+        return (None, None, None, None) + _deliver(ctx.sinks, grads)
 
 
 def input_mlp(x, l2: bool, p: float, seeds, params):
@@ -126,6 +198,7 @@ class _Encoder(torch.autograd.Function):
     def forward(ctx, x, pe, pool_mask, k: int, p: float, seeds, *params):
         x = _chk(x, "x")                       # (M, L, D)
         pe = _chk(pe, "pe")
+        ctx.sinks = _sinks(params)
         params = _params(params)
         M, L, D = x.shape
         n_conv = (len(params) - 2) // 6
@@ -156,7 +229,7 @@ class _Encoder(torch.autograd.Function):
         _rc(lib.stage_grp_encoder_bwd(dout.data_ptr(), x.data_ptr(), None if pm is None else pm.data_ptr(), _ptrs(params), _ptrs(grads),
                                       None if dx is None else dx.data_ptr(), arena.data_ptr(), ab, flags, tmp.data_ptr(), tb, M, L, D,
                                       n_conv, k, p, _u64(seeds), _stream()), "stage_grp_encoder_bwd")
-        return (dx, None, None, None, None, None) + tuple(grads)
+        return (dx, None, None, None, None, None) + _deliver(ctx.sinks, grads)
 
 
 def encoder_block(x, pe, pool_mask, k: int, p: float, seeds, params):
@@ -173,6 +246,7 @@ class _QaCtx(torch.autograd.Function):
     def forward(ctx, qa, cx, qa_mask, cx_mask, scale: float, p: float, seeds, *params):
         qa, cx = _chk(qa, "qa"), _chk(cx, "ctx")                # (N, NA, Lqa, D), (N, Li, Lr, D)
         qa_mask, cx_mask = _chk(qa_mask, "qa_mask"), _chk(cx_mask, "ctx_mask")
+        ctx.sinks = _sinks(params)
         params = _params(params)
         N, NA, Lqa, D = qa.shape
         _, Li, Lr, _ = cx.shape
@@ -208,7 +282,7 @@ class _QaCtx(torch.autograd.Function):
                                      cx_mask.data_ptr(), mixed.data_ptr(), Sn.data_ptr(), _ptrs(params), _ptrs(grads), d_qa.data_ptr(),
                                      d_cx.data_ptr(), arena.data_ptr(), ab, flags, tmp.data_ptr(), tb, N, NA, Li, Lqa, Lr, D, scale, p,
                                      _u64(seeds), _stream()), "stage_grp_qa_ctx_bwd")
-        return (d_qa, d_cx, None, None, None, None, None) + tuple(grads)
+        return (d_qa, d_cx, None, None, None, None, None) + _deliver(ctx.sinks, grads)
 
 
 def qa_ctx(qa, cx, qa_mask, cx_mask, scale: float, p: float, seeds, params):

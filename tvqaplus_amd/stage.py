@@ -203,6 +203,8 @@ class STAGE(nn.Module):
         # same dropout streams: tests/test_hip_groups.py holds the two equal.  Groups cover fp32 storage and encoder blocks
         # without self-attention; everything else falls back to the per-op path group by group.
         self.use_groups = os.environ.get("STAGE_NO_GROUPS") is None
+        self.gate_shared = os.environ.get("STAGE_NO_PARAM_GATE") is None   # groups.gate for the modules applied to several streams
+        self._gate_map = {}
         # storage type of the activations between kernels: fp32 (the reference's), or bf16 with ``opt.storage_dtype = "bf16"``
         # (BASELINE.json configs[4]: bf16 weights / activations, fp32 softmax / statistics / accumulation; parameters stay
         # fp32 master copies, a weight is rounded to bf16 when a GEMM stages it; scores, losses and logits are fp32)
@@ -272,6 +274,7 @@ class STAGE(nn.Module):
                 params += [blk.layer_norm[i].weight, blk.layer_norm[i].bias, c.depthwise_conv.weight, c.depthwise_conv.bias,
                            c.pointwise_conv.weight, c.pointwise_conv.bias]
             params += [blk.final_layer_norm.weight, blk.final_layer_norm.bias]
+            params = [self._g(w) for w in params]
             y = self._try_group(lambda seeds: groups.encoder_block(x, blk.position_encoding.rows(L), pool_mask, k, self._p(), seeds,
                                                                    params), (blk.n_conv + 1) // 2)
             if y is not None:
@@ -326,6 +329,7 @@ class STAGE(nn.Module):
             params = [init_encoder[0].weight, init_encoder[0].bias, init_encoder[2].weight, init_encoder[2].bias,
                       init_encoder[4].weight, init_encoder[4].bias, downsize_encoder[1].weight, downsize_encoder[1].bias,
                       downsize_encoder[3].weight, downsize_encoder[3].bias]
+            params = [self._g(w) for w in params]
             y = self._try_group(lambda seeds: groups.input_mlp(data, l2_normalize, self._p(), seeds, params), 2)
             if y is not None:
                 return self._stacked_encoder(y.view(M, L, -1), data_mask, input_encoder)
@@ -353,7 +357,8 @@ class STAGE(nn.Module):
         if self._grouped() and qa_embed.dtype == torch.float32 and ctx_embed.shape[2] <= 64:
             proj = self.c2q_down_projection
             res = self._try_group(lambda seeds: groups.qa_ctx(qa_embed, ctx_embed, qa_mask, ctx_mask, self.scale, p, seeds,
-                                                              [proj[0].weight, proj[0].bias, proj[2].weight, proj[2].bias]), 3)
+                                                              [self._g(w) for w in (proj[0].weight, proj[0].bias, proj[2].weight,
+                                                                                    proj[2].bias)]), 3)
             if res is not None:
                 return res[0], mixed_mask, res[1], res[2]
         u_a, raw_s, s_norm = ops.structured_attention(qa_embed, ctx_embed, qa_mask, ctx_mask, self.scale, p=p,
@@ -569,8 +574,33 @@ class STAGE(nn.Module):
         out, att_loss, att_predictions, temporal_loss, temporal_predictions, _ = self.forward_main(batch)
         return out, att_loss, att_predictions, temporal_loss, temporal_predictions
 
+    def _g(self, w):
+        """The parameter, or its alias of this step when its module is gated (groups.gate)."""
+        return self._gate_map.get(id(w), w)
+
+    def _open_gates(self):
+        # modules applied to two or three streams (model/stage.py:226-269): their parameter gradients leave the graph once
+        self._gate_map = {}
+        if not (self.gate_shared and self._grouped() and self.training and torch.is_grad_enabled()):
+            return
+        mods = [self.bert_word_encoding_fc, self.input_embedding, self.input_encoder]
+        if self.flag_cnt == 2:
+            mods.append(self.c2q_down_projection)
+        for m in mods:
+            ps = [w for w in m.parameters() if w.requires_grad]
+            if ps:
+                for w, a in zip(ps, groups.gate(ps)):
+                    self._gate_map[id(w)] = a
+
     def forward_main(self, batch):
         """model/stage.py:199-348."""
+        try:
+            self._open_gates()
+            return self._forward_main(batch)
+        finally:
+            self._gate_map = {}
+
+    def _forward_main(self, batch):
         ops.new_step()
         self.bsz = len(batch.qid)
         N, D = self.bsz, self.hsz
