@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--gc", choices=("freeze", "default", "off"), default="freeze",
                     help="cyclic garbage collector during the timed steps: freeze (default) = gc.freeze() after the warm-up")
+    ap.add_argument("--adam", choices=["fused", "foreach"], default="fused", help="torch.optim.Adam implementation (same update)")
     ap.add_argument("--dump_steps", action="store_true", help="developer: add every timed step's duration (ms) to the record")
     ap.add_argument("--no_device_time", action="store_true", help="skip the torch.profiler pass behind device_ms_per_step")
     ap.add_argument("--only_roofline", action="store_true")
@@ -365,7 +366,16 @@ def main():
     model = model.to(device).train()
     params = [p for p in model.parameters() if p.requires_grad]
     bucket = parallel.FlatGradBucket(params)
-    optimizer = torch.optim.Adam(params, lr=1e-3, weight_decay=3e-7)
+    # torch.optim.Adam, as main.py:209; fused=True is the same update as ONE multi-tensor kernel instead of ~10 (--adam foreach =
+    # torch's default implementation)
+    optimizer = None
+    if args.adam == "fused":
+        try:
+            optimizer = torch.optim.Adam(params, lr=1e-3, weight_decay=3e-7, fused=True)
+        except (RuntimeError, TypeError):
+            args.adam = "foreach"
+    if optimizer is None:
+        optimizer = torch.optim.Adam(params, lr=1e-3, weight_decay=3e-7)
     if args.scaling == "strong":      # global batch of --bsz examples, example-major shards
         full = make_batch(N=args.bsz, Li=args.frames, Lr=args.regions, Lw=args.sub_words, Lqa=args.qa_words, seed=2018,
                           ragged=not args.dense, att_imgs=args.att_imgs if sup else 0, att_words=args.att_words)
@@ -463,7 +473,7 @@ def main():
                                       "bf16 activations / bf16-rounded weights, fp32 statistics, softmax and accumulation"
                                       if args.storage == "bf16" else
                                       "fp32 via fp16-split MFMA GEMMs (error below an fp32 FMA chain)"),
-                       "step": "fwd + loss (main.py:55-60) + bwd + grad all-reduce + clip_grad_norm_ + Adam",
+                       "step": "fwd + loss (main.py:55-60) + bwd + grad all-reduce + clip_grad_norm_ + Adam (torch.optim.Adam, %s)" % args.adam,
                        "global_batch": n_global, "parallelism": "dp%d (example-sharded, flat 2.2MB grad "
                                                                   "all-reduce over RCCL)" % world,
                        "final_loss": round(loss_v, 4), "peak_hbm_gib": round(peak_gb, 2)},
