@@ -347,7 +347,12 @@ def main():
     from tvqaplus_amd import parallel
     from tvqaplus_amd.stage import STAGE
     from tvqaplus_amd.synth import make_batch, make_opt
-    rank, local, world = parallel.init_from_env()
+    # STAGE_BENCH_SHARED_GPU (test hook, tests/test_parallel_hip.py): every rank on cuda:0, collectives over gloo -- the N > 1 control
+    # flow of this file (barriers, max over ranks, the all-rank passes after the timed region) on a one-GPU box
+    shared = os.environ.get("STAGE_BENCH_SHARED_GPU") is not None
+    rank, local, world = parallel.init_from_env(backend="gloo" if shared else None)
+    if shared:
+        local = 0
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -448,12 +453,18 @@ def main():
     host_wait_ms = 1e3 * waits[0] / args.steps
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if shared else device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     loss_v = float(loss.detach())
     peak_gb = torch.cuda.max_memory_allocated() / 2 ** 30
 
+    # device time per step: a torch.profiler pass over 3 extra steps AFTER the timed region -- on EVERY rank (the step contains the
+    # gradient all-reduce: rank 0 alone would wait for its peers forever)
+    dev_ms = None
+    if not args.no_device_time:
+        dev_ms = device_time(
+            lambda: train_step(model, nxt() if not args.h2d else batch_dev(), bucket, params, optimizer, n_local, world))
     if rank == 0:
         rec = {
             "metric": "QA-examples/sec (5-candidate fwd+bwd) at B=16",
@@ -486,9 +497,8 @@ def main():
         rec["step_ms"] = {"min": round(step_ms[0], 3), "median": round(step_ms[len(step_ms) // 2], 3), "max": round(step_ms[-1], 3)}
         if args.dump_steps:
             rec["step_ms_all"] = [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(args.steps)]
-        if not args.no_device_time:
-            rec["device_ms_per_step"], rec["launches_per_step"] = device_time(
-                lambda: train_step(model, nxt() if not args.h2d else batch_dev(), bucket, params, optimizer, n_local, world))
+        if dev_ms is not None:
+            rec["device_ms_per_step"], rec["launches_per_step"] = dev_ms
         if not args.no_roofline and args.config == "stress":
             rec["roofline"] = k1_long_roofline(args, device)
         elif not args.no_roofline:   # rank 0's GPU, after the timed region (the other ranks wait at the final barrier)

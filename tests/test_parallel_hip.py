@@ -144,3 +144,24 @@ def test_bench_strong_scaling_single_rank(hip_device):
     import json
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec["scaling"] == "strong" and rec["n_gpus"] == 1 and rec["value"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_sharing_one_gpu(hip_device):
+    """``bench.py`` launched as the driver launches it for N = 2 (``python -m torch.distributed.run --nproc-per-node 2``), with both
+    ranks on cuda:0 and the collectives over gloo (STAGE_BENCH_SHARED_GPU): barriers, the max over ranks, the all-rank device-time
+    pass after the timed region (rank 0 alone would hang in the gradient all-reduce) and rank 0's one JSON line."""
+    import json
+    port = 29000 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--bsz", "2", "--frames", "12", "--regions", "8", "--sub_words", "10", "--qa_words", "9", "--hsz", "64",
+           "--no_cpu_baseline", "--no_roofline"]
+    env = dict(os.environ, STAGE_BENCH_SHARED_GPU="1")
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=800)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                       # rank 0 prints the one line
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["config"]["global_batch"] == 4 and rec["device_ms_per_step"] > 0
