@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--dump_steps", action="store_true", help="developer: add every timed step's duration (ms) to the record")
     ap.add_argument("--no_device_time", action="store_true", help="skip the torch.profiler pass behind device_ms_per_step")
     ap.add_argument("--only_roofline", action="store_true")
+    ap.add_argument("--with_bwd", action="store_true", help="with --only_roofline: the fused K1 backward as well (the PMC child)")
+    ap.add_argument("--no_pmc", action="store_true", help="do not measure `traffic` with rocprofv3 counter passes in this run")
     ap.add_argument("--cpu_seconds", type=float, default=20.0, help="CPU-baseline time budget")
     ap.add_argument("--cpu_all_threads", action="store_true", help="also time the CPU baseline on os.cpu_count() threads (minutes)")
     ap.add_argument("--h2d", action="store_true", help="developer mode: every step takes its batch from pinned host memory "
@@ -100,6 +102,50 @@ def _profile_traffic(name, kernel="str_attn_fwd"):
     except (OSError, ValueError, IndexError):
         pass
     return None
+
+
+def pmc_traffic_in_run(args):
+    """HBM bytes per launch of the K1 kernels MEASURED IN THIS RUN: two rocprofv3 counter passes (FETCH_SIZE, then WRITE_SIZE; counters +
+    kernel trace only, as MI355X_MICROARCH.md prescribes: separate passes, KiB units, FETCH_SIZE x 2 on gfx950) around a child
+    ``bench.py --only_roofline --with_bwd``.  {(direction, stream): bytes} for what could be measured; {} when rocprofv3 is missing,
+    fails or takes too long (the record then quotes the committed profiles and says so)."""
+    import collections, csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {}
+    names = {("fwd", "vid"): ("str_attn_fwd_reg_kernel", ""), ("fwd", "sub"): ("str_attn_fwd_d128_kernel", ""),
+             ("bwd", "vid"): ("str_attn_bwd_fused_kernel", "<2,"), ("bwd", "sub"): ("str_attn_bwd_fused_kernel", "<4,")}
+    got = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="stage_pmc_", dir="/tmp")
+            try:
+                cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                       os.path.abspath(__file__), "--only_roofline", "--with_bwd", "--bsz", str(args.bsz), "--frames", str(args.frames),
+                       "--regions", str(args.regions), "--sub_words", str(args.sub_words), "--qa_words", str(args.qa_words),
+                       "--hsz", str(args.hsz)]
+                subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=240, check=True)
+                per = collections.defaultdict(float)            # (key, dispatch) -> KiB, summed over the counter's instances
+                for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                    with open(f) as fh:
+                        for row in csv.DictReader(fh):
+                            if row.get("Counter_Name") != ctr:
+                                continue
+                            kn = row.get("Kernel_Name", "")
+                            for key, (sub, tmpl) in names.items():
+                                if sub in kn and (not tmpl or (sub + tmpl) in kn.replace(" ", "")):
+                                    per[(key, row.get("Dispatch_Id"))] += float(row["Counter_Value"])
+                by_key = collections.defaultdict(list)
+                for (key, _), v in per.items():
+                    by_key[key].append(v)
+                for key, vs in by_key.items():
+                    got.setdefault(key, {})[ctr] = sum(vs) / len(vs)
+            finally:
+                shutil.rmtree(d, ignore_errors=True)
+    except Exception:                                            # noqa: BLE001 -- any profiler problem: fall back, never fail the bench
+        return {}
+    return {key: round((v["WRITE_SIZE"] + 2.0 * v["FETCH_SIZE"]) * 1024.0) for key, v in got.items() if len(v) == 2}
 
 
 def _event_times(launch, stream, reps=30, warm=5):
@@ -358,8 +404,12 @@ def main():
     device = torch.device("cuda", local)
     if args.only_roofline:  # developer shortcut: just the K1 kernel line (video and subtitle stream shapes)
         print(json.dumps({"vid": k1_roofline(args, device)}))
+        if args.with_bwd:
+            print(json.dumps({"vid_bwd": k1_bwd_roofline(args, device)}))
         args.regions = args.sub_words
         print(json.dumps({"sub": k1_roofline(args, device)}))
+        if args.with_bwd:
+            print(json.dumps({"sub_bwd": k1_bwd_roofline(args, device)}))
         return
     torch.manual_seed(2018)
     sup = not args.no_sup_att
@@ -509,6 +559,16 @@ def main():
             sub_args.regions = args.sub_words          # the same kernel family on the subtitle stream (50 words per frame)
             rec["roofline_sub"] = k1_roofline(sub_args, device)
             rec["roofline_sub_bwd"] = k1_bwd_roofline(sub_args, device)
+            if (not args.no_pmc and not args.dense and args.storage == "fp32" and
+                    (args.bsz, args.frames, args.qa_words, args.hsz, args.regions, args.sub_words) == (16, 300, 40, 128, 20, 50)):
+                # `traffic` as an observation of THIS box, not a constant from the repo (published shapes only)
+                meas = pmc_traffic_in_run(args)
+                for name, key in (("roofline", ("fwd", "vid")), ("roofline_sub", ("fwd", "sub")), ("roofline_bwd", ("bwd", "vid")),
+                                  ("roofline_sub_bwd", ("bwd", "sub"))):
+                    if key in meas:
+                        rec[name]["traffic"] = meas[key]
+                        rec[name]["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes in this run "
+                                                       "(WRITE_SIZE + 2 x FETCH_SIZE, KiB; MI355X_MICROARCH.md)")
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args, opt)
         print(json.dumps(rec))
