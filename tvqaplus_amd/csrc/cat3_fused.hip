@@ -404,9 +404,10 @@ __global__ __launch_bounds__(256, 2) void cf_bwd_kernel(const float* __restrict_
 }
 
 void cf_chunks(long long groups, int rep, int mode, int* CH, int* fpc) {
-    // ~8 workgroups per resident slot (2 per CU): with about one workgroup per slot the last few run alone.  MODE 2 walks the
+    // ~4 workgroups per resident slot (2 per CU): with about one workgroup per slot the last few run alone.  MODE 2 walks the
     // frames four at a time: chunks of a multiple of four frames
-    int ch = (int)((4096 + groups - 1) / groups);
+    static const long wg_target = getenv("STAGE_CF_WGS") ? atol(getenv("STAGE_CF_WGS")) : 2048;       // (developer sweep: 1536-2560 measured 1-2 % faster than 4096, 1024 10 % slower)
+    int ch = (int)((wg_target + groups - 1) / groups);
     if (ch > rep) ch = rep;
     if (ch < 1) ch = 1;
     int f = (rep + ch - 1) / ch;
@@ -415,6 +416,10 @@ void cf_chunks(long long groups, int rep, int mode, int* CH, int* fpc) {
     *CH = (rep + f - 1) / f;
 }
 inline size_t cf_align(size_t v) { return (v + 255) & ~(size_t)255; }
+inline long cf_flat_grid() {                          // MODE 0: workgroups that stride the 32-row tiles (developer sweep: STAGE_CF_FLAT_GRID)
+    static const long g = getenv("STAGE_CF_FLAT_GRID") ? atol(getenv("STAGE_CF_FLAT_GRID")) : 1024;
+    return g;
+}
 inline int cf_mode(int rep, int inner) { return rep == 1 ? 0 : (inner <= 32 ? 1 : (inner == 40 ? 2 : -1)); }
 }  // namespace
 
@@ -432,7 +437,7 @@ extern "C" size_t stage_cat3_dx_ln_bwd_ws_bytes(long long rows, int D, int rep, 
         cf_chunks(rows / ((long long)rep * inner), rep, cf_mode(rep, inner), &CH, &fpc);
         wg = (size_t)(rows / ((long long)rep * inner)) * CH;
     } else {
-        wg = 1024;
+        wg = (size_t)cf_flat_grid();
     }
     size_t b = cf_align((size_t)CF_WFRAG * sizeof(uint4)) + 256;                 // weight image + scale word
     b += cf_align(wg * 2 * 3 * CF_D * sizeof(float));                            // d gamma / d beta partials
@@ -472,7 +477,7 @@ extern "C" int stage_cat3_dx_ln_bwd(const float* dy, const unsigned* relu_mask, 
         da_out = (float*)wsp;                                  // slabs [G][CH][inner][D]
     } else {
         const long tiles = (long)((rows + 31) / 32);
-        grid = (int)(tiles < 1024 ? tiles : 1024);
+        grid = (int)(tiles < cf_flat_grid() ? tiles : cf_flat_grid());
     }
 #define CF_LAUNCH(DR, MD)                                                                                                          \
     hipLaunchKernelGGL((cf_bwd_kernel<DR, MD>), dim3(grid), dim3(256), lds, st, dy, relu_mask, img, w_up, a, b, mean, rstd, gamma,    \
@@ -735,7 +740,8 @@ extern "C" int stage_cat3_ln_gemm_fwd(const float* a, const float* b, const floa
     const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
     const size_t lds = (size_t)CFF_KS * 2 * 64 * 16 + 32 * 4;
     const long tiles = (long)((rows + 31) / 32);
-    const int grid = (int)(tiles < 3072 ? tiles : 3072);
+    static const long grid_cap = getenv("STAGE_CFF_GRID") ? atol(getenv("STAGE_CFF_GRID")) : 3072;   // (developer sweep)
+    const int grid = (int)(tiles < grid_cap ? tiles : grid_cap);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)cff_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
