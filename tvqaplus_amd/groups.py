@@ -1,11 +1,11 @@
 """K-groups: one ``torch.autograd.Function`` per fused-op GROUP of STAGE, each backed by one forward and one backward entry point of
 ``libstage_hip.so`` that sequences the group's kernels on the C side (csrc/groups.hip; SURVEY.md section 8b, last bullet).
 
-The per-op path (``tvqaplus_amd.ops``: one Function and ~4 ``torch.empty`` per kernel) issues ~360 launches per training step from
-Python; here the interpreter sees one call per group -- input MLP, encoder block, QA<->context attention + down-projection,
-two-stream fusion, temporal head -- i.e. ~12 forward and ~12 backward calls.  The kernels, their order and their arguments are
-the per-op path's (``tests/test_hip_groups.py`` holds the two paths equal, dropout on), so this is sequencing only: what changes
-is that the step no longer depends on how fast the host can issue launches.
+The per-op path (``tvqaplus_amd.ops``: one Function and ~4 ``torch.empty`` per kernel) makes ~140 library calls per training step
+from Python; here the interpreter sees one call per group -- input MLP, encoder block, QA<->context attention + down-projection,
+two-stream fusion, temporal head, span scores / proposal pooling + classifier, the two losses -- ~31 calls per step.  The kernels
+and their arguments are the per-op path's except for the fused ``[a, b, a*b]`` kernels (``tests/test_hip_groups.py`` holds the two
+paths equal, dropout on): what changes is that the step no longer depends on how fast the host can issue launches.
 
 Memory: the caller (this module) owns everything.  ``arena`` = one buffer per group call that the C side carves into what the
 backward needs; ``tmp`` = backward-only scratch, freed when the backward returns (stream-ordered, like every torch temporary).

@@ -1,13 +1,6 @@
-"""``torch.ops.stage_hip.*`` -- the fused-op groups of the STAGE hot path registered as torch custom operators
-(BASELINE.json north_star: "hand-written HIP C++ kernels bound as torch custom ops").
-
-Registration goes through ``torch.library`` from Python: every operator is defined with a schema in the ``stage_hip``
-namespace and implemented (``CompositeImplicitAutograd``) by the autograd-aware wrapper of ``tvqaplus_amd.ops``, whose
-``torch.autograd.Function`` records the hand-written backward kernel.  The kernels themselves stay behind the C ABI of
-``libstage_hip.so`` (include/stage_hip.h) -- there is no second, TORCH_LIBRARY-compiled copy of them: a C++ extension
-would add a multi-minute torch-header compile to ``build()`` for the same launches.  The model (``tvqaplus_amd.stage``)
-calls the wrappers directly; the dispatcher round trip costs ~10 us per call, which the ~120 calls of a step can do
-without, and gains nothing there.  ``import tvqaplus_amd`` registers the operators (idempotent).
+"""``torch.ops.stage_hip.*``: the per-kernel wrappers of ``tvqaplus_amd.ops`` registered as torch custom operators through
+``torch.library`` (CompositeImplicitAutograd: the wrappers' ``autograd.Function``s carry the hand-written backward kernels).
+The kernels stay behind the C ABI of ``libstage_hip.so``; the model itself calls the K-group entry points (``groups.py``).
 """
 from __future__ import annotations
 
