@@ -15,8 +15,10 @@
 #define LD_GRID_CAP 16384
 #define LD_PART_CAP 512
 
+// (up to five taps the kernel fits 128 registers -- four waves per SIMD instead of three: 398 / 357 -> 371 / 341 us at the classifier
+// encoder; with seven taps the cap spills 22-26 registers and doubles the run time)
 template <int KT, bool DROP, typename T = float>
-__global__ __launch_bounds__(256) void ln_dwconv_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+__global__ __launch_bounds__(256, (KT <= 5 ? 4 : 1)) void ln_dwconv_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                             int res_period, T* __restrict__ sum_out,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ w, const float* __restrict__ bias,
@@ -106,6 +108,7 @@ __global__ __launch_bounds__(256) void ln_dwconv_fwd_kernel(const T* __restrict_
 }
 
 // dx = LN-backward(conv-backward(dh)) + dx_add ; partials of dw/db (conv) and dgamma/dbeta (LayerNorm) per workgroup.
+// (register caps for more waves per SIMD were measured here too: 168 registers spill 80-100 and run 4x slower)
 template <int KT, bool DROP, typename T = float>
 __global__ __launch_bounds__(256) void ln_dwconv_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ xin,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
