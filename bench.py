@@ -463,6 +463,10 @@ def main():
         batch_dev = lambda: host.to(device)
     else:
         nxt = lambda: batch
+    import gc
+    if args.gc == "freeze":
+        gc.collect()      # (the collection itself BEFORE the warm-up: ~0.1 s of host time right in front of the timed region would
+                          # let the GPU fall back to its idle clocks)
     for _ in range(args.warmup):
         train_step(model, nxt(), bucket, params, optimizer, n_local, world)
     # Python's cyclic collector: a full (generation 2) collection walks every tracked object of the process -- millions once torch
@@ -470,9 +474,7 @@ def main():
     # on the mean of 20 steps).  The objects alive after the warm-up (modules, parameters, the batch) are permanent, so they are
     # moved out of the collector's sight (gc.freeze, what long-running Python services do); the collector stays ON for what the
     # steps allocate.  --gc default leaves everything as the interpreter ships it.
-    import gc
     if args.gc == "freeze":
-        gc.collect()
         gc.freeze()
     elif args.gc == "off":
         gc.disable()
