@@ -561,7 +561,7 @@ def main():
             sub_args.regions = args.sub_words          # the same kernel family on the subtitle stream (50 words per frame)
             rec["roofline_sub"] = k1_roofline(sub_args, device)
             rec["roofline_sub_bwd"] = k1_bwd_roofline(sub_args, device)
-            if (not args.no_pmc and not args.dense and args.storage == "fp32" and
+            if (world == 1 and not args.no_pmc and not args.dense and args.storage == "fp32" and
                     (args.bsz, args.frames, args.qa_words, args.hsz, args.regions, args.sub_words) == (16, 300, 40, 128, 20, 50)):
                 # `traffic` as an observation of THIS box, not a constant from the repo (published shapes only)
                 meas = pmc_traffic_in_run(args)
