@@ -78,7 +78,7 @@ def train_step(model, batch, bucket, params, optimizer, n_examples, world=1):
     bucket.zero()
     (out, targets), att_loss, _, t_loss, _ = model(batch)
     # main.py:59 -- len(qids) / len(targets) of the gathered batch (N_new is data dependent with add_local)
-    scale = (1.0 * n_examples / len(targets)) if world == 1 else parallel.global_loss_scale(n_examples, len(targets), out.device)
+    scale = (1.0 * n_examples / len(targets)) if world == 1 else parallel.global_loss_scale(n_examples, len(targets), out.device, as_tensor=True)
     loss = F.cross_entropy(out, targets, reduction="sum") * scale + 0.1 * att_loss + 0.5 * t_loss   # att_weight 0.1, ts_weight 0.5 (config.py)
     loss.backward()
     bucket.all_reduce()

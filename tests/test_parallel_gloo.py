@@ -134,6 +134,8 @@ def _worker_add_local(rank, world, port, q):
     out = O.stage_forward(P, opt, local, training=True)
     n_loc, n_new = len(local.qid), out["targets"].shape[0]
     scale = parallel.global_loss_scale(n_loc, n_new, device="cpu")
+    scale_t = parallel.global_loss_scale(n_loc, n_new, device="cpu", as_tensor=True)     # the no-read-back form bench.py uses
+    assert scale_t.dim() == 0 and abs(float(scale_t) - scale) < 1e-6 * scale
     loss = F.cross_entropy(out["logits"], out["targets"], reduction="sum") * scale + 0.5 * out["temporal_loss"]
     loss.backward()
     bucket.all_reduce()

@@ -194,17 +194,23 @@ class FlatGradBucket:
 # ---------------------------------------------------------------------------------------------------------------
 # reference-faithful loss normalisation across ranks (main.py:57-60)
 # ---------------------------------------------------------------------------------------------------------------
-def global_loss_scale(n_examples_local: int, n_targets_local: int, device=None, count_this_rank: bool = True) -> float:
+def global_loss_scale(n_examples_local: int, n_targets_local: int, device=None, count_this_rank: bool = True,
+                      as_tensor: bool = False):
     """len(qids) / len(targets) of the GATHERED batch: one 2-element all-reduce.  ``count_this_rank=False`` for the ranks of
-    a candidate group that replicate the examples of the group's first rank."""
+    a candidate group that replicate the examples of the group's first rank.  ``as_tensor=True`` returns the ratio as a 0-dim
+    tensor on ``device`` WITHOUT reading it back: the training step then has no host synchronisation between forward and backward
+    (the collective is stream-ordered on RCCL)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return float(n_examples_local) / float(n_targets_local)
+        r = float(n_examples_local) / float(n_targets_local)
+        return torch.tensor(r, dtype=torch.float32, device=device) if as_tensor else r
     if device is None:
         device = "cuda" if dist.get_backend() == "nccl" else "cpu"
     v = torch.tensor([float(n_examples_local), float(n_targets_local)], dtype=torch.float64, device=device)
     if not count_this_rank:
         v.zero_()
     _all_reduce_sum(v)
+    if as_tensor:
+        return (v[0] / v[1]).to(torch.float32)
     return float(v[0].item() / v[1].item())
 
 
