@@ -213,6 +213,40 @@ def k1_roofline(args, device, dense=None):
             "shape": {"N": N, "NA": NA, "Li": Li, "Lqa": Lqa, "Lr": Lr, "D": D}}
 
 
+def k1k2_roofline(args, device, model):
+    """'if K1+K2 are fused ... report both the isolated-K1 number and the fused number'.  K1 + K2 (StructuredAttention +
+    c2q_down_projection, model/stage.py:365-387) as the model issues them: ONE group call (stage_grp_qa_ctx_fwd: K1 forward kernel + the
+    fused LayerNorm -> dropout -> Linear -> ReLU kernel), training mode, events on the launch stream.  Algorithmic bytes: the inputs + the
+    block's output `mixed` + the two score maps (the attended tensor and the 3D-wide concat are internal)."""
+    (N, NA, Li, Lqa, Lr, D), g, Cn, Q, cm, qm = _k1_inputs(args, device, args.dense)
+    qa = torch.randn(N, NA, Lqa, D, generator=g).to(device)
+    stream = torch.cuda.current_stream()
+    was = model.training
+    model.train()
+
+    def launch():
+        with torch.no_grad():
+            model.qa_ctx_attention(qa, Q, cm, qm)
+    try:
+        ms = _event_times(launch, stream, reps=20, warm=3)
+    finally:
+        model.train(was)
+    avg_ms = sum(ms) / len(ms)
+    U = N * NA * Li * Lqa
+    alg = 4 * (N * NA * Lqa * D + N * Li * Lr * D + N * NA * Lqa + N * Li * Lr + U * D + 2 * U * Lr)
+    gbs = alg / (avg_ms * 1e-3) / 1e9
+    # K2 is a dense 3D -> D contraction: compute bound in fp32 (SURVEY.md 8d: 94.4 GFLOP per instance + K1's two small products);
+    # priced against the dense fp32 matrix-core peak (the products run as fp16 pairs, three MFMAs each: fp32-equivalent FLOPs)
+    flops = 2.0 * U * (3 * D) * D + 2.0 * 2.0 * U * Lr * D
+    tf = flops / (avg_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "K1 + K2 group forward (stage_grp_qa_ctx_fwd: str_attn_fwd + cff_fwd_kernel; the 1.47 GB normalised "
+            "concat is still written once for the weight gradient)", "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s",
+            "frac": round(tf / 157.3, 4), "flops_fp32_equivalent": flops, "hbm_gbs_algorithmic": round(gbs, 1),
+            "hbm_frac_algorithmic": round(gbs / 8000.0, 4), "traffic": None, "algorithmic_bytes": alg,
+            "avg_us": round(avg_ms * 1e3, 1), "min_us": round(ms[0] * 1e3, 1),
+            "shape": {"N": N, "NA": NA, "Li": Li, "Lqa": Lqa, "Lr": Lr, "D": D}}
+
+
 def k1_long_roofline(args, device):
     """BASELINE.json configs[4]: the long-row StructuredAttention forward (csrc/str_attn_long.hip; rows of 512 subtitle words, D = 256,
     bf16 operands / output, fp32 scores, softmax and accumulation), the C-ABI call alone, events on the launch stream."""
@@ -561,6 +595,8 @@ def main():
             sub_args.regions = args.sub_words          # the same kernel family on the subtitle stream (50 words per frame)
             rec["roofline_sub"] = k1_roofline(sub_args, device)
             rec["roofline_sub_bwd"] = k1_bwd_roofline(sub_args, device)
+            if args.storage == "fp32" and args.hsz == 128:
+                rec["roofline_k1k2"] = k1k2_roofline(args, device, model)
             if (world == 1 and not args.no_pmc and not args.dense and args.storage == "fp32" and
                     (args.bsz, args.frames, args.qa_words, args.hsz, args.regions, args.sub_words) == (16, 300, 40, 128, 20, 50)):
                 # `traffic` as an observation of THIS box, not a constant from the repo (published shapes only)
