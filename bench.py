@@ -525,15 +525,35 @@ def main():
     torch.cuda.Event.synchronize = _timed_sync
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     stream = torch.cuda.current_stream()
+    # the K1 forward kernels of every timed step carry an event pair on their launch stream (include/stage_hip.h:
+    # stage_k1_fwd_timer): their duration INSIDE the timed region is what `roofline` quotes
+    from tvqaplus_amd import _lib as _L
+    lib = _L.load()
+    k1_ev = {}
+    if rank == 0 and args.storage == "fp32" and args.hsz == 128 and not args.no_roofline:
+        for lr in {args.regions, args.sub_words}:
+            if lr <= 64:
+                k1_ev[lr] = [(lib.stage_timer_create(), lib.stage_timer_create()) for _ in range(args.steps)]
     sync()
     t0 = time.perf_counter()
     marks[0].record(stream)
     for i in range(args.steps):
+        for lr, evs in k1_ev.items():
+            lib.stage_k1_fwd_timer(evs[i][0], evs[i][1], lr)
         loss = train_step(model, nxt(), bucket, params, optimizer, n_local, world)
         marks[i + 1].record(stream)
     t_issued = time.perf_counter()
     sync()
     dt = time.perf_counter() - t0
+    lib.stage_k1_fwd_timer(None, None, 0)
+    k1_in_step = {}
+    for lr, evs in k1_ev.items():
+        ts = sorted(lib.stage_timer_elapsed_ms(a, b) for a, b in evs)
+        for a, b in evs:
+            lib.stage_timer_destroy(a)
+            lib.stage_timer_destroy(b)
+        if ts and ts[0] > 0:
+            k1_in_step[lr] = ts
     torch.cuda.Event.synchronize = _ev_sync
     host_issue_ms = 1e3 * (t_issued - t0 - waits[0]) / args.steps
     host_wait_ms = 1e3 * waits[0] / args.steps
@@ -597,6 +617,18 @@ def main():
             rec["roofline_sub_bwd"] = k1_bwd_roofline(sub_args, device)
             if args.storage == "fp32" and args.hsz == 128:
                 rec["roofline_k1k2"] = k1k2_roofline(args, device, model)
+            # the same kernels INSIDE the timed steps (training mode, dropout on): `achieved` / `frac` / `avg_us` from there; the
+            # back-to-back sequence above stays as `isolated_*` (30 launches in a row run into the chip's power management)
+            for name, lr in (("roofline", args.regions), ("roofline_sub", args.sub_words)):
+                ts = k1_in_step.get(lr)
+                if ts:
+                    r = rec[name]
+                    avg = sum(ts) / len(ts)
+                    r["isolated_avg_us"], r["isolated_min_us"], r["isolated_frac"] = r["avg_us"], r["min_us"], r["frac"]
+                    r["avg_us"], r["min_us"] = round(avg * 1e3, 1), round(ts[0] * 1e3, 1)
+                    r["achieved"] = round(r["algorithmic_bytes"] / (avg * 1e-3) / 1e9, 1)
+                    r["frac"] = round(r["achieved"] / 8000.0, 4)
+                    r["timed"] = "HIP events on the launch stream around the kernel in each of the %d timed training steps" % len(ts)
             if (world == 1 and not args.no_pmc and not args.dense and args.storage == "fp32" and
                     (args.bsz, args.frames, args.qa_words, args.hsz, args.regions, args.sub_words) == (16, 300, 40, 128, 20, 50)):
                 # `traffic` as an observation of THIS box, not a constant from the repo (published shapes only)

@@ -29,6 +29,13 @@ extern "C" {
 /* ---- library info -------------------------------------------------------------------------------------------- */
 int stage_hip_abi_version(void);
 const char* stage_hip_error_string(int code);
+/* Measurement helpers (bench.py; no reference counterpart): events for hosts without a HIP binding, and a one-shot hook that makes the
+ * next stage_str_attn_fwd call with `Lr` regions record (start, stop) on its stream around its kernel -- the K1 forward's duration
+ * INSIDE a training step.  stage_k1_fwd_timer(NULL, NULL, 0) disarms.  stage_timer_elapsed_ms waits for `stop`; < 0 on error. */
+void* stage_timer_create(void);
+void stage_timer_destroy(void* event);
+float stage_timer_elapsed_ms(void* start, void* stop);
+void stage_k1_fwd_timer(void* start, void* stop, int Lr);
 
 /* ---- K1: StructuredAttention (model/context_query_attention.py:35-101, called at model/stage.py:378) ----------
  * Cn      (N, NA, Lqa, D)  L2-normalised (+dropout) QA/context side, produced by stage_l2norm_fwd

@@ -16,7 +16,7 @@ def _declared():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(int|size_t|const char\*)\s+(stage_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(int|size_t|const char\*|void\*|void|float)\s+(stage_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = [a.strip() for a in m.group(3).split(",")]
         if args == ["void"]:
             args = []
@@ -60,7 +60,8 @@ def test_ctypes_signatures_match_header(built_lib):
         assert len(args) == len(argtypes), name
         for i, (a, t) in enumerate(zip(args, argtypes)):
             assert kind(a) is t, (name, i, a, t)
-        exp_ret = {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "const char*": ctypes.c_char_p}[ret]
+        exp_ret = {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "const char*": ctypes.c_char_p, "void*": ctypes.c_void_p,
+                   "void": None, "float": ctypes.c_float}[ret]
         assert res is exp_ret, name
 
 

@@ -20,6 +20,10 @@ I, LL, F, U64, SZ = c_int, c_longlong, c_float, c_ulonglong, c_size_t
 SIGNATURES = {
     "stage_hip_abi_version": (I, []),
     "stage_hip_error_string": (c_char_p, [I]),
+    "stage_timer_create": (P, []),
+    "stage_timer_destroy": (None, [P]),
+    "stage_timer_elapsed_ms": (F, [P, P]),
+    "stage_k1_fwd_timer": (None, [P, P, I]),
     "stage_str_attn_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, U64, P]),
     "stage_str_attn_bwd_ws_bytes": (SZ, [I, I, I, I]),
     "stage_str_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, SZ, P]),

@@ -11,3 +11,15 @@ extern "C" const char* stage_hip_error_string(int code) {
     if (code > 0) return hipGetErrorString((hipError_t)code);
     return "stage_hip: unknown error";
 }
+
+// event helpers for hosts without a HIP binding of their own (bench.py times kernels on the launch stream with them)
+extern "C" void* stage_timer_create(void) {
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? (void*)e : nullptr;
+}
+extern "C" void stage_timer_destroy(void* e) { if (e) (void)hipEventDestroy((hipEvent_t)e); }
+extern "C" float stage_timer_elapsed_ms(void* start, void* stop) {
+    float ms = -1.f;
+    if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess || hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) return -1.f;
+    return ms;
+}

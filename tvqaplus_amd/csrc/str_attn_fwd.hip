@@ -681,9 +681,38 @@ static int str_attn_fwd_d128_t(const float* Cn, const TQ* Q, const float* c_mask
 #undef ARGS
 }
 
+// Measurement hook (bench.py: the K1 forward's duration INSIDE the timed training steps): stage_k1_fwd_timer arms an event pair for the
+// next stage_str_attn_fwd call with the given region count; the call records the pair on its stream around its kernel and disarms it.
+namespace {
+struct K1Timer { hipEvent_t a, b; int Lr; bool armed; };
+K1Timer g_k1_timer[4];
+}
+extern "C" void stage_k1_fwd_timer(void* start, void* stop, int Lr) {
+    for (auto& t : g_k1_timer) {
+        if (!start) { t.armed = false; continue; }     // NULL: disarm everything
+        if (!t.armed || t.Lr == Lr) { t = K1Timer{(hipEvent_t)start, (hipEvent_t)stop, Lr, true}; return; }
+    }
+}
+static int str_attn_fwd_dispatch(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A,
+                                 float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D,
+                                 float scale, float p_drop, unsigned long long seed, void* stream);
 extern "C" int stage_str_attn_fwd(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A,
                                   float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D,
                                   float scale, float p_drop, unsigned long long seed, void* stream) {
+    K1Timer* tm = nullptr;
+    for (auto& t : g_k1_timer)
+        if (t.armed && t.Lr == Lr) { tm = &t; break; }
+    if (tm) (void)hipEventRecord(tm->a, (hipStream_t)stream);
+    const int rc = str_attn_fwd_dispatch(Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, D, scale, p_drop, seed, stream);
+    if (tm) {
+        (void)hipEventRecord(tm->b, (hipStream_t)stream);
+        tm->armed = false;
+    }
+    return rc;
+}
+static int str_attn_fwd_dispatch(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A,
+                                 float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D,
+                                 float scale, float p_drop, unsigned long long seed, void* stream) {
     if (N <= 0 || Li <= 0) return 0;
     if (D % 16 != 0 || D > 256 || Lr < 1 || Lr > 64 || Lqa < 1 || NA < 1) return STAGE_ERR_SHAPE;
     if (D != DD || getenv("STAGE_K1_GENERIC"))
