@@ -420,6 +420,83 @@ int stage_grp_pool_cls_bwd(const float* d_logits, const float* mask, const int* 
                            float* const* grads, float* d_first, const void* arena, size_t arena_bytes, void* tmp, size_t tmp_bytes,
                            int N, int NA, int Li, int D, long long P, float p_drop, const unsigned long long* seeds, void* stream);
 
+
+/* ==== Ragged token rows: live-range execution of the (N, 5, Li, Lqa, .) kernels ===================================================
+ * The reference computes every padded row of the (N,5,Li,Lqa,D) tensors (model/stage.py:365-387 qa_ctx_attention, :276-279 concat_fc,
+ * :484-505 classifier head; no masking inside LayerNorm / Linear / the convolutions of model/encoder.py:35-52, model/cnn.py:42-47).
+ * Only this reaches an output or a gradient: frames whose statement mask is not all zero (the others pool to the constant -1e10 at
+ * model/stage.py:503 and get the gradient dout * mask = 0), and of those the words below Lc = min(Lqa, last valid word + 1 + halo),
+ * halo = (convolution layers of the classifier encoder) * (kernel_size / 2) -- the receptive field through which padded words leak
+ * into valid ones.  The entry points below run on exactly those rows ("compact rows": [group g = (n, a)][live frame][word < Lc(g)]);
+ * the attention output A and its gradient keep all Lqa words of a live frame ("frame-compact rows":
+ * [sequence = first(n) + a * slots(n) + slot][word], slots(n) = live frames of example n + one dump slot that dead frames use).
+ * Tables (device int32, built by tvqaplus_amd/ragged.py from the masks):
+ *   fmap    [N*Li] slot of each frame (< 0 dead) | [N] slots(n) | [N] first(n)
+ *   gdesc   (N*NA, 4)  first compact row, Lc, slots(n), first frame-compact sequence of the group
+ *   seq     (S, 4)     first compact row, length, group, dense output row g*Li + i            one per (group, live frame)
+ *   seqfc   (S)        frame-compact sequence of each entry of seq
+ *   rowinfo (U, 4)     QA row g*Lqa + w, frame-compact row, dense output row, w                 (stage_rag_rowinfo)                 */
+int stage_rag_rowinfo(const int* seq, const int* seqfc, long long S, int Lqa, int* rowinfo, void* stream);
+int stage_rag_fill_pooled(float* out, int* argmax, long long rows, int D, void* stream);      /* -1e10 / 0: model/stage.py:503 on an all-masked group */
+int stage_rag_zero_dump(float* A_fc, const int* fmap, int N, int NA, int Li, int Lqa, int D, void* stream);
+/* K1 with a frame-compact A / dA (model/context_query_attention.py:35-101; D == 128, the fast kernels only) */
+int stage_str_attn_fwd_fc(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A_fc, float* S_raw,
+                          float* S_norm, const int* fmap, int N, int NA, int Li, int Lqa, int Lr, int D, float scale, float p_drop,
+                          unsigned long long seed, void* stream);
+int stage_str_attn_bwd_fused_fc(const float* dA_fc, const float* dS_raw_ext, const float* Cn, const float* Q, const float* Qn,
+                                const float* S_norm, const float* q_mask, float* dQraw, float* dQn, float* dCn, const int* fmap,
+                                int N, int NA, int Li, int Lqa, int Lr, int D, float scale, void* ws, size_t ws_bytes, void* stream);
+/* [a, b, a*b] LayerNorm -> Linear -> ReLU (model/stage.py:381-385) on compact rows: a = QA rows, b = frame-compact rows */
+int stage_cat3_ln_gemm_fwd_rag_supported(long long rows, long long a_rows, long long b_rows, int D);
+int stage_cat3_ln_gemm_fwd_rag(const float* a, const float* b, const float* gamma, const float* beta, const float* W,
+                               const float* bias, float* z, float* mean, float* rstd, float* y, unsigned* relu_mask_out,
+                               const int* rowinfo, long long rows, long long a_rows, long long b_rows, int D, float eps,
+                               float p_drop, unsigned long long seed, void* ws, size_t ws_bytes, void* stream);
+int stage_cat3_dx_ln_bwd_rag_supported(long long rows, long long fc_rows, int D, int groups, int max_frames, int Lqa);
+size_t stage_cat3_dx_ln_bwd_rag_ws_bytes(int groups, int max_frames, int Lqa);
+int stage_cat3_dx_ln_bwd_rag(const float* dy, const unsigned* relu_mask, const float* W, const float* a, const float* b_fc,
+                             const float* mean, const float* rstd, const float* gamma, float* da, float* db_fc, float* dgamma,
+                             float* dbeta, const int* gdesc, long long rows, long long fc_rows, int D, int groups, int max_frames,
+                             int Lqa, float p_drop, unsigned long long seed, void* ws, size_t ws_bytes, void* stream);
+/* encoder block pieces on ragged sequences (model/encoder.py:35-52; model/stage.py:503 for the pooled LayerNorm) */
+int stage_ln_dwconv_rag_fwd(const float* x, const float* res, const float* pe, float* sum_out, const float* gamma,
+                            const float* beta, const float* w, const float* bias, float* h, float* mean, float* rstd,
+                            const int* seq, long long S, int Lmax, int D, int k, float eps, float p_drop,
+                            unsigned long long seed, void* stream);
+int stage_ln_dwconv_rag_bwd(const float* dh, const float* xin, const float* mean, const float* rstd, const float* gamma,
+                            const float* beta, const float* w, float* dx, const float* dx_add, float* dgamma, float* dbeta,
+                            float* dw, float* db, const int* seq, long long S, int Lmax, int D, int k, float p_drop,
+                            unsigned long long seed, void* ws, size_t ws_bytes, void* stream);
+int stage_ln_masked_max_rag_fwd(const float* x, const float* res, float* sum_out, const float* gamma, const float* beta,
+                                const float* qmask, float* out, int* argmax, float* mean, float* rstd, const int* seq,
+                                long long S, int Lq, int K, float eps, void* stream);
+int stage_ln_masked_max_rag_bwd(const float* dout, const int* argmax, const float* qmask, const float* xin, const float* mean,
+                                const float* rstd, const float* gamma, float* dx, float* dgamma, float* dbeta,
+                                const int* rowinfo, long long rows, int K, void* ws, size_t ws_bytes, void* stream);
+/* K-groups on ragged rows (csrc/groups.hip "RAGGED TOKEN ROWS"): T = host array of the four device tables fmap, gdesc, seq, rowinfo */
+int stage_grp_qa_ctx_rag_supported(int N, int NA, int Li, int Lqa, int Lr, int D, long long U, long long Fc);
+size_t stage_grp_qa_ctx_rag_arena_bytes(int N, int NA, int Lqa, int D, long long Ucap, long long Fc);
+size_t stage_grp_qa_ctx_rag_bwd_tmp_bytes(int N, int NA, int Li, int Lqa, int Lr, int D, long long Ucap);
+int stage_grp_qa_ctx_rag_fwd(const float* qa, const float* ctx, const float* qa_mask, const float* ctx_mask,
+                             const float* const* P, float* mixed, float* S_raw, float* S_norm, const int* const* T, void* arena,
+                             size_t arena_bytes, int* flags, int N, int NA, int Li, int Lqa, int Lr, int D, long long U,
+                             long long Ucap, long long Fc, float scale, float p, const unsigned long long* seeds, void* stream);
+int stage_grp_qa_ctx_rag_bwd(const float* d_mixed, const float* dS_ext, const float* qa, const float* ctx, const float* ctx_mask,
+                             const float* mixed, const float* S_norm, const float* const* P, float* const* G, float* d_qa,
+                             float* d_ctx, const int* const* T, void* arena, size_t arena_bytes, const int* flags, void* tmp,
+                             size_t tmp_bytes, int N, int NA, int Li, int Lqa, int Lr, int D, long long U, long long Ucap,
+                             long long Fc, float scale, float p, const unsigned long long* seeds, void* stream);
+size_t stage_grp_encoder_rag_arena_bytes(long long Ucap, long long Rd, int D, int n_conv);
+size_t stage_grp_encoder_rag_bwd_tmp_bytes(long long Ucap, int D, int k);
+int stage_grp_encoder_rag_fwd(const float* x, const float* pe, const float* qa_mask, const float* const* P, float* out,
+                              const int* const* T, void* arena, size_t arena_bytes, int* flags, long long U, long long Ucap,
+                              long long S, long long Rd, int Lqa, int D, int n_conv, int k, float p,
+                              const unsigned long long* seeds, void* stream);
+int stage_grp_encoder_rag_bwd(const float* dout, const float* qa_mask, const float* const* P, float* const* Gr, float* dx,
+                              const int* const* T, const void* arena, size_t arena_bytes, const int* flags, void* tmp,
+                              size_t tmp_bytes, long long U, long long Ucap, long long S, long long Rd, int Lqa, int D, int n_conv,
+                              int k, float p, const unsigned long long* seeds, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,154 @@
+"""CPU: the ragged-token-row tables (tvqaplus_amd/ragged.py) -- layout invariants, and the CLAIM they rest on, checked with the oracle's own
+classifier encoder in fp64: running model/stage.py:502-503 (cls_encoder + mask_logits + max over the words) on the live rows only, with
+zero padding behind Lc = min(Lqa, last valid word + 1 + halo) and -1e10 for dead frames, gives the same pooled outputs, the same
+gradient on every live row, the same parameter gradients -- and the dense computation's gradient on every other row is exactly zero."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import stage_oracle as O
+from tvqaplus_amd import ragged
+
+
+def _masks(rng, N, NA, Li, Lqa, holes=False):
+    qa = np.zeros((N, NA, Lqa), dtype=bool)
+    for n in range(N):
+        for a in range(NA):
+            qa[n, a, : rng.integers(0 if (n + a) % 7 == 3 else 1, Lqa + 1)] = True
+    fl = np.zeros((N, Li), dtype=bool)
+    for n in range(N):
+        fl[n, : rng.integers(1, Li + 1)] = True
+    if holes:
+        qa[0, 0, 1] = False                      # a hole inside the valid words stays live
+        fl[0, 0] = False                         # dead frames need not be trailing
+        if N > 1:
+            fl[1] = False                        # an example without a live frame
+    return qa, fl
+
+
+@pytest.mark.parametrize("holes", [False, True])
+def test_tables_partition_the_live_rows(holes):
+    rng = np.random.default_rng(5)
+    N, NA, Li, Lqa, halo = 3, 5, 7, 12, 4
+    qa, fl = _masks(rng, N, NA, Li, Lqa, holes)
+    t = ragged.RaggedTables(qa, fl, halo)
+    idx = t.compact_index()
+    # every live (n, a, i, w) exactly once, in (n, a, i, w) order
+    want = [(n, a, i, w) for n in range(N) for a in range(NA) for i in range(Li) if fl[n, i]
+            for w in range(int(t.Lc[n * NA + a]))]
+    assert [tuple(r) for r in idx.tolist()] == want
+    assert t.U == len(want) and t.S == t.seq.shape[0]
+    # Lc: last valid word + 1 + halo, clipped; 0 for a candidate without a valid word
+    for g in range(N * NA):
+        v = np.nonzero(qa[g // NA, g % NA])[0]
+        assert int(t.Lc[g]) == (0 if v.size == 0 else min(Lqa, int(v[-1]) + 1 + halo))
+    # frame-compact rows: distinct, inside the tensor, never in a dump slot
+    ri = t.rowinfo_host()
+    slots, first = t.fmap[N * Li: N * Li + N], t.fmap[N * Li + N:]
+    dump = {int(first[n] + a * slots[n] + slots[n] - 1) for n in range(N) for a in range(NA)}
+    fc_seq = ri[:, 1] // Lqa
+    assert len(set(ri[:, 1].tolist())) == t.U and ri[:, 1].max(initial=-1) < t.Fc
+    assert not (set(fc_seq.tolist()) & dump) and len(dump) == N * NA
+    assert t.Fc == NA * int(slots.sum()) * Lqa
+    # rowinfo agrees with the index: QA row, dense output row, word
+    n_, a_, i_, w_ = idx.T
+    assert np.array_equal(ri[:, 0], (n_ * NA + a_) * Lqa + w_)
+    assert np.array_equal(ri[:, 2], (n_ * NA + a_) * Li + i_)
+    assert np.array_equal(ri[:, 3], w_)
+    # the frame map: slot of a live frame = its rank among the live frames of its example; dead frames negative
+    fm = t.fmap[: N * Li].reshape(N, Li)
+    for n in range(N):
+        assert fm[n][fl[n]].tolist() == list(range(int(fl[n].sum()))) and (fm[n][~fl[n]] < 0).all()
+    # frame-compact row of (n, a, live frame slot s, w)
+    assert np.array_equal(ri[:, 1], (first[n_] + a_ * slots[n_] + fm[n_, i_]) * Lqa + w_)
+
+
+def test_layout_uploads_and_aligns():
+    rng = np.random.default_rng(7)
+    qa, fl = _masks(rng, 2, 5, 4, 9)
+    t = ragged.RaggedTables(qa, fl, 4)
+    lay = ragged.RaggedLayout(t, "cpu")
+    assert lay.Ucap >= lay.U and lay.Ucap % ragged.CAP_STEP == 0
+    assert np.array_equal(lay.fmap.numpy(), t.fmap) and np.array_equal(lay.gdesc.numpy().reshape(-1, 4), t.gdesc)
+    assert np.array_equal(lay.seq.numpy().reshape(-1, 4), t.seq) and np.array_equal(lay.seqfc.numpy(), t.seqfc)
+    for v in (lay.gdesc, lay.seq, lay.seqfc):           # int4 loads on the device
+        assert (v.data_ptr() - lay.tables.data_ptr()) % 16 == 0
+
+
+def test_host_masks_from_batch_and_device():
+    from tvqaplus_amd.synth import make_batch
+    b = make_batch(N=2, Li=5, Lr=4, Lw=6, Lqa=7, wd_size=8, vfeat_size=8, seed=3, empty_frames=True)
+    qa, fl = ragged.host_masks(b, "vid")
+    qa2, fl2 = ragged.masks_from_device(b.qas_mask, b.vid_mask)
+    assert np.array_equal(qa, qa2) and np.array_equal(fl, fl2)
+    assert not np.array_equal(fl, ragged.host_masks(b, "sub")[1])      # the blanked video frame is live in the subtitle stream
+
+
+@pytest.mark.parametrize("k,n_conv", [(5, 2), (3, 3), (7, 1)])
+def test_live_rows_are_all_the_reference_needs(k, n_conv):
+    """fp64, the oracle's encoder: dense (reference semantics) against the live-row computation."""
+    torch.manual_seed(11)
+    rng = np.random.default_rng(11)
+    N, NA, Li, Lqa, D = 2, 3, 4, 14, 8
+    qa, fl = _masks(rng, N, NA, Li, Lqa, holes=True)
+    halo = ragged.conv_halo(1, n_conv, k)
+    t = ragged.RaggedTables(qa, fl, halo)
+    key = "cls_encoder.stacked_encoderBlocks.0"
+    P = {key + ".position_encoding.pe": O.position_table({}, "none", 500, D).double() if False else None}
+    # parameters of one encoder block (names as in the reference's state_dict)
+    from tvqaplus_amd.stage import _PositionTable
+    P = {key + ".position_encoding.pe": _PositionTable.table(500, D).double()}
+    for i in range(n_conv):
+        P[f"{key}.layer_norm.{i}.weight"] = (1 + 0.1 * torch.randn(D)).double()
+        P[f"{key}.layer_norm.{i}.bias"] = (0.1 * torch.randn(D)).double()
+        P[f"{key}.conv.{i}.depthwise_conv.weight"] = (0.5 * torch.randn(D, 1, k)).double()
+        P[f"{key}.conv.{i}.depthwise_conv.bias"] = (0.1 * torch.randn(D)).double()
+        P[f"{key}.conv.{i}.pointwise_conv.weight"] = (0.4 * torch.randn(D, D, 1)).double()
+        P[f"{key}.conv.{i}.pointwise_conv.bias"] = (0.1 * torch.randn(D)).double()
+    P[key + ".final_layer_norm.weight"] = (1 + 0.1 * torch.randn(D)).double()
+    P[key + ".final_layer_norm.bias"] = (0.1 * torch.randn(D)).double()
+    names = [n for n in P if not n.endswith(".pe")]
+
+    stmt = torch.randn(N, NA, Li, Lqa, D, dtype=torch.float64)
+    mask = torch.from_numpy(qa[:, :, None, :] & fl[:, None, :, None]).double()           # model/stage.py:386
+    w_out = torch.randn(N, NA, Li, D, dtype=torch.float64)                                # a fixed functional of the pooled output
+
+    def run_dense():
+        x = stmt.clone().requires_grad_(True)
+        Pd = {n: (v.clone().requires_grad_(True) if n in names else v) for n, v in P.items()}
+        y = O.encoder_block(x.view(N * NA * Li, Lqa, D), mask.view(-1, Lqa), Pd, key, n_conv, 0, 0.0, False)
+        mx = O.mask_logits(y, mask.view(-1, Lqa, 1)).max(dim=1)[0].view(N, NA, Li, D)
+        (mx * w_out).sum().backward()
+        return mx.detach(), x.grad, {n: Pd[n].grad for n in names}
+
+    def run_live():
+        x = stmt.clone().requires_grad_(True)
+        Pd = {n: (v.clone().requires_grad_(True) if n in names else v) for n, v in P.items()}
+        mx = torch.full((N, NA, Li, D), -1e10, dtype=torch.float64)
+        pieces = []
+        for s in range(t.S):
+            start, ln, g, dense = (int(v) for v in t.seq[s])
+            n, a, i = g // NA, g % NA, dense - g * Li
+            y = O.encoder_block(x[n, a, i, :ln].unsqueeze(0), mask[n, a, i, :ln].unsqueeze(0), Pd, key, n_conv, 0, 0.0, False)
+            pieces.append((n, a, i, O.mask_logits(y, mask[n, a, i, :ln].view(1, ln, 1)).max(dim=1)[0][0]))
+        tot = sum((p * w_out[n, a, i]).sum() for n, a, i, p in pieces)
+        tot.backward()
+        for n, a, i, p in pieces:
+            mx[n, a, i] = p.detach()
+        return mx, x.grad, {n: Pd[n].grad for n in names}
+
+    mx_d, gx_d, gp_d = run_dense()
+    mx_l, gx_l, gp_l = run_live()
+    assert torch.equal(mx_d == -1e10, mx_l == -1e10)
+    assert torch.allclose(mx_d, mx_l, rtol=1e-12, atol=1e-12)
+    live = torch.zeros(N, NA, Li, Lqa, dtype=torch.bool)
+    for n, a, i, w in t.compact_index().tolist():
+        live[n, a, i, w] = True
+    assert float(gx_d[~live].abs().max()) == 0.0            # the reference's own gradient is exactly zero off the live rows
+    assert torch.allclose(gx_d, gx_l, rtol=1e-10, atol=1e-12)
+    for n in names:
+        assert torch.allclose(gp_d[n], gp_l[n], rtol=1e-9, atol=1e-11), n
+    # and the halo is tight: one word less is not enough whenever a padded word exists behind the valid ones
+    if (t.Lc < Lqa).any() and halo > 0:
+        t2 = ragged.RaggedTables(qa, fl, halo - 1)
+        assert t2.U < t.U

@@ -76,6 +76,11 @@ __device__ __forceinline__ unsigned cf_quad_bcast(unsigned v, int sel) {
 
 // MODE 0: rep == 1, tiles of 32 consecutive rows, grid-stride.  MODE 1: rep > 1, inner <= 32: one tile per frame (rows past `inner`
 // are padding).  MODE 2: rep > 1, inner == 40: per four frames, four main tiles + one rest tile (file comment).
+// MODE 3: RAGGED token rows (include/stage_hip.h): group g = (example, candidate) keeps gdesc[g] = (first compact row, live words
+// Lc <= 40, frame slots of its example = live frames + 1, first frame-compact sequence); its rows are [live frame][word < Lc]; dy /
+// mask / statistics are compact rows, b and db rows of the FRAME-COMPACT tensor (sequence * Lqa + word; db may alias b: a row is read
+// before it is written, by the same lane), `a` rows g * Lqa + word.  Lc <= 32 walks like MODE 1, longer groups like MODE 2 with
+// Lc - 32 rows in the rest tile; `inner` = Lqa (slab pitch), `rep` = the largest frame count (chunking).
 template <bool DROP, int MODE>
 __global__ __launch_bounds__(256, 2) void cf_bwd_kernel(const float* __restrict__ dy, const unsigned* __restrict__ rmask,
                                                         const uint4* __restrict__ wimg, const int* __restrict__ w_up_p,
@@ -83,8 +88,10 @@ __global__ __launch_bounds__(256, 2) void cf_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, float* __restrict__ da,
                                                         float* __restrict__ db, float* __restrict__ part, long M, int rep, int inner,
-                                                        int CH, int frames_per_chunk, uint64_t seed, uint32_t th, float inv_keep) {
+                                                        int CH, int frames_per_chunk, uint64_t seed, uint32_t th, float inv_keep,
+                                                        const int4* __restrict__ gdesc, long b_rows, long a_rows) {
     constexpr bool REP = MODE > 0;
+    constexpr bool RAG = MODE == 3;
     // LDS: A planes [ks][plane][lane] uint4 (16 KB) | row scale exponent fields [32] | row mean / rstd [32][2] | partial row
     //      statistics [wave][32][2]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -100,23 +107,35 @@ __global__ __launch_bounds__(256, 2) void cf_bwd_kernel(const float* __restrict_
     // per-load addresses cost two VGPRs each: 64 operand loads per tile spilled hundreds of registers); rows past the end read 0
     const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)(M * CF_D * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_mk = __builtin_amdgcn_make_buffer_rsrc((void*)rmask, 0, (int)(M * (CF_D / 32) * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)b, 0, (int)(M * CF_D * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a, 0, (int)((REP ? M / rep : M) * CF_D * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)b, 0, (int)((RAG ? b_rows : M) * CF_D * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a, 0, (int)((RAG ? a_rows : (REP ? M / rep : M)) * CF_D * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_mean = __builtin_amdgcn_make_buffer_rsrc((void*)mean, 0, (int)(M * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_rstd = __builtin_amdgcn_make_buffer_rsrc((void*)rstd, 0, (int)(M * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_db = __builtin_amdgcn_make_buffer_rsrc((void*)db, 0, (int)(M * CF_D * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_db = __builtin_amdgcn_make_buffer_rsrc((void*)db, 0, (int)((RAG ? b_rows : M) * CF_D * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_da = __builtin_amdgcn_make_buffer_rsrc((void*)da, 0, REP ? 0 : (int)(M * CF_D * 4), 0x00020000);
     // work of this workgroup.  REP: frames [f_beg, f_end) of group g; else tiles blockIdx.x, + gridDim.x, ...
     const long GR = REP ? (long)rep * inner : 0;
     int g = 0, f_beg = 0, f_end = 0;
     long n_tiles;
+    long rg_row0 = 0, rg_seq0 = 0;                        // RAG: first compact row / first frame-compact sequence of the group
+    int rg_lc = 0;                                        //      live words per frame
+    bool rg_big = false;
     if (REP) {
         g = blockIdx.x / CH;
         const int ch = blockIdx.x % CH;
         f_beg = ch * frames_per_chunk;
-        f_end = min(rep, f_beg + frames_per_chunk);
+        int frames = rep;
+        if (RAG) {
+            const int4 gd = gdesc[g];
+            rg_row0 = __builtin_amdgcn_readfirstlane(gd.x);
+            rg_lc = __builtin_amdgcn_readfirstlane(gd.y);
+            frames = rg_lc > 0 ? __builtin_amdgcn_readfirstlane(gd.z) - 1 : 0;
+            rg_seq0 = __builtin_amdgcn_readfirstlane(gd.w);
+            rg_big = rg_lc > 32;
+        }
+        f_end = min(frames, f_beg + frames_per_chunk);
         const int nf = max(f_end - f_beg, 0);
-        n_tiles = MODE == 1 ? nf : 5l * ((nf + 3) / 4);
+        n_tiles = (MODE == 1 || (RAG && !rg_big)) ? nf : 5l * ((nf + 3) / 4);
     } else {
         const long all = (M + 31) / 32;
         n_tiles = all > (long)blockIdx.x ? (all - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
@@ -143,9 +162,31 @@ __global__ __launch_bounds__(256, 2) void cf_bwd_kernel(const float* __restrict_
     for (long it = 0; it < n_tiles; it++) {
         // ---- the tile: four passes of 8 rows; pass p covers rows pb[p] .. pb[p] + nv[p] - 1 (uniform values) ----
         long pb[4];
+        long pbB[4];                                      // the same passes in the rows of b / db (RAG: frame-compact rows)
         int nv[4];
         bool rest = false;                                // MODE 2: the tile that gathers rows 32..39 of four frames
-        if (MODE == 0) {
+        if (RAG) {
+            if (!rg_big) {
+                const long f = f_beg + it;
+#pragma unroll
+                for (int p2 = 0; p2 < 4; p2++) {
+                    pb[p2] = rg_row0 + f * rg_lc + 8 * p2;
+                    pbB[p2] = (rg_seq0 + f) * inner + 8 * p2;
+                    nv[p2] = max(0, min(8, rg_lc - 8 * p2));
+                }
+            } else {
+                const int quad = (int)(it / 5), k = (int)(it - 5l * quad);
+                rest = k == 4;
+                const int f0 = f_beg + 4 * quad;
+#pragma unroll
+                for (int p2 = 0; p2 < 4; p2++) {
+                    const int f = rest ? f0 + p2 : f0 + k;
+                    pb[p2] = rg_row0 + (long)f * rg_lc + (rest ? 32 : 8 * p2);
+                    pbB[p2] = (rg_seq0 + f) * inner + (rest ? 32 : 8 * p2);
+                    nv[p2] = f < f_end ? (rest ? rg_lc - 32 : 8) : 0;
+                }
+            }
+        } else if (MODE == 0) {
             const long t0 = ((long)blockIdx.x + it * gridDim.x) * 32;
 #pragma unroll
             for (int p2 = 0; p2 < 4; p2++) { pb[p2] = t0 + 8 * p2; nv[p2] = (int)max(0l, min(8l, M - pb[p2])); }
@@ -163,6 +204,10 @@ __global__ __launch_bounds__(256, 2) void cf_bwd_kernel(const float* __restrict_
                 pb[p2] = (long)g * GR + (long)f * inner + (rest ? 32 : 8 * p2);
                 nv[p2] = f < f_end ? 8 : 0;
             }
+        }
+        if (!RAG) {
+#pragma unroll
+            for (int p2 = 0; p2 < 4; p2++) pbB[p2] = pb[p2];
         }
         // (with a loop-invariant `inner` the optimiser would hoist the 16 per-slot validity selects out of the tile loop and hold
         // them in registers -- which then spill; behind an empty asm the counts look loop-variant)
@@ -231,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void cf_bwd_kernel(const float* __restrict_
         float av[16], bv[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int so = (int)(pb[r >> 2] * CF_D * 4) + (r & 3) * CF_D * 4;       // uniform
+            const int so = (int)(pbB[r >> 2] * CF_D * 4) + (r & 3) * CF_D * 4;       // uniform
             if (!REP) av[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_a, vo_row, so, 0));
             bv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_b, vo_row, so, 0));
         }
@@ -300,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void cf_bwd_kernel(const float* __restrict_
             // phase (16 registers fewer across it: the gradient of `a` already occupies 20)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int pos0 = MODE == 1 ? 8 * (r >> 2) : (rest ? 32 : 8 * (r >> 2));   // uniform; + (r & 3) + 4 h
+                const int pos0 = MODE == 1 ? 8 * (r >> 2) : (rest ? 32 : 8 * (r >> 2));   // uniform; + (r & 3) + 4 h  (RAG: rest is false for short groups)
                 av[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_a, vo_row, (g * inner + pos0 + (r & 3)) * CF_D * 4, 0));
             }
         }
@@ -368,12 +413,12 @@ __global__ __launch_bounds__(256, 2) void cf_bwd_kernel(const float* __restrict_
                 }
                 // z = [a, b, a*b]:  da = dz0 + dz2 * b ; db = dz1 + dz2 * a
                 const float da_v = dz[0] + dz[2] * bv[r], db_v = dz[1] + dz[2] * av[r];
-                const int so = (int)(pb[r >> 2] * CF_D * 4) + (r & 3) * CF_D * 4;
+                const int so = (int)(pbB[r >> 2] * CF_D * 4) + (r & 3) * CF_D * 4;
                 // straight-line stores: an invalid slot (a row of the next frame / past the end) gets an out-of-range lane offset
                 // and is dropped by the descriptor's bounds check
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(db_v), rs_db, ok ? vo_row : 0x7ffffff0, so, 0);
                 if (!REP) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(da_v), rs_da, ok ? vo_row : 0x7ffffff0, so, 0);
-                else if (MODE == 2 && rest) dacc_rest[r & 3] += ok ? da_v : 0.f;
+                else if (MODE >= 2 && rest) dacc_rest[r & 3] += ok ? da_v : 0.f;
                 else dacc[r] += ok ? da_v : 0.f;
                 if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
@@ -399,6 +444,11 @@ __global__ __launch_bounds__(256, 2) void cf_bwd_kernel(const float* __restrict_
         if (MODE == 2) {
 #pragma unroll
             for (int r = 0; r < 4; r++) dst[(32 + r + h4) * CF_D + c] = dacc_rest[r];
+        }
+        if (RAG) {                                        // every one of the Lqa (<= 40) positions is written: zeros past the live words
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (32 + r + h4 < inner) dst[(32 + r + h4) * CF_D + c] = dacc_rest[r];
         }
     }
 }
@@ -481,7 +531,7 @@ extern "C" int stage_cat3_dx_ln_bwd(const float* dy, const unsigned* relu_mask, 
     }
 #define CF_LAUNCH(DR, MD)                                                                                                          \
     hipLaunchKernelGGL((cf_bwd_kernel<DR, MD>), dim3(grid), dim3(256), lds, st, dy, relu_mask, img, w_up, a, b, mean, rstd, gamma,    \
-                       da_out, db, part, (long)rows, rep, inner, CH, fpc, (uint64_t)seed, th, inv_keep)
+                       da_out, db, part, (long)rows, rep, inner, CH, fpc, (uint64_t)seed, th, inv_keep, (const int4*)nullptr, 0l, 0l)
     if (drop) { if (mode == 0) CF_LAUNCH(true, 0); else if (mode == 1) CF_LAUNCH(true, 1); else CF_LAUNCH(true, 2); }
     else { if (mode == 0) CF_LAUNCH(false, 0); else if (mode == 1) CF_LAUNCH(false, 1); else CF_LAUNCH(false, 2); }
 #undef CF_LAUNCH
@@ -491,6 +541,58 @@ extern "C" int stage_cat3_dx_ln_bwd(const float* dy, const unsigned* relu_mask, 
     STAGE_LAUNCH_CHECK();
     if (rep > 1) return stage_reduce_rep(da_out, da, groups, CH, (long long)inner * CF_D, st);
     return 0;
+}
+
+// ---- ragged token rows (MODE 3) -------------------------------------------------------------------------------------
+extern "C" int stage_cat3_dx_ln_bwd_rag_supported(long long rows, long long fc_rows, int D, int groups, int max_frames, int Lqa) {
+    if (getenv("STAGE_NO_CAT3_FUSED")) return 0;
+    return (D == CF_D && rows >= 1 && rows * (long long)D * 4 < (1ll << 31) && fc_rows * (long long)D * 4 < (1ll << 31) && groups >= 1 &&
+            max_frames >= 1 && Lqa >= 1 && Lqa <= 40) ? 1 : 0;
+}
+extern "C" size_t stage_cat3_dx_ln_bwd_rag_ws_bytes(int groups, int max_frames, int Lqa) {
+    int CH, fpc;
+    cf_chunks(groups, max_frames, 2, &CH, &fpc);
+    const size_t wg = (size_t)groups * CH;
+    size_t b = cf_align((size_t)CF_WFRAG * sizeof(uint4)) + 256;
+    b += cf_align(wg * 2 * 3 * CF_D * sizeof(float));
+    b += cf_align(wg * (size_t)Lqa * CF_D * sizeof(float));
+    return b;
+}
+// As stage_cat3_dx_ln_bwd with a broadcast `a`, on ragged token rows: dy / relu_mask / mean / rstd are compact (rows), b_fc and db_fc
+// rows of the frame-compact tensor (fc_rows; db_fc may be b_fc itself), a and da (groups, Lqa, D); gdesc: see cf_bwd_kernel MODE 3.
+extern "C" int stage_cat3_dx_ln_bwd_rag(const float* dy, const unsigned* relu_mask, const float* W, const float* a, const float* b_fc,
+                                        const float* mean, const float* rstd, const float* gamma, float* da, float* db_fc,
+                                        float* dgamma, float* dbeta, const int* gdesc, long long rows, long long fc_rows, int D,
+                                        int groups, int max_frames, int Lqa, float p_drop, unsigned long long seed, void* ws,
+                                        size_t ws_bytes, void* stream) {
+    if (!stage_cat3_dx_ln_bwd_rag_supported(rows, fc_rows, D, groups, max_frames, Lqa)) return STAGE_ERR_SHAPE;
+    if (ws_bytes < stage_cat3_dx_ln_bwd_rag_ws_bytes(groups, max_frames, Lqa)) return STAGE_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* wsp = (char*)ws;
+    uint4* img = (uint4*)wsp;
+    int* w_up = (int*)(wsp + cf_align((size_t)CF_WFRAG * sizeof(uint4)));
+    wsp += cf_align((size_t)CF_WFRAG * sizeof(uint4)) + 256;
+    hipLaunchKernelGGL(cf_prep_w_kernel, dim3(6), dim3(1024), 0, st, W, img, w_up);
+    const uint32_t th = drop_thresh16(p_drop);
+    const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const int K3 = 3 * CF_D;
+    int CH, fpc;
+    cf_chunks(groups, max_frames, 2, &CH, &fpc);
+    const int grid = groups * CH;
+    float* part = (float*)wsp;
+    wsp += cf_align((size_t)grid * 2 * K3 * sizeof(float));
+    float* da_out = (float*)wsp;                               // slabs [G][CH][Lqa][D]
+    const size_t lds = (size_t)CF_KS * 2 * 64 * 16 + (size_t)32 * (4 + 8 + 32);
+#define CF_LAUNCH3(DR)                                                                                                                \
+    hipLaunchKernelGGL((cf_bwd_kernel<DR, 3>), dim3(grid), dim3(256), lds, st, dy, relu_mask, img, w_up, a, b_fc, mean, rstd, gamma,    \
+                       da_out, db_fc, part, (long)rows, max_frames, Lqa, CH, fpc, (uint64_t)seed, th, inv_keep, (const int4*)gdesc,    \
+                       (long)fc_rows, (long)groups * Lqa)
+    if (p_drop > 0.f) CF_LAUNCH3(true); else CF_LAUNCH3(false);
+#undef CF_LAUNCH3
+    STAGE_LAUNCH_CHECK();
+    stage_colreduce2(part, dgamma, 2 * K3, K3, part + K3, dbeta, 2 * K3, K3, grid, st);
+    STAGE_LAUNCH_CHECK();
+    return stage_reduce_rep(da_out, da, groups, CH, (long long)Lqa * CF_D, st);
 }
 
 // =====================================================================================================================
@@ -540,14 +642,17 @@ __global__ __launch_bounds__(1024) void cff_prep_w_kernel(const float* __restric
     }
 }
 
-template <bool DROP>
+// RAG: ragged token rows (include/stage_hip.h): row r of the compact output takes a[rowinfo[r].x] and b[rowinfo[r].y] (the QA row of
+// its word / its row in the frame-compact attention output); a has a_rows rows, b has b_rows.
+template <bool DROP, bool RAG = false>
 __global__ __launch_bounds__(256, 3) void cff_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const uint4* __restrict__ wimg, const int* __restrict__ w_up_p,
                                                          const float* __restrict__ bias, float* __restrict__ z,
                                                          float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ y,
                                                          unsigned* __restrict__ mask_out, long M, int rep, int inner, float eps,
-                                                         uint64_t seed, uint32_t th, float inv_keep) {
+                                                         uint64_t seed, uint32_t th, float inv_keep,
+                                                         const int4* __restrict__ rowinfo = nullptr, long a_rows = 0, long b_rows = 0) {
     // LDS: A planes [ks][plane][lane] uint4 (48 KB) | row scale exponent fields [32]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4* Ap = reinterpret_cast<uint4*>(smem_raw);
@@ -557,8 +662,8 @@ __global__ __launch_bounds__(256, 3) void cff_fwd_kernel(const float* __restrict
     constexpr int K3 = 3 * CF_D, K4 = K3 / 4, D4 = CF_D / 4;
     const float invK = 1.0f / (float)K3;
     const long GR = (long)rep * inner;
-    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)b, 0, (int)(M * CF_D * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a, 0, (int)((M / rep) * CF_D * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)b, 0, (int)((RAG ? b_rows : M) * CF_D * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a, 0, (int)((RAG ? a_rows : M / rep) * CF_D * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc((void*)z, 0, (int)(M * K3 * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)(M * CF_D * 4), 0x00020000);
     const int sj = tid >> 5, sl = tid & 31;               // staging: row inside a pass, float4 index inside each third
@@ -589,6 +694,19 @@ __global__ __launch_bounds__(256, 3) void cff_fwd_kernel(const float* __restrict
         // at most three conditional subtractions (inner >= 11)
         const long g0 = rep > 1 ? t0 / GR : 0;
         const int r0 = rep > 1 ? (int)(t0 - g0 * GR) : 0, p0 = rep > 1 ? r0 % inner : 0;
+        if (RAG) {
+            int2 ri[4];
+#pragma unroll
+            for (int pass = 0; pass < 4; pass++) {
+                const long rc = min(t0 + 8 * pass + sj, M - 1);          // rows past the end: any valid pair (their results are dropped)
+                ri[pass] = *reinterpret_cast<const int2*>(rowinfo + rc);
+            }
+#pragma unroll
+            for (int pass = 0; pass < 4; pass++) {
+                ra[pass] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, ri[pass].x * (CF_D * 4) + 16 * sl, 0, 0);
+                rb[pass] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, ri[pass].y * (CF_D * 4) + 16 * sl, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int pass = 0; pass < 4; pass++) {
             const int rl = 8 * pass + sj;
@@ -724,6 +842,11 @@ extern "C" int stage_cat3_ln_gemm_fwd_supported(long long rows, int D, int rep, 
             rows % ((long long)rep * inner) == 0) ? 1 : 0;
 }
 extern "C" size_t stage_cat3_ln_gemm_fwd_ws_bytes(void) { return cf_align((size_t)CFF_WFRAG * sizeof(uint4)) + 256; }
+extern "C" int stage_cat3_ln_gemm_fwd_rag_supported(long long rows, long long a_rows, long long b_rows, int D) {
+    if (getenv("STAGE_NO_CAT3_FUSED") || getenv("STAGE_NO_CAT3_FUSED_FWD")) return 0;
+    return (D == CF_D && rows >= 1 && rows * 3ll * D * 4 < (1ll << 31) && a_rows >= 1 && a_rows * (long long)D * 4 < (1ll << 31) &&
+            b_rows >= 1 && b_rows * (long long)D * 4 < (1ll << 31)) ? 1 : 0;
+}
 
 // z (rows, 3D), mean / rstd (rows), y (rows, D) = ReLU(z W^T + bias), relu_mask_out [D/32][rows] (as stage_gemm_nt_mask).  W (D, 3D).
 extern "C" int stage_cat3_ln_gemm_fwd(const float* a, const float* b, const float* gamma, const float* beta, const float* W,
@@ -750,10 +873,44 @@ extern "C" int stage_cat3_ln_gemm_fwd(const float* a, const float* b, const floa
     }
     if (p_drop > 0.f)
         hipLaunchKernelGGL(cff_fwd_kernel<true>, dim3(grid), dim3(256), lds, st, a, b, gamma, beta, img, w_up, bias, z, mean, rstd, y,
-                           relu_mask_out, (long)rows, rep, inner, eps, (uint64_t)seed, th, inv_keep);
+                           relu_mask_out, (long)rows, rep, inner, eps, (uint64_t)seed, th, inv_keep, (const int4*)nullptr, 0l, 0l);
     else
         hipLaunchKernelGGL(cff_fwd_kernel<false>, dim3(grid), dim3(256), lds, st, a, b, gamma, beta, img, w_up, bias, z, mean, rstd, y,
-                           relu_mask_out, (long)rows, rep, inner, eps, (uint64_t)seed, th, inv_keep);
+                           relu_mask_out, (long)rows, rep, inner, eps, (uint64_t)seed, th, inv_keep, (const int4*)nullptr, 0l, 0l);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+// The same on ragged token rows: row r of z / mean / rstd / y / relu_mask_out (rows) is built from a[rowinfo[r].x] (a_rows x D) and
+// b[rowinfo[r].y] (b_rows x D); rowinfo (rows, 4) int32 from stage_rag_rowinfo.
+extern "C" int stage_cat3_ln_gemm_fwd_rag(const float* a, const float* b, const float* gamma, const float* beta, const float* W,
+                                          const float* bias, float* z, float* mean, float* rstd, float* y, unsigned* relu_mask_out,
+                                          const int* rowinfo, long long rows, long long a_rows, long long b_rows, int D, float eps,
+                                          float p_drop, unsigned long long seed, void* ws, size_t ws_bytes, void* stream) {
+    if (!stage_cat3_ln_gemm_fwd_rag_supported(rows, a_rows, b_rows, D) || !rowinfo) return STAGE_ERR_SHAPE;
+    if (ws_bytes < stage_cat3_ln_gemm_fwd_ws_bytes()) return STAGE_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    uint4* img = (uint4*)ws;
+    int* w_up = (int*)((char*)ws + cf_align((size_t)CFF_WFRAG * sizeof(uint4)));
+    hipLaunchKernelGGL(cff_prep_w_kernel, dim3(6), dim3(1024), 0, st, W, img, w_up);
+    const uint32_t th = drop_thresh16(p_drop);
+    const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const size_t lds = (size_t)CFF_KS * 2 * 64 * 16 + 32 * 4;
+    const long tiles = (long)((rows + 31) / 32);
+    static const long grid_cap = getenv("STAGE_CFF_GRID") ? atol(getenv("STAGE_CFF_GRID")) : 3072;
+    const int grid = (int)(tiles < grid_cap ? tiles : grid_cap);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)cff_fwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void*)cff_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_done = true;
+    }
+    if (p_drop > 0.f)
+        hipLaunchKernelGGL((cff_fwd_kernel<true, true>), dim3(grid), dim3(256), lds, st, a, b, gamma, beta, img, w_up, bias, z, mean, rstd, y,
+                           relu_mask_out, (long)rows, 1, 1, eps, (uint64_t)seed, th, inv_keep, (const int4*)rowinfo, (long)a_rows, (long)b_rows);
+    else
+        hipLaunchKernelGGL((cff_fwd_kernel<false, true>), dim3(grid), dim3(256), lds, st, a, b, gamma, beta, img, w_up, bias, z, mean, rstd, y,
+                           relu_mask_out, (long)rows, 1, 1, eps, (uint64_t)seed, th, inv_keep, (const int4*)rowinfo, (long)a_rows, (long)b_rows);
     STAGE_LAUNCH_CHECK();
     return 0;
 }

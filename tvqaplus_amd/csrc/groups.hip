@@ -619,6 +619,206 @@ extern "C" int stage_grp_temporal_head_bwd(const float* d_first, const float* d_
 }
 
 // =====================================================================================================================
+// RAGGED TOKEN ROWS (csrc/ragged.hip, include/stage_hip.h): the groups that touch the (N, 5, Li, Lqa, .) tensors, on live rows only.
+//   U = live (compact) rows, Ucap >= U the row count the caller sized the arena for (a few distinct sizes per run instead of one per
+//   batch), Fc = rows of the frame-compact attention output (incl. the dump slots), T = device int32 tables:
+//     T[0] fmap   [N*Li] slot of every frame (< 0: dead) | [N] slots of the example | [N] first sequence of the example
+//     T[1] gdesc  (N*NA, 4): first compact row, live words Lc, slots, first frame-compact sequence
+//     T[2] seq    (S, 4): first compact row, length, group g, dense output row g*Li + i         (one per (group, live frame))
+//     T[3] rowinfo (U, 4) from stage_rag_rowinfo
+// G3r  as G3; `mixed` is (U, D) compact, S_raw / S_norm stay dense.  The backward overwrites the arena's copy of the attention
+//      output with its gradient (in place: a row is read before it is written): ONE backward per forward.
+// G2r  as G2 pooled: x (U, D) compact, out (N*NA*Li, D) dense; n_conv >= 1; the word mask comes from qa_mask (N*NA, Lqa).
+// =====================================================================================================================
+namespace {
+struct QaRagArena { float *Cn, *A, *z, *mean, *rstd; unsigned* mask; void* fwd_ws; size_t bytes; };
+QaRagArena qa_rag_layout(void* base, int N, int NA, int Lqa, int D, long long Ucap, long long Fc) {
+    Bump b{(char*)base, 0};
+    QaRagArena a;
+    a.Cn = b.take<float>((size_t)N * NA * Lqa * D);
+    a.A = b.take<float>((size_t)Fc * D);
+    a.z = b.take<float>((size_t)Ucap * 3 * D);
+    a.mean = b.take<float>((size_t)Ucap);
+    a.rstd = b.take<float>((size_t)Ucap);
+    a.mask = b.take<unsigned>(lin_mask_words(Ucap, D));
+    a.fwd_ws = b.take<char>(stage_cat3_ln_gemm_fwd_ws_bytes());
+    a.bytes = b.off;
+    return a;
+}
+struct QaRagTmp { float *Qn, *dQn, *dCn, *wt; void* ws; size_t wsb, bytes; };
+QaRagTmp qa_rag_tmp(void* base, int N, int NA, int Li, int Lqa, int Lr, int D, long long Ucap) {
+    Bump b{(char*)base, 0};
+    QaRagTmp t;
+    const size_t Qe = (size_t)N * Li * Lr * D;
+    t.Qn = b.take<float>(Qe);
+    t.dQn = b.take<float>(Qe);
+    t.dCn = b.take<float>((size_t)N * NA * Lqa * D);
+    t.wt = b.take<float>((size_t)3 * D * D);
+    t.wsb = umax(lin_bwd_ws(Ucap, D, 3 * D), stage_cat3_dx_ln_bwd_rag_ws_bytes(N * NA, Li, Lqa));
+    t.wsb = umax(t.wsb, stage_str_attn_bwd_fused_ws_bytes(N, NA, Li, Lqa, D));
+    t.ws = b.take<char>(t.wsb);
+    t.bytes = b.off;
+    return t;
+}
+bool qa_rag_ok(int N, int NA, int Li, int Lqa, int Lr, int D, long long U, long long Fc) {
+    return N > 0 && NA > 0 && Li > 0 && U > 0 && D == 128 && Lr >= 2 && Lr <= 64 && (Lr & 1) == 0 && Lqa >= 4 && Lqa <= 40 && NA * Lqa <= 256 &&
+           (long long)NA * (Li + 1) * Lqa * D < (1ll << 29) && stage_cat3_ln_gemm_fwd_rag_supported(U, (long long)N * NA * Lqa, Fc, D) &&
+           stage_cat3_dx_ln_bwd_rag_supported(U, Fc, D, N * NA, Li, Lqa) &&
+           stage_gemm_mask_supported(U > 4096 ? U : 4096, D, 3 * D);   // (off in the exact-fp32 / no-mask developer modes; any row count)
+}
+}  // namespace
+
+extern "C" int stage_grp_qa_ctx_rag_supported(int N, int NA, int Li, int Lqa, int Lr, int D, long long U, long long Fc) {
+    return qa_rag_ok(N, NA, Li, Lqa, Lr, D, U, Fc) ? 1 : 0;
+}
+extern "C" size_t stage_grp_qa_ctx_rag_arena_bytes(int N, int NA, int Lqa, int D, long long Ucap, long long Fc) {
+    return qa_rag_layout(nullptr, N, NA, Lqa, D, Ucap, Fc).bytes;
+}
+extern "C" size_t stage_grp_qa_ctx_rag_bwd_tmp_bytes(int N, int NA, int Li, int Lqa, int Lr, int D, long long Ucap) {
+    return qa_rag_tmp(nullptr, N, NA, Li, Lqa, Lr, D, Ucap).bytes;
+}
+
+extern "C" int stage_grp_qa_ctx_rag_fwd(const float* qa, const float* ctx, const float* qa_mask, const float* ctx_mask,
+                                        const float* const* P, float* mixed, float* S_raw, float* S_norm, const int* const* T,
+                                        void* arena, size_t arena_bytes, int* flags, int N, int NA, int Li, int Lqa, int Lr, int D,
+                                        long long U, long long Ucap, long long Fc, float scale, float p,
+                                        const unsigned long long* seeds, void* st) {
+    if (!qa_rag_ok(N, NA, Li, Lqa, Lr, D, U, Fc) || Ucap < U || !al16(P[2])) return STAGE_ERR_SHAPE;
+    QaRagArena a = qa_rag_layout(arena, N, NA, Lqa, D, Ucap, Fc);
+    if (arena_bytes < a.bytes) return STAGE_ERR_WORKSPACE;
+    TRY(stage_l2norm_fwd(qa, a.Cn, nullptr, (long long)N * NA * Lqa, D, EPS_L2, p, seeds[0], st));
+    TRY(stage_str_attn_fwd_fc(a.Cn, ctx, qa_mask, ctx_mask, a.A, S_raw, S_norm, T[0], N, NA, Li, Lqa, Lr, D, scale, p, seeds[1], st));
+    TRY(stage_cat3_ln_gemm_fwd_rag(qa, a.A, P[0], P[1], P[2], P[3], a.z, a.mean, a.rstd, mixed, a.mask, T[3], U, (long long)N * NA * Lqa, Fc,
+                                   D, EPS_LN, p, seeds[2], a.fwd_ws, stage_cat3_ln_gemm_fwd_ws_bytes(), st));
+    flags[0] = 1;
+    return 0;
+}
+
+// d_mixed (U, D) compact; dS_ext dense or NULL.  Outputs as stage_grp_qa_ctx_bwd.  The arena's attention output is overwritten.
+extern "C" int stage_grp_qa_ctx_rag_bwd(const float* d_mixed, const float* dS_ext, const float* qa, const float* ctx,
+                                        const float* ctx_mask, const float* mixed, const float* S_norm, const float* const* P,
+                                        float* const* G, float* d_qa, float* d_ctx, const int* const* T, void* arena,
+                                        size_t arena_bytes, const int* flags, void* tmp, size_t tmp_bytes, int N, int NA, int Li,
+                                        int Lqa, int Lr, int D, long long U, long long Ucap, long long Fc, float scale, float p,
+                                        const unsigned long long* seeds, void* st) {
+    (void)flags;
+    QaRagArena a = qa_rag_layout(arena, N, NA, Lqa, D, Ucap, Fc);
+    QaRagTmp t = qa_rag_tmp(tmp, N, NA, Li, Lqa, Lr, D, Ucap);
+    if (arena_bytes < a.bytes || tmp_bytes < t.bytes) return STAGE_ERR_WORKSPACE;
+    if (!al16(d_mixed)) return STAGE_ERR_SHAPE;
+    const long long Crows = (long long)N * NA * Lqa, Qrows = (long long)N * Li * Lr;
+    // weight / bias gradient of the Linear (contracts over the saved normalised concat), then its input gradient fused with the
+    // LayerNorm backward: da accumulated over the live frames, db written over the attention output it came from
+    TRY(lin_bwd(d_mixed, a.z, mixed, a.mask, 1, 1, P[2], t.wt, nullptr, G[2], G[3], U, D, 3 * D, t.ws, t.wsb, st));
+    TRY(stage_cat3_dx_ln_bwd_rag(d_mixed, a.mask, P[2], qa, a.A, a.mean, a.rstd, P[0], d_qa, a.A, G[0], G[1], T[1], U, Fc, D, N * NA, Li, Lqa,
+                                 p, seeds[2], t.ws, stage_cat3_dx_ln_bwd_rag_ws_bytes(N * NA, Li, Lqa), st));
+    TRY(stage_rag_zero_dump(a.A, T[0], N, NA, Li, Lqa, D, st));
+    TRY(stage_l2norm_fwd(ctx, t.Qn, nullptr, Qrows, D, EPS_L2, p, seeds[1], st));
+    TRY(stage_str_attn_bwd_fused_fc(a.A, dS_ext, a.Cn, ctx, t.Qn, S_norm, ctx_mask, d_ctx, t.dQn, t.dCn, T[0], N, NA, Li, Lqa, Lr, D, scale,
+                                    t.ws, stage_str_attn_bwd_fused_ws_bytes(N, NA, Li, Lqa, D), st));
+    TRY(stage_l2norm_bwd(t.dCn, qa, d_qa, Crows, D, EPS_L2, p, seeds[0], 1, st));
+    return stage_l2norm_bwd(t.dQn, ctx, d_ctx, Qrows, D, EPS_L2, p, seeds[1], 1, st);
+}
+
+namespace {
+EncArena enc_rag_layout(void* base, long long Ucap, long long Rd, int D, int n_conv) {
+    Bump b{(char*)base, 0};
+    EncArena a;
+    const size_t R = (size_t)Ucap;
+    for (int i = 0; i < n_conv; i++) {
+        a.h[i] = b.take<float>(R * D);
+        a.s[i] = b.take<float>(R * D);
+        a.mean[i] = b.take<float>(R);
+        a.rstd[i] = b.take<float>(R);
+        a.g[i] = b.take<float>(R * D);
+        a.mask[i] = b.take<unsigned>(lin_mask_words((long long)R, D));
+    }
+    a.sf = b.take<float>(R * D);
+    a.meanf = b.take<float>(R);
+    a.rstdf = b.take<float>(R);
+    a.yf = nullptr;
+    a.idx = b.take<int>((size_t)Rd * D);
+    a.bytes = b.off;
+    return a;
+}
+EncTmp enc_rag_tmp(void* base, long long Ucap, int D, int k) {
+    Bump b{(char*)base, 0};
+    EncTmp t;
+    const size_t R = (size_t)Ucap;
+    t.Ga = b.take<float>(R * D);
+    t.Gb = b.take<float>(R * D);
+    t.dh = b.take<float>(R * D);
+    t.dyf = nullptr;
+    t.wt = b.take<float>((size_t)D * D);
+    t.wsb = umax(umax(stage_ln_bwd_ws_bytes(D), stage_ln_dwconv_bwd_ws_bytes(D, k)), lin_bwd_ws(Ucap, D, D));
+    t.ws = b.take<char>(t.wsb);
+    t.bytes = b.off;
+    return t;
+}
+}  // namespace
+
+extern "C" size_t stage_grp_encoder_rag_arena_bytes(long long Ucap, long long Rd, int D, int n_conv) {
+    if (n_conv > ENC_MAX_CONV) return 0;
+    return enc_rag_layout(nullptr, Ucap, Rd, D, n_conv).bytes;
+}
+extern "C" size_t stage_grp_encoder_rag_bwd_tmp_bytes(long long Ucap, int D, int k) { return enc_rag_tmp(nullptr, Ucap, D, k).bytes; }
+
+// x (U, D) compact; pe (>= Lqa, D) position table; qa_mask (groups, Lqa); out (Rd, D) dense: the masked max over the words of every
+// (group, frame).  T as above (seq has S entries).
+extern "C" int stage_grp_encoder_rag_fwd(const float* x, const float* pe, const float* qa_mask, const float* const* P, float* out,
+                                         const int* const* T, void* arena, size_t arena_bytes, int* flags, long long U, long long Ucap,
+                                         long long S, long long Rd, int Lqa, int D, int n_conv, int k, float p,
+                                         const unsigned long long* seeds, void* st) {
+    if (U <= 0 || S <= 0 || Ucap < U || n_conv < 1 || n_conv > ENC_MAX_CONV || !ln_dwconv_ok(D, k) || D != 128 || Lqa < 1 || Lqa > 48)
+        return STAGE_ERR_SHAPE;
+    EncArena a = enc_rag_layout(arena, Ucap, Rd, D, n_conv);
+    if (arena_bytes < a.bytes) return STAGE_ERR_WORKSPACE;
+    const float* pending = x;
+    const float* cur = nullptr;
+    for (int i = 0; i < n_conv; i++) {
+        const float* const* Q = P + 6 * i;
+        const bool drop = (i % 2) == 0;
+        const unsigned long long seed = drop ? seeds[i / 2] : 0ull;
+        TRY(stage_ln_dwconv_rag_fwd(pending, cur, i == 0 ? pe : nullptr, a.s[i], Q[0], Q[1], Q[2], Q[3], a.h[i], a.mean[i], a.rstd[i], T[2], S,
+                                    Lqa, D, k, EPS_LN, drop ? p : 0.f, seed, st));
+        cur = a.s[i];
+        TRY(lin_fwd(a.h[i], Q[4], Q[5], a.g[i], a.mask[i], &flags[i], U, D, D, 1, st));
+        pending = a.g[i];
+    }
+    const float* const* F = P + 6 * n_conv;
+    flags[n_conv] = 1;
+    TRY(stage_rag_fill_pooled(out, a.idx, Rd, D, st));
+    return stage_ln_masked_max_rag_fwd(pending, cur, a.sf, F[0], F[1], qa_mask, out, a.idx, a.meanf, a.rstdf, T[2], S, Lqa, D, EPS_LN, st);
+}
+
+// dout (Rd, D) dense; dx (U, D) compact (may be NULL); grads in params order
+extern "C" int stage_grp_encoder_rag_bwd(const float* dout, const float* qa_mask, const float* const* P, float* const* Gr, float* dx,
+                                         const int* const* T, const void* arena, size_t arena_bytes, const int* flags, void* tmp,
+                                         size_t tmp_bytes, long long U, long long Ucap, long long S, long long Rd, int Lqa, int D,
+                                         int n_conv, int k, float p, const unsigned long long* seeds, void* st) {
+    if (n_conv < 1 || n_conv > ENC_MAX_CONV) return STAGE_ERR_SHAPE;
+    EncArena a = enc_rag_layout((void*)arena, Ucap, Rd, D, n_conv);
+    EncTmp t = enc_rag_tmp(tmp, Ucap, D, k);
+    if (arena_bytes < a.bytes || tmp_bytes < t.bytes) return STAGE_ERR_WORKSPACE;
+    const float* const* F = P + 6 * n_conv;
+    float* const* GF = Gr + 6 * n_conv;
+    float* G = t.Ga;
+    TRY(stage_ln_masked_max_rag_bwd(dout, a.idx, qa_mask, a.sf, a.meanf, a.rstdf, F[0], G, GF[0], GF[1], T[3], U, D, t.ws, stage_ln_bwd_ws_bytes(D), st));
+    for (int i = n_conv - 1; i >= 0; i--) {
+        const float* const* Q = P + 6 * i;
+        float* const* GQ = Gr + 6 * i;
+        const bool drop = (i % 2) == 0;
+        const unsigned long long seed = drop ? seeds[i / 2] : 0ull;
+        TRY(lin_bwd(G, a.h[i], a.g[i], a.mask[i], flags[i], 1, Q[4], t.wt, t.dh, GQ[4], GQ[5], U, D, D, t.ws, t.wsb, st));
+        float* Gn = (i == 0 && dx) ? dx : (G == t.Ga ? t.Gb : t.Ga);
+        TRY(stage_ln_dwconv_rag_bwd(t.dh, a.s[i], a.mean[i], a.rstd[i], Q[0], Q[1], Q[2], Gn, G, GQ[0], GQ[1], GQ[2], GQ[3], T[2], S, Lqa, D, k,
+                                    drop ? p : 0.f, seed, t.ws, stage_ln_dwconv_bwd_ws_bytes(D, k), st));
+        G = Gn;
+    }
+    return 0;
+}
+
+// =====================================================================================================================
 // Head glue: the small tensor algebra around the temporal scores, span proposals, pooling, classifier and the two auxiliary
 // losses (model/stage.py:389-467, 484-555, 613-746).  In the per-op path this is ~100 tiny ATen / HIP launches issued right
 // after the step's only host synchronisation (the proposal read-back), i.e. while the device has nothing else queued.

@@ -17,14 +17,18 @@
 
 // (up to five taps the kernel fits 128 registers -- four waves per SIMD instead of three: 398 / 357 -> 371 / 341 us at the classifier
 // encoder; with seven taps the cap spills 22-26 registers and doubles the run time)
-template <int KT, bool DROP, typename T = float>
+// RAG: ragged sequences (include/stage_hip.h "ragged token rows"): sequence m = seq[m] = (first row, length <= L, ., .) of a compact row
+// space; rows outside [0, length) are the conv's zero padding, exactly as the ends of a dense sequence are.  res_period > 0 then means
+// "res is a (L, D) position table": row ll of a sequence takes res[ll].
+template <int KT, bool DROP, typename T = float, bool RAG = false>
 __global__ __launch_bounds__(256, (KT <= 5 ? 4 : 1)) void ln_dwconv_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                             int res_period, T* __restrict__ sum_out,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ w, const float* __restrict__ bias,
                                                             T* __restrict__ h, float* __restrict__ mean,
                                                             float* __restrict__ rstd, long M, int L, int D, float eps,
-                                                            uint64_t seed, uint32_t th, float inv_keep, int clen) {
+                                                            uint64_t seed, uint32_t th, float inv_keep, int clen,
+                                                            const int4* __restrict__ seq = nullptr) {
     constexpr int pad = KT / 2;
     const int D4 = D >> 2, rpi = blockDim.x / D4;
     const int q = threadIdx.x % D4, rsub = threadIdx.x / D4;
@@ -38,20 +42,28 @@ __global__ __launch_bounds__(256, (KT <= 5 ? 4 : 1)) void ln_dwconv_fwd_kernel(c
     const long items = M * chunks;
     for (long it = (long)blockIdx.x * rpi + rsub; it < items; it += (long)gridDim.x * rpi) {
         const long m = it / chunks;
-        const int l0 = (int)(it % chunks) * clen, l1 = min(L, l0 + clen);
+        long sbase = m * L;                  // first row of the sequence
+        int Ls = L;                          // its length
+        if (RAG) {
+            const int4 sq = seq[m];
+            sbase = sq.x;
+            Ls = sq.y;
+        }
+        const int l0 = (int)(it % chunks) * clen, l1 = min(Ls, l0 + clen);
         // normalised (and dropped) row ll of sequence m is 0 outside the sequence.  Rows of this chunk also export the
         // sum and the statistics (every row is normalised by exactly one chunk as its own row, halo rows are recomputed).
         // Rows enter the window in batches: all loads of a batch first (clamped addresses), then the statistics (two
         // cross-lane reductions per row, independent chains), then the stores of the chunk's own rows -- a store or a
         // guarded load in the middle of the chain makes the compiler wait for every load before it.
         auto load_row = [&](int ll, float4& v) {
-            const long row = m * L + min(max(ll, 0), L - 1);
+            const int lc = min(max(ll, 0), max(Ls - 1, 0));
+            const long row = sbase + lc;
             v = ldv4(x + row * D + 4 * q);
-            if (res) v = f4add(v, ldv4(res + (res_period > 0 ? (long)((unsigned long)row % (unsigned)res_period) : row) * D + 4 * q));
+            if (res) v = f4add(v, ldv4(res + (res_period > 0 ? (RAG ? (long)lc : (long)((unsigned long)row % (unsigned)res_period)) : row) * D + 4 * q));
         };
         auto norm_row = [&](int ll, const float4& v, float& mu, float& rs) -> float4 {
-            const bool inside = ll >= 0 && ll < L;
-            const long row = m * L + min(max(ll, 0), L - 1);
+            const bool inside = ll >= 0 && ll < Ls;
+            const long row = sbase + min(max(ll, 0), max(Ls - 1, 0));
             mu = group_sum(f4hsum(v), D4) * invK;
             const float4 d = make_float4(v.x - mu, v.y - mu, v.z - mu, v.w - mu);
             rs = 1.0f / sqrtf(group_sum(f4hsum(f4mul(d, d)), D4) * invK + eps);
@@ -65,7 +77,7 @@ __global__ __launch_bounds__(256, (KT <= 5 ? 4 : 1)) void ln_dwconv_fwd_kernel(c
         };
         auto export_row = [&](int ll, const float4& v, float mu, float rs) {   // the chunk's own rows only
             if (ll >= l0 && ll < l1) {
-                const long row = m * L + ll;
+                const long row = sbase + ll;
                 if (sum_out) stv4(sum_out + row * D + 4 * q, v);
                 if (q == 0) {
                     mean[row] = mu;
@@ -101,7 +113,7 @@ __global__ __launch_bounds__(256, (KT <= 5 ? 4 : 1)) void ln_dwconv_fwd_kernel(c
                 float4 acc = bq;
 #pragma unroll
                 for (int t = 0; t < KT; t++) acc = f4add(acc, f4mul(win[t], wt[t]));
-                if (l + u < l1) stv4s(h + ((m * L + l + u) * D + 4 * q), acc);
+                if (l + u < l1) stv4s(h + ((sbase + l + u) * D + 4 * q), acc);
             }
         }
     }
@@ -109,14 +121,15 @@ __global__ __launch_bounds__(256, (KT <= 5 ? 4 : 1)) void ln_dwconv_fwd_kernel(c
 
 // dx = LN-backward(conv-backward(dh)) + dx_add ; partials of dw/db (conv) and dgamma/dbeta (LayerNorm) per workgroup.
 // (register caps for more waves per SIMD were measured here too: 168 registers spill 80-100 and run 4x slower)
-template <int KT, bool DROP, typename T = float>
+template <int KT, bool DROP, typename T = float, bool RAG = false>
 __global__ __launch_bounds__(256) void ln_dwconv_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ xin,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ w, T* __restrict__ dx,
                                                             const T* __restrict__ dx_add, float* __restrict__ part_conv,
                                                             float* __restrict__ part_ln, long M, int L, int D,
-                                                            uint64_t seed, uint32_t th, float inv_keep, int clen) {
+                                                            uint64_t seed, uint32_t th, float inv_keep, int clen,
+                                                            const int4* __restrict__ seq = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // reduction scratch [rpi][KT + 1][D]
     constexpr int pad = KT / 2;
     const int D4 = D >> 2, rpi = blockDim.x / D4;
@@ -133,11 +146,19 @@ __global__ __launch_bounds__(256) void ln_dwconv_bwd_kernel(const T* __restrict_
     const long items = M * chunks;
     for (long it = (long)blockIdx.x * rpi + rsub; it < items; it += (long)gridDim.x * rpi) {
         const long m = it / chunks;
-        const int l0 = (int)(it % chunks) * clen, l1 = min(L, l0 + clen);
+        long sbase = m * L;
+        int Ls = L;
+        if (RAG) {
+            const int4 sq = seq[m];
+            sbase = sq.x;
+            Ls = sq.y;
+        }
+        const int l0 = (int)(it % chunks) * clen, l1 = min(Ls, l0 + clen);
+        const int Lm1 = max(Ls - 1, 0);
         // recomputed LayerNorm output (after dropout) of row ll, 0 outside the sequence
         auto y_row = [&](int ll) -> float4 {
-            const bool inside = ll >= 0 && ll < L;
-            const long row = m * L + min(max(ll, 0), L - 1);
+            const bool inside = ll >= 0 && ll < Ls;
+            const long row = sbase + min(max(ll, 0), Lm1);
             const float4 v = ldv4(xin + row * D + 4 * q);
             const float mu = mean[row], rs = rstd[row];
             float4 o;
@@ -149,8 +170,8 @@ __global__ __launch_bounds__(256) void ln_dwconv_bwd_kernel(const T* __restrict_
             return inside ? o : f4zero();
         };
         auto dh_row = [&](int ll) -> float4 {
-            const bool inside = ll >= 0 && ll < L;
-            const float4 v = ldv4(dh + (m * L + min(max(ll, 0), L - 1)) * D + 4 * q);
+            const bool inside = ll >= 0 && ll < Ls;
+            const float4 v = ldv4(dh + (sbase + min(max(ll, 0), Lm1)) * D + 4 * q);
             return inside ? v : f4zero();
         };
         float4 wy[KT], wo[KT];   // wy[t] = y[l + t - pad], wo[t] = dh[l + t - pad]
@@ -168,7 +189,7 @@ __global__ __launch_bounds__(256) void ln_dwconv_bwd_kernel(const T* __restrict_
             for (int u = 0; u < 4; u++) {
                 ny[u] = y_row(l + u + pad);
                 no[u] = dh_row(l + u + pad);
-                const long row = m * L + min(l + u, L - 1);
+                const long row = sbase + min(l + u, Lm1);
                 cv[u] = ldv4(xin + row * D + 4 * q);
                 cmu[u] = mean[row];
                 crs[u] = rstd[row];
@@ -191,7 +212,7 @@ __global__ __launch_bounds__(256) void ln_dwconv_bwd_kernel(const T* __restrict_
                     din = f4add(din, f4mul(wo[KT - 1 - t], wt[t]));           // dy[l] += dh[l - t + pad] * w[t]
                 }
                 // LayerNorm backward of the row (same expressions as rowops.hip)
-                const long row = m * L + min(l + u, L - 1);
+                const long row = sbase + min(l + u, Lm1);
                 const float mu = cmu[u], rs = crs[u];
                 float4 dd = live ? din : f4zero();
                 if (DROP) dd = f4mul(dd, drop4(seed, (uint64_t)row * D4 + q, th, inv_keep));
@@ -287,7 +308,84 @@ extern "C" int stage_ln_dwconv_fwd_bf16(const void* x, const void* res, int res_
                               k, eps, p_drop, seed, stream);
 }
 
+// Ragged sequences: S sequences seq[s] = (first row, length <= Lmax, ., .) in a compact row space; pe != NULL: the (Lmax, D) position
+// table added to row ll of every sequence (the encoder's first LayerNorm), else res (compact rows, may be NULL) is added row by row.
+extern "C" int stage_ln_dwconv_rag_fwd(const float* x, const float* res, const float* pe, float* sum_out, const float* gamma,
+                                       const float* beta, const float* w, const float* bias, float* h, float* mean, float* rstd,
+                                       const int* seq, long long S, int Lmax, int D, int k, float eps, float p_drop,
+                                       unsigned long long seed, void* stream) {
+    if (S <= 0 || Lmax <= 0) return 0;
+    if (!ld_shape_ok(D, k) || (pe && res)) return STAGE_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int rpi = 256 / (D / 4);
+    const int clen = stage_chunk_len(Lmax);
+    const long items = (long)S * ((Lmax + clen - 1) / clen);
+    const int grid = stage_grid_for(items, rpi, LD_GRID_CAP);
+    const bool dr = p_drop > 0.f;
+    const uint64_t sd = dr ? (uint64_t)seed : 0;
+    const uint32_t th = dr ? drop_thresh16(p_drop) : 0u;
+    const float ik = dr ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const float* r = pe ? pe : res;
+    const int period = pe ? Lmax : 0;
+#define LD_FWD(KV, DR)                                                                                                       \
+    hipLaunchKernelGGL((ln_dwconv_fwd_kernel<KV, DR, float, true>), dim3(grid), dim3(256), 0, st, x, r, period, sum_out, gamma,  \
+                       beta, w, bias, h, mean, rstd, (long)S, Lmax, D, eps, sd, th, ik, clen, (const int4*)seq)
+    switch (k) {
+        case 1: if (dr) LD_FWD(1, true); else LD_FWD(1, false); break;
+        case 3: if (dr) LD_FWD(3, true); else LD_FWD(3, false); break;
+        case 5: if (dr) LD_FWD(5, true); else LD_FWD(5, false); break;
+        case 7: if (dr) LD_FWD(7, true); else LD_FWD(7, false); break;
+        default: if (dr) LD_FWD(9, true); else LD_FWD(9, false); break;
+    }
+#undef LD_FWD
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" size_t stage_ln_dwconv_bwd_ws_bytes(int D, int k) { return (size_t)LD_PART_CAP * (k + 3) * D * sizeof(float); }
+
+extern "C" int stage_ln_dwconv_rag_bwd(const float* dh, const float* xin, const float* mean, const float* rstd, const float* gamma,
+                                       const float* beta, const float* w, float* dx, const float* dx_add, float* dgamma,
+                                       float* dbeta, float* dw, float* db, const int* seq, long long S, int Lmax, int D, int k,
+                                       float p_drop, unsigned long long seed, void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!ld_shape_ok(D, k)) return STAGE_ERR_SHAPE;
+    if (ws_bytes < stage_ln_dwconv_bwd_ws_bytes(D, k)) return STAGE_ERR_WORKSPACE;
+    if (S <= 0 || Lmax <= 0) {
+        (void)hipMemsetAsync(dw, 0, sizeof(float) * D * k, st);
+        (void)hipMemsetAsync(db, 0, sizeof(float) * D, st);
+        (void)hipMemsetAsync(dgamma, 0, sizeof(float) * D, st);
+        (void)hipMemsetAsync(dbeta, 0, sizeof(float) * D, st);
+        return 0;
+    }
+    const int rpi = 256 / (D / 4);
+    const int clen = stage_chunk_len(Lmax);
+    const long items = (long)S * ((Lmax + clen - 1) / clen);
+    const int grid = stage_grid_for(items, rpi, LD_PART_CAP);
+    float* part_conv = (float*)ws;
+    float* part_ln = part_conv + (size_t)LD_PART_CAP * (k + 1) * D;
+    const size_t lds = (size_t)rpi * (k + 1) * D * sizeof(float);
+    const bool dr = p_drop > 0.f;
+    const uint64_t sd = dr ? (uint64_t)seed : 0;
+    const uint32_t th = dr ? drop_thresh16(p_drop) : 0u;
+    const float ik = dr ? 1.0f / (1.0f - p_drop) : 1.0f;
+#define LD_BWD(KV, DR)                                                                                                              \
+    hipLaunchKernelGGL((ln_dwconv_bwd_kernel<KV, DR, float, true>), dim3(grid), dim3(256), lds, st, dh, xin, mean, rstd, gamma, beta, w, \
+                       dx, dx_add, part_conv, part_ln, (long)S, Lmax, D, sd, th, ik, clen, (const int4*)seq)
+    switch (k) {
+        case 1: if (dr) LD_BWD(1, true); else LD_BWD(1, false); break;
+        case 3: if (dr) LD_BWD(3, true); else LD_BWD(3, false); break;
+        case 5: if (dr) LD_BWD(5, true); else LD_BWD(5, false); break;
+        case 7: if (dr) LD_BWD(7, true); else LD_BWD(7, false); break;
+        default: if (dr) LD_BWD(9, true); else LD_BWD(9, false); break;
+    }
+#undef LD_BWD
+    STAGE_LAUNCH_CHECK();
+    stage_colreduce(part_conv, dw, db, grid, (long)(k + 1) * D, (k + 1) * D, D, k, st);
+    stage_colreduce(part_ln, dgamma, dbeta, grid, (long)2 * D, 2 * D, D, 1, st);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
 
 template <typename T>
 static int ln_dwconv_bwd_t(const T* dh, const T* xin, const float* mean, const float* rstd, const float* gamma,

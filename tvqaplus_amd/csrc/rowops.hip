@@ -341,7 +341,9 @@ __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(RowSrcT<T> src, const 
                                                           T* __restrict__ db_out, float* __restrict__ part, long rows,
                                                           int K, int LPR, uint64_t seed, uint32_t th, float inv_keep,
                                                           const int* __restrict__ mm_idx = nullptr,
-                                                          const float* __restrict__ mm_mask = nullptr, int mm_L = 1) {
+                                                          const float* __restrict__ mm_mask = nullptr, int mm_L = 1,
+                                                          const int4* __restrict__ mm_rowinfo = nullptr) {
+    // mm_rowinfo != NULL (ragged token rows): row r belongs to group mm_rowinfo[r].z at position .w and its mask is mm_mask[.x]
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [wpb*RPW][2][K]
     constexpr int NQ = (MODE == 0) ? NQ0 : 3;
     constexpr int NX = (MODE == 0) ? NQ0 : 2;
@@ -382,9 +384,16 @@ __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(RowSrcT<T> src, const 
                 xv[u][1] = ldv4s(src.b + rc * D + 4 * sl);
             }
             if (MM) {
-                const long grp = rc / mm_L;
-                const int l = (int)(rc - grp * mm_L);
-                const float mk = mm_mask[rc];
+                long grp = rc / mm_L;
+                int l = (int)(rc - grp * mm_L);
+                long mrow = rc;
+                if (mm_rowinfo) {
+                    const int4 ri = mm_rowinfo[rc];
+                    grp = ri.z;
+                    l = ri.w;
+                    mrow = ri.x;
+                }
+                const float mk = mm_mask[mrow];
 #pragma unroll
                 for (int t = 0; t < NQ; t++) {
                     const int4 bi = *reinterpret_cast<const int4*>(mm_idx + grp * K + 4 * jc[t]);
@@ -1021,21 +1030,33 @@ extern "C" int stage_masked_max_bwd(const float* dout, const int* argmax, const 
 //     v = x + res ; sum_out = v ; y = (v - mean) * rstd * gamma + beta ; out[g, d] = max_l ( y * m + (1 - m) * NEG )
 // Backward: ln_bwd_fast_kernel<..., MM = true> (the row gradient is gathered from (dout, argmax) on the fly).
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+// RAG (ragged token rows): group s = seq[s] = (first compact row, length, mask row g, output row): the Lseq rows of one (example, candidate,
+// live frame), mask = qmask[g * Lq + l] (the QA word mask), result written to the DENSE row seq[s].w of out / idx (the caller pre-fills
+// the rows of dead frames with -1e10 / 0, which is what the dense kernel computes for an all-masked group)
+template <typename T, bool RAG = false>
 __global__ __launch_bounds__(256) void ln_mm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                         T* __restrict__ sum_out, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ mask,
                                                         T* __restrict__ out, int* __restrict__ idx,
-                                                        float* __restrict__ mean, float* __restrict__ rstd, long R, int L,
-                                                        float eps) {
+                                                        float* __restrict__ mean, float* __restrict__ rstd, long R, int L_in,
+                                                        float eps, const int4* __restrict__ seq = nullptr, int Lq = 0) {
     constexpr int K = 128;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int sub = lane >> 5, sl = lane & 31;
     const float4 gm = ld4(gamma + 4 * sl), bt = ld4(beta + 4 * sl);
-    for (long grp = (long)blockIdx.x * wpb + wave; grp < R; grp += (long)gridDim.x * wpb) {
+    for (long grp0 = (long)blockIdx.x * wpb + wave; grp0 < R; grp0 += (long)gridDim.x * wpb) {
         float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         int4 bi = make_int4(-1, -1, -1, -1);
-        const long row0 = grp * L;
+        long row0 = grp0 * L_in, grp = grp0;
+        int L = L_in;
+        const float* mrow = mask + row0;
+        if (RAG) {
+            const int4 sq = seq[grp0];
+            row0 = sq.x;
+            L = sq.y;
+            mrow = mask + (long)sq.z * Lq;
+            grp = sq.w;
+        }
         for (int l0 = 0; l0 < L; l0 += 8) {
             float4 v[4], rv[4];
             float mk[4];
@@ -1044,7 +1065,7 @@ __global__ __launch_bounds__(256) void ln_mm_fwd_kernel(const T* __restrict__ x,
                 const int l = min(l0 + 2 * u + sub, L - 1);
                 v[u] = ldv4s(x + (row0 + l) * K + 4 * sl);
                 if (res) rv[u] = ldv4s(res + (row0 + l) * K + 4 * sl);
-                mk[u] = mask[row0 + l];
+                mk[u] = mrow[l];
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -1118,6 +1139,47 @@ extern "C" int stage_dropout_keepmask(float p_drop, unsigned long long seed, uns
 }
 
 extern "C" int stage_ln_masked_max_supported(int L, int K) { return (K == 128 && L >= 1) ? 1 : 0; }
+
+// Ragged token rows: S groups seq[s] = (first row, length, mask row, output row) over compact rows; qmask (G, Lq); out / argmax are
+// DENSE (the caller pre-fills them for the groups that do not exist: stage_rag_fill_pooled).  K == 128.
+extern "C" int stage_ln_masked_max_rag_fwd(const float* x, const float* res, float* sum_out, const float* gamma, const float* beta,
+                                           const float* qmask, float* out, int* argmax, float* mean, float* rstd, const int* seq,
+                                           long long S, int Lq, int K, float eps, void* stream) {
+    if (S <= 0) return 0;
+    if (K != 128 || Lq < 1 || (res && !sum_out)) return STAGE_ERR_SHAPE;
+    const int grid = stage_grid_for(S, 4, GRID_CAP * 8);
+    hipLaunchKernelGGL((ln_mm_fwd_kernel<float, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, res, sum_out, gamma, beta, qmask,
+                       out, argmax, mean, rstd, (long)S, 0, eps, (const int4*)seq, Lq);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+// dout / argmax dense (as written by the forward), xin / mean / rstd / dx compact (rows), rowinfo (rows, 4) from stage_rag_rowinfo
+extern "C" int stage_ln_masked_max_rag_bwd(const float* dout, const int* argmax, const float* qmask, const float* xin, const float* mean,
+                                           const float* rstd, const float* gamma, float* dx, float* dgamma, float* dbeta,
+                                           const int* rowinfo, long long rows, int K, void* ws, size_t ws_bytes, void* stream) {
+    if (K != 128) return STAGE_ERR_SHAPE;
+    if (ws_bytes < stage_ln_bwd_ws_bytes(K)) return STAGE_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (rows <= 0) {
+        (void)hipMemsetAsync(dgamma, 0, sizeof(float) * K, st);
+        (void)hipMemsetAsync(dbeta, 0, sizeof(float) * K, st);
+        return 0;
+    }
+    if (rows >= (1ll << 31)) return STAGE_ERR_SHAPE;
+    const int LPR = ln_lpr(K / 4);
+    const int rows_per_block = 4 * (64 / LPR);
+    const int grid = stage_grid_for(rows, rows_per_block * 8, PART_CAP);
+    const size_t lds = (size_t)rows_per_block * 2 * K * sizeof(float);
+    float* part = (float*)ws;
+    RowSrcT<float> src{xin, nullptr, 0, 1, 0, nullptr};
+    if ((K / 4 + LPR - 1) / LPR != 1) return STAGE_ERR_SHAPE;
+    hipLaunchKernelGGL((ln_bwd_fast_kernel<0, false, 1, float, float, true>), dim3(grid), dim3(256), lds, st, src, dout, mean, rstd,
+                       gamma, dx, (float*)nullptr, part, (long)rows, K, LPR, (uint64_t)0, 0u, 1.0f, argmax, qmask, 1, (const int4*)rowinfo);
+    STAGE_LAUNCH_CHECK();
+    stage_colreduce(part, dgamma, dbeta, grid, (long)2 * K, 2 * K, K, 1, st);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int stage_ln_masked_max_fwd(const float* x, const float* res, float* sum_out, const float* gamma, const float* beta,
                                        const float* mask, float* out, int* argmax, float* mean, float* rstd, long long R, int L,

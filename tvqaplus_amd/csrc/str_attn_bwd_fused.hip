@@ -77,10 +77,11 @@ __device__ __forceinline__ int fswz(int c) { return ((c & 1) << 5) | (((c >> 1) 
 // instruction touches 64 different lines and the eight instructions of a tile re-touch them; with 100+ KB of tiles in flight
 // per CU the 32 KB vector L1 evicts them in between and refills them up to eight times (measured ~9 GB/s per CU instead of
 // ~25).  The tile is transposed through the LDS copy that phase 2 needs anyway.
+// relA / LiA: the same for the rows of dA, whose frames may be compacted (LiA = frame slots of the example; dense: relA = rel, LiA = Li)
 template <int NRT, bool HAS_EXT, bool COAL = false, typename TD = float>   // NRT = pieces fetched; TD = storage type of dA
 __device__ __forceinline__ void fus_p1_fetch(FusTile<NRT, HAS_EXT>& T, const TD* __restrict__ dAf, const float* __restrict__ Snf,
-                                             const float* __restrict__ extf, unsigned rel, int Lr, int g, int tile = 0, int lane = 0,
-                                             int NA = 0, int Li = 0, int Lqa = 1) {
+                                             const float* __restrict__ extf, unsigned rel, unsigned relA, int Lr, int g, int tile = 0, int lane = 0,
+                                             int NA = 0, int LiA = 0, int Lqa = 1) {
     if (COAL) {
         const int CR = NA * Lqa;
         int c = tile * 16 + (lane >> 5);
@@ -88,7 +89,7 @@ __device__ __forceinline__ void fus_p1_fetch(FusTile<NRT, HAS_EXT>& T, const TD*
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const bool ok = c < CR;
-            const unsigned r = ok ? (unsigned)(a * Li * Lqa + w) : (unsigned)((NA - 1) * Li * Lqa + Lqa - 1);
+            const unsigned r = ok ? (unsigned)(a * LiA * Lqa + w) : (unsigned)((NA - 1) * LiA * Lqa + Lqa - 1);
             T.gv[i] = ldv4(dAf + (r * FD + 4u * (lane & 31)));
             c += 2; w += 2;
             const bool wrap = w >= Lqa;        // Lqa >= 4: at most one wrap per step
@@ -96,7 +97,7 @@ __device__ __forceinline__ void fus_p1_fetch(FusTile<NRT, HAS_EXT>& T, const TD*
             a += wrap ? 1 : 0;
         }
     } else {
-        const unsigned offa = rel * FD + 4u * fchunk(g, 0);
+        const unsigned offa = relA * FD + 4u * fchunk(g, 0);
 #pragma unroll
         for (int m = 0; m < 8; m++) T.gv[m] = ldv4(dAf + (offa + 4u * m));
     }
@@ -227,9 +228,9 @@ __device__ __forceinline__ float fus_elt(const float4& v, int e) { return e == 0
 __device__ __forceinline__ float fus_elt(const float2& v, int e) { return e == 0 ? v.x : v.y; }
 
 template <int RT, int NRT, int E, bool RAW, bool PIPE, typename TD = float>
-__device__ __forceinline__ void fus_p2(const TD* __restrict__ dA, const float* __restrict__ Sn, const float* __restrict__ Cn,
+__device__ __forceinline__ void fus_p2(const TD* __restrict__ dAf, const float* __restrict__ Sn, const float* __restrict__ Cn,
                                        const float* Gs, float* __restrict__ out, long frame, int n, int i, int NA, int Li,
-                                       int Lqa, int Lr, int d0, int c15, int g) {
+                                       int Lqa, int Lr, int d0, int c15, int g, int LiA) {
     typedef typename FusVec<E>::T vec_t;
     constexpr int LG = FusLay<RT>::LG;
     const int CR = NA * Lqa;
@@ -244,7 +245,8 @@ __device__ __forceinline__ void fus_p2(const TD* __restrict__ dA, const float* _
     const long nbase = ((long)n * NA * Li + i) * Lqa;
     const int jump = (Li - 1) * Lqa;                      // extra row offset when w wraps into the next answer
     const int rel_last = (NA - 1) * Li * Lqa + Lqa - 1;   // clamp target for c >= CR
-    int c = g, w = g, rel = g;                            // Lqa >= 4 > g
+    const int jumpA = (LiA - 1) * Lqa, relA_last = (NA - 1) * LiA * Lqa + Lqa - 1;   // the rows of dA (dAf = the frame's first row)
+    int c = g, w = g, rel = g, relA = g;                  // Lqa >= 4 > g
     int rcl[NRT];
 #pragma unroll
     for (int rt = 0; rt < NRT; rt++) rcl[rt] = min(rt * 16 + c15, Lr - 1);
@@ -257,7 +259,7 @@ __device__ __forceinline__ void fus_p2(const TD* __restrict__ dA, const float* _
             const int cc = ok ? c : CR - 1;
             const long orow = nbase + (ok ? rel : rel_last);
             if (RAW) {
-                bv[u] = fus_ldv<E>(dA + orow * FD + d0);
+                bv[u] = fus_ldv<E>(dAf + (long)(ok ? relA : relA_last) * FD + d0);
 #pragma unroll
                 for (int rt = 0; rt < NRT; rt++) av[u][rt] = Sn[orow * Lr + rcl[rt]];
             } else {
@@ -265,10 +267,11 @@ __device__ __forceinline__ void fus_p2(const TD* __restrict__ dA, const float* _
 #pragma unroll
                 for (int rt = 0; rt < NRT; rt++) av[u][rt] = Gs[cc * LG + gcol<RT>(cc, rt * 16 + c15)];
             }
-            c += 4; w += 4; rel += 4;
+            c += 4; w += 4; rel += 4; relA += 4;
             const bool wrap = w >= Lqa;      // Lqa >= 4: at most one wrap per step; selects, not a divergent loop
             w -= wrap ? Lqa : 0;
             rel += wrap ? jump : 0;
+            relA += wrap ? jumpA : 0;
         }
     };
     auto mul = [&](const vec_t (&bv)[FUS_U], const float (&av)[FUS_U][NRT], const bool (&okv)[FUS_U]) {
@@ -331,7 +334,7 @@ __device__ __forceinline__ void fus_p2(const TD* __restrict__ dA, const float* _
 template <int RT, int NRT, int E, bool RAW, bool PIPE, bool LDSA = false, int UG = FUS_U, typename TD = float>
 __device__ __forceinline__ void fus_p2_unif(const TD* __restrict__ dAf, const float* __restrict__ Snf,
                                             const float* __restrict__ Cnn, const float* Gs, float* __restrict__ outf, int NA,
-                                            int Li, int Lqa, int Lr, int d0, int c15, int g, const float* dAs = nullptr) {
+                                            int Li, int Lqa, int Lr, int d0, int c15, int g, const float* dAs = nullptr, int LiA = 0) {
     typedef typename FusVec<E>::T vec_t;
     constexpr int LG = FusLay<RT>::LG;
     const int ngroups = (NA * Lqa) / (4 * UG);
@@ -348,7 +351,7 @@ __device__ __forceinline__ void fus_p2_unif(const TD* __restrict__ dAf, const fl
     const TD* pBd = dAf;                                  // row 4*step of the B operand (uniform): dA rows (RAW) ...
     const float* pBc = Cnn;                               // ... or Cn rows
     const float* pA = Snf;
-    const long jumpB = (long)(Li - 1) * Lqa * FD, jumpA = (long)(Li - 1) * Lqa * Lr;
+    const long jumpB = (long)(LiA - 1) * Lqa * FD, jumpA = (long)(Li - 1) * Lqa * Lr;
     const int wq_n = Lqa >> 2;
     int wq = 0, gs = 0, bs = 0;
 
@@ -424,7 +427,8 @@ __device__ __forceinline__ void fus_frame(const TD* __restrict__ dA, const float
                                           const float* QnT, float* Gs, float* dAs, float* __restrict__ dQraw, float* __restrict__ dQn,
                                           long frame, int n, int i, int NA, int Li, int Lqa, int Lr, float scale,
                                           const unsigned (&orel)[16 / NW], int ntiles, f32x4 (&dcn)[16 / NW][8], int wave, int lane,
-                                          unsigned long long* tim, unsigned long long (&tacc)[6], unsigned long long& tlast) {
+                                          unsigned long long* tim, unsigned long long (&tacc)[6], unsigned long long& tlast,
+                                          const unsigned (&orelA)[16 / NW], long arow0, int LiA) {
     constexpr int TPW = 16 / NW, E = NW == 4 ? 4 : 2;
     const int CR = NA * Lqa;
     // c15 / g re-derived from an opaque copy of the lane id per frame: hoisted out of the frame loop, the address
@@ -433,21 +437,21 @@ __device__ __forceinline__ void fus_frame(const TD* __restrict__ dA, const float
     asm volatile("" : "+v"(l));
     const int c15 = l & 15, g = l >> 4;
     const long rowbase = ((long)n * NA * Li + i) * Lqa;     // uniform
-    const TD* dAf = dA + rowbase * FD;
+    const TD* dAf = dA + arow0 * FD;                        // first row of the frame in dA (dense: rowbase)
     const float* Snf = Sn + rowbase * Lr;
     const float* extf = HAS_EXT ? ext + rowbase * Lr : nullptr;
     if (PIPE) {
         FusTile<NRT, HAS_EXT> Ta, Tb;
-        if (ntiles > 0) fus_p1_fetch<NRT, HAS_EXT, LDSA, TD>(Ta, dAf, Snf, extf, orel[0], Lr, g, wave, l, NA, Li, Lqa);
+        if (ntiles > 0) fus_p1_fetch<NRT, HAS_EXT, LDSA, TD>(Ta, dAf, Snf, extf, orel[0], orelA[0], Lr, g, wave, l, NA, LiA, Lqa);
 #pragma unroll
         for (int s = 0; s < TPW; s++) {
             if (s < ntiles) {
                 const int c = (wave + NW * s) * 16 + c15;
                 if (s & 1) {
-                    if (s + 1 < TPW && s + 1 < ntiles) fus_p1_fetch<NRT, HAS_EXT, LDSA, TD>(Ta, dAf, Snf, extf, orel[s + 1 < TPW ? s + 1 : 0], Lr, g, wave + NW * (s + 1), l, NA, Li, Lqa);
+                    if (s + 1 < TPW && s + 1 < ntiles) fus_p1_fetch<NRT, HAS_EXT, LDSA, TD>(Ta, dAf, Snf, extf, orel[s + 1 < TPW ? s + 1 : 0], orelA[s + 1 < TPW ? s + 1 : 0], Lr, g, wave + NW * (s + 1), l, NA, LiA, Lqa);
                     fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(Tb, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, dAs, CR);
                 } else {
-                    if (s + 1 < TPW && s + 1 < ntiles) fus_p1_fetch<NRT, HAS_EXT, LDSA, TD>(Tb, dAf, Snf, extf, orel[s + 1 < TPW ? s + 1 : 0], Lr, g, wave + NW * (s + 1), l, NA, Li, Lqa);
+                    if (s + 1 < TPW && s + 1 < ntiles) fus_p1_fetch<NRT, HAS_EXT, LDSA, TD>(Tb, dAf, Snf, extf, orel[s + 1 < TPW ? s + 1 : 0], orelA[s + 1 < TPW ? s + 1 : 0], Lr, g, wave + NW * (s + 1), l, NA, LiA, Lqa);
                     fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(Ta, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, dAs, CR);
                 }
             }
@@ -458,7 +462,7 @@ __device__ __forceinline__ void fus_frame(const TD* __restrict__ dA, const float
             if (s < ntiles) {
                 const int c = (wave + NW * s) * 16 + c15;
                 FusTile<NRT, HAS_EXT> T;
-                fus_p1_fetch<NRT, HAS_EXT, LDSA, TD>(T, dAf, Snf, extf, orel[s], Lr, g, wave + NW * s, l, NA, Li, Lqa);
+                fus_p1_fetch<NRT, HAS_EXT, LDSA, TD>(T, dAf, Snf, extf, orel[s], orelA[s], Lr, g, wave + NW * s, l, NA, LiA, Lqa);
                 fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(T, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, dAs, CR);
             }
         }
@@ -472,11 +476,11 @@ __device__ __forceinline__ void fus_frame(const TD* __restrict__ dA, const float
     const bool unif = (Lqa & 3) == 0 && ((CR >> 2) % UG) == 0;
     if (FUS_ABL & 1) return;
     if (unif) {
-        if (wave < NW / 2) fus_p2_unif<RT, NRT, E, true, PIPE, LDSA, UG, TD>(dAf, Snf, nullptr, Gs, dQraw + frame * Lr * FD, NA, Li, Lqa, Lr, d0, c15, g, dAs);
-        else fus_p2_unif<RT, NRT, E, false, PIPE, false, UG, TD>(dAf, Snf, Cn + (long)n * CR * FD, Gs, dQn + frame * Lr * FD, NA, Li, Lqa, Lr, d0, c15, g);
+        if (wave < NW / 2) fus_p2_unif<RT, NRT, E, true, PIPE, LDSA, UG, TD>(dAf, Snf, nullptr, Gs, dQraw + frame * Lr * FD, NA, Li, Lqa, Lr, d0, c15, g, dAs, LiA);
+        else fus_p2_unif<RT, NRT, E, false, PIPE, false, UG, TD>(dAf, Snf, Cn + (long)n * CR * FD, Gs, dQn + frame * Lr * FD, NA, Li, Lqa, Lr, d0, c15, g, nullptr, LiA);
     } else {
-        if (wave < NW / 2) fus_p2<RT, NRT, E, true, PIPE, TD>(dA, Sn, Cn, Gs, dQraw, frame, n, i, NA, Li, Lqa, Lr, d0, c15, g);
-        else fus_p2<RT, NRT, E, false, PIPE, TD>(dA, Sn, Cn, Gs, dQn, frame, n, i, NA, Li, Lqa, Lr, d0, c15, g);
+        if (wave < NW / 2) fus_p2<RT, NRT, E, true, PIPE, TD>(dAf, Sn, Cn, Gs, dQraw, frame, n, i, NA, Li, Lqa, Lr, d0, c15, g, LiA);
+        else fus_p2<RT, NRT, E, false, PIPE, TD>(dAf, Sn, Cn, Gs, dQn, frame, n, i, NA, Li, Lqa, Lr, d0, c15, g, LiA);
     }
 }
 
@@ -487,7 +491,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OC
     const TD* __restrict__ dA, const float* __restrict__ ext, const float* __restrict__ Cn, const TD* __restrict__ Q,
     const TD* __restrict__ Qn, const float* __restrict__ Sn, const float* __restrict__ qmask, float* __restrict__ dQraw,
     float* __restrict__ dQn, float* __restrict__ part, int N, int NA, int Li, int Lqa, int Lr, float scale,
-    const int4* __restrict__ sched, const unsigned char* __restrict__ fnv, unsigned long long* __restrict__ tim) {
+    const int4* __restrict__ sched, const unsigned char* __restrict__ fnv, unsigned long long* __restrict__ tim,
+    const int* __restrict__ fmap) {
+    // fmap != NULL: dA is frame-compact (str_attn_fwd_reg.hip, include/stage_hip.h "ragged token rows"): the frames of example n sit in
+    // fmap[N*Li + n] slots per candidate from sequence fmap[N*Li + N + n]; a dead frame (fmap[frame] < 0) reads the example's dump
+    // slot, which the caller has zeroed -- its dA is exactly zero by construction (the statement mask blocks the gradient)
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = tim ? __builtin_readcyclecounter() : 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int LT = FusLay<RT>::LT, TPW = 16 / NW, NT = 64 * NW;
@@ -506,13 +514,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OC
     for (int e = tid; e < FusLay<RT>::QT_FLOATS; e += NT) QnT[e] = 0.f;
 
     // this wave's context tiles (phase 1): slot s -> tile wave + NW*s
-    unsigned orel[TPW];   // row offset of context row c inside a frame's row block: a*Li*Lqa + w
+    unsigned orel[TPW], orelA[TPW];   // row offset of context row c inside a frame's row block: a*Li*Lqa + w (score maps) / a*LiA*Lqa + w (dA)
     const int ntiles = wave < CT ? (CT - 1 - wave) / NW + 1 : 0;
+    const int LiA = fmap ? fmap[(long)N * Li + n] : Li;
+    const long afirst = fmap ? (long)fmap[(long)N * Li + N + n] : (long)n * NA * Li;
 #pragma unroll
     for (int s = 0; s < TPW; s++) {
         const int c = (wave + NW * s) * 16 + (lane & 15);
         const int cc = c < CR ? c : CR - 1;
         orel[s] = (unsigned)((cc / Lqa) * Li * Lqa + cc % Lqa);
+        orelA[s] = (unsigned)((cc / Lqa) * LiA * Lqa + cc % Lqa);
     }
     f32x4 dcn[TPW][8];
 #pragma unroll
@@ -561,9 +572,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OC
         __syncthreads();
         TICK(1);
         const int nrt = (nvalid + 15) >> 4;
+        int aslot = i;
+        if (fmap) {
+            aslot = __builtin_amdgcn_readfirstlane(fmap[frame]);
+            aslot = aslot < 0 ? LiA - 1 : aslot;
+        }
+        const long arow0 = (afirst + aslot) * Lqa;
 #define FUS_FRAME(NRTV)                                                                                                  \
     fus_frame<RT, (NRTV) <= RT ? (NRTV) : RT, NW, HAS_EXT, (OCC == 2 && NW == 8), LDSA, TD>(dA, ext, Cn, Sn, Qr, QnT, Gs, dAs, dQraw, dQn, frame, n, i, NA, Li, \
-                                                         Lqa, Lr, scale, orel, ntiles, dcn, wave, lane, tim, tacc, tlast)
+                                                         Lqa, Lr, scale, orel, ntiles, dcn, wave, lane, tim, tacc, tlast, orelA, arow0, LiA)
         if (RT == 1 || nrt == 1) FUS_FRAME(1);
         else if (RT == 2 || nrt == 2) FUS_FRAME(2);
         else if (RT == 3 || nrt == 3) FUS_FRAME(3);
@@ -726,7 +743,7 @@ static int fus_num_wgs(int N, int Li = 1 << 20) {
 template <int RT, int NW, int OCC, typename TD>
 static int fus_launch(const TD* dA, const float* ext, const float* Cn, const TD* Q, const TD* Qn, const float* Sn,
                       const float* qmask, float* dQraw, float* dQn, float* dCn, int N, int NA, int Li, int Lqa, int Lr,
-                      float scale, void* ws, hipStream_t st) {
+                      float scale, void* ws, hipStream_t st, const int* fmap) {
     const int CR = NA * Lqa;
     const int G = fus_num_wgs(N, Li);
     int4* sched = (int4*)ws;
@@ -755,7 +772,7 @@ static int fus_launch(const TD* dA, const float* ext, const float* Cn, const TD*
         if (lds > 64 * 1024)                                                                                                    \
             (void)hipFuncSetAttribute((const void*)str_attn_bwd_fused_kernel<RT, NW, EXTV, OCC, LDSAV, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((str_attn_bwd_fused_kernel<RT, NW, EXTV, OCC, LDSAV, TD>), grid, block, lds, st, dA, ext, Cn, Q, Qn, Sn, qmask, \
-                           dQraw, dQn, part, N, NA, Li, Lqa, Lr, scale, (const int4*)sched, (const unsigned char*)fnv, tim);                               \
+                           dQraw, dQn, part, N, NA, Li, Lqa, Lr, scale, (const int4*)sched, (const unsigned char*)fnv, tim, fmap);                         \
     } while (0)
     if (ext) { if (ldsa) FUS_GO(true, (NW == 8 && OCC == 2)); else FUS_GO(true, false); }
     else { if (ldsa) FUS_GO(false, (NW == 8 && OCC == 2)); else FUS_GO(false, false); }
@@ -776,14 +793,15 @@ extern "C" size_t stage_str_attn_bwd_fused_ws_bytes(int N, int NA, int Li, int L
 template <typename TD>
 static int str_attn_bwd_fused_t(const TD* dA, const float* dS_raw_ext, const float* Cn, const TD* Q, const TD* Qn,
                                 const float* S_norm, const float* q_mask, float* dQraw, float* dQn, float* dCn, int N, int NA,
-                                int Li, int Lqa, int Lr, int D, float scale, void* ws, size_t ws_bytes, void* stream) {
+                                int Li, int Lqa, int Lr, int D, float scale, void* ws, size_t ws_bytes, void* stream,
+                                const int* fmap = nullptr) {
     if (N <= 0 || Li <= 0) return 0;
     if (D != FD || Lr < 2 || Lr > 64 || (Lr & 1) || Lqa < 4 || NA < 1 || NA * Lqa > 256 ||
-        (long)NA * Li * Lqa * FD >= (1l << 29)) return STAGE_ERR_SHAPE;   // 32-bit element offsets inside an example
+        (long)NA * (Li + 1) * Lqa * FD >= (1l << 29)) return STAGE_ERR_SHAPE;   // 32-bit element offsets inside an example (+1: dump slot)
     if (ws_bytes < stage_str_attn_bwd_fused_ws_bytes(N, NA, Li, Lqa, D)) return STAGE_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int RT = (Lr + 15) / 16;
-#define FUS_ARGS dA, dS_raw_ext, Cn, Q, Qn, S_norm, q_mask, dQraw, dQn, dCn, N, NA, Li, Lqa, Lr, scale, ws, st
+#define FUS_ARGS dA, dS_raw_ext, Cn, Q, Qn, S_norm, q_mask, dQraw, dQn, dCn, N, NA, Li, Lqa, Lr, scale, ws, st, fmap
     switch (RT) {
         case 1: return fus_launch<1, 8, 2, TD>(FUS_ARGS);
         case 2: return fus_launch<2, 8, 2, TD>(FUS_ARGS);
@@ -799,6 +817,16 @@ extern "C" int stage_str_attn_bwd_fused(const float* dA, const float* dS_raw_ext
                                         void* ws, size_t ws_bytes, void* stream) {
     return str_attn_bwd_fused_t<float>(dA, dS_raw_ext, Cn, Q, Qn, S_norm, q_mask, dQraw, dQn, dCn, N, NA, Li, Lqa, Lr, D, scale, ws,
                                        ws_bytes, stream);
+}
+
+// dA frame-compact (ragged token rows, include/stage_hip.h): the rows of dA are addressed through `fmap`; everything else as above
+extern "C" int stage_str_attn_bwd_fused_fc(const float* dA_fc, const float* dS_raw_ext, const float* Cn, const float* Q,
+                                           const float* Qn, const float* S_norm, const float* q_mask, float* dQraw,
+                                           float* dQn, float* dCn, const int* fmap, int N, int NA, int Li, int Lqa, int Lr, int D,
+                                           float scale, void* ws, size_t ws_bytes, void* stream) {
+    if (!fmap) return STAGE_ERR_SHAPE;
+    return str_attn_bwd_fused_t<float>(dA_fc, dS_raw_ext, Cn, Q, Qn, S_norm, q_mask, dQraw, dQn, dCn, N, NA, Li, Lqa, Lr, D, scale, ws,
+                                       ws_bytes, stream, fmap);
 }
 
 // bf16 storage mode: dA, Q, Qn are bf16; the score maps, Cn and the three gradients (dQraw, dQn, dCn) stay fp32

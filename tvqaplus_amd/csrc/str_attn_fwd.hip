@@ -35,7 +35,7 @@ extern "C" int stage_str_attn_fwd_v1(const float* Cn, const float* Q, const floa
 
 int stage_str_attn_fwd_reg(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A,
                            float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D, float scale,
-                           float p_drop, unsigned long long seed, void* stream);
+                           float p_drop, unsigned long long seed, void* stream, const int* fmap = nullptr);
 int stage_str_attn_fwd_reg_bf16(const float* Cn, const void* Q, const float* c_mask, const float* q_mask, void* A, float* S_raw,
                                 float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D, float scale, float p_drop,
                                 unsigned long long seed, void* stream);
@@ -71,7 +71,9 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
     const float* __restrict__ Cn, const TQ* __restrict__ Q, const float* __restrict__ cmask,
     const float* __restrict__ qmask, TQ* __restrict__ A, float* __restrict__ S, float* __restrict__ Sn, int N,
     int NA, int Li, int Lqa, int Lr, float scale, int slices, int tiles_per_slice, uint64_t seed, uint32_t th,
-    float inv_keep, unsigned int* __restrict__ ticket, unsigned int ticket_base, unsigned long long* __restrict__ tim) {
+    float inv_keep, unsigned int* __restrict__ ticket, unsigned int ticket_base, unsigned long long* __restrict__ tim,
+    const int* __restrict__ fmap) {
+    // fmap != NULL: frame-compact A (see str_attn_fwd_reg.hip / include/stage_hip.h "ragged token rows"); S / S_ stay dense
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = tim ? __builtin_readcyclecounter() : 0;
 #define TICK(ph) do { if (tim) { unsigned long long tn = __builtin_readcyclecounter(); tacc[ph] += tn - tlast; tlast = tn; } } while (0)
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -163,6 +165,17 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
         const int n = (int)(frame / Li), i = (int)(frame % Li);
         const int tile0 = WGF ? 0 : slice * tiles_per_slice;
         const int tile1 = WGF ? CT : min(CT, tile0 + tiles_per_slice);
+        // rows of A: dense ((n*NA + a)*Li + i)*Lqa + w = (afirst + a*aslots + aslot)*Lqa + w ; frame-compact: from fmap
+        long afirst = (long)n * NA * Li;
+        int aslots = Li, aslot = i;
+        bool dead = false;
+        if (fmap) {
+            aslots = __builtin_amdgcn_readfirstlane(fmap[(long)N * Li + n]);
+            afirst = __builtin_amdgcn_readfirstlane(fmap[(long)N * Li + N + n]);
+            aslot = __builtin_amdgcn_readfirstlane(fmap[frame]);
+            dead = aslot < 0;
+            aslot = dead ? aslots - 1 : aslot;     // dead frames: the dump slot (never read; keeps the store count of the tile loop exact)
+        }
 
         TICK(5);
         // ---- stage the frame: raw rows -> LDS, 1/|row| (x * (1/n) instead of x / n: 1 ulp), region mask ----
@@ -262,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
             const int c_lo = tile0 * 16, c_hi = min(CR, tile1 * 16);
             for (int c = c_lo + (lane >> 5) + (WGF ? 2 * wave : 0); c < c_hi; c += WGF ? 8 : 2) {
                 const long orow = ((long)(n * NA + c / Lqa) * Li + i) * Lqa + c % Lqa;
-                stv4(A + orow * DD + 4 * sq, f4zero());
+                if (!dead) stv4(A + ((afirst + (long)(c / Lqa) * aslots + aslot) * Lqa + c % Lqa) * DD + 4 * sq, f4zero());
                 for (int r = sq; r < Lr; r += 32) { S[orow * Lr + r] = STAGE_NEG; Sn[orow * Lr + r] = 0.f; }
             }
             item = next_item;
@@ -331,13 +344,14 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
         // fragments of the next pair are issued right after stage 1 has read the current ones (before this pair's
         // stores) and awaited at the top of the next step.
         auto do_pair = [&](f32x4 (&cf)[NU][NCH], int t0, int t1, bool more, int nt0, int nt1) {
-            long orow[NU];
+            long orow[NU], arowA[NU];
             float cmv[NU];
 #pragma unroll
             for (int u = 0; u < NU; u++) {
                 const int tile = u ? t1 : t0;
                 const int c = min(tile * 16 + c15, CR - 1);
                 orow[u] = ((long)(n * NA + c / Lqa) * Li + i) * Lqa + c % Lqa;
+                arowA[u] = (afirst + (long)(c / Lqa) * aslots + aslot) * Lqa + c % Lqa;
                 cmv[u] = cms[(tile - tile0) * 16 + c15];
             }
             f32x4 acc[NU][RT];
@@ -504,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
                         o = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh8, wl8, o, 0, 0, 0);
                         o = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh8, wh8, o, 0, 0, 0);
                     }
-                    stv4(A + orow[0] * DD + dt * 16 + 4 * g, make_float4(o[0] * inv2, o[1] * inv2, o[2] * inv2, o[3] * inv2));
+                    stv4(A + arowA[0] * DD + dt * 16 + 4 * g, make_float4(o[0] * inv2, o[1] * inv2, o[2] * inv2, o[3] * inv2));
                 }
             } else
 #pragma unroll
@@ -522,7 +536,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
                     }
 #pragma unroll
                 for (int u = 0; u < NU; u++)
-                    stv4(A + orow[u] * DD + dt * 16 + 4 * g, make_float4(o[u][0], o[u][1], o[u][2], o[u][3]));
+                    stv4(A + arowA[u] * DD + dt * 16 + 4 * g, make_float4(o[u][0], o[u][1], o[u][2], o[u][3]));
             }
         };
 
@@ -583,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
 template <int RT, int KL, bool PERM, bool TRAIN, bool VEC_S, typename TQ>
 static int launch_d128_t(const float* Cn, const TQ* Q, const float* cm, const float* qm, TQ* A, float* S, float* Sn,
                          int N, int NA, int Li, int Lqa, int Lr, float scale, float p_drop, unsigned long long seed,
-                         hipStream_t st) {
+                         hipStream_t st, const int* fmap) {
     const int CR = NA * Lqa, CT = (CR + 15) / 16;
     // slices of the context tiles: enough work items (frames x slices) to balance ~2048 waves, >= 3 tiles per item
     int slices = 1;
@@ -613,7 +627,7 @@ static int launch_d128_t(const float* Cn, const TQ* Q, const float* cm, const fl
         const StageTicket tk = stage_next_ticket((unsigned int)((long)N * Li));
         if (!tk.word) return (int)hipErrorOutOfMemory;
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, 1,
-                           CT, (uint64_t)seed, th, ik, tk.word, tk.base, tim);
+                           CT, (uint64_t)seed, th, ik, tk.word, tk.base, tim, fmap);
         STAGE_LAUNCH_CHECK_TICKET(tk);
         return 0;
     }
@@ -640,7 +654,7 @@ static int launch_d128_t(const float* Cn, const TQ* Q, const float* cm, const fl
     const StageTicket tk = stage_next_ticket((unsigned int)items);   // every processed item draws one ticket (common.h)
     if (!tk.word) return (int)hipErrorOutOfMemory;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * wpb), lds, st, Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr,
-                       scale, slices, tps, (uint64_t)seed, th, ik, tk.word, tk.base, tim);
+                       scale, slices, tps, (uint64_t)seed, th, ik, tk.word, tk.base, tim, fmap);
     STAGE_LAUNCH_CHECK_TICKET(tk);
     return 0;
 }
@@ -648,13 +662,13 @@ static int launch_d128_t(const float* Cn, const TQ* Q, const float* cm, const fl
 template <int RT, bool TRAIN, typename TQ>
 static int launch_d128(const float* Cn, const TQ* Q, const float* cm, const float* qm, TQ* A, float* S, float* Sn,
                        int N, int NA, int Li, int Lqa, int Lr, float scale, float p_drop, unsigned long long seed,
-                       hipStream_t st) {
+                       hipStream_t st, const int* fmap) {
     const int rem = Lr - 16 * (RT - 1);
     // 16-byte score stores need rows that start on 8 bytes only (the hardware takes dwordx4 at dword alignment; 8-byte rows measured
     // as fast as 16-byte ones); odd Lr keeps the scalar stores
     static const bool no_vec8 = getenv("STAGE_K1_NO_VEC8") != nullptr;
     const bool vec = (Lr & 3) == 0 || ((Lr & 1) == 0 && !no_vec8);
-#define ARGS Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st
+#define ARGS Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st, fmap
     if (rem == 16) return vec ? launch_d128_t<RT, 4, false, TRAIN, true, TQ>(ARGS) : launch_d128_t<RT, 4, false, TRAIN, false, TQ>(ARGS);
     switch ((rem + 3) / 4) {
         case 1: return vec ? launch_d128_t<RT, 1, true, TRAIN, true, TQ>(ARGS) : launch_d128_t<RT, 1, true, TRAIN, false, TQ>(ARGS);
@@ -668,10 +682,10 @@ static int launch_d128(const float* Cn, const TQ* Q, const float* cm, const floa
 template <typename TQ>
 static int str_attn_fwd_d128_t(const float* Cn, const TQ* Q, const float* c_mask, const float* q_mask, TQ* A, float* S_raw,
                                float* S_norm, int N, int NA, int Li, int Lqa, int Lr, float scale, float p_drop,
-                               unsigned long long seed, void* stream) {
+                               unsigned long long seed, void* stream, const int* fmap = nullptr) {
     hipStream_t st = (hipStream_t)stream;
     const bool train = p_drop > 0.f;
-#define ARGS Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st
+#define ARGS Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st, fmap
     switch ((Lr + 15) / 16) {
         case 1: return train ? launch_d128<1, true, TQ>(ARGS) : launch_d128<1, false, TQ>(ARGS);
         case 2: return train ? launch_d128<2, true, TQ>(ARGS) : launch_d128<2, false, TQ>(ARGS);
@@ -695,7 +709,7 @@ extern "C" void stage_k1_fwd_timer(void* start, void* stop, int Lr) {
 }
 static int str_attn_fwd_dispatch(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A,
                                  float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D,
-                                 float scale, float p_drop, unsigned long long seed, void* stream);
+                                 float scale, float p_drop, unsigned long long seed, void* stream, const int* fmap = nullptr);
 extern "C" int stage_str_attn_fwd(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A,
                                   float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D,
                                   float scale, float p_drop, unsigned long long seed, void* stream) {
@@ -712,18 +726,37 @@ extern "C" int stage_str_attn_fwd(const float* Cn, const float* Q, const float* 
 }
 static int str_attn_fwd_dispatch(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A,
                                  float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D,
-                                 float scale, float p_drop, unsigned long long seed, void* stream) {
+                                 float scale, float p_drop, unsigned long long seed, void* stream, const int* fmap) {
     if (N <= 0 || Li <= 0) return 0;
     if (D % 16 != 0 || D > 256 || Lr < 1 || Lr > 64 || Lqa < 1 || NA < 1) return STAGE_ERR_SHAPE;
-    if (D != DD || getenv("STAGE_K1_GENERIC"))
+    if (D != DD || getenv("STAGE_K1_GENERIC")) {
+        if (fmap) return STAGE_ERR_SHAPE;     // the frame-compact layout exists for the two fast kernels only
         return stage_str_attn_fwd_v1(Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, D, scale, p_drop, seed,
                                      stream);
+    }
     if (!getenv("STAGE_K1_LDS")) {   // register-resident kernel for Lr <= 32 (str_attn_fwd_reg.hip); 1 = not handled
         const int rc = stage_str_attn_fwd_reg(Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, D, scale, p_drop,
-                                              seed, stream);
+                                              seed, stream, fmap);
         if (rc != 1) return rc;
     }
-    return str_attn_fwd_d128_t<float>(Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, scale, p_drop, seed, stream);
+    return str_attn_fwd_d128_t<float>(Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, scale, p_drop, seed, stream, fmap);
+}
+
+// Frame-compact A (ragged token rows, include/stage_hip.h): same kernels, A rows addressed through `fmap`
+extern "C" int stage_str_attn_fwd_fc(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A_fc,
+                                     float* S_raw, float* S_norm, const int* fmap, int N, int NA, int Li, int Lqa, int Lr, int D,
+                                     float scale, float p_drop, unsigned long long seed, void* stream) {
+    if (!fmap || D != DD) return STAGE_ERR_SHAPE;
+    K1Timer* tm = nullptr;
+    for (auto& t : g_k1_timer)
+        if (t.armed && t.Lr == Lr) { tm = &t; break; }
+    if (tm) (void)hipEventRecord(tm->a, (hipStream_t)stream);
+    const int rc = str_attn_fwd_dispatch(Cn, Q, c_mask, q_mask, A_fc, S_raw, S_norm, N, NA, Li, Lqa, Lr, D, scale, p_drop, seed, stream, fmap);
+    if (tm) {
+        (void)hipEventRecord(tm->b, (hipStream_t)stream);
+        tm->armed = false;
+    }
+    return rc;
 }
 
 // bf16 storage mode: Q and A are bf16 (Cn, masks and the score maps stay fp32).  D == 128 and Lr <= 64 only (the fast

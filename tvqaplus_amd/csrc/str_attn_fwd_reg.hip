@@ -46,7 +46,11 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
     const float* __restrict__ Cn, const TQ* __restrict__ Q, const float* __restrict__ cmask,
     const float* __restrict__ qmask, TQ* __restrict__ A, float* __restrict__ S, float* __restrict__ Sn, int N,
     int NA, int Li, int Lqa, int Lr, float scale, int slices, int tiles_per_slice, uint64_t seed, uint32_t th,
-    float inv_keep, unsigned int* __restrict__ ticket, unsigned int ticket_base, int static_rounds) {
+    float inv_keep, unsigned int* __restrict__ ticket, unsigned int ticket_base, int static_rounds,
+    const int* __restrict__ fmap) {
+    // fmap != NULL: A is FRAME-COMPACT (include/stage_hip.h, "ragged token rows"): example n keeps slots = fmap[N*Li + n] frame slots per
+    // candidate (its live frames + one dump slot), first sequence fmap[N*Li + N + n]; fmap[frame] = slot of the frame, < 0: dead (the
+    // frame's A rows are never read: they go to the dump slot so that the store count of the tile loop stays exact).  S / S_ stay dense.
     constexpr int NK2 = (RT - 1) * 4 + KL;            // stage-2 k-steps (4 regions each)
     constexpr int base_last = (RT - 1) * 16;
     // A last region tile with <= 4 regions (the headline Lr = 20) does not pay a 16-row stage-1 tile for them: its scores
@@ -90,6 +94,12 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
         const int a = (int)(((float)c + 0.5f) * inv_lqa);
         return (unsigned)c + __umul24((unsigned)a, row_k1) + row_k0;
     };
+    // the same for the rows of A: dense (fmap == NULL) they are the rows above; frame-compact: ((first + a * slots + slot) * Lqa + w
+    unsigned arow_k1 = row_k1, arow_k0 = 0u;        // per item
+    auto a_row = [&](int c) -> unsigned {
+        const int a = (int)(((float)c + 0.5f) * inv_lqa);
+        return (unsigned)c + __umul24((unsigned)a, arow_k1) + arow_k0;
+    };
 
     const long n_items = (long)N * Li * slices;
     const long n_waves = (long)gridDim.x * wpb;
@@ -117,6 +127,17 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
         const int tile1 = min(CT, tile0 + tiles_per_slice);
         const TQ* qf = Q + frame * Lr * RD;
         row_k0 = ((unsigned)n * NA * Li + i) * Lqa;
+        arow_k0 = row_k0;
+        bool dead = false;
+        if (fmap) {
+            const int slots = __builtin_amdgcn_readfirstlane(fmap[(long)N * Li + n]);
+            const int first = __builtin_amdgcn_readfirstlane(fmap[(long)N * Li + N + n]);
+            int slot = __builtin_amdgcn_readfirstlane(fmap[frame]);
+            dead = slot < 0;
+            slot = dead ? slots - 1 : slot;
+            arow_k1 = (unsigned)(slots - 1) * (unsigned)Lqa;
+            arow_k0 = (unsigned)(first + slot) * (unsigned)Lqa;
+        }
 
         // region fed by this lane as stage-1 A row (i = c15), per region tile.  Derived per item from an opaque copy of
         // c15: hoisted out of the item loop, the 64-bit row offsets built from it stay live across the whole kernel and
@@ -174,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
             const int sq = lane & 31;
             for (int c = c_lo + (lane >> 5); c < c_hi; c += 2) {
                 const unsigned orow = out_row(c);
-                stv4(A + (size_t)orow * RD + 4 * sq, f4zero());
+                if (!dead) stv4(A + (size_t)a_row(c) * RD + 4 * sq, f4zero());
                 for (int r = sq; r < Lr; r += 32) { S[(size_t)orow * Lr + r] = STAGE_NEG; Sn[(size_t)orow * Lr + r] = 0.f; }
             }
             item = next_item;
@@ -410,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
             size_t arow4[4];
 #pragma unroll
             for (int reg = 0; reg < 4; reg++)   // rows past the end alias the last valid row
-                arow4[reg] = (size_t)out_row(min(t * 16 + 4 * g + reg, CR - 1)) * RD + 4 * c15;
+                arow4[reg] = (size_t)a_row(min(t * 16 + 4 * g + reg, CR - 1)) * RD + 4 * c15;
             uint4 wh4 = make_uint4(0u, 0u, 0u, 0u), wl4 = make_uint4(0u, 0u, 0u, 0u);
             if (F16S2) {   // weights in slot order ks = 4 rt + k (masked / padded slots are exactly 0)
                 float w8[8];
@@ -468,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
 template <int RT, int KL, bool PERM, bool TRAIN, bool VEC_S, typename TQ>
 static int launch_reg_t(const float* Cn, const TQ* Q, const float* cm, const float* qm, TQ* A, float* S, float* Sn,
                         int N, int NA, int Li, int Lqa, int Lr, float scale, float p_drop, unsigned long long seed,
-                        hipStream_t st) {
+                        hipStream_t st, const int* fmap) {
     const int CR = NA * Lqa, CT = (CR + 15) / 16;
     // slices of the context tiles: enough work items (frames x slices) to balance ~2048 waves, >= 3 tiles per item
     int slices = 1;
@@ -499,7 +520,7 @@ static int launch_reg_t(const float* Cn, const TQ* Q, const float* cm, const flo
     const size_t park = K1_F16 ? (size_t)4 * 16 * 64 * sizeof(uint4) : 0;   // 64 KB per workgroup
     hipLaunchKernelGGL((str_attn_fwd_reg_kernel<RT, KL, PERM, TRAIN, VEC_S, TQ>), dim3((unsigned)blocks), dim3(256), park, st, Cn, Q,
                        cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, slices, tps, (uint64_t)seed, th, ik, tk.word, tk.base,
-                       static_rounds);
+                       static_rounds, fmap);
     STAGE_LAUNCH_CHECK_TICKET(tk);
     return 0;
 }
@@ -507,11 +528,11 @@ static int launch_reg_t(const float* Cn, const TQ* Q, const float* cm, const flo
 template <int RT, bool TRAIN, typename TQ>
 static int launch_reg(const float* Cn, const TQ* Q, const float* cm, const float* qm, TQ* A, float* S, float* Sn,
                       int N, int NA, int Li, int Lqa, int Lr, float scale, float p_drop, unsigned long long seed,
-                      hipStream_t st) {
+                      hipStream_t st, const int* fmap) {
     const int rem = Lr - 16 * (RT - 1);
     static const bool no_vec8 = getenv("STAGE_K1_NO_VEC8") != nullptr;       // (see str_attn_fwd.hip: 16-byte stores at 8-byte row starts)
     const bool vec = (Lr & 3) == 0 || ((Lr & 1) == 0 && !no_vec8);
-#define ARGS Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st
+#define ARGS Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st, fmap
     if (rem == 16) return vec ? launch_reg_t<RT, 4, false, TRAIN, true, TQ>(ARGS) : launch_reg_t<RT, 4, false, TRAIN, false, TQ>(ARGS);
     switch ((rem + 3) / 4) {
         case 1: return vec ? launch_reg_t<RT, 1, true, TRAIN, true, TQ>(ARGS) : launch_reg_t<RT, 1, true, TRAIN, false, TQ>(ARGS);
@@ -526,12 +547,12 @@ static int launch_reg(const float* Cn, const TQ* Q, const float* cm, const float
 template <typename TQ>
 static int str_attn_fwd_reg_t(const float* Cn, const TQ* Q, const float* c_mask, const float* q_mask, TQ* A, float* S_raw,
                               float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D, float scale, float p_drop,
-                              unsigned long long seed, void* stream) {
+                              unsigned long long seed, void* stream, const int* fmap = nullptr) {
     if (D != RD || Lr > 32 || (long)NA * Lqa >= (1 << 22)) return 1;
-    if ((long)N * NA * Li * Lqa >= (1l << 24) || (long)(Li - 1) * Lqa >= (1l << 24)) return 1;   // 24-bit row arithmetic
+    if ((long)N * NA * (Li + 1) * Lqa >= (1l << 24) || (long)Li * Lqa >= (1l << 24)) return 1;   // 24-bit row arithmetic (+1: the dump slots of the frame-compact layout)
     hipStream_t st = (hipStream_t)stream;
     const bool train = p_drop > 0.f;
-#define ARGS Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st
+#define ARGS Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st, fmap
     if (Lr <= 16) return train ? launch_reg<1, true, TQ>(ARGS) : launch_reg<1, false, TQ>(ARGS);
     return train ? launch_reg<2, true, TQ>(ARGS) : launch_reg<2, false, TQ>(ARGS);
 #undef ARGS
@@ -539,8 +560,8 @@ static int str_attn_fwd_reg_t(const float* Cn, const TQ* Q, const float* c_mask,
 
 int stage_str_attn_fwd_reg(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A,
                            float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D, float scale,
-                           float p_drop, unsigned long long seed, void* stream) {
-    return str_attn_fwd_reg_t<float>(Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, D, scale, p_drop, seed, stream);
+                           float p_drop, unsigned long long seed, void* stream, const int* fmap) {
+    return str_attn_fwd_reg_t<float>(Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, D, scale, p_drop, seed, stream, fmap);
 }
 int stage_str_attn_fwd_reg_bf16(const float* Cn, const void* Q, const float* c_mask, const float* q_mask, void* A, float* S_raw,
                                 float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D, float scale, float p_drop,

@@ -60,8 +60,22 @@ def _size(fn_name: str, *dims) -> int:
     return v
 
 
+_QUANT = 32 << 20
+
+
 def _buf(nbytes: int, device) -> torch.Tensor:
-    return torch.empty(max(int(nbytes), 256), dtype=_U8, device=device)
+    # large buffers in 32 MB steps: with ragged token rows the row count changes from batch to batch, and a caching allocator
+    # that sees a new size every step keeps going back to hipMalloc
+    n = max(int(nbytes), 256)
+    if n > _QUANT:
+        n = (n + _QUANT - 1) // _QUANT * _QUANT
+    return torch.empty(n, dtype=_U8, device=device)
+
+
+def _rows(rows: int, D: int, device) -> torch.Tensor:
+    """(rows, D) fp32, carved from an allocation whose row count is rounded up (same reason)."""
+    cap = (rows + 16383) // 16384 * 16384 if rows > 16384 else rows
+    return torch.empty(cap, D, dtype=torch.float32, device=device)[:rows]
 
 
 def _grad_views(params: Sequence[torch.Tensor]) -> List[torch.Tensor]:
@@ -291,6 +305,117 @@ def qa_ctx(qa, cx, qa_mask, cx_mask, scale: float, p: float, seeds, params):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# G3r / G2r: the same groups on RAGGED TOKEN ROWS (tvqaplus_amd/ragged.py, csrc/groups.hip "RAGGED TOKEN ROWS")
+# ---------------------------------------------------------------------------------------------------------------
+def qa_ctx_rag_supported(N, NA, Li, Lqa, Lr, D, lay) -> bool:
+    return bool(_lib.load().stage_grp_qa_ctx_rag_supported(N, NA, Li, Lqa, Lr, D, lay.U, lay.Fc))
+
+
+class _QaCtxRag(torch.autograd.Function):
+    @_on_device
+    def forward(ctx, qa, cx, qa_mask, cx_mask, lay, scale: float, p: float, seeds, *params):
+        qa, cx = _chk(qa, "qa"), _chk(cx, "ctx")
+        qa_mask, cx_mask = _chk(qa_mask, "qa_mask"), _chk(cx_mask, "ctx_mask")
+        ctx.sinks = _sinks(params)
+        params = _params(params)
+        N, NA, Lqa, D = qa.shape
+        _, Li, Lr, _ = cx.shape
+        lib = _lib.load()
+        ab = _size("stage_grp_qa_ctx_rag_arena_bytes", N, NA, Lqa, D, lay.Ucap, lay.Fc)
+        arena = _buf(ab, qa.device)
+        mixed = torch.empty(lay.Ucap, D, dtype=torch.float32, device=qa.device)[:lay.U]
+        S = torch.empty(N, NA, Li, Lqa, Lr, dtype=torch.float32, device=qa.device)
+        Sn = torch.empty_like(S)
+        flags = _flags()
+        _rc(lib.stage_grp_qa_ctx_rag_fwd(qa.data_ptr(), cx.data_ptr(), qa_mask.data_ptr(), cx_mask.data_ptr(), _ptrs(params),
+                                         mixed.data_ptr(), S.data_ptr(), Sn.data_ptr(), lay.T, arena.data_ptr(), ab, flags, N, NA, Li, Lqa, Lr,
+                                         D, lay.U, lay.Ucap, lay.Fc, float(scale), float(p), _u64(seeds), _stream()),
+            "stage_grp_qa_ctx_rag_fwd")
+        ctx.save_for_backward(qa, cx, cx_mask, mixed, Sn, arena, *params)
+        ctx.cfg = (N, NA, Li, Lqa, Lr, D, float(scale), float(p), tuple(seeds), flags, ab)
+        ctx.lay = lay
+        ctx.spent = False
+        ctx.set_materialize_grads(False)
+        return mixed, S, Sn
+
+    @_on_device
+    def backward(ctx, d_mixed, dS, dSn):
+        from .ops import _fold_dsn
+        if ctx.spent:      # the backward overwrites the saved attention output with its gradient (csrc/groups.hip G3r)
+            raise RuntimeError("tvqaplus_amd: the ragged attention group can be differentiated once per forward "
+                               "(retain_graph + a second backward: set STAGE_NO_RAGGED=1)")
+        ctx.spent = True
+        qa, cx, cx_mask, mixed, Sn, arena, *params = ctx.saved_tensors
+        N, NA, Li, Lqa, Lr, D, scale, p, seeds, flags, ab = ctx.cfg
+        lay = ctx.lay
+        dS = _fold_dsn(dS, dSn, Sn, scale)
+        d_mixed = _chk(d_mixed, "d_mixed") if d_mixed is not None else torch.zeros_like(mixed)
+        dS = _chk(dS, "dS") if dS is not None else None
+        lib = _lib.load()
+        grads = _grad_views(params)
+        d_qa, d_cx = torch.empty_like(qa), torch.empty_like(cx)
+        tb = _size("stage_grp_qa_ctx_rag_bwd_tmp_bytes", N, NA, Li, Lqa, Lr, D, lay.Ucap)
+        tmp = _buf(tb, qa.device)
+        _rc(lib.stage_grp_qa_ctx_rag_bwd(d_mixed.data_ptr(), None if dS is None else dS.data_ptr(), qa.data_ptr(), cx.data_ptr(),
+                                         cx_mask.data_ptr(), mixed.data_ptr(), Sn.data_ptr(), _ptrs(params), _ptrs(grads), d_qa.data_ptr(),
+                                         d_cx.data_ptr(), lay.T, arena.data_ptr(), ab, flags, tmp.data_ptr(), tb, N, NA, Li, Lqa, Lr, D,
+                                         lay.U, lay.Ucap, lay.Fc, scale, p, _u64(seeds), _stream()), "stage_grp_qa_ctx_rag_bwd")
+        return (d_qa, d_cx, None, None, None, None, None, None) + _deliver(ctx.sinks, grads)
+
+
+def qa_ctx_rag(qa, cx, qa_mask, cx_mask, lay, scale: float, p: float, seeds, params):
+    """As ``qa_ctx``; ``mixed`` comes back as the (U, D) compact rows of ``lay`` (a ``ragged.RaggedLayout``), the score maps dense."""
+    return _QaCtxRag.apply(qa, cx, qa_mask, cx_mask, lay, scale, p, tuple(seeds), *params)
+
+
+class _EncoderRag(torch.autograd.Function):
+    @_on_device
+    def forward(ctx, x, pe, qa_mask, lay, k: int, p: float, seeds, *params):
+        x = _chk(x, "x")                       # (U, D) compact
+        pe, qa_mask = _chk(pe, "pe"), _chk(qa_mask, "qa_mask")
+        ctx.sinks = _sinks(params)
+        params = _params(params)
+        U, D = x.shape
+        n_conv = (len(params) - 2) // 6
+        Rd = lay.N * lay.NA * lay.Li
+        lib = _lib.load()
+        ab = _size("stage_grp_encoder_rag_arena_bytes", lay.Ucap, Rd, D, n_conv)
+        arena = _buf(ab, x.device)
+        out = torch.empty(Rd, D, dtype=torch.float32, device=x.device)
+        flags = _flags()
+        _rc(lib.stage_grp_encoder_rag_fwd(x.data_ptr(), pe.data_ptr(), qa_mask.data_ptr(), _ptrs(params), out.data_ptr(), lay.T,
+                                          arena.data_ptr(), ab, flags, lay.U, lay.Ucap, lay.S, Rd, lay.Lqa, D, n_conv, int(k), float(p),
+                                          _u64(seeds), _stream()), "stage_grp_encoder_rag_fwd")
+        ctx.save_for_backward(qa_mask, arena, *params)
+        ctx.cfg = (U, D, Rd, n_conv, int(k), float(p), tuple(seeds), flags, ab)
+        ctx.lay = lay
+        return out
+
+    @_on_device
+    def backward(ctx, dout):
+        qa_mask, arena, *params = ctx.saved_tensors
+        U, D, Rd, n_conv, k, p, seeds, flags, ab = ctx.cfg
+        lay = ctx.lay
+        dout = _chk(dout, "dout")
+        lib = _lib.load()
+        grads = _grad_views(params)
+        dx = torch.empty(lay.Ucap, D, dtype=torch.float32, device=dout.device)[:U] if ctx.needs_input_grad[0] else None
+        tb = _size("stage_grp_encoder_rag_bwd_tmp_bytes", lay.Ucap, D, k)
+        tmp = _buf(tb, dout.device)
+        _rc(lib.stage_grp_encoder_rag_bwd(dout.data_ptr(), qa_mask.data_ptr(), _ptrs(params), _ptrs(grads),
+                                          None if dx is None else dx.data_ptr(), lay.T, arena.data_ptr(), ab, flags, tmp.data_ptr(), tb,
+                                          lay.U, lay.Ucap, lay.S, Rd, lay.Lqa, D, n_conv, k, p, _u64(seeds), _stream()),
+            "stage_grp_encoder_rag_bwd")
+        return (dx, None, None, None, None, None, None) + _deliver(ctx.sinks, grads)
+
+
+def encoder_block_rag(x, pe, qa_mask, lay, k: int, p: float, seeds, params):
+    """x (U, D) compact rows of ``lay`` -> (N*NA*Li, D): the classifier encoder block + the masked max over the words of every
+    (example, candidate, frame) (model/stage.py:502-503); qa_mask (N*NA, Lqa)."""
+    return _EncoderRag.apply(x, pe, qa_mask, lay, k, p, tuple(seeds), *params)
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # G4 two-stream fusion
 # ---------------------------------------------------------------------------------------------------------------
 class _ConcatFc(torch.autograd.Function):
@@ -303,7 +428,7 @@ class _ConcatFc(torch.autograd.Function):
         lib = _lib.load()
         ab = _size("stage_grp_concat_fc_arena_bytes", U, D)
         arena = _buf(ab, s.device)
-        out = torch.empty_like(s)
+        out = _rows(U, D, s.device)
         flags = _flags()
         _rc(lib.stage_grp_concat_fc_fwd(s.data_ptr(), v.data_ptr(), _ptrs(params), out.data_ptr(), arena.data_ptr(), ab, flags, U, D,
                                         float(p), _u64(seeds), _stream()), "stage_grp_concat_fc_fwd")
@@ -318,7 +443,7 @@ class _ConcatFc(torch.autograd.Function):
         dout = _chk(dout, "dout")
         lib = _lib.load()
         grads = _grad_views(params)
-        ds, dv = torch.empty_like(s), torch.empty_like(v)
+        ds, dv = _rows(U, D, s.device), _rows(U, D, s.device)
         tb = _size("stage_grp_concat_fc_bwd_tmp_bytes", U, D)
         tmp = _buf(tb, s.device)
         _rc(lib.stage_grp_concat_fc_bwd(dout.data_ptr(), s.data_ptr(), v.data_ptr(), _ptrs(params), _ptrs(grads), ds.data_ptr(),

@@ -97,6 +97,8 @@ def shard_batch(batch, rank: int, world: int):
             out[k] = {kk: vv[lo:hi] for kk, vv in v.items()}
         elif k in _LIST_KEYS and isinstance(v, list):
             out[k] = v[lo:hi]
+        elif k == "mask_host" and isinstance(v, dict):     # host copies of the word / frame validity (tvqaplus_amd/ragged.py)
+            out[k] = {kk: vv[lo:hi] for kk, vv in v.items()}
         else:
             out[k] = v
     return out
@@ -297,6 +299,8 @@ class CandidateLayout:
                 out[k] = {kk: vv[lo:hi] for kk, vv in v.items()}
             elif k in _LIST_KEYS and isinstance(v, list):
                 out[k] = v[lo:hi]
+            elif k == "mask_host" and isinstance(v, dict):
+                out[k] = {kk: (vv[lo:hi, k0:k1] if kk == "qas" else vv[lo:hi]) for kk, vv in v.items()}
             else:
                 out[k] = v
         out["cand_offset"] = k0

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import groups, ops
+from . import groups, ops, ragged
 
 NEG = -1e10
 
@@ -205,6 +205,13 @@ class STAGE(nn.Module):
         self.use_groups = os.environ.get("STAGE_NO_GROUPS") is None
         self.gate_shared = os.environ.get("STAGE_NO_PARAM_GATE") is None   # groups.gate for the modules applied to several streams
         self._gate_map = {}
+        # ragged token rows (tvqaplus_amd/ragged.py): the (N, 5, Li, Lqa, .) kernels run on the rows that can reach an output or a
+        # gradient -- live frames x (valid words + the classifier encoder's convolution halo).  False / STAGE_NO_RAGGED=1: every padded
+        # row is computed, as the reference does.  Needs the K-group path at hsz = 128 (otherwise the dense path runs, silently: it is
+        # the same function).  ``last_ragged``: the layout of the last forward (None = dense), for tests and the bench record.
+        self.use_ragged = os.environ.get("STAGE_NO_RAGGED") is None
+        self.last_ragged: Optional[ragged.RaggedLayout] = None
+        self._rag_stage = None
         # storage type of the activations between kernels: fp32 (the reference's), or bf16 with ``opt.storage_dtype = "bf16"``
         # (BASELINE.json configs[4]: bf16 weights / activations, fp32 softmax / statistics / accumulation; parameters stay
         # fp32 master copies, a weight is rounded to bf16 when a GEMM stages it; scores, losses and logits are fp32)
@@ -347,13 +354,19 @@ class STAGE(nn.Module):
         y, _ = self._ln(y, downsize_encoder[3])
         return self._stacked_encoder(y.view(M, L, -1), data_mask, input_encoder)
 
-    def qa_ctx_attention(self, qa_embed, ctx_embed, qa_mask, ctx_mask):
-        """model/stage.py:365-387.  qa_embed (N,5,Lqa,D), ctx_embed (N,Li,Lr,D), qa_mask (N,5,Lqa), ctx_mask (N,Li,Lr)."""
+    def qa_ctx_attention(self, qa_embed, ctx_embed, qa_mask, ctx_mask, lay=None):
+        """model/stage.py:365-387.  qa_embed (N,5,Lqa,D), ctx_embed (N,Li,Lr,D), qa_mask (N,5,Lqa), ctx_mask (N,Li,Lr).
+        ``lay`` (ragged.RaggedLayout): the mixed rows come back compact, (U, D)."""
         N, NA, Lqa, D = qa_embed.shape
         Li = ctx_embed.shape[1]
         p = self._p()
         # (s_mask.sum(-1) != 0) with s_mask = qa_mask (x) ctx_mask
         mixed_mask = ((qa_mask != 0).view(N, NA, 1, Lqa) & (ctx_mask.sum(-1) != 0).view(N, 1, Li, 1)).float()
+        if lay is not None:
+            proj = self.c2q_down_projection
+            res = groups.qa_ctx_rag(qa_embed, ctx_embed, qa_mask, ctx_mask, lay, self.scale, p, self._seeds(3),
+                                    [self._g(w) for w in (proj[0].weight, proj[0].bias, proj[2].weight, proj[2].bias)])
+            return res[0], mixed_mask, res[1], res[2]
         if self._grouped() and qa_embed.dtype == torch.float32 and ctx_embed.shape[2] <= 64:
             proj = self.c2q_down_projection
             res = self._try_group(lambda seeds: groups.qa_ctx(qa_embed, ctx_embed, qa_mask, ctx_mask, self.scale, p, seeds,
@@ -442,13 +455,25 @@ class STAGE(nn.Module):
         return ops.linear(y, lw.conv[2].weight, lw.conv[2].bias, relu=lw.relu), s
 
     def classfier_head_multi_proposal(self, statement, statement_mask, targets, ts_labels, ts_labels_mask,
-                                      extra_span_length=3, gt_scores_fn=None, pool_mask_factors=None):
-        """model/stage.py:484-537."""
+                                      extra_span_length=3, gt_scores_fn=None, pool_mask_factors=None, lay=None, qa_mask=None):
+        """model/stage.py:484-537.  ``lay``: ``statement`` holds the compact rows of a ragged layout, (U, D)."""
         N, NA, Li, Lqa = statement_mask.shape
         D = statement.shape[-1]
-        x = statement.reshape(N * NA * Li, Lqa, D)
         m = statement_mask.reshape(N * NA * Li, Lqa).contiguous()
-        mx = self._stacked_encoder(x, m, self.cls_encoder, pool_mask=m)                # encoder + :503 (max over the words)
+        if lay is not None:
+            blk = self.cls_encoder.stacked_encoderBlocks[0]
+            params = []
+            for i in range(blk.n_conv):
+                c = blk.conv[i]
+                params += [blk.layer_norm[i].weight, blk.layer_norm[i].bias, c.depthwise_conv.weight, c.depthwise_conv.bias,
+                           c.pointwise_conv.weight, c.pointwise_conv.bias]
+            params += [blk.final_layer_norm.weight, blk.final_layer_norm.bias]
+            k = blk.conv[0].depthwise_conv.weight.shape[-1]
+            mx = groups.encoder_block_rag(statement, blk.position_encoding.rows(Lqa), qa_mask.reshape(N * NA, Lqa).contiguous(), lay, k,
+                                          self._p(), self._seeds((blk.n_conv + 1) // 2), [self._g(w) for w in params])
+        else:
+            x = statement.reshape(N * NA * Li, Lqa, D)
+            mx = self._stacked_encoder(x, m, self.cls_encoder, pool_mask=m)            # encoder + :503 (max over the words)
         if pool_mask_factors is not None:
             # :504 from the factors of the statement mask (qa word mask x frame validity): any word valid AND the frame valid --
             # two reductions over KBs instead of one over the 154 MB (N, 5, Li, Lqa) mask
@@ -562,6 +587,51 @@ class STAGE(nn.Module):
                + F.cross_entropy(ca[:, :, 1], ts_labels["ed"], reduction="none"))
         return (per * here.to(per.dtype)).sum() / 2.
 
+    # ---- ragged token rows --------------------------------------------------------------------------------------
+    def _ragged_layout(self, batch, qas_mask, a_embed):
+        """The ragged layout of this batch (tvqaplus_amd/ragged.py), or None when the dense path runs: switched off, a configuration
+        the ragged kernels do not cover (decided BEFORE anything is launched: hsz = 128 on the K-group path, one classifier-encoder
+        block without self-attention, <= 40 QA words, even region / word counts <= 64), or no live row at all."""
+        if not (self.use_ragged and self._grouped() and self.fuse_ln_dwconv and self.fuse_ln_max and a_embed.is_cuda
+                and a_embed.dtype == torch.float32):
+            return None
+        N, NA, Lqa, D = a_embed.shape
+        blocks = list(self.cls_encoder.stacked_encoderBlocks)
+        if D != 128 or len(blocks) != 1 or blocks[0].num_heads != 0 or not (1 <= blocks[0].n_conv <= 8) or not (4 <= Lqa <= 40):
+            return None
+        k = blocks[0].conv[0].depthwise_conv.weight.shape[-1]
+        if k % 2 == 0 or k > 9:
+            return None
+        streams = []
+        if self.sub_flag:
+            streams.append((batch.sub_mask, batch.sub_bert.shape[1], batch.sub_bert.shape[2]))
+        if self.vfeat_flag:
+            streams.append((batch.vid_mask, batch.vid.shape[1], batch.vid.shape[2]))
+        if not streams or any(Li != streams[0][1] for _, Li, _ in streams):
+            return None
+        Li = streams[0][1]
+        # the statement mask's frame side comes from the video stream when there is one (model/stage.py:283-289)
+        frame_stream = "vid" if self.vfeat_flag else "sub"
+        hm = ragged.host_masks(batch, frame_stream)
+        if hm is not None and (hm[0].shape != (N, NA, Lqa) or hm[1].shape != (N, Li)):
+            hm = None                                    # stale host copies (a batch sliced by foreign code): read the masks
+        if hm is None:
+            ctx_m = batch.vid_mask if self.vfeat_flag else batch.sub_mask
+            hm = ragged.masks_from_device(batch.qas_mask.view(N, NA, Lqa), ctx_m.view(N, Li, -1))
+        qa_valid, frame_live = hm
+        if qa_valid.shape != (N, NA, Lqa) or frame_live.shape != (N, Li):
+            return None
+        tab = ragged.RaggedTables(qa_valid, frame_live, ragged.conv_halo(1, blocks[0].n_conv, k))
+        if tab.U == 0:
+            return None
+        lib_ok = all(bool(groups._lib.load().stage_grp_qa_ctx_rag_supported(N, NA, Li, Lqa, int(Lr), D, tab.U, tab.Fc))
+                     for _, _, Lr in streams)
+        if not lib_ok:
+            return None
+        lay = ragged.RaggedLayout(tab, a_embed.device, self._rag_stage)
+        self._rag_stage = lay.stage
+        return lay
+
     # ---- forward ----------------------------------------------------------------------------------------------
     def forward(self, batch):
         if getattr(self, "_is_replica", False):
@@ -615,13 +685,14 @@ class STAGE(nn.Module):
         a_embed = a_embed.view(N, NA, -1, D)
         attended_sub = attended_vid = attended_vid_mask = attended_sub_mask = None
         other_outputs: Dict[str, torch.Tensor] = {}
+        lay = self.last_ragged = self._ragged_layout(batch, qas_mask, a_embed)
         if self.sub_flag:
             Li, Lw = batch.sub_bert.shape[1:3]
             sub_mask = batch.sub_mask.view(N, Li, Lw).float()
             sub_embed = self.base_encoder(batch.sub_bert.view(N * Li, Lw, -1), sub_mask.view(N * Li, Lw),
                                           self.bert_word_encoding_fc, self.input_embedding, self.input_encoder)
             attended_sub, attended_sub_mask, raw, norm = self.qa_ctx_attention(
-                a_embed, sub_embed.view(N, Li, Lw, D), qas_mask, sub_mask)
+                a_embed, sub_embed.view(N, Li, Lw, D), qas_mask, sub_mask, lay)
             other_outputs["sub_normalized_s"], other_outputs["sub_raw_s"] = norm, raw
         if self.vfeat_flag:
             Li, Lr = batch.vid.shape[1:3]
@@ -629,7 +700,7 @@ class STAGE(nn.Module):
             vid_embed = self.base_encoder(batch.vid.view(N * Li, Lr, -1), vid_mask.view(N * Li, Lr), self.vid_fc,
                                           self.input_embedding, self.input_encoder, l2_normalize=True)
             attended_vid, attended_vid_mask, raw, norm = self.qa_ctx_attention(
-                a_embed, vid_embed.view(N, Li, Lr, D), qas_mask, vid_mask)
+                a_embed, vid_embed.view(N, Li, Lr, D), qas_mask, vid_mask, lay)
             other_outputs["vid_normalized_s"], other_outputs["vid_raw_s"] = norm, raw
         if self.flag_cnt == 2:
             fc = self.concat_fc
@@ -669,7 +740,7 @@ class STAGE(nn.Module):
         factors = ((qas_mask != 0).any(-1), ctx_m.sum(-1) != 0)
         out, target, t_scores = self.classfier_head_multi_proposal(
             statement, statement_mask, batch.target, batch.ts_label, batch.ts_label_mask.float(),
-            extra_span_length=self.extra_span_length, gt_scores_fn=gt_scores_fn, pool_mask_factors=factors)
+            extra_span_length=self.extra_span_length, gt_scores_fn=gt_scores_fn, pool_mask_factors=factors, lay=lay, qa_mask=qas_mask)
         assert len(out) == len(target)
         other_outputs["temporal_scores"] = t_scores
 

@@ -105,6 +105,11 @@ def make_batch(N: int = 16, Li: int = 300, Lr: int = 20, Lw: int = 50, Lqa: int 
     b = Batch(qas_bert=qas_bert, qas_mask=qas_mask, sub_bert=sub_bert, sub_mask=sub_mask, vid=vid, vid_mask=vid_mask,
               target=target, ts_label=dict(st=st, ed=ed), ts_label_mask=frame_mask,
               target_list=target.tolist(),     # host copy kept by the input pipeline (att_host.build_att_pairs)
+              # host copies of what the masks say about whole words / frames (the collate function builds the masks from
+              # lengths on the host, tvqa_dataset.py:515-590): lets STAGE lay out its ragged token rows without reading the
+              # device masks back (tvqaplus_amd/ragged.py: host_masks)
+              mask_host=dict(qas=(qas_mask != 0).numpy(), sub_frames=(sub_mask.sum(-1) != 0).numpy(),
+                             vid_frames=(vid_mask.sum(-1) != 0).numpy()),
               qid=list(range(N)), vid_name=["synthetic_%d" % i for i in range(N)],
               qas=torch.zeros(N, 5, Lqa, dtype=torch.long), att_labels=None, anno_st_idx=[0] * N, q_l=[1] * N,
               image_indices=[list(range(Li)) for _ in range(N)], boxes=[[] for _ in range(N)],
