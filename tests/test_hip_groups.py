@@ -21,6 +21,9 @@ def _build(kw, seed=3):
     with torch.no_grad():
         for p in model.parameters():
             p.add_(0.05 * torch.randn_like(p))
+    # dense rows here: the comparison is "same kernels, same dropout stream"; ragged token rows index the dropout counter by compact
+    # row and are held to the dense path in tests/test_hip_ragged.py
+    model.use_ragged = False
     return model
 
 

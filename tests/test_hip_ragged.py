@@ -172,8 +172,10 @@ def test_ragged_model_equals_dense_model(hip_device, cfg):
 
 
 def test_ragged_model_vs_oracle_fp64(hip_device):
-    """The ragged path directly against the CPU oracle (fp64) on a batch with ragged words, dead frames and a blanked valid frame."""
-    model, batch = _pair(dict(add_local=True, dropout=0.0), dict(N=2, Li=13, Lr=20, Lw=18, Lqa=40, seed=41, empty_frames=True), "cpu")
+    """The ragged path directly against the CPU oracle (fp64) on a batch with ragged words and dead frames.  (No blanked valid frame
+    here: x * m + (1 - m) * -1e10 absorbs x only in fp32, so fp64 is no yardstick for that case -- the dense-vs-ragged test above and
+    the small_emptyframe_train fixture cover it.)"""
+    model, batch = _pair(dict(add_local=True, dropout=0.0), dict(N=2, Li=13, Lr=20, Lw=18, Lqa=40, seed=41), "cpu")
     opt = model.opt
     P = {k: (v.double().requires_grad_(not k.endswith(".pe")) if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
     b64 = type(batch)({k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in batch.items()})
@@ -188,12 +190,7 @@ def test_ragged_model_vs_oracle_fp64(hip_device):
     assert abs(loss - float(ref_loss)) < 1e-3 * (1 + abs(float(ref_loss)))
     for k in ("sub_raw_s", "sub_normalized_s", "vid_raw_s", "vid_normalized_s"):
         assert rel_err(other[k], ref[k]) < 1e-3, k
-    from conftest import UNDEFINED_GRADS
-    skip = set(UNDEFINED_GRADS["small_emptyframe_train"])      # a blanked valid frame: the reference's own values are undefined there
     for k, g in grads.items():
-        if k in skip:
-            assert torch.isfinite(g).all(), k
-            continue
         e = P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])
         assert rel_err(g, e) < 4e-3, (k, rel_err(g, e))
 

@@ -492,3 +492,54 @@ def test_gradients_against_fp64(hip_device, name):
                 for k, p in model.named_parameters())
     assert e_hip < 4e-3, (e_hip, e_ref)
     assert e_hip < max(1.5 * e_ref, 1e-3), (e_hip, e_ref)
+
+
+@pytest.mark.parametrize("path", ["ragged", "groups", "per_op"])
+def test_training_trajectory_vs_oracle(hip_device, path):
+    """main.py:45-66 for TEN optimizer steps: forward, CE * N / N_new + 0.5 * temporal + 0.1 * attention loss, backward, clip_grad_norm_(10),
+    Adam(lr 1e-3, wd 3e-7) -- the HIP model against the oracle stepping the same parameters on the CPU (fp32, dropout 0, add_local,
+    supervised attention on).  Every step's loss within 1e-3, the final parameters within 6e-3 (the gradient tolerance of this file): what
+    a single forward / backward cannot show is state carried from step to step -- parameter gates, transposed-weight caches, arenas,
+    the fused optimizer updating in place, the ragged layout rebuilt per step."""
+    from tvqaplus_amd import att_host
+    from tvqaplus_amd.stage import STAGE
+    from tvqaplus_amd.synth import make_batch, make_opt
+    torch.manual_seed(5)
+    opt = make_opt(hsz=128, embedding_size=96, vfeat_size=64, dropout=0.0, add_local=True, use_sup_att=True)
+    model = STAGE(opt)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    batches = [make_batch(N=2, Li=12, Lr=20, Lw=18, Lqa=40, wd_size=96, vfeat_size=64, seed=70 + i, att_imgs=3, att_words=2) for i in range(2)]
+    P = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(".pe")) for k, v in model.state_dict().items()}
+    ref_params = [v for v in P.values() if v.requires_grad]
+    ref_opt = torch.optim.Adam(ref_params, lr=1e-3, weight_decay=3e-7)
+    model = model.to(hip_device).train()
+    model.use_ragged = path == "ragged"
+    model.use_groups = path != "per_op"
+    params = [p for p in model.parameters() if p.requires_grad]
+    optim = torch.optim.Adam(params, lr=1e-3, weight_decay=3e-7, fused=(path != "per_op"))
+    dev_batches = [b.to(hip_device) for b in batches]
+    for step in range(10):
+        b, bd = batches[step % 2], dev_batches[step % 2]
+        # oracle step
+        ref_opt.zero_grad(set_to_none=True)
+        torch.manual_seed(1000 + step)             # the attention loss draws its negatives from the default generator
+        out = O.stage_forward(P, opt, b, training=True)
+        ref_loss = O.training_loss(out, n_examples=2) + 0.1 * att_host.get_att_loss(opt, out["vid_raw_s"], b)[0]
+        ref_loss.backward()
+        torch.nn.utils.clip_grad_norm_(ref_params, 10.0)
+        ref_opt.step()
+        # product step
+        optim.zero_grad(set_to_none=True)
+        torch.manual_seed(1000 + step)
+        (logits, targets), att_loss, _, t_loss, _ = model(bd)
+        loss = F.cross_entropy(logits, targets, reduction="sum") * (2 / len(targets)) + 0.5 * t_loss + 0.1 * att_loss
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 10.0)
+        optim.step()
+        assert (model.last_ragged is not None) == (path == "ragged")
+        assert torch.equal(targets.cpu(), out["targets"]), step
+        assert abs(float(loss) - float(ref_loss)) < TOL * (1 + abs(float(ref_loss))), (step, float(loss), float(ref_loss))
+    worst = max((rel_err(p, P[k]), k) for k, p in model.named_parameters())
+    assert worst[0] < GTOL, worst

@@ -94,7 +94,6 @@ def test_live_rows_are_all_the_reference_needs(k, n_conv):
     halo = ragged.conv_halo(1, n_conv, k)
     t = ragged.RaggedTables(qa, fl, halo)
     key = "cls_encoder.stacked_encoderBlocks.0"
-    P = {key + ".position_encoding.pe": O.position_table({}, "none", 500, D).double() if False else None}
     # parameters of one encoder block (names as in the reference's state_dict)
     from tvqaplus_amd.stage import _PositionTable
     P = {key + ".position_encoding.pe": _PositionTable.table(500, D).double()}

@@ -1,0 +1,20 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_hip_ragged.py -x -q -m gpu > gpurun_out/r4_ragged_tests.log 2>&1; echo "ragged tests rc=$?"
+timeout 300 python tools/rag_step_probe.py > gpurun_out/r4_probe.log 2>&1; tail -8 gpurun_out/r4_probe.log
+timeout 600 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_pmc --dump_steps > gpurun_out/r4_bench_ragged.log 2>&1; echo "bench rc=$?"
+cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r4_trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_pmc --no_roofline --no_device_time > $GRAFT_REPO_ROOT/gpurun_out/r4_trace_bench.log 2>&1; echo "trace rc=$?"
+cd $GRAFT_REPO_ROOT
+tail -3 gpurun_out/r4_ragged_tests.log
+python - <<'PY'
+import json
+d=json.loads([l for l in open("gpurun_out/r4_bench_ragged.log") if l.startswith("{")][-1])
+print(d["ms_per_step"], d["value"], d["host_issue_ms_per_step"], d["host_wait_ms_per_step"], d.get("device_ms_per_step"), d.get("launches_per_step"))
+print(d.get("step_ms_all"))
+for k in d:
+    if k.startswith("roofline"):
+        r=d[k]; print(k,{kk:r.get(kk) for kk in ("avg_us","frac","isolated_avg_us")})
+PY
+ls gpurun_out/r4_trace | head

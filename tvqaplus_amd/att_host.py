@@ -122,15 +122,22 @@ class PinnedStage:
         self.events = [None, None]
         self.turn = 0
 
-    def upload(self, t: torch.Tensor, device) -> torch.Tensor:
+    def upload(self, t, device) -> torch.Tensor:
+        """t: a host tensor or a numpy array (staged with numpy: a torch CPU copy of more than 32 K elements goes through the intra-op
+        thread pool, and waking that pool inside the training step cost 50-130 ms every few steps on a 256-thread host)."""
         i = self.turn
         self.turn ^= 1
         if self.events[i] is not None:
             self.events[i].synchronize()           # the copy that read this buffer two steps ago has finished
-        n = t.numel()
-        if self.bufs[i] is None or self.bufs[i].numel() < n:
-            self.bufs[i] = torch.empty(max(2 * n, 4096), dtype=t.dtype, pin_memory=True)
-        self.bufs[i][:n].copy_(t)
+        is_np = isinstance(t, np.ndarray)
+        n = int(t.size) if is_np else t.numel()
+        dt = torch.from_numpy(t[:0]).dtype if is_np else t.dtype
+        if self.bufs[i] is None or self.bufs[i].numel() < n or self.bufs[i].dtype != dt:
+            self.bufs[i] = torch.empty(max(2 * n, 4096), dtype=dt, pin_memory=True)
+        if is_np:
+            np.copyto(self.bufs[i].numpy()[:n], t.reshape(-1))
+        else:
+            self.bufs[i][:n].copy_(t)
         with torch.cuda.device(device):
             dev = self.bufs[i][:n].to(device, non_blocking=True)
             ev = torch.cuda.Event()
@@ -176,10 +183,13 @@ def get_att_loss(model, scores: torch.Tensor, batch, pairs=None):
         pairs = AttPairs(pos, neg, scores.shape, scores.device)
     assert pairs.shape == tuple(scores.shape), (pairs.shape, tuple(scores.shape))
     grouped = getattr(model, "_grouped", None)
-    if grouped is not None and grouped() and scores.is_cuda and scores.dtype == torch.float32:
+    if grouped is not None and grouped() and scores.is_cuda and scores.dtype == torch.float32 and pairs.m > 0:
         # gather + loss + per-pair gradient coefficients in one kernel; the backward zero-fills and scatters (csrc/groups.hip)
         from . import groups
-        return groups.att_loss(scores.contiguous(), pairs.flat, pairs.m, model.att_loss_type, model.alpha, model.margin), None
+        try:
+            return groups.att_loss(scores.contiguous(), pairs.flat, pairs.m, model.att_loss_type, model.alpha, model.margin), None
+        except groups.Unsupported:
+            pass      # the plain gather below
     # ONE flat gather: the gradient reaches raw_s as a sparse scatter
     vals = scores.contiguous().reshape(-1).index_select(0, pairs.flat)
     s_pos, s_neg = vals[: pairs.m], vals[pairs.m:]

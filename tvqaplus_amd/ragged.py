@@ -123,14 +123,13 @@ class RaggedLayout:
         host = np.zeros(total, dtype=np.int32)
         for o, p in zip(offs, parts):
             host[o:o + p.size] = p
-        t = torch.from_numpy(host)
         if torch.device(device).type == "cuda":
             if stage is None:
                 from .att_host import PinnedStage
                 stage = PinnedStage()
-            self.tables = stage.upload(t, device)
+            self.tables = stage.upload(host, device)      # (numpy in: staged without torch's intra-op thread pool)
         else:                                             # host-logic tests
-            self.tables = t.to(device)
+            self.tables = torch.from_numpy(host).to(device)
         self.stage = stage
         self.fmap = self.tables[offs[0]: offs[0] + tab.fmap.size]
         self.gdesc = self.tables[offs[1]: offs[1] + tab.gdesc.size]

@@ -498,7 +498,9 @@ class STAGE(nn.Module):
             h, _ = self._linear_wrapper(enc, self.cls_projection_layers[0])
             t_st, first = self._linear_wrapper(h, st_lw, res=enc)                        # first = enc + h
             t_ed, _ = self._linear_wrapper(first, ed_lw)
-        grouped_tail = res is not None
+        # the head-glue kernels (csrc/groups.hip) take Li <= 2048 frames and 2 * hsz <= 1024 columns; past that the per-op branches
+        # below run (pre-checked here: those entry points would decline the shape in the middle of the step)
+        grouped_tail = res is not None and Li <= 2048 and 2 * D <= 1024
         if grouped_tail:
             t_scores = groups.tscores(t_st, t_ed, ts_labels_mask.reshape(N, Li), N, NA, Li)  # cat + :521 mask_logits, one kernel
         else:
@@ -571,9 +573,12 @@ class STAGE(nn.Module):
         ranks of the group is the full loss)."""
         bsz = len(answer_indices)
         NA_loc, Li = temporal_scores.shape[1:3]
-        if self._grouped() and temporal_scores.is_cuda and temporal_scores.dtype == torch.float32:
+        if self._grouped() and temporal_scores.is_cuda and temporal_scores.dtype == torch.float32 and 1 <= Li <= 2048 and bsz > 0:
             # loss and its gradient in one pass (csrc/groups.hip: ts_loss_kernel) instead of gather + 2 x (log-softmax, nll) + add
-            return groups.ts_loss(temporal_scores, answer_indices, ts_labels["st"], ts_labels["ed"], cand_offset)
+            try:
+                return groups.ts_loss(temporal_scores, answer_indices, ts_labels["st"], ts_labels["ed"], cand_offset)
+            except groups.Unsupported:
+                pass
         local = answer_indices - cand_offset
         if cand_offset == 0 and NA_loc == self.num_a:
             ca = temporal_scores.gather(1, local.view(bsz, 1, 1, 1).expand(bsz, 1, Li, 2)).squeeze(1)   # [n, target_n]
