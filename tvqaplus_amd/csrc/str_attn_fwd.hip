@@ -66,14 +66,15 @@ __device__ __forceinline__ int dchunk(int g, int m) {
 // cooperatively (a quarter of the work per wave), the waves take the context tiles round-robin, and the 27 KB copy no
 // longer limits the CU to 5 waves (8 fit their registers).  Items are whole frames handed out per workgroup.
 // TQ: storage type of Q and A (float, or bf16 in the bf16 storage mode); the LDS copy, Cn and the score maps are fp32
-template <int RT, int KL, bool PERM, bool TRAIN, bool VEC_S, bool WGF, typename TQ = float>
+template <int RT, int KL, bool PERM, bool TRAIN, bool VEC_S, bool WGF, typename TQ = float, bool FC = false>
 __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
     const float* __restrict__ Cn, const TQ* __restrict__ Q, const float* __restrict__ cmask,
     const float* __restrict__ qmask, TQ* __restrict__ A, float* __restrict__ S, float* __restrict__ Sn, int N,
     int NA, int Li, int Lqa, int Lr, float scale, int slices, int tiles_per_slice, uint64_t seed, uint32_t th,
     float inv_keep, unsigned int* __restrict__ ticket, unsigned int ticket_base, unsigned long long* __restrict__ tim,
     const int* __restrict__ fmap) {
-    // fmap != NULL: frame-compact A (see str_attn_fwd_reg.hip / include/stage_hip.h "ragged token rows"); S / S_ stay dense
+    // FC (fmap != NULL; compile time, the dense kernels stay the code they were): frame-compact A (see str_attn_fwd_reg.hip /
+    // include/stage_hip.h "ragged token rows"); S / S_ stay dense
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = tim ? __builtin_readcyclecounter() : 0;
 #define TICK(ph) do { if (tim) { unsigned long long tn = __builtin_readcyclecounter(); tacc[ph] += tn - tlast; tlast = tn; } } while (0)
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
         long afirst = (long)n * NA * Li;
         int aslots = Li, aslot = i;
         bool dead = false;
-        if (fmap) {
+        if (FC) {
             aslots = __builtin_amdgcn_readfirstlane(fmap[(long)N * Li + n]);
             afirst = __builtin_amdgcn_readfirstlane(fmap[(long)N * Li + N + n]);
             aslot = __builtin_amdgcn_readfirstlane(fmap[frame]);
@@ -275,7 +276,8 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
             const int c_lo = tile0 * 16, c_hi = min(CR, tile1 * 16);
             for (int c = c_lo + (lane >> 5) + (WGF ? 2 * wave : 0); c < c_hi; c += WGF ? 8 : 2) {
                 const long orow = ((long)(n * NA + c / Lqa) * Li + i) * Lqa + c % Lqa;
-                if (!dead) stv4(A + ((afirst + (long)(c / Lqa) * aslots + aslot) * Lqa + c % Lqa) * DD + 4 * sq, f4zero());
+                if (!FC) stv4(A + orow * DD + 4 * sq, f4zero());
+                else if (!dead) stv4(A + ((afirst + (long)(c / Lqa) * aslots + aslot) * Lqa + c % Lqa) * DD + 4 * sq, f4zero());
                 for (int r = sq; r < Lr; r += 32) { S[orow * Lr + r] = STAGE_NEG; Sn[orow * Lr + r] = 0.f; }
             }
             item = next_item;
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
                 const int tile = u ? t1 : t0;
                 const int c = min(tile * 16 + c15, CR - 1);
                 orow[u] = ((long)(n * NA + c / Lqa) * Li + i) * Lqa + c % Lqa;
-                arowA[u] = (afirst + (long)(c / Lqa) * aslots + aslot) * Lqa + c % Lqa;
+                arowA[u] = FC ? (afirst + (long)(c / Lqa) * aslots + aslot) * Lqa + c % Lqa : orow[u];
                 cmv[u] = cms[(tile - tile0) * 16 + c15];
             }
             f32x4 acc[NU][RT];
@@ -616,7 +618,9 @@ static int launch_d128_t(const float* Cn, const TQ* Q, const float* cm, const fl
         // K1_F16: prepared fp16 pairs + transposed fp16 planes; otherwise raw + prepared fp32 copy
         const size_t lds = ((f16l ? (size_t)(Lr + 1) * LDQ + 2 * QT_PLANE / 4 : (size_t)2 * (Lr + 1) * LDQ) + 2 * RT * 16 +
                             (size_t)CT * 16 + 8) * sizeof(float);
-        auto kern = str_attn_fwd_d128_kernel<RT, KL, PERM, TRAIN, VEC_S, true, TQ>;
+        auto kern = str_attn_fwd_d128_kernel<RT, KL, PERM, TRAIN, VEC_S, true, TQ, false>;
+        if constexpr (std::is_same<TQ, float>::value) { if (fmap) kern = str_attn_fwd_d128_kernel<RT, KL, PERM, TRAIN, VEC_S, true, TQ, true>; }
+        else if (fmap) return STAGE_ERR_SHAPE;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         long wg_per_cu = (long)((160 * 1024) / ((lds + 511) / 512 * 512));
         if (wg_per_cu > 2) wg_per_cu = 2;
@@ -643,7 +647,9 @@ static int launch_d128_t(const float* Cn, const TQ* Q, const float* cm, const fl
     }
     if (getenv("STAGE_K1_WPB")) wpb = atoi(getenv("STAGE_K1_WPB"));
     const size_t lds = wpb * wave_bytes;
-    auto kern = str_attn_fwd_d128_kernel<RT, KL, PERM, TRAIN, VEC_S, false, TQ>;
+    auto kern = str_attn_fwd_d128_kernel<RT, KL, PERM, TRAIN, VEC_S, false, TQ, false>;
+    if constexpr (std::is_same<TQ, float>::value) { if (fmap) kern = str_attn_fwd_d128_kernel<RT, KL, PERM, TRAIN, VEC_S, false, TQ, true>; }
+    else if (fmap) return STAGE_ERR_SHAPE;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const long items = (long)N * Li * slices;
     int waves_per_cu = best > 0 ? best : 1;

@@ -41,14 +41,15 @@ __device__ __forceinline__ void st4_out(stage_bf16* p, float4 v) { stv4(p, v); }
 #define RNCH 8          // 4-float chunks per lane group
 
 // TQ: storage type of Q and A (float, or bf16 in the bf16 storage mode; Cn -- small, L2 resident -- and the score maps stay fp32)
-template <int RT, int KL, bool PERM, bool TRAIN, bool VEC_S, typename TQ = float>
+template <int RT, int KL, bool PERM, bool TRAIN, bool VEC_S, typename TQ = float, bool FC = false>
 __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
     const float* __restrict__ Cn, const TQ* __restrict__ Q, const float* __restrict__ cmask,
     const float* __restrict__ qmask, TQ* __restrict__ A, float* __restrict__ S, float* __restrict__ Sn, int N,
     int NA, int Li, int Lqa, int Lr, float scale, int slices, int tiles_per_slice, uint64_t seed, uint32_t th,
     float inv_keep, unsigned int* __restrict__ ticket, unsigned int ticket_base, int static_rounds,
     const int* __restrict__ fmap) {
-    // fmap != NULL: A is FRAME-COMPACT (include/stage_hip.h, "ragged token rows"): example n keeps slots = fmap[N*Li + n] frame slots per
+    // FC (fmap != NULL; a template parameter so that the dense kernels stay exactly the code they were: their hand-counted waits
+    // are sensitive to any change of the tile loop): A is FRAME-COMPACT (include/stage_hip.h, "ragged token rows"): example n keeps slots = fmap[N*Li + n] frame slots per
     // candidate (its live frames + one dump slot), first sequence fmap[N*Li + N + n]; fmap[frame] = slot of the frame, < 0: dead (the
     // frame's A rows are never read: they go to the dump slot so that the store count of the tile loop stays exact).  S / S_ stay dense.
     constexpr int NK2 = (RT - 1) * 4 + KL;            // stage-2 k-steps (4 regions each)
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
     // the same for the rows of A: dense (fmap == NULL) they are the rows above; frame-compact: ((first + a * slots + slot) * Lqa + w
     unsigned arow_k1 = row_k1, arow_k0 = 0u;        // per item
     auto a_row = [&](int c) -> unsigned {
+        if (!FC) return out_row(c);
         const int a = (int)(((float)c + 0.5f) * inv_lqa);
         return (unsigned)c + __umul24((unsigned)a, arow_k1) + arow_k0;
     };
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
         row_k0 = ((unsigned)n * NA * Li + i) * Lqa;
         arow_k0 = row_k0;
         bool dead = false;
-        if (fmap) {
+        if (FC) {
             const int slots = __builtin_amdgcn_readfirstlane(fmap[(long)N * Li + n]);
             const int first = __builtin_amdgcn_readfirstlane(fmap[(long)N * Li + N + n]);
             int slot = __builtin_amdgcn_readfirstlane(fmap[frame]);
@@ -518,7 +520,16 @@ static int launch_reg_t(const float* Cn, const TQ* Q, const float* cm, const flo
     const StageTicket tk = stage_next_ticket((unsigned int)draws);
     if (!tk.word) return (int)hipErrorOutOfMemory;
     const size_t park = K1_F16 ? (size_t)4 * 16 * 64 * sizeof(uint4) : 0;   // 64 KB per workgroup
-    hipLaunchKernelGGL((str_attn_fwd_reg_kernel<RT, KL, PERM, TRAIN, VEC_S, TQ>), dim3((unsigned)blocks), dim3(256), park, st, Cn, Q,
+    if constexpr (std::is_same<TQ, float>::value) {      // the frame-compact layout exists for fp32 storage only
+        if (fmap) {
+            hipLaunchKernelGGL((str_attn_fwd_reg_kernel<RT, KL, PERM, TRAIN, VEC_S, TQ, true>), dim3((unsigned)blocks), dim3(256), park, st, Cn, Q,
+                               cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, slices, tps, (uint64_t)seed, th, ik, tk.word, tk.base,
+                               static_rounds, fmap);
+            STAGE_LAUNCH_CHECK_TICKET(tk);
+            return 0;
+        }
+    }
+    hipLaunchKernelGGL((str_attn_fwd_reg_kernel<RT, KL, PERM, TRAIN, VEC_S, TQ, false>), dim3((unsigned)blocks), dim3(256), park, st, Cn, Q,
                        cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, slices, tps, (uint64_t)seed, th, ik, tk.word, tk.base,
                        static_rounds, fmap);
     STAGE_LAUNCH_CHECK_TICKET(tk);
