@@ -437,15 +437,34 @@ int stage_grp_pool_cls_bwd(const float* d_logits, const float* mask, const int* 
  *   seqfc   (S)        frame-compact sequence of each entry of seq
  *   rowinfo (U, 4)     QA row g*Lqa + w, frame-compact row, dense output row, w                 (stage_rag_rowinfo)                 */
 int stage_rag_rowinfo(const int* seq, const int* seqfc, long long S, int Lqa, int* rowinfo, void* stream);
+/* Ragged CONTEXT rows (the (N, Li, Lw|Lr, .) streams in front of the attention: model/stage.py:235-270): frame f keeps its valid words /
+ * regions plus the halo of the input encoder's convolutions, cq[f] = (first compact row, rows); src_rows[r] = row of the padded feature
+ * tensor that compact row r reads (stage_rag_ctx_rows).  The *_gather entry points are LayerNorm / L2 normalisation reading those rows
+ * in place (model/stage.py:85-91, 98-104, 256); everything behind them runs on the compact rows. */
+int stage_rag_ctx_rows(const int* cq, long long frames, int L, int* src_rows, void* stream);
+int stage_layernorm_gather_fwd(const float* x, const int* gather, const float* gamma, const float* beta, float* y, float* mean,
+                               float* rstd, long long rows, int K, float eps, float p_drop, unsigned long long seed, void* stream);
+int stage_layernorm_gather_bwd(const float* dy, const float* x, const int* gather, const float* mean, const float* rstd,
+                               const float* gamma, float* dgamma, float* dbeta, long long rows, int K, float p_drop,
+                               unsigned long long seed, void* ws, size_t ws_bytes, void* stream);
+int stage_l2norm_gather_fwd(const float* x, const int* gather, float* y, long long rows, int K, float eps, void* stream);
+int stage_grp_input_mlp_rag_fwd(const float* x, const int* src_rows, const float* const* P, float* out, void* arena,
+                                size_t arena_bytes, int* flags, long long M, int K0, int H, int D, int l2, float p,
+                                const unsigned long long* seeds, void* stream);
+int stage_grp_input_mlp_rag_bwd(const float* dout, const float* x, const int* src_rows, const float* const* P, float* const* G,
+                                const void* arena, size_t arena_bytes, const int* flags, void* tmp, size_t tmp_bytes, long long M,
+                                int K0, int H, int D, int l2, float p, const unsigned long long* seeds, void* stream);
 int stage_rag_fill_pooled(float* out, int* argmax, long long rows, int D, void* stream);      /* -1e10 / 0: model/stage.py:503 on an all-masked group */
 int stage_rag_zero_dump(float* A_fc, const int* fmap, int N, int NA, int Li, int Lqa, int D, void* stream);
 /* K1 with a frame-compact A / dA (model/context_query_attention.py:35-101; D == 128, the fast kernels only) */
+/* cq (may be NULL): Q / Qn / dQraw / dQn hold compact context rows (above); q_mask stays dense (N, Li, Lr) */
 int stage_str_attn_fwd_fc(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A_fc, float* S_raw,
-                          float* S_norm, const int* fmap, int N, int NA, int Li, int Lqa, int Lr, int D, float scale, float p_drop,
-                          unsigned long long seed, void* stream);
+                          float* S_norm, const int* fmap, const int* cq, int N, int NA, int Li, int Lqa, int Lr, int D, float scale,
+                          float p_drop, unsigned long long seed, void* stream);
 int stage_str_attn_bwd_fused_fc(const float* dA_fc, const float* dS_raw_ext, const float* Cn, const float* Q, const float* Qn,
                                 const float* S_norm, const float* q_mask, float* dQraw, float* dQn, float* dCn, const int* fmap,
-                                int N, int NA, int Li, int Lqa, int Lr, int D, float scale, void* ws, size_t ws_bytes, void* stream);
+                                const int* cq, int N, int NA, int Li, int Lqa, int Lr, int D, float scale, void* ws, size_t ws_bytes,
+                                void* stream);
 /* [a, b, a*b] LayerNorm -> Linear -> ReLU (model/stage.py:381-385) on compact rows: a = QA rows, b = frame-compact rows */
 int stage_cat3_ln_gemm_fwd_rag_supported(long long rows, long long a_rows, long long b_rows, int D);
 int stage_cat3_ln_gemm_fwd_rag(const float* a, const float* b, const float* gamma, const float* beta, const float* W,
@@ -473,19 +492,21 @@ int stage_ln_masked_max_rag_fwd(const float* x, const float* res, float* sum_out
 int stage_ln_masked_max_rag_bwd(const float* dout, const int* argmax, const float* qmask, const float* xin, const float* mean,
                                 const float* rstd, const float* gamma, float* dx, float* dgamma, float* dbeta,
                                 const int* rowinfo, long long rows, int K, void* ws, size_t ws_bytes, void* stream);
-/* K-groups on ragged rows (csrc/groups.hip "RAGGED TOKEN ROWS"): T = host array of the four device tables fmap, gdesc, seq, rowinfo */
+/* K-groups on ragged rows (csrc/groups.hip "RAGGED TOKEN ROWS"): T = host array of the device tables fmap, gdesc, seq, rowinfo, cq
+ * (cq NULL: dense context stream; Uc = rows of ctx / d_ctx).  The encoder group pools when qa_mask != NULL, else returns (U, D). */
 int stage_grp_qa_ctx_rag_supported(int N, int NA, int Li, int Lqa, int Lr, int D, long long U, long long Fc);
 size_t stage_grp_qa_ctx_rag_arena_bytes(int N, int NA, int Lqa, int D, long long Ucap, long long Fc);
-size_t stage_grp_qa_ctx_rag_bwd_tmp_bytes(int N, int NA, int Li, int Lqa, int Lr, int D, long long Ucap);
+size_t stage_grp_qa_ctx_rag_bwd_tmp_bytes(int N, int NA, int Li, int Lqa, int Lr, int D, long long Ucap, long long Uc);
 int stage_grp_qa_ctx_rag_fwd(const float* qa, const float* ctx, const float* qa_mask, const float* ctx_mask,
                              const float* const* P, float* mixed, float* S_raw, float* S_norm, const int* const* T, void* arena,
                              size_t arena_bytes, int* flags, int N, int NA, int Li, int Lqa, int Lr, int D, long long U,
-                             long long Ucap, long long Fc, float scale, float p, const unsigned long long* seeds, void* stream);
+                             long long Ucap, long long Fc, long long Uc, float scale, float p, const unsigned long long* seeds,
+                             void* stream);
 int stage_grp_qa_ctx_rag_bwd(const float* d_mixed, const float* dS_ext, const float* qa, const float* ctx, const float* ctx_mask,
                              const float* mixed, const float* S_norm, const float* const* P, float* const* G, float* d_qa,
                              float* d_ctx, const int* const* T, void* arena, size_t arena_bytes, const int* flags, void* tmp,
                              size_t tmp_bytes, int N, int NA, int Li, int Lqa, int Lr, int D, long long U, long long Ucap,
-                             long long Fc, float scale, float p, const unsigned long long* seeds, void* stream);
+                             long long Fc, long long Uc, float scale, float p, const unsigned long long* seeds, void* stream);
 size_t stage_grp_encoder_rag_arena_bytes(long long Ucap, long long Rd, int D, int n_conv);
 size_t stage_grp_encoder_rag_bwd_tmp_bytes(long long Ucap, int D, int k);
 int stage_grp_encoder_rag_fwd(const float* x, const float* pe, const float* qa_mask, const float* const* P, float* out,

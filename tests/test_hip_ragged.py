@@ -45,8 +45,22 @@ def test_k1_frame_compact_equals_dense(hip_device, Lr, train):
     Afc = torch.full((lay.Fc, D), 7.0, device=dev)
     S2, Sn2 = torch.empty_like(S), torch.empty_like(Sn)
     assert lib.stage_str_attn_fwd_fc(Cn.data_ptr(), Q.data_ptr(), cmask.data_ptr(), qmask.data_ptr(), Afc.data_ptr(), S2.data_ptr(),
-                                     Sn2.data_ptr(), lay.fmap.data_ptr(), N, NA, Li, Lqa, Lr, D, 10.0, p, seed, _stream()) == 0
+                                     Sn2.data_ptr(), lay.fmap.data_ptr(), None, N, NA, Li, Lqa, Lr, D, 10.0, p, seed, _stream()) == 0
     assert torch.equal(S, S2) and torch.equal(Sn, Sn2)
+    # the same with COMPACT region rows (valid regions + a halo of 3): identical outputs without dropout; with dropout the counter is
+    # indexed by compact row, so only the maps' support and the masked entries are compared
+    from tvqaplus_amd import ragged
+    ct = ragged.CtxTables(b.mask_host["vid_len"], Lr, 3)
+    cl = ragged.CtxLayout(ct, dev)
+    Qc = Q.view(-1, D)[cl.src_rows[:cl.U].long()].contiguous()
+    Afc3 = torch.full((lay.Fc, D), 7.0, device=dev)
+    S3, Sn3 = torch.empty_like(S), torch.empty_like(Sn)
+    assert lib.stage_str_attn_fwd_fc(Cn.data_ptr(), Qc.data_ptr(), cmask.data_ptr(), qmask.data_ptr(), Afc3.data_ptr(), S3.data_ptr(),
+                                     Sn3.data_ptr(), lay.fmap.data_ptr(), cl.cq.data_ptr(), N, NA, Li, Lqa, Lr, D, 10.0, p, seed, _stream()) == 0
+    if not train:
+        assert torch.equal(S, S3) and torch.equal(Sn, Sn3) and torch.equal(Afc, Afc3)
+    else:
+        assert torch.equal(S <= -1e9, S3 <= -1e9) and torch.equal(Sn == 0, Sn3 == 0) and bool(torch.isfinite(Afc3).all())
     t = lay.tab
     slots, first = t.fmap[N * Li: N * Li + N], t.fmap[N * Li + N:]
     fm = t.fmap[: N * Li].reshape(N, Li)
@@ -91,8 +105,8 @@ def test_k1_frame_compact_equals_dense(hip_device, Lr, train):
             if fc:
                 rc = lib.stage_str_attn_bwd_fused_fc(dA_fc.data_ptr(), None if e is None else e.data_ptr(), Cn.data_ptr(), Q.data_ptr(),
                                                      Qn.data_ptr(), Sn.data_ptr(), qmask.data_ptr(), dQ.data_ptr(), dQn.data_ptr(),
-                                                     dCn.data_ptr(), lay.fmap.data_ptr(), N, NA, Li, Lqa, Lr, D, 10.0, ws.data_ptr(), wsb,
-                                                     _stream())
+                                                     dCn.data_ptr(), lay.fmap.data_ptr(), None, N, NA, Li, Lqa, Lr, D, 10.0, ws.data_ptr(),
+                                                     wsb, _stream())
             else:
                 rc = lib.stage_str_attn_bwd_fused(dA.data_ptr(), None if e is None else e.data_ptr(), Cn.data_ptr(), Q.data_ptr(),
                                                   Qn.data_ptr(), Sn.data_ptr(), qmask.data_ptr(), dQ.data_ptr(), dQn.data_ptr(),
@@ -101,6 +115,20 @@ def test_k1_frame_compact_equals_dense(hip_device, Lr, train):
             outs.append((dQ.clone(), dQn.clone(), dCn.clone()))
         for x, y in zip(*outs):
             assert torch.equal(x, y)
+        if not train:      # compact region rows: the same gradients on the rows that exist (the others are exact zeros in the dense result)
+            dQ, dQn, dCn = torch.full((cl.U, D), 5.0, device=dev), torch.full((cl.U, D), 5.0, device=dev), torch.empty_like(Cn)
+            Qnc = torch.empty_like(Qc)
+            assert lib.stage_l2norm_fwd(Qc.data_ptr(), Qnc.data_ptr(), None, cl.U, D, 1e-12, 0.0, 0, _stream()) == 0
+            assert lib.stage_str_attn_bwd_fused_fc(dA_fc.data_ptr(), None if e is None else e.data_ptr(), Cn.data_ptr(), Qc.data_ptr(),
+                                                   Qnc.data_ptr(), Sn.data_ptr(), qmask.data_ptr(), dQ.data_ptr(), dQn.data_ptr(),
+                                                   dCn.data_ptr(), lay.fmap.data_ptr(), cl.cq.data_ptr(), N, NA, Li, Lqa, Lr, D, 10.0,
+                                                   ws.data_ptr(), wsb, _stream()) == 0
+            src = cl.src_rows[:cl.U].long()
+            gone = torch.ones(N * Li * Lr, dtype=torch.bool, device=dev)
+            gone[src] = False
+            assert torch.equal(dQ, outs[0][0].view(-1, D)[src]) and torch.equal(dQn, outs[0][1].view(-1, D)[src])
+            assert torch.equal(dCn, outs[0][2])
+            assert float(outs[0][0].view(-1, D)[gone].abs().max()) == 0.0 and float(outs[0][1].view(-1, D)[gone].abs().max()) == 0.0
 
 
 def _pair(opt_kw, batch_kw, device, seed=21):
@@ -150,6 +178,14 @@ def test_ragged_model_equals_dense_model(hip_device, cfg):
     lay = model.last_ragged
     assert lay is not None, "the ragged path did not take this configuration"
     assert lay.U < lay.N * lay.NA * lay.Li * lay.Lqa
+    streams = (["sub"] if model.sub_flag else []) + (["vid"] if model.vfeat_flag else [])
+    assert sorted(model.last_ragged_ctx) == sorted(streams), "the context streams did not run on ragged rows"
+    model.use_ragged_ctx = False                 # ragged statement rows over dense context streams: the same numbers again
+    m = _train_step(model, batch, n_ex, att)
+    assert model.last_ragged is not None and not model.last_ragged_ctx
+    assert torch.equal(r[1], m[1]) and rel_err(r[0], m[0]) < 2e-5 and rel_err(r[2], m[2]) < 2e-5
+    assert max(rel_err(r[5][k], m[5][k]) for k in m[5]) < 3e-4
+    model.use_ragged_ctx = True
     model.use_ragged = False
     d = _train_step(model, batch, n_ex, att)
     assert model.last_ragged is None

@@ -151,3 +151,77 @@ def test_live_rows_are_all_the_reference_needs(k, n_conv):
     if (t.Lc < Lqa).any() and halo > 0:
         t2 = ragged.RaggedTables(qa, fl, halo - 1)
         assert t2.U < t.U
+
+
+def test_context_tables():
+    rng = np.random.default_rng(3)
+    N, Li, L, halo = 3, 6, 11, 4
+    lens = rng.integers(0, L + 1, size=(N, Li))
+    lens[0, 0], lens[1, 2] = L, 0
+    t = ragged.CtxTables(lens, L, halo)
+    qlen = np.where(lens > 0, np.minimum(L, lens + halo), 0).reshape(-1)
+    assert np.array_equal(t.cq[:, 1], qlen) and t.U == int(qlen.sum()) and t.S == int((qlen > 0).sum())
+    src = t.src_rows_host()
+    want = [f * L + w for f in range(N * Li) for w in range(int(qlen[f]))]
+    assert src.tolist() == want
+    # frames in order, back to back; a dead frame points at a valid row (0) with no rows of its own
+    live = qlen > 0
+    assert np.array_equal(t.cq[live, 0], np.concatenate([[0], np.cumsum(qlen[live])[:-1]]))
+    assert (t.cq[~live] == 0).all()
+    assert np.array_equal(t.seq[:, 0], t.cq[live, 0]) and np.array_equal(t.seq[:, 1], qlen[live])
+    lay = ragged.CtxLayout(t, "cpu")
+    assert np.array_equal(lay.cq.numpy().reshape(-1, 2), t.cq) and (lay.seq.data_ptr() - lay.tables.data_ptr()) % 16 == 0
+    assert np.array_equal(ragged.mask_lens(np.arange(L)[None, :] < lens.reshape(-1, 1)), lens.reshape(-1))
+
+
+@pytest.mark.parametrize("k,n_conv", [(7, 2), (3, 1)])
+def test_context_rows_are_all_the_attention_needs(k, n_conv):
+    """fp64, the oracle's encoder over a context stream: the valid positions of every frame -- the only ones the attention reads
+    (model/context_query_attention.py:58-61: everything else is masked) -- and all gradients are the same whether the encoder sees the
+    padded frame or its first len + halo rows; the padded computation's own input gradient is exactly zero behind them."""
+    torch.manual_seed(4)
+    rng = np.random.default_rng(4)
+    F_, L, D = 7, 16, 8
+    lens = rng.integers(0, L + 1, size=(1, F_))
+    lens[0, 0], lens[0, 1] = L, 0
+    halo = ragged.conv_halo(1, n_conv, k)
+    t = ragged.CtxTables(lens, L, halo)
+    key = "input_encoder.stacked_encoderBlocks.0"
+    from tvqaplus_amd.stage import _PositionTable
+    P = {key + ".position_encoding.pe": _PositionTable.table(500, D).double()}
+    for i in range(n_conv):
+        P[f"{key}.layer_norm.{i}.weight"] = (1 + 0.1 * torch.randn(D)).double()
+        P[f"{key}.layer_norm.{i}.bias"] = (0.1 * torch.randn(D)).double()
+        P[f"{key}.conv.{i}.depthwise_conv.weight"] = (0.5 * torch.randn(D, 1, k)).double()
+        P[f"{key}.conv.{i}.depthwise_conv.bias"] = (0.1 * torch.randn(D)).double()
+        P[f"{key}.conv.{i}.pointwise_conv.weight"] = (0.4 * torch.randn(D, D, 1)).double()
+        P[f"{key}.conv.{i}.pointwise_conv.bias"] = (0.1 * torch.randn(D)).double()
+    P[key + ".final_layer_norm.weight"] = (1 + 0.1 * torch.randn(D)).double()
+    P[key + ".final_layer_norm.bias"] = (0.1 * torch.randn(D)).double()
+    names = [n for n in P if not n.endswith(".pe")]
+    valid = torch.from_numpy(np.arange(L)[None, :] < lens.reshape(-1, 1)).double()       # (F, L)
+    x0 = torch.randn(F_, L, D, dtype=torch.float64) * valid.unsqueeze(-1)                  # padded features are zero
+    w_out = torch.randn(F_, L, D, dtype=torch.float64) * valid.unsqueeze(-1)               # the attention only reads valid positions
+
+    def run(ragged_rows):
+        x = x0.clone().requires_grad_(True)
+        Pd = {n: (v.clone().requires_grad_(True) if n in names else v) for n, v in P.items()}
+        if not ragged_rows:
+            y = O.encoder_block(x, valid, Pd, key, n_conv, 0, 0.0, False)
+        else:
+            y = torch.zeros(F_, L, D, dtype=torch.float64)
+            for f in range(F_):
+                n = int(t.cq[f, 1])
+                if n:
+                    y[f, :n] = O.encoder_block(x[f, :n].unsqueeze(0), valid[f, :n].unsqueeze(0), Pd, key, n_conv, 0, 0.0, False)[0]
+        (y * w_out).sum().backward()
+        return y.detach() * valid.unsqueeze(-1), x.grad, {n: Pd[n].grad for n in names}
+
+    yd, gxd, gpd = run(False)
+    yr, gxr, gpr = run(True)
+    assert torch.allclose(yd, yr, rtol=1e-12, atol=1e-12)
+    keep = torch.from_numpy(np.arange(L)[None, :] < t.cq[:, 1:2]).bool()
+    assert float(gxd[~keep].abs().max()) == 0.0
+    assert torch.allclose(gxd, gxr, rtol=1e-10, atol=1e-12)
+    for n in names:
+        assert torch.allclose(gpd[n], gpr[n], rtol=1e-9, atol=1e-11), n

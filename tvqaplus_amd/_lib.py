@@ -134,8 +134,14 @@ SIGNATURES = {
     "stage_rag_rowinfo": (I, [P, P, LL, I, P, P]),
     "stage_rag_fill_pooled": (I, [P, P, LL, I, P]),
     "stage_rag_zero_dump": (I, [P, P, I, I, I, I, I, P]),
-    "stage_str_attn_fwd_fc": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, U64, P]),
-    "stage_str_attn_bwd_fused_fc": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, SZ, P]),
+    "stage_str_attn_fwd_fc": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, U64, P]),
+    "stage_str_attn_bwd_fused_fc": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, SZ, P]),
+    "stage_rag_ctx_rows": (I, [P, LL, I, P, P]),
+    "stage_layernorm_gather_fwd": (I, [P, P, P, P, P, P, P, LL, I, F, F, U64, P]),
+    "stage_layernorm_gather_bwd": (I, [P, P, P, P, P, P, P, P, LL, I, F, U64, P, SZ, P]),
+    "stage_l2norm_gather_fwd": (I, [P, P, P, LL, I, F, P]),
+    "stage_grp_input_mlp_rag_fwd": (I, [P, P, P, P, P, SZ, P, LL, I, I, I, I, F, P, P]),
+    "stage_grp_input_mlp_rag_bwd": (I, [P, P, P, P, P, P, SZ, P, P, SZ, LL, I, I, I, I, F, P, P]),
     "stage_cat3_ln_gemm_fwd_rag_supported": (I, [LL, LL, LL, I]),
     "stage_cat3_ln_gemm_fwd_rag": (I, [P, P, P, P, P, P, P, P, P, P, P, P, LL, LL, LL, I, F, F, U64, P, SZ, P]),
     "stage_cat3_dx_ln_bwd_rag_supported": (I, [LL, LL, I, I, I, I]),
@@ -147,9 +153,9 @@ SIGNATURES = {
     "stage_ln_masked_max_rag_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, LL, I, P, SZ, P]),
     "stage_grp_qa_ctx_rag_supported": (I, [I, I, I, I, I, I, LL, LL]),
     "stage_grp_qa_ctx_rag_arena_bytes": (SZ, [I, I, I, I, LL, LL]),
-    "stage_grp_qa_ctx_rag_bwd_tmp_bytes": (SZ, [I, I, I, I, I, I, LL]),
-    "stage_grp_qa_ctx_rag_fwd": (I, [P, P, P, P, P, P, P, P, P, P, SZ, P, I, I, I, I, I, I, LL, LL, LL, F, F, P, P]),
-    "stage_grp_qa_ctx_rag_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, SZ, P, P, SZ, I, I, I, I, I, I, LL, LL, LL, F, F, P, P]),
+    "stage_grp_qa_ctx_rag_bwd_tmp_bytes": (SZ, [I, I, I, I, I, I, LL, LL]),
+    "stage_grp_qa_ctx_rag_fwd": (I, [P, P, P, P, P, P, P, P, P, P, SZ, P, I, I, I, I, I, I, LL, LL, LL, LL, F, F, P, P]),
+    "stage_grp_qa_ctx_rag_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, SZ, P, P, SZ, I, I, I, I, I, I, LL, LL, LL, LL, F, F, P, P]),
     "stage_grp_encoder_rag_arena_bytes": (SZ, [LL, LL, I, I]),
     "stage_grp_encoder_rag_bwd_tmp_bytes": (SZ, [LL, I, I]),
     "stage_grp_encoder_rag_fwd": (I, [P, P, P, P, P, P, P, SZ, P, LL, LL, LL, LL, I, I, I, I, F, P, P]),

@@ -141,17 +141,37 @@ extern "C" size_t stage_grp_input_mlp_arena_bytes(long long M, int K0, int H, in
     return mlp_layout(nullptr, M, K0, H, D, l2).bytes;
 }
 
+namespace {
+// gather != NULL (ragged context rows): the M rows are rows gather[0..M) of the padded feature tensor x
+int input_mlp_fwd(const float* x, const int* gather, const float* const* P, float* out, void* arena, size_t arena_bytes, int* flags,
+                  long long M, int K0, int H, int D, int l2, float p, const unsigned long long* seeds, void* st);
+}
 extern "C" int stage_grp_input_mlp_fwd(const float* x, const float* const* P, float* out, void* arena, size_t arena_bytes,
                                        int* flags, long long M, int K0, int H, int D, int l2, float p,
                                        const unsigned long long* seeds, void* st) {
+    return input_mlp_fwd(x, nullptr, P, out, arena, arena_bytes, flags, M, K0, H, D, l2, p, seeds, st);
+}
+// ragged context rows (csrc/ragged.hip): x is the padded (frames * L, K0) feature tensor, src_rows (M) its live rows in order
+extern "C" int stage_grp_input_mlp_rag_fwd(const float* x, const int* src_rows, const float* const* P, float* out, void* arena,
+                                           size_t arena_bytes, int* flags, long long M, int K0, int H, int D, int l2, float p,
+                                           const unsigned long long* seeds, void* st) {
+    if (!src_rows) return STAGE_ERR_SHAPE;
+    return input_mlp_fwd(x, src_rows, P, out, arena, arena_bytes, flags, M, K0, H, D, l2, p, seeds, st);
+}
+namespace {
+int input_mlp_fwd(const float* x, const int* gather, const float* const* P, float* out, void* arena, size_t arena_bytes, int* flags,
+                  long long M, int K0, int H, int D, int l2, float p, const unsigned long long* seeds, void* st) {
     if (M <= 0 || K0 % 4 || H % 4 || D % 4 || K0 > 1024 || H > 1024 || D > 1024) return STAGE_ERR_SHAPE;
     MlpArena a = mlp_layout(arena, M, K0, H, D, l2);
     if (arena_bytes < a.bytes) return STAGE_ERR_WORKSPACE;
     const float* xin = x;
     if (l2) {
-        TRY(stage_l2norm_fwd(x, a.xn, nullptr, M, K0, EPS_L2, 0.f, 0ull, st));
+        if (gather) TRY(stage_l2norm_gather_fwd(x, gather, a.xn, M, K0, EPS_L2, st));
+        else TRY(stage_l2norm_fwd(x, a.xn, nullptr, M, K0, EPS_L2, 0.f, 0ull, st));
         xin = a.xn;
     }
+    if (gather && !l2) TRY(stage_layernorm_gather_fwd(x, gather, P[0], P[1], a.y0, a.mean0, a.rstd0, M, K0, EPS_LN, p, seeds[0], st));
+    else
     TRY(stage_layernorm_fwd(xin, nullptr, 0, nullptr, P[0], P[1], a.y0, a.mean0, a.rstd0, M, K0, EPS_LN, p, seeds[0], st));
     TRY(lin_fwd(a.y0, P[2], P[3], a.h1, a.mask1, &flags[0], M, H, K0, 1, st));
     TRY(stage_layernorm_fwd(a.h1, nullptr, 0, nullptr, P[4], P[5], a.y1, a.mean1, a.rstd1, M, H, EPS_LN, p, seeds[1], st));
@@ -159,6 +179,7 @@ extern "C" int stage_grp_input_mlp_fwd(const float* x, const float* const* P, fl
     TRY(stage_layernorm_fwd(a.h2, nullptr, 0, nullptr, P[8], P[9], out, a.mean2, a.rstd2, M, D, EPS_LN, 0.f, 0ull, st));
     return 0;
 }
+}  // namespace
 
 namespace {
 struct MlpTmp { float *dh2, *dy1, *dh1, *dy0, *wt; void* ws; size_t wsb, bytes; };
@@ -181,9 +202,27 @@ MlpTmp mlp_tmp(void* base, long long M, int K0, int H, int D) {
 extern "C" size_t stage_grp_input_mlp_bwd_tmp_bytes(long long M, int K0, int H, int D) { return mlp_tmp(nullptr, M, K0, H, D).bytes; }
 
 // grads: same order as params (dg0 db0 dW1 dc1 dg1 db1 dW2 dc2 dg2 db2).  The features need no gradient (they are data).
+namespace {
+int input_mlp_bwd(const float* dout, const float* x, const int* gather, const float* const* P, float* const* G, const void* arena,
+                  size_t arena_bytes, const int* flags, void* tmp, size_t tmp_bytes, long long M, int K0, int H, int D, int l2, float p,
+                  const unsigned long long* seeds, void* st);
+}
 extern "C" int stage_grp_input_mlp_bwd(const float* dout, const float* x, const float* const* P, float* const* G, const void* arena,
                                        size_t arena_bytes, const int* flags, void* tmp, size_t tmp_bytes, long long M, int K0,
                                        int H, int D, int l2, float p, const unsigned long long* seeds, void* st) {
+    return input_mlp_bwd(dout, x, nullptr, P, G, arena, arena_bytes, flags, tmp, tmp_bytes, M, K0, H, D, l2, p, seeds, st);
+}
+extern "C" int stage_grp_input_mlp_rag_bwd(const float* dout, const float* x, const int* src_rows, const float* const* P,
+                                           float* const* G, const void* arena, size_t arena_bytes, const int* flags, void* tmp,
+                                           size_t tmp_bytes, long long M, int K0, int H, int D, int l2, float p,
+                                           const unsigned long long* seeds, void* st) {
+    if (!src_rows) return STAGE_ERR_SHAPE;
+    return input_mlp_bwd(dout, x, src_rows, P, G, arena, arena_bytes, flags, tmp, tmp_bytes, M, K0, H, D, l2, p, seeds, st);
+}
+namespace {
+int input_mlp_bwd(const float* dout, const float* x, const int* gather, const float* const* P, float* const* G, const void* arena,
+                  size_t arena_bytes, const int* flags, void* tmp, size_t tmp_bytes, long long M, int K0, int H, int D, int l2, float p,
+                  const unsigned long long* seeds, void* st) {
     MlpArena a = mlp_layout((void*)arena, M, K0, H, D, l2);
     MlpTmp t = mlp_tmp(tmp, M, K0, H, D);
     if (arena_bytes < a.bytes || tmp_bytes < t.bytes) return STAGE_ERR_WORKSPACE;
@@ -192,9 +231,12 @@ extern "C" int stage_grp_input_mlp_bwd(const float* dout, const float* x, const 
     TRY(lin_bwd(t.dh2, a.y1, a.h2, a.mask2, flags[1], 1, P[6], t.wt, t.dy1, G[6], G[7], M, D, H, t.ws, t.wsb, st));
     TRY(stage_layernorm_bwd(t.dy1, a.h1, a.mean1, a.rstd1, P[4], t.dh1, nullptr, G[4], G[5], M, H, p, seeds[1], t.ws, stage_ln_bwd_ws_bytes(H), st));
     TRY(lin_bwd(t.dh1, a.y0, a.h1, a.mask1, flags[0], 1, P[2], t.wt, t.dy0, G[2], G[3], M, H, K0, t.ws, t.wsb, st));
+    if (gather && !l2)
+        return stage_layernorm_gather_bwd(t.dy0, x, gather, a.mean0, a.rstd0, P[0], G[0], G[1], M, K0, p, seeds[0], t.ws, stage_ln_bwd_ws_bytes(K0), st);
     TRY(stage_layernorm_bwd(t.dy0, xin, a.mean0, a.rstd0, P[0], nullptr, nullptr, G[0], G[1], M, K0, p, seeds[0], t.ws, stage_ln_bwd_ws_bytes(K0), st));
     return 0;
 }
+}  // namespace
 
 // =====================================================================================================================
 // G2  encoder block without self-attention (model/encoder.py:29-52, model/cnn.py:37-47, model/position_encoding.py:38-43):
@@ -626,6 +668,8 @@ extern "C" int stage_grp_temporal_head_bwd(const float* d_first, const float* d_
 //     T[1] gdesc  (N*NA, 4): first compact row, live words Lc, slots, first frame-compact sequence
 //     T[2] seq    (S, 4): first compact row, length, group g, dense output row g*Li + i         (one per (group, live frame))
 //     T[3] rowinfo (U, 4) from stage_rag_rowinfo
+//     T[4] cq     (N*Li, 2) or NULL: the context stream itself is ragged -- frame f = rows cq[f].x .. + cq[f].y - 1 of ctx / d_ctx
+//                 (Uc rows in all: its valid words / regions + the halo of the input encoder's convolutions); NULL: dense (N, Li, Lr, D)
 // G3r  as G3; `mixed` is (U, D) compact, S_raw / S_norm stay dense.  The backward overwrites the arena's copy of the attention
 //      output with its gradient (in place: a row is read before it is written): ONE backward per forward.
 // G2r  as G2 pooled: x (U, D) compact, out (N*NA*Li, D) dense; n_conv >= 1; the word mask comes from qa_mask (N*NA, Lqa).
@@ -646,10 +690,10 @@ QaRagArena qa_rag_layout(void* base, int N, int NA, int Lqa, int D, long long Uc
     return a;
 }
 struct QaRagTmp { float *Qn, *dQn, *dCn, *wt; void* ws; size_t wsb, bytes; };
-QaRagTmp qa_rag_tmp(void* base, int N, int NA, int Li, int Lqa, int Lr, int D, long long Ucap) {
+QaRagTmp qa_rag_tmp(void* base, int N, int NA, int Li, int Lqa, int Lr, int D, long long Ucap, long long Uc) {
     Bump b{(char*)base, 0};
     QaRagTmp t;
-    const size_t Qe = (size_t)N * Li * Lr * D;
+    const size_t Qe = (size_t)Uc * D;
     t.Qn = b.take<float>(Qe);
     t.dQn = b.take<float>(Qe);
     t.dCn = b.take<float>((size_t)N * NA * Lqa * D);
@@ -674,20 +718,20 @@ extern "C" int stage_grp_qa_ctx_rag_supported(int N, int NA, int Li, int Lqa, in
 extern "C" size_t stage_grp_qa_ctx_rag_arena_bytes(int N, int NA, int Lqa, int D, long long Ucap, long long Fc) {
     return qa_rag_layout(nullptr, N, NA, Lqa, D, Ucap, Fc).bytes;
 }
-extern "C" size_t stage_grp_qa_ctx_rag_bwd_tmp_bytes(int N, int NA, int Li, int Lqa, int Lr, int D, long long Ucap) {
-    return qa_rag_tmp(nullptr, N, NA, Li, Lqa, Lr, D, Ucap).bytes;
+extern "C" size_t stage_grp_qa_ctx_rag_bwd_tmp_bytes(int N, int NA, int Li, int Lqa, int Lr, int D, long long Ucap, long long Uc) {
+    return qa_rag_tmp(nullptr, N, NA, Li, Lqa, Lr, D, Ucap, Uc).bytes;
 }
 
 extern "C" int stage_grp_qa_ctx_rag_fwd(const float* qa, const float* ctx, const float* qa_mask, const float* ctx_mask,
                                         const float* const* P, float* mixed, float* S_raw, float* S_norm, const int* const* T,
                                         void* arena, size_t arena_bytes, int* flags, int N, int NA, int Li, int Lqa, int Lr, int D,
-                                        long long U, long long Ucap, long long Fc, float scale, float p,
+                                        long long U, long long Ucap, long long Fc, long long Uc, float scale, float p,
                                         const unsigned long long* seeds, void* st) {
-    if (!qa_rag_ok(N, NA, Li, Lqa, Lr, D, U, Fc) || Ucap < U || !al16(P[2])) return STAGE_ERR_SHAPE;
+    if (!qa_rag_ok(N, NA, Li, Lqa, Lr, D, U, Fc) || Ucap < U || !al16(P[2]) || Uc < 1) return STAGE_ERR_SHAPE;
     QaRagArena a = qa_rag_layout(arena, N, NA, Lqa, D, Ucap, Fc);
     if (arena_bytes < a.bytes) return STAGE_ERR_WORKSPACE;
     TRY(stage_l2norm_fwd(qa, a.Cn, nullptr, (long long)N * NA * Lqa, D, EPS_L2, p, seeds[0], st));
-    TRY(stage_str_attn_fwd_fc(a.Cn, ctx, qa_mask, ctx_mask, a.A, S_raw, S_norm, T[0], N, NA, Li, Lqa, Lr, D, scale, p, seeds[1], st));
+    TRY(stage_str_attn_fwd_fc(a.Cn, ctx, qa_mask, ctx_mask, a.A, S_raw, S_norm, T[0], T[4], N, NA, Li, Lqa, Lr, D, scale, p, seeds[1], st));
     TRY(stage_cat3_ln_gemm_fwd_rag(qa, a.A, P[0], P[1], P[2], P[3], a.z, a.mean, a.rstd, mixed, a.mask, T[3], U, (long long)N * NA * Lqa, Fc,
                                    D, EPS_LN, p, seeds[2], a.fwd_ws, stage_cat3_ln_gemm_fwd_ws_bytes(), st));
     flags[0] = 1;
@@ -699,14 +743,14 @@ extern "C" int stage_grp_qa_ctx_rag_bwd(const float* d_mixed, const float* dS_ex
                                         const float* ctx_mask, const float* mixed, const float* S_norm, const float* const* P,
                                         float* const* G, float* d_qa, float* d_ctx, const int* const* T, void* arena,
                                         size_t arena_bytes, const int* flags, void* tmp, size_t tmp_bytes, int N, int NA, int Li,
-                                        int Lqa, int Lr, int D, long long U, long long Ucap, long long Fc, float scale, float p,
-                                        const unsigned long long* seeds, void* st) {
+                                        int Lqa, int Lr, int D, long long U, long long Ucap, long long Fc, long long Uc, float scale,
+                                        float p, const unsigned long long* seeds, void* st) {
     (void)flags;
     QaRagArena a = qa_rag_layout(arena, N, NA, Lqa, D, Ucap, Fc);
-    QaRagTmp t = qa_rag_tmp(tmp, N, NA, Li, Lqa, Lr, D, Ucap);
+    QaRagTmp t = qa_rag_tmp(tmp, N, NA, Li, Lqa, Lr, D, Ucap, Uc);
     if (arena_bytes < a.bytes || tmp_bytes < t.bytes) return STAGE_ERR_WORKSPACE;
     if (!al16(d_mixed)) return STAGE_ERR_SHAPE;
-    const long long Crows = (long long)N * NA * Lqa, Qrows = (long long)N * Li * Lr;
+    const long long Crows = (long long)N * NA * Lqa, Qrows = Uc;
     // weight / bias gradient of the Linear (contracts over the saved normalised concat), then its input gradient fused with the
     // LayerNorm backward: da accumulated over the live frames, db written over the attention output it came from
     TRY(lin_bwd(d_mixed, a.z, mixed, a.mask, 1, 1, P[2], t.wt, nullptr, G[2], G[3], U, D, 3 * D, t.ws, t.wsb, st));
@@ -714,7 +758,7 @@ extern "C" int stage_grp_qa_ctx_rag_bwd(const float* d_mixed, const float* dS_ex
                                  p, seeds[2], t.ws, stage_cat3_dx_ln_bwd_rag_ws_bytes(N * NA, Li, Lqa), st));
     TRY(stage_rag_zero_dump(a.A, T[0], N, NA, Li, Lqa, D, st));
     TRY(stage_l2norm_fwd(ctx, t.Qn, nullptr, Qrows, D, EPS_L2, p, seeds[1], st));
-    TRY(stage_str_attn_bwd_fused_fc(a.A, dS_ext, a.Cn, ctx, t.Qn, S_norm, ctx_mask, d_ctx, t.dQn, t.dCn, T[0], N, NA, Li, Lqa, Lr, D, scale,
+    TRY(stage_str_attn_bwd_fused_fc(a.A, dS_ext, a.Cn, ctx, t.Qn, S_norm, ctx_mask, d_ctx, t.dQn, t.dCn, T[0], T[4], N, NA, Li, Lqa, Lr, D, scale,
                                     t.ws, stage_str_attn_bwd_fused_ws_bytes(N, NA, Li, Lqa, D), st));
     TRY(stage_l2norm_bwd(t.dCn, qa, d_qa, Crows, D, EPS_L2, p, seeds[0], 1, st));
     return stage_l2norm_bwd(t.dQn, ctx, d_ctx, Qrows, D, EPS_L2, p, seeds[1], 1, st);
@@ -764,13 +808,16 @@ extern "C" size_t stage_grp_encoder_rag_arena_bytes(long long Ucap, long long Rd
 extern "C" size_t stage_grp_encoder_rag_bwd_tmp_bytes(long long Ucap, int D, int k) { return enc_rag_tmp(nullptr, Ucap, D, k).bytes; }
 
 // x (U, D) compact; pe (>= Lqa, D) position table; qa_mask (groups, Lqa); out (Rd, D) dense: the masked max over the words of every
-// (group, frame).  T as above (seq has S entries).
+// (group, frame).  T as above (seq has S entries).  qa_mask == NULL: no pooling -- out is (U, D), the block's output on the same
+// ragged sequences (the input encoder over a ragged context stream: T[2] = one entry per live frame, Rd is ignored)
 extern "C" int stage_grp_encoder_rag_fwd(const float* x, const float* pe, const float* qa_mask, const float* const* P, float* out,
                                          const int* const* T, void* arena, size_t arena_bytes, int* flags, long long U, long long Ucap,
                                          long long S, long long Rd, int Lqa, int D, int n_conv, int k, float p,
                                          const unsigned long long* seeds, void* st) {
-    if (U <= 0 || S <= 0 || Ucap < U || n_conv < 1 || n_conv > ENC_MAX_CONV || !ln_dwconv_ok(D, k) || D != 128 || Lqa < 1 || Lqa > 48)
+    const bool pooled = qa_mask != nullptr;
+    if (U <= 0 || S <= 0 || Ucap < U || n_conv < 1 || n_conv > ENC_MAX_CONV || !ln_dwconv_ok(D, k) || (pooled && D != 128) || Lqa < 1 || D > 1024)
         return STAGE_ERR_SHAPE;
+    if (!pooled) Rd = 0;
     EncArena a = enc_rag_layout(arena, Ucap, Rd, D, n_conv);
     if (arena_bytes < a.bytes) return STAGE_ERR_WORKSPACE;
     const float* pending = x;
@@ -786,7 +833,8 @@ extern "C" int stage_grp_encoder_rag_fwd(const float* x, const float* pe, const 
         pending = a.g[i];
     }
     const float* const* F = P + 6 * n_conv;
-    flags[n_conv] = 1;
+    flags[n_conv] = pooled ? 1 : 0;
+    if (!pooled) return stage_layernorm_fwd(pending, cur, 0, a.sf, F[0], F[1], out, a.meanf, a.rstdf, U, D, EPS_LN, 0.f, 0ull, st);
     TRY(stage_rag_fill_pooled(out, a.idx, Rd, D, st));
     return stage_ln_masked_max_rag_fwd(pending, cur, a.sf, F[0], F[1], qa_mask, out, a.idx, a.meanf, a.rstdf, T[2], S, Lqa, D, EPS_LN, st);
 }
@@ -797,13 +845,16 @@ extern "C" int stage_grp_encoder_rag_bwd(const float* dout, const float* qa_mask
                                          size_t tmp_bytes, long long U, long long Ucap, long long S, long long Rd, int Lqa, int D,
                                          int n_conv, int k, float p, const unsigned long long* seeds, void* st) {
     if (n_conv < 1 || n_conv > ENC_MAX_CONV) return STAGE_ERR_SHAPE;
+    const bool pooled = qa_mask != nullptr;
+    if (!pooled) Rd = 0;
     EncArena a = enc_rag_layout((void*)arena, Ucap, Rd, D, n_conv);
     EncTmp t = enc_rag_tmp(tmp, Ucap, D, k);
     if (arena_bytes < a.bytes || tmp_bytes < t.bytes) return STAGE_ERR_WORKSPACE;
     const float* const* F = P + 6 * n_conv;
     float* const* GF = Gr + 6 * n_conv;
     float* G = t.Ga;
-    TRY(stage_ln_masked_max_rag_bwd(dout, a.idx, qa_mask, a.sf, a.meanf, a.rstdf, F[0], G, GF[0], GF[1], T[3], U, D, t.ws, stage_ln_bwd_ws_bytes(D), st));
+    if (pooled) TRY(stage_ln_masked_max_rag_bwd(dout, a.idx, qa_mask, a.sf, a.meanf, a.rstdf, F[0], G, GF[0], GF[1], T[3], U, D, t.ws, stage_ln_bwd_ws_bytes(D), st));
+    else TRY(stage_layernorm_bwd(dout, a.sf, a.meanf, a.rstdf, F[0], G, nullptr, GF[0], GF[1], U, D, 0.f, 0ull, t.ws, stage_ln_bwd_ws_bytes(D), st));
     for (int i = n_conv - 1; i >= 0; i--) {
         const float* const* Q = P + 6 * i;
         float* const* GQ = Gr + 6 * i;

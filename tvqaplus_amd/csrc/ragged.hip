@@ -46,7 +46,27 @@ __global__ __launch_bounds__(256) void rag_zero_dump_kernel(float4* __restrict__
     for (int e = threadIdx.x; e < Lqa * D4; e += blockDim.x) dst[e] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// source row (in the padded (frames, L, .) feature tensor) of every compact context row: frame f holds rows cq[f].x .. + cq[f].y - 1
+__global__ __launch_bounds__(256) void rag_ctx_rows_kernel(const int2* __restrict__ cq, long frames, int L, int* __restrict__ src) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long f = t / L;
+    const int l = (int)(t - f * L);
+    if (f >= frames) return;
+    const int2 q = cq[f];
+    if (l < q.y) src[(long)q.x + l] = (int)(f * L + l);
+}
+
 }  // namespace
+
+extern "C" int stage_rag_ctx_rows(const int* cq, long long frames, int L, int* src_rows, void* stream) {
+    if (frames <= 0) return 0;
+    if (L < 1 || frames * L >= (1ll << 31)) return STAGE_ERR_SHAPE;
+    const long total = (long)frames * L;
+    hipLaunchKernelGGL(rag_ctx_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const int2*)cq,
+                       (long)frames, L, src_rows);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int stage_rag_rowinfo(const int* seq, const int* seqfc, long long S, int Lqa, int* rowinfo, void* stream) {
     if (S <= 0) return 0;

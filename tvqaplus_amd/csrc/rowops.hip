@@ -26,6 +26,8 @@ template <typename T> struct RowSrcT {
     int rep, inner;   // MODE 1: broadcast description of a (rep == 1 -> none)
                       // MODE 0: inner = residual period in rows (0: res row == row; L: res row = row % L -> pe table)
     T* sum_out;       // MODE 0: where to write x + res (NULL: not needed)
+    const int* gather;  // MODE 0, fast kernels: row r reads x[gather[r]] (ragged context rows: the compact rows of a padded feature
+                        // tensor, csrc/ragged.hip); everything else -- y, statistics, dropout counter -- is indexed by r.  NULL: x[r]
 };
 typedef RowSrcT<float> RowSrc;   // T = stage_bf16: bf16 storage (generic kernels only; statistics, affine parameters and
                                  // all arithmetic stay fp32)
@@ -243,7 +245,7 @@ __device__ __forceinline__ long a_row_fast(long row, int rep, int inner) {
     return (long)(gq * (unsigned)inner + r % (unsigned)inner);
 }
 
-template <int MODE, bool DROP, int NQ0, typename T = float>
+template <int MODE, bool DROP, int NQ0, typename T = float, bool GATHER = false>
 __global__ __launch_bounds__(256) void ln_fwd_fast_kernel(RowSrcT<T> src, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, T* __restrict__ y,
                                                           float* __restrict__ mean, float* __restrict__ rstd, long rows,
@@ -275,9 +277,10 @@ __global__ __launch_bounds__(256) void ln_fwd_fast_kernel(RowSrcT<T> src, const 
             const long rc = row[u] < rows ? row[u] : rows - 1;
             if (MODE == 0) {
                 const long rr = src.b ? (src.inner > 0 ? (long)((unsigned)rc % (unsigned)src.inner) : rc) : 0;
+                const long xr = GATHER ? (long)src.gather[rc] : rc;
 #pragma unroll
                 for (int t = 0; t < NQ; t++) {
-                    v[u][t] = ldv4s(src.x + rc * K + 4 * jc[t]);
+                    v[u][t] = ldv4s(src.x + xr * K + 4 * jc[t]);
                     if (src.b) rv[u][t] = ldv4(src.b + rr * K + 4 * jc[t]);
                 }
             } else {
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(256) void ln_fwd_fast_kernel(RowSrcT<T> src, const 
 // MM (MODE 0): the incoming gradient is that of a masked max over groups of mm_L consecutive rows (stage_ln_masked_max_*): `dy`
 // is the (rows / mm_L, K) gradient of the maxima and the row gradient dy[row][d] = (mm_idx[grp][d] == l) ? dy[grp][d] * mask[row] : 0
 // is formed while it is loaded -- the dense (rows, K) gradient tensor (491 MB at the classifier head) is never written or read.
-template <int MODE, bool DROP, int NQ0, typename T = float, typename TDX = T, bool MM = false>
+template <int MODE, bool DROP, int NQ0, typename T = float, typename TDX = T, bool MM = false, bool GATHER = false>
 __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(RowSrcT<T> src, const T* __restrict__ dy,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, TDX* __restrict__ dx,
@@ -374,9 +377,10 @@ __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(RowSrcT<T> src, const 
             mu[u] = mean[rc];
             rs[u] = rstd[rc];
             if (MODE == 0) {
+                const long xr = GATHER ? (long)src.gather[rc] : rc;
 #pragma unroll
                 for (int t = 0; t < NQ; t++) {
-                    xv[u][t] = ldv4s(src.x + rc * K + 4 * jc[t]);
+                    xv[u][t] = ldv4s(src.x + xr * K + 4 * jc[t]);
                     if (dx && src.b) ra[u][t] = ldv4(src.b + rc * K + 4 * jc[t]);
                 }
             } else {
@@ -600,8 +604,14 @@ static int ln_fwd_launch(RowSrcT<T> src, const float* gamma, const float* beta, 
         const uint32_t th = dr ? drop_thresh16(p_drop) : 0u;
         const float ik = dr ? 1.0f / (1.0f - p_drop) : 1.0f;
 #define LN_FWD_FAST(DR, NQV)                                                                                           \
-    hipLaunchKernelGGL((ln_fwd_fast_kernel<MODE, DR, NQV, T>), dim3(gridf), dim3(256), 0, st, src, gamma, beta, y, mean, rstd, \
-                       (long)rows, K, eps, LPR, sd, th, ik)
+    do {                                                                                                                \
+        if (MODE == 0 && src.gather)                                                                                    \
+            hipLaunchKernelGGL((ln_fwd_fast_kernel<MODE, DR, NQV, T, MODE == 0>), dim3(gridf), dim3(256), 0, st, src, gamma, beta, y, mean, \
+                               rstd, (long)rows, K, eps, LPR, sd, th, ik);                                              \
+        else                                                                                                            \
+            hipLaunchKernelGGL((ln_fwd_fast_kernel<MODE, DR, NQV, T>), dim3(gridf), dim3(256), 0, st, src, gamma, beta, y, mean, rstd, \
+                               (long)rows, K, eps, LPR, sd, th, ik);                                                    \
+    } while (0)
         switch (MODE == 0 ? nq : 1) {
             case 1: if (dr) LN_FWD_FAST(true, 1); else LN_FWD_FAST(false, 1); break;
             case 2: if (dr) LN_FWD_FAST(true, 2); else LN_FWD_FAST(false, 2); break;
@@ -612,6 +622,7 @@ static int ln_fwd_launch(RowSrcT<T> src, const float* gamma, const float* beta, 
         STAGE_LAUNCH_CHECK();
         return 0;
     }
+    if (src.gather) return STAGE_ERR_SHAPE;      // gathered rows: fast kernels only
     const int grid = stage_grid_for(rows, rows_per_block, GRID_CAP * 4);
     if (p_drop > 0.f)
         hipLaunchKernelGGL((ln_fwd_kernel<MODE, true, T>), dim3(grid), dim3(256), 0, st, src, gamma, beta, y, mean, rstd,
@@ -646,8 +657,14 @@ static int ln_bwd_launch(RowSrcT<T> src, const T* dy, const float* mean, const f
         const uint32_t th = dr ? drop_thresh16(p_drop) : 0u;
         const float ik = dr ? 1.0f / (1.0f - p_drop) : 1.0f;
 #define LN_BWD_FAST(DR, NQV)                                                                                            \
-    hipLaunchKernelGGL((ln_bwd_fast_kernel<MODE, DR, NQV, T, TDX>), dim3(grid), dim3(256), lds, st, src, dy, mean, rstd, gamma, dx, \
-                       db_out, part, (long)rows, K, LPR, sd, th, ik)
+    do {                                                                                                                 \
+        if (MODE == 0 && src.gather)                                                                                     \
+            hipLaunchKernelGGL((ln_bwd_fast_kernel<MODE, DR, NQV, T, TDX, false, MODE == 0>), dim3(grid), dim3(256), lds, st, src, dy, mean, \
+                               rstd, gamma, dx, db_out, part, (long)rows, K, LPR, sd, th, ik);                           \
+        else                                                                                                             \
+            hipLaunchKernelGGL((ln_bwd_fast_kernel<MODE, DR, NQV, T, TDX>), dim3(grid), dim3(256), lds, st, src, dy, mean, rstd, gamma, dx, \
+                               db_out, part, (long)rows, K, LPR, sd, th, ik);                                            \
+    } while (0)
         switch (MODE == 0 ? nq : 1) {
             case 1: if (dr) LN_BWD_FAST(true, 1); else LN_BWD_FAST(false, 1); break;
             case 2: if (dr) LN_BWD_FAST(true, 2); else LN_BWD_FAST(false, 2); break;
@@ -656,6 +673,7 @@ static int ln_bwd_launch(RowSrcT<T> src, const T* dy, const float* mean, const f
         }
 #undef LN_BWD_FAST
     }
+    else if (src.gather) return STAGE_ERR_SHAPE;
     else if (p_drop > 0.f)
         hipLaunchKernelGGL((ln_bwd_kernel<MODE, true, T, TDX>), dim3(grid), dim3(256), lds, st, src, dy, mean, rstd, gamma, dx,
                            db_out, part, (long)rows, K, LPR, (uint64_t)seed, drop_thresh16(p_drop),
@@ -688,6 +706,26 @@ extern "C" int stage_layernorm_bwd(const float* dy, const float* x, const float*
     RowSrc src{x, dx_add, 0, 1, 0, nullptr};
     return ln_bwd_launch<0, float, float>(src, dy, mean, rstd, gamma, dx, (float*)nullptr, dgamma, dbeta, rows, K, ln_lpr(K / 4), p_drop,
                             seed, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// The same with GATHERED input rows: row r of y / mean / rstd / the dropout stream reads x[gather[r]] (ragged context rows: the first
+// LayerNorm of the input MLPs reads the live rows of the padded feature tensor in place).  The backward gives no input gradient
+// (features are data): d gamma / d beta only.
+extern "C" int stage_layernorm_gather_fwd(const float* x, const int* gather, const float* gamma, const float* beta, float* y,
+                                          float* mean, float* rstd, long long rows, int K, float eps, float p_drop,
+                                          unsigned long long seed, void* stream) {
+    if (rows <= 0) return 0;
+    if (K % 4 != 0 || K > 4 * MAXV * 64 || !gather) return STAGE_ERR_SHAPE;
+    RowSrc src{x, nullptr, 0, 1, 0, nullptr, gather};
+    return ln_fwd_launch<0, float>(src, gamma, beta, y, mean, rstd, rows, K, ln_lpr(K / 4), eps, p_drop, seed, (hipStream_t)stream);
+}
+extern "C" int stage_layernorm_gather_bwd(const float* dy, const float* x, const int* gather, const float* mean, const float* rstd,
+                                          const float* gamma, float* dgamma, float* dbeta, long long rows, int K, float p_drop,
+                                          unsigned long long seed, void* ws, size_t ws_bytes, void* stream) {
+    if (K % 4 != 0 || K > 4 * MAXV * 64 || !gather) return STAGE_ERR_SHAPE;
+    RowSrc src{x, nullptr, 0, 1, 0, nullptr, gather};
+    return ln_bwd_launch<0, float, float>(src, dy, mean, rstd, gamma, (float*)nullptr, (float*)nullptr, dgamma, dbeta, rows, K, ln_lpr(K / 4),
+                                          p_drop, seed, ws, ws_bytes, (hipStream_t)stream);
 }
 
 // y[rows, 3D] = drop(LN([a, b, a*b]))     a: [rows/(rep) , D] broadcast over `rep` (see a_row_of), b: [rows, D]
@@ -815,20 +853,22 @@ extern "C" int stage_reduce_rep(const float* in, float* out, long long groups, i
 template <bool DROP, typename T = float>
 __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                          float* __restrict__ nrm, long rows, int K, float eps, int LPR,
-                                                         uint64_t seed, uint32_t th, float inv_keep) {
+                                                         uint64_t seed, uint32_t th, float inv_keep,
+                                                         const int* __restrict__ gather = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int RPW = 64 / LPR, sub = lane / LPR, sl = lane % LPR;
     const int K4 = K >> 2;
     for (long base = ((long)blockIdx.x * wpb + wave) * RPW; base < rows; base += (long)gridDim.x * wpb * RPW) {
         const long row = base + sub;
         const bool ok = row < rows;
+        const long xr = (gather && ok) ? (long)gather[row] : row;     // (gathered rows: ragged context rows, see RowSrcT)
         float4 v[MAXV];
         float s = 0.f;
 #pragma unroll
         for (int t = 0; t < MAXV; t++) {
             int j = sl + t * LPR;
             if (ok && j < K4) {
-                v[t] = ldv4(x + row * K + 4 * j);
+                v[t] = ldv4(x + xr * K + 4 * j);
                 s += f4hsum(f4mul(v[t], v[t]));
             } else v[t] = f4zero();
         }
@@ -910,6 +950,17 @@ extern "C" int stage_l2norm_fwd(const float* x, float* y, float* norm_out, long 
     else
         hipLaunchKernelGGL((l2norm_fwd_kernel<false>), dim3(grid), dim3(256), 0, st, x, y, norm_out, (long)rows, K,
                            eps, LPR, (uint64_t)0, 0u, 1.0f);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int stage_l2norm_gather_fwd(const float* x, const int* gather, float* y, long long rows, int K, float eps, void* stream) {
+    if (rows <= 0) return 0;
+    if (K % 4 != 0 || K > 4 * MAXV * 64 || !gather) return STAGE_ERR_SHAPE;
+    const int LPR = ln_lpr(K / 4);
+    const int grid = stage_grid_for(rows, 4 * (64 / LPR), GRID_CAP * 4);
+    hipLaunchKernelGGL((l2norm_fwd_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, (float*)nullptr, (long)rows, K, eps,
+                       LPR, (uint64_t)0, 0u, 1.0f, gather);
     STAGE_LAUNCH_CHECK();
     return 0;
 }

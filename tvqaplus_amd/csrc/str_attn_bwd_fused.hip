@@ -230,7 +230,7 @@ __device__ __forceinline__ float fus_elt(const float2& v, int e) { return e == 0
 template <int RT, int NRT, int E, bool RAW, bool PIPE, typename TD = float>
 __device__ __forceinline__ void fus_p2(const TD* __restrict__ dAf, const float* __restrict__ Sn, const float* __restrict__ Cn,
                                        const float* Gs, float* __restrict__ out, long frame, int n, int i, int NA, int Li,
-                                       int Lqa, int Lr, int d0, int c15, int g, int LiA) {
+                                       int Lqa, int Lr, int d0, int c15, int g, int LiA, int Lrs) {
     typedef typename FusVec<E>::T vec_t;
     constexpr int LG = FusLay<RT>::LG;
     const int CR = NA * Lqa;
@@ -308,14 +308,14 @@ __device__ __forceinline__ void fus_p2(const TD* __restrict__ dAf, const float* 
             mul(b0, a0, k0);
         }
     }
-    // C layout: row 4g + reg = region inside the tile, column c15 -> d = d0 + e
-    float* o = out + frame * Lr * FD + d0;
+    // C layout: row 4g + reg = region inside the tile, column c15 -> d = d0 + e.  `out` = the frame's first output row; Lrs = rows it has
+    float* o = out + d0;
 #pragma unroll
     for (int rt = 0; rt < RT; rt++)
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
             const int r = rt * 16 + 4 * g + reg;
-            if (r < Lr) {
+            if (r < Lrs) {
                 constexpr int Z = 0;
                 const int ra = rt < NRT ? rt : Z;
                 if (E == 4) {
@@ -334,7 +334,8 @@ __device__ __forceinline__ void fus_p2(const TD* __restrict__ dAf, const float* 
 template <int RT, int NRT, int E, bool RAW, bool PIPE, bool LDSA = false, int UG = FUS_U, typename TD = float>
 __device__ __forceinline__ void fus_p2_unif(const TD* __restrict__ dAf, const float* __restrict__ Snf,
                                             const float* __restrict__ Cnn, const float* Gs, float* __restrict__ outf, int NA,
-                                            int Li, int Lqa, int Lr, int d0, int c15, int g, const float* dAs = nullptr, int LiA = 0) {
+                                            int Li, int Lqa, int Lr, int d0, int c15, int g, const float* dAs = nullptr, int LiA = 0,
+                                            int Lrs = 0) {
     typedef typename FusVec<E>::T vec_t;
     constexpr int LG = FusLay<RT>::LG;
     const int ngroups = (NA * Lqa) / (4 * UG);
@@ -408,7 +409,7 @@ __device__ __forceinline__ void fus_p2_unif(const TD* __restrict__ dAf, const fl
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
             const int r = rt * 16 + 4 * g + reg;
-            if (r < Lr) {
+            if (r < Lrs) {
                 constexpr int Z = 0;
                 const int ra = rt < NRT ? rt : Z;
                 if (E == 4) {
@@ -428,7 +429,7 @@ __device__ __forceinline__ void fus_frame(const TD* __restrict__ dA, const float
                                           long frame, int n, int i, int NA, int Li, int Lqa, int Lr, float scale,
                                           const unsigned (&orel)[16 / NW], int ntiles, f32x4 (&dcn)[16 / NW][8], int wave, int lane,
                                           unsigned long long* tim, unsigned long long (&tacc)[6], unsigned long long& tlast,
-                                          const unsigned (&orelA)[16 / NW], long arow0, int LiA) {
+                                          const unsigned (&orelA)[16 / NW], long arow0, int LiA, long qrow0, int Lrs) {
     constexpr int TPW = 16 / NW, E = NW == 4 ? 4 : 2;
     const int CR = NA * Lqa;
     // c15 / g re-derived from an opaque copy of the lane id per frame: hoisted out of the frame loop, the address
@@ -476,11 +477,11 @@ __device__ __forceinline__ void fus_frame(const TD* __restrict__ dA, const float
     const bool unif = (Lqa & 3) == 0 && ((CR >> 2) % UG) == 0;
     if (FUS_ABL & 1) return;
     if (unif) {
-        if (wave < NW / 2) fus_p2_unif<RT, NRT, E, true, PIPE, LDSA, UG, TD>(dAf, Snf, nullptr, Gs, dQraw + frame * Lr * FD, NA, Li, Lqa, Lr, d0, c15, g, dAs, LiA);
-        else fus_p2_unif<RT, NRT, E, false, PIPE, false, UG, TD>(dAf, Snf, Cn + (long)n * CR * FD, Gs, dQn + frame * Lr * FD, NA, Li, Lqa, Lr, d0, c15, g, nullptr, LiA);
+        if (wave < NW / 2) fus_p2_unif<RT, NRT, E, true, PIPE, LDSA, UG, TD>(dAf, Snf, nullptr, Gs, dQraw + qrow0 * FD, NA, Li, Lqa, Lr, d0, c15, g, dAs, LiA, Lrs);
+        else fus_p2_unif<RT, NRT, E, false, PIPE, false, UG, TD>(dAf, Snf, Cn + (long)n * CR * FD, Gs, dQn + qrow0 * FD, NA, Li, Lqa, Lr, d0, c15, g, nullptr, LiA, Lrs);
     } else {
-        if (wave < NW / 2) fus_p2<RT, NRT, E, true, PIPE, TD>(dAf, Sn, Cn, Gs, dQraw, frame, n, i, NA, Li, Lqa, Lr, d0, c15, g, LiA);
-        else fus_p2<RT, NRT, E, false, PIPE, TD>(dAf, Sn, Cn, Gs, dQn, frame, n, i, NA, Li, Lqa, Lr, d0, c15, g, LiA);
+        if (wave < NW / 2) fus_p2<RT, NRT, E, true, PIPE, TD>(dAf, Sn, Cn, Gs, dQraw + qrow0 * FD, frame, n, i, NA, Li, Lqa, Lr, d0, c15, g, LiA, Lrs);
+        else fus_p2<RT, NRT, E, false, PIPE, TD>(dAf, Sn, Cn, Gs, dQn + qrow0 * FD, frame, n, i, NA, Li, Lqa, Lr, d0, c15, g, LiA, Lrs);
     }
 }
 
@@ -492,7 +493,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OC
     const TD* __restrict__ Qn, const float* __restrict__ Sn, const float* __restrict__ qmask, float* __restrict__ dQraw,
     float* __restrict__ dQn, float* __restrict__ part, int N, int NA, int Li, int Lqa, int Lr, float scale,
     const int4* __restrict__ sched, const unsigned char* __restrict__ fnv, unsigned long long* __restrict__ tim,
-    const int* __restrict__ fmap) {
+    const int* __restrict__ fmap, const int2* __restrict__ cq) {
+    // cq != NULL: Q, Qn, dQraw, dQn hold COMPACT region rows (frame f = rows cq[f].x .. + cq[f].y - 1); q_mask stays dense
     // fmap != NULL: dA is frame-compact (str_attn_fwd_reg.hip, include/stage_hip.h "ragged token rows"): the frames of example n sit in
     // fmap[N*Li + n] slots per candidate from sequence fmap[N*Li + N + n]; a dead frame (fmap[frame] < 0) reads the example's dump
     // slot, which the caller has zeroed -- its dA is exactly zero by construction (the statement mask blocks the gradient)
@@ -512,6 +514,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OC
     if (n < 0) return;
 
     for (int e = tid; e < FusLay<RT>::QT_FLOATS; e += NT) QnT[e] = 0.f;
+    if (cq) for (int e = tid; e < Lr * FLDQ; e += NT) Qr[e] = 0.f;    // rows a frame does not have keep what an earlier frame left: finite
 
     // this wave's context tiles (phase 1): slot s -> tile wave + NW*s
     unsigned orel[TPW], orelA[TPW];   // row offset of context row c inside a frame's row block: a*Li*Lqa + w (score maps) / a*LiA*Lqa + w (dA)
@@ -546,10 +549,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OC
             const unsigned long long bal = __ballot(mv != 0.f);
             nvalid = bal ? 64 - __builtin_clzll(bal) : 0;
         }
+        long qrow0 = frame * Lr;                 // first row of the frame in Q / Qn / dQraw / dQn
+        int Lrs = Lr;                            // rows it has
+        if (cq) {
+            const int2 qd = cq[frame];
+            qrow0 = __builtin_amdgcn_readfirstlane(qd.x);
+            Lrs = __builtin_amdgcn_readfirstlane(qd.y);
+        }
         if (nvalid == 0) {   // uniform over the workgroup: no region contributes, both gradients of the frame are zero
-            for (int e = tid; e < Lr * 32; e += NT) {
-                st4(dQraw + frame * Lr * FD + 4 * e, f4zero());
-                st4(dQn + frame * Lr * FD + 4 * e, f4zero());
+            for (int e = tid; e < Lrs * 32; e += NT) {
+                st4(dQraw + qrow0 * FD + 4 * e, f4zero());
+                st4(dQn + qrow0 * FD + 4 * e, f4zero());
             }
             continue;
         }
@@ -558,9 +568,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OC
         for (int s = 0; s < NST; s++) {
             const int u = wave + NW * s;
             const int r = 8 * (u >> 2) + (lane & 7), q = 8 * (u & 3) + (lane >> 3);
-            if (u < UNITS && r < Lr) {
-                const float4 vq = ldv4(Q + (frame * Lr + r) * FD + 4 * q);
-                const float4 vn = ldv4(Qn + (frame * Lr + r) * FD + 4 * q);
+            if (u < UNITS && r < Lrs) {
+                const float4 vq = ldv4(Q + (qrow0 + r) * FD + 4 * q);
+                const float4 vn = ldv4(Qn + (qrow0 + r) * FD + 4 * q);
                 st4(&Qr[r * FLDQ + 4 * q], vq);
                 QnT[(4 * q + 0) * LT + r] = vn.x;
                 QnT[(4 * q + 1) * LT + r] = vn.y;
@@ -580,7 +590,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OC
         const long arow0 = (afirst + aslot) * Lqa;
 #define FUS_FRAME(NRTV)                                                                                                  \
     fus_frame<RT, (NRTV) <= RT ? (NRTV) : RT, NW, HAS_EXT, (OCC == 2 && NW == 8), LDSA, TD>(dA, ext, Cn, Sn, Qr, QnT, Gs, dAs, dQraw, dQn, frame, n, i, NA, Li, \
-                                                         Lqa, Lr, scale, orel, ntiles, dcn, wave, lane, tim, tacc, tlast, orelA, arow0, LiA)
+                                                         Lqa, Lr, scale, orel, ntiles, dcn, wave, lane, tim, tacc, tlast, orelA, arow0, LiA, qrow0, Lrs)
         if (RT == 1 || nrt == 1) FUS_FRAME(1);
         else if (RT == 2 || nrt == 2) FUS_FRAME(2);
         else if (RT == 3 || nrt == 3) FUS_FRAME(3);
@@ -743,7 +753,7 @@ static int fus_num_wgs(int N, int Li = 1 << 20) {
 template <int RT, int NW, int OCC, typename TD>
 static int fus_launch(const TD* dA, const float* ext, const float* Cn, const TD* Q, const TD* Qn, const float* Sn,
                       const float* qmask, float* dQraw, float* dQn, float* dCn, int N, int NA, int Li, int Lqa, int Lr,
-                      float scale, void* ws, hipStream_t st, const int* fmap) {
+                      float scale, void* ws, hipStream_t st, const int* fmap, const int* cq) {
     const int CR = NA * Lqa;
     const int G = fus_num_wgs(N, Li);
     int4* sched = (int4*)ws;
@@ -772,7 +782,8 @@ static int fus_launch(const TD* dA, const float* ext, const float* Cn, const TD*
         if (lds > 64 * 1024)                                                                                                    \
             (void)hipFuncSetAttribute((const void*)str_attn_bwd_fused_kernel<RT, NW, EXTV, OCC, LDSAV, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((str_attn_bwd_fused_kernel<RT, NW, EXTV, OCC, LDSAV, TD>), grid, block, lds, st, dA, ext, Cn, Q, Qn, Sn, qmask, \
-                           dQraw, dQn, part, N, NA, Li, Lqa, Lr, scale, (const int4*)sched, (const unsigned char*)fnv, tim, fmap);                         \
+                           dQraw, dQn, part, N, NA, Li, Lqa, Lr, scale, (const int4*)sched, (const unsigned char*)fnv, tim, fmap,                          \
+                           (const int2*)cq);                                                                                                               \
     } while (0)
     if (ext) { if (ldsa) FUS_GO(true, (NW == 8 && OCC == 2)); else FUS_GO(true, false); }
     else { if (ldsa) FUS_GO(false, (NW == 8 && OCC == 2)); else FUS_GO(false, false); }
@@ -794,14 +805,14 @@ template <typename TD>
 static int str_attn_bwd_fused_t(const TD* dA, const float* dS_raw_ext, const float* Cn, const TD* Q, const TD* Qn,
                                 const float* S_norm, const float* q_mask, float* dQraw, float* dQn, float* dCn, int N, int NA,
                                 int Li, int Lqa, int Lr, int D, float scale, void* ws, size_t ws_bytes, void* stream,
-                                const int* fmap = nullptr) {
+                                const int* fmap = nullptr, const int* cq = nullptr) {
     if (N <= 0 || Li <= 0) return 0;
     if (D != FD || Lr < 2 || Lr > 64 || (Lr & 1) || Lqa < 4 || NA < 1 || NA * Lqa > 256 ||
         (long)NA * (Li + 1) * Lqa * FD >= (1l << 29)) return STAGE_ERR_SHAPE;   // 32-bit element offsets inside an example (+1: dump slot)
     if (ws_bytes < stage_str_attn_bwd_fused_ws_bytes(N, NA, Li, Lqa, D)) return STAGE_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int RT = (Lr + 15) / 16;
-#define FUS_ARGS dA, dS_raw_ext, Cn, Q, Qn, S_norm, q_mask, dQraw, dQn, dCn, N, NA, Li, Lqa, Lr, scale, ws, st, fmap
+#define FUS_ARGS dA, dS_raw_ext, Cn, Q, Qn, S_norm, q_mask, dQraw, dQn, dCn, N, NA, Li, Lqa, Lr, scale, ws, st, fmap, cq
     switch (RT) {
         case 1: return fus_launch<1, 8, 2, TD>(FUS_ARGS);
         case 2: return fus_launch<2, 8, 2, TD>(FUS_ARGS);
@@ -822,11 +833,11 @@ extern "C" int stage_str_attn_bwd_fused(const float* dA, const float* dS_raw_ext
 // dA frame-compact (ragged token rows, include/stage_hip.h): the rows of dA are addressed through `fmap`; everything else as above
 extern "C" int stage_str_attn_bwd_fused_fc(const float* dA_fc, const float* dS_raw_ext, const float* Cn, const float* Q,
                                            const float* Qn, const float* S_norm, const float* q_mask, float* dQraw,
-                                           float* dQn, float* dCn, const int* fmap, int N, int NA, int Li, int Lqa, int Lr, int D,
-                                           float scale, void* ws, size_t ws_bytes, void* stream) {
+                                           float* dQn, float* dCn, const int* fmap, const int* cq, int N, int NA, int Li, int Lqa, int Lr,
+                                           int D, float scale, void* ws, size_t ws_bytes, void* stream) {
     if (!fmap) return STAGE_ERR_SHAPE;
     return str_attn_bwd_fused_t<float>(dA_fc, dS_raw_ext, Cn, Q, Qn, S_norm, q_mask, dQraw, dQn, dCn, N, NA, Li, Lqa, Lr, D, scale, ws,
-                                       ws_bytes, stream, fmap);
+                                       ws_bytes, stream, fmap, cq);
 }
 
 // bf16 storage mode: dA, Q, Qn are bf16; the score maps, Cn and the three gradients (dQraw, dQn, dCn) stay fp32

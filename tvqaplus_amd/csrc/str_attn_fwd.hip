@@ -35,7 +35,7 @@ extern "C" int stage_str_attn_fwd_v1(const float* Cn, const float* Q, const floa
 
 int stage_str_attn_fwd_reg(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A,
                            float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D, float scale,
-                           float p_drop, unsigned long long seed, void* stream, const int* fmap = nullptr);
+                           float p_drop, unsigned long long seed, void* stream, const int* fmap = nullptr, const int* cq = nullptr);
 int stage_str_attn_fwd_reg_bf16(const float* Cn, const void* Q, const float* c_mask, const float* q_mask, void* A, float* S_raw,
                                 float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D, float scale, float p_drop,
                                 unsigned long long seed, void* stream);
@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
     const float* __restrict__ qmask, TQ* __restrict__ A, float* __restrict__ S, float* __restrict__ Sn, int N,
     int NA, int Li, int Lqa, int Lr, float scale, int slices, int tiles_per_slice, uint64_t seed, uint32_t th,
     float inv_keep, unsigned int* __restrict__ ticket, unsigned int ticket_base, unsigned long long* __restrict__ tim,
-    const int* __restrict__ fmap) {
+    const int* __restrict__ fmap, const int2* __restrict__ cq) {
+    // cq (FC + the workgroup-staged fp16 path only, may be NULL): compact region rows, frame f = rows cq[f].x .. + cq[f].y - 1 of Q
     // FC (fmap != NULL; compile time, the dense kernels stay the code they were): frame-compact A (see str_attn_fwd_reg.hip /
     // include/stage_hip.h "ragged token rows"); S / S_ stay dense
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = tim ? __builtin_readcyclecounter() : 0;
@@ -177,6 +178,13 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
             dead = aslot < 0;
             aslot = dead ? aslots - 1 : aslot;     // dead frames: the dump slot (never read; keeps the store count of the tile loop exact)
         }
+        long qrow0 = frame * Lr;                   // first row of the frame in Q (and in the dropout counter)
+        int Lrf = Lr;                              // rows it has
+        if (FC && cq) {
+            const int2 qd = cq[frame];
+            qrow0 = __builtin_amdgcn_readfirstlane(qd.x);
+            Lrf = __builtin_amdgcn_readfirstlane(qd.y);
+        }
 
         TICK(5);
         // ---- stage the frame: raw rows -> LDS, 1/|row| (x * (1/n) instead of x / n: 1 ulp), region mask ----
@@ -191,9 +199,9 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
             for (int j = 0; j < 8; j++) {
                 const int tile = 2 * ks + (j >> 2), k = j & 3;
                 const int r = (PERM && tile == RT - 1) ? base_last + gq + 4 * k : 16 * tile + 4 * gq + k;
-                ok[j] = tile < RT && r < Lr;
+                ok[j] = tile < RT && r < (FC ? Lrf : Lr);
                 rr[j] = ok[j] ? r : 0;
-                fv[j] = ok[j] ? ldv4(Q + (frame * Lr + rr[j]) * DD + 4 * sq) : f4zero();
+                fv[j] = ok[j] ? ldv4(Q + ((FC ? qrow0 : frame * Lr) + rr[j]) * DD + 4 * sq) : f4zero();
                 pmv[j] = (ok[j] && sq == 0) ? qmask[frame * Lr + rr[j]] : 0.f;
             }
             float lmx = 0.f;
@@ -205,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
                 if (ok[j]) {
                     float4 pv4 = f4scale(fv[j], (1.0f / fmaxf(sqrtf(ss), 1e-12f)) * (TRAIN ? inv_keep : 1.0f));
                     if (TRAIN) {   // dropout first (zeros stay zeros), then the fp16 pair of 2^qexp * value
-                        const unsigned kb4 = drop4_bits(seed, (uint64_t)(frame * Lr + r) * D4 + sq, th);
+                        const unsigned kb4 = drop4_bits(seed, (uint64_t)((FC ? qrow0 : frame * Lr) + r) * D4 + sq, th);
                         pv4.x = (kb4 & 1u) ? pv4.x : 0.f;
                         pv4.y = (kb4 & 2u) ? pv4.y : 0.f;
                         pv4.z = (kb4 & 4u) ? pv4.z : 0.f;
@@ -225,6 +233,24 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
                     }
                 }
                 anyb |= __ballot(pmv[j] != 0.f);
+            }
+            if (FC) {
+                // compact rows: the rows [Lrf, Lr) of this frame do not exist -- their prepared fp16 pairs (stale: an earlier frame's) and
+                // their region mask must read as zero (their scores are exactly -1e10 / 0 whatever the row holds, as for a padded region)
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int tile = 2 * ks + (j >> 2), k = j & 3;
+                    const int r = (PERM && tile == RT - 1) ? base_last + gq + 4 * k : 16 * tile + 4 * gq + k;
+                    if (tile < RT && r < Lr && r >= Lrf) {
+                        char* prow = reinterpret_cast<char*>(&Qp[r * LDQ]) + 256 * (sq >> 4) + 8 * (sq & 15);
+                        *reinterpret_cast<uint2*>(prow) = make_uint2(0u, 0u);
+                        *reinterpret_cast<uint2*>(prow + 128) = make_uint2(0u, 0u);
+                        if (sq == 0) {
+                            rinv[r] = 0.f;
+                            qm[r] = 0.f;
+                        }
+                    }
+                }
             }
             lmx = wave_max(lmx);
             if (lane == 0) fmaxs[wave] = lmx;
@@ -599,7 +625,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
 template <int RT, int KL, bool PERM, bool TRAIN, bool VEC_S, typename TQ>
 static int launch_d128_t(const float* Cn, const TQ* Q, const float* cm, const float* qm, TQ* A, float* S, float* Sn,
                          int N, int NA, int Li, int Lqa, int Lr, float scale, float p_drop, unsigned long long seed,
-                         hipStream_t st, const int* fmap) {
+                         hipStream_t st, const int* fmap, const int* cq) {
     const int CR = NA * Lqa, CT = (CR + 15) / 16;
     // slices of the context tiles: enough work items (frames x slices) to balance ~2048 waves, >= 3 tiles per item
     int slices = 1;
@@ -631,10 +657,11 @@ static int launch_d128_t(const float* Cn, const TQ* Q, const float* cm, const fl
         const StageTicket tk = stage_next_ticket((unsigned int)((long)N * Li));
         if (!tk.word) return (int)hipErrorOutOfMemory;
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, 1,
-                           CT, (uint64_t)seed, th, ik, tk.word, tk.base, tim, fmap);
+                           CT, (uint64_t)seed, th, ik, tk.word, tk.base, tim, fmap, (const int2*)cq);
         STAGE_LAUNCH_CHECK_TICKET(tk);
         return 0;
     }
+    if (cq) return STAGE_ERR_SHAPE;      // compact region rows: the workgroup-staged fp16 kernel above (and the register kernel) only
     const size_t wave_bytes = ((size_t)(Lr + 1) * LDQ + 2 * RT * 16 + (size_t)tps * 16) * sizeof(float);
     // waves per workgroup: the grouping that lets the most waves share a CU's 160 KB of LDS (Lr = 50: 27.9 KB per wave,
     // 5 one-wave workgroups fit where 2 two-wave ones would); ties go to the larger workgroup
@@ -660,7 +687,7 @@ static int launch_d128_t(const float* Cn, const TQ* Q, const float* cm, const fl
     const StageTicket tk = stage_next_ticket((unsigned int)items);   // every processed item draws one ticket (common.h)
     if (!tk.word) return (int)hipErrorOutOfMemory;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * wpb), lds, st, Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr,
-                       scale, slices, tps, (uint64_t)seed, th, ik, tk.word, tk.base, tim, fmap);
+                       scale, slices, tps, (uint64_t)seed, th, ik, tk.word, tk.base, tim, fmap, (const int2*)nullptr);
     STAGE_LAUNCH_CHECK_TICKET(tk);
     return 0;
 }
@@ -668,13 +695,13 @@ static int launch_d128_t(const float* Cn, const TQ* Q, const float* cm, const fl
 template <int RT, bool TRAIN, typename TQ>
 static int launch_d128(const float* Cn, const TQ* Q, const float* cm, const float* qm, TQ* A, float* S, float* Sn,
                        int N, int NA, int Li, int Lqa, int Lr, float scale, float p_drop, unsigned long long seed,
-                       hipStream_t st, const int* fmap) {
+                       hipStream_t st, const int* fmap, const int* cq) {
     const int rem = Lr - 16 * (RT - 1);
     // 16-byte score stores need rows that start on 8 bytes only (the hardware takes dwordx4 at dword alignment; 8-byte rows measured
     // as fast as 16-byte ones); odd Lr keeps the scalar stores
     static const bool no_vec8 = getenv("STAGE_K1_NO_VEC8") != nullptr;
     const bool vec = (Lr & 3) == 0 || ((Lr & 1) == 0 && !no_vec8);
-#define ARGS Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st, fmap
+#define ARGS Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st, fmap, cq
     if (rem == 16) return vec ? launch_d128_t<RT, 4, false, TRAIN, true, TQ>(ARGS) : launch_d128_t<RT, 4, false, TRAIN, false, TQ>(ARGS);
     switch ((rem + 3) / 4) {
         case 1: return vec ? launch_d128_t<RT, 1, true, TRAIN, true, TQ>(ARGS) : launch_d128_t<RT, 1, true, TRAIN, false, TQ>(ARGS);
@@ -688,10 +715,10 @@ static int launch_d128(const float* Cn, const TQ* Q, const float* cm, const floa
 template <typename TQ>
 static int str_attn_fwd_d128_t(const float* Cn, const TQ* Q, const float* c_mask, const float* q_mask, TQ* A, float* S_raw,
                                float* S_norm, int N, int NA, int Li, int Lqa, int Lr, float scale, float p_drop,
-                               unsigned long long seed, void* stream, const int* fmap = nullptr) {
+                               unsigned long long seed, void* stream, const int* fmap = nullptr, const int* cq = nullptr) {
     hipStream_t st = (hipStream_t)stream;
     const bool train = p_drop > 0.f;
-#define ARGS Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st, fmap
+#define ARGS Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st, fmap, cq
     switch ((Lr + 15) / 16) {
         case 1: return train ? launch_d128<1, true, TQ>(ARGS) : launch_d128<1, false, TQ>(ARGS);
         case 2: return train ? launch_d128<2, true, TQ>(ARGS) : launch_d128<2, false, TQ>(ARGS);
@@ -715,7 +742,8 @@ extern "C" void stage_k1_fwd_timer(void* start, void* stop, int Lr) {
 }
 static int str_attn_fwd_dispatch(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A,
                                  float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D,
-                                 float scale, float p_drop, unsigned long long seed, void* stream, const int* fmap = nullptr);
+                                 float scale, float p_drop, unsigned long long seed, void* stream, const int* fmap = nullptr,
+                                 const int* cq = nullptr);
 extern "C" int stage_str_attn_fwd(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A,
                                   float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D,
                                   float scale, float p_drop, unsigned long long seed, void* stream) {
@@ -732,7 +760,7 @@ extern "C" int stage_str_attn_fwd(const float* Cn, const float* Q, const float* 
 }
 static int str_attn_fwd_dispatch(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A,
                                  float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D,
-                                 float scale, float p_drop, unsigned long long seed, void* stream, const int* fmap) {
+                                 float scale, float p_drop, unsigned long long seed, void* stream, const int* fmap, const int* cq) {
     if (N <= 0 || Li <= 0) return 0;
     if (D % 16 != 0 || D > 256 || Lr < 1 || Lr > 64 || Lqa < 1 || NA < 1) return STAGE_ERR_SHAPE;
     if (D != DD || getenv("STAGE_K1_GENERIC")) {
@@ -742,22 +770,24 @@ static int str_attn_fwd_dispatch(const float* Cn, const float* Q, const float* c
     }
     if (!getenv("STAGE_K1_LDS")) {   // register-resident kernel for Lr <= 32 (str_attn_fwd_reg.hip); 1 = not handled
         const int rc = stage_str_attn_fwd_reg(Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, D, scale, p_drop,
-                                              seed, stream, fmap);
+                                              seed, stream, fmap, cq);
         if (rc != 1) return rc;
     }
-    return str_attn_fwd_d128_t<float>(Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, scale, p_drop, seed, stream, fmap);
+    return str_attn_fwd_d128_t<float>(Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, scale, p_drop, seed, stream, fmap, cq);
 }
 
 // Frame-compact A (ragged token rows, include/stage_hip.h): same kernels, A rows addressed through `fmap`
+// cq (may be NULL): Q holds COMPACT region rows -- frame f = rows cq[2f] .. cq[2f] + cq[2f+1] - 1 (its valid regions + the halo of the
+// input encoder's convolutions; q_mask stays dense (N, Li, Lr))
 extern "C" int stage_str_attn_fwd_fc(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A_fc,
-                                     float* S_raw, float* S_norm, const int* fmap, int N, int NA, int Li, int Lqa, int Lr, int D,
-                                     float scale, float p_drop, unsigned long long seed, void* stream) {
+                                     float* S_raw, float* S_norm, const int* fmap, const int* cq, int N, int NA, int Li, int Lqa, int Lr,
+                                     int D, float scale, float p_drop, unsigned long long seed, void* stream) {
     if (!fmap || D != DD) return STAGE_ERR_SHAPE;
     K1Timer* tm = nullptr;
     for (auto& t : g_k1_timer)
         if (t.armed && t.Lr == Lr) { tm = &t; break; }
     if (tm) (void)hipEventRecord(tm->a, (hipStream_t)stream);
-    const int rc = str_attn_fwd_dispatch(Cn, Q, c_mask, q_mask, A_fc, S_raw, S_norm, N, NA, Li, Lqa, Lr, D, scale, p_drop, seed, stream, fmap);
+    const int rc = str_attn_fwd_dispatch(Cn, Q, c_mask, q_mask, A_fc, S_raw, S_norm, N, NA, Li, Lqa, Lr, D, scale, p_drop, seed, stream, fmap, cq);
     if (tm) {
         (void)hipEventRecord(tm->b, (hipStream_t)stream);
         tm->armed = false;

@@ -47,7 +47,9 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
     const float* __restrict__ qmask, TQ* __restrict__ A, float* __restrict__ S, float* __restrict__ Sn, int N,
     int NA, int Li, int Lqa, int Lr, float scale, int slices, int tiles_per_slice, uint64_t seed, uint32_t th,
     float inv_keep, unsigned int* __restrict__ ticket, unsigned int ticket_base, int static_rounds,
-    const int* __restrict__ fmap) {
+    const int* __restrict__ fmap, const int2* __restrict__ cq) {
+    // cq (FC only, may be NULL): COMPACT region rows -- frame f holds cq[f].y <= Lr rows starting at row cq[f].x of Q (the valid regions
+    // + the halo the input encoder's convolutions need; the rows behind them do not exist).  q_mask stays dense.
     // FC (fmap != NULL; a template parameter so that the dense kernels stay exactly the code they were: their hand-counted waits
     // are sensitive to any change of the tile loop): A is FRAME-COMPACT (include/stage_hip.h, "ragged token rows"): example n keeps slots = fmap[N*Li + n] frame slots per
     // candidate (its live frames + one dump slot), first sequence fmap[N*Li + N + n]; fmap[frame] = slot of the frame, < 0: dead (the
@@ -128,6 +130,15 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
         const int tile0 = slice * tiles_per_slice;
         const int tile1 = min(CT, tile0 + tiles_per_slice);
         const TQ* qf = Q + frame * Lr * RD;
+        long qrow0 = frame * Lr;                    // first row of the frame in Q (also the dropout counter's row)
+        int Lrf = Lr;                               // rows the frame has
+        if (FC && cq) {
+            const int2 qd = cq[frame];
+            qrow0 = __builtin_amdgcn_readfirstlane(qd.x);
+            Lrf = __builtin_amdgcn_readfirstlane(qd.y);
+            qf = Q + qrow0 * RD;
+        }
+        const int Lrc = max(Lrf - 1, 0);            // clamp for the rows that do not exist (masked: their values never count)
         row_k0 = ((unsigned)n * NA * Li + i) * Lqa;
         arow_k0 = row_k0;
         bool dead = false;
@@ -155,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
         float4 qa[RT][RNCH];
 #pragma unroll
         for (int rt = 0; rt < RT; rt++) {
-            const int rc = min(areg[rt], Lr - 1);
+            const int rc = FC ? min(areg[rt], Lrc) : min(areg[rt], Lr - 1);
 #pragma unroll
             for (int m = 0; m < RNCH; m++) qa[rt][m] = (K1_ABL & 128) ? make_float4(rc, m, g, 1.f) : ldv4(qf + rc * RD + 4 * (4 * m + g));
         }
@@ -165,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
         for (int rt = 0; rt < RT; rt++)
 #pragma unroll
             for (int k = 0; k < ((rt == RT - 1) ? KL : 4); k++) {
-                const int rc = min(Rk(rt, k), Lr - 1);
+                const int rc = FC ? min(Rk(rt, k), Lrc) : min(Rk(rt, k), Lr - 1);
 #pragma unroll
                 for (int b = 0; b < 2; b++) q2[rt * 4 + k][b] = (K1_ABL & 128) ? make_float4(rc, b, c15, 1.f) : ldv4(qf + rc * RD + 64 * b + 4 * c15);
             }
@@ -216,12 +227,12 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
 #pragma unroll
             for (int m = 0; m < RNCH; m++) ss += f4hsum(f4mul(qa[rt][m], qa[rt][m]));
             ss = cross_row_sum(ss);
-            const float ri = areg[rt] < Lr ? 1.0f / fmaxf(sqrtf(ss), 1e-12f) : 0.f;
+            const float ri = areg[rt] < (FC ? Lrf : Lr) ? 1.0f / fmaxf(sqrtf(ss), 1e-12f) : 0.f;
 #pragma unroll
             for (int m = 0; m < RNCH; m++) {
                 qa[rt][m] = f4scale(qa[rt][m], ri);
                 if (TRAIN)
-                    qa[rt][m] = f4mul(qa[rt][m], drop4(seed, (uint64_t)(frame * Lr + areg[rt]) * 32 + 4 * m + g, th, inv_keep));
+                    qa[rt][m] = f4mul(qa[rt][m], drop4(seed, (uint64_t)((FC ? qrow0 : frame * Lr) + areg[rt]) * 32 + 4 * m + g, th, inv_keep));
             }
         }
 
@@ -491,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
 template <int RT, int KL, bool PERM, bool TRAIN, bool VEC_S, typename TQ>
 static int launch_reg_t(const float* Cn, const TQ* Q, const float* cm, const float* qm, TQ* A, float* S, float* Sn,
                         int N, int NA, int Li, int Lqa, int Lr, float scale, float p_drop, unsigned long long seed,
-                        hipStream_t st, const int* fmap) {
+                        hipStream_t st, const int* fmap, const int* cq) {
     const int CR = NA * Lqa, CT = (CR + 15) / 16;
     // slices of the context tiles: enough work items (frames x slices) to balance ~2048 waves, >= 3 tiles per item
     int slices = 1;
@@ -524,14 +535,14 @@ static int launch_reg_t(const float* Cn, const TQ* Q, const float* cm, const flo
         if (fmap) {
             hipLaunchKernelGGL((str_attn_fwd_reg_kernel<RT, KL, PERM, TRAIN, VEC_S, TQ, true>), dim3((unsigned)blocks), dim3(256), park, st, Cn, Q,
                                cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, slices, tps, (uint64_t)seed, th, ik, tk.word, tk.base,
-                               static_rounds, fmap);
+                               static_rounds, fmap, (const int2*)cq);
             STAGE_LAUNCH_CHECK_TICKET(tk);
             return 0;
         }
     }
     hipLaunchKernelGGL((str_attn_fwd_reg_kernel<RT, KL, PERM, TRAIN, VEC_S, TQ, false>), dim3((unsigned)blocks), dim3(256), park, st, Cn, Q,
                        cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, slices, tps, (uint64_t)seed, th, ik, tk.word, tk.base,
-                       static_rounds, fmap);
+                       static_rounds, fmap, (const int2*)nullptr);
     STAGE_LAUNCH_CHECK_TICKET(tk);
     return 0;
 }
@@ -539,11 +550,11 @@ static int launch_reg_t(const float* Cn, const TQ* Q, const float* cm, const flo
 template <int RT, bool TRAIN, typename TQ>
 static int launch_reg(const float* Cn, const TQ* Q, const float* cm, const float* qm, TQ* A, float* S, float* Sn,
                       int N, int NA, int Li, int Lqa, int Lr, float scale, float p_drop, unsigned long long seed,
-                      hipStream_t st, const int* fmap) {
+                      hipStream_t st, const int* fmap, const int* cq) {
     const int rem = Lr - 16 * (RT - 1);
     static const bool no_vec8 = getenv("STAGE_K1_NO_VEC8") != nullptr;       // (see str_attn_fwd.hip: 16-byte stores at 8-byte row starts)
     const bool vec = (Lr & 3) == 0 || ((Lr & 1) == 0 && !no_vec8);
-#define ARGS Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st, fmap
+#define ARGS Cn, Q, cm, qm, A, S, Sn, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st, fmap, cq
     if (rem == 16) return vec ? launch_reg_t<RT, 4, false, TRAIN, true, TQ>(ARGS) : launch_reg_t<RT, 4, false, TRAIN, false, TQ>(ARGS);
     switch ((rem + 3) / 4) {
         case 1: return vec ? launch_reg_t<RT, 1, true, TRAIN, true, TQ>(ARGS) : launch_reg_t<RT, 1, true, TRAIN, false, TQ>(ARGS);
@@ -558,12 +569,12 @@ static int launch_reg(const float* Cn, const TQ* Q, const float* cm, const float
 template <typename TQ>
 static int str_attn_fwd_reg_t(const float* Cn, const TQ* Q, const float* c_mask, const float* q_mask, TQ* A, float* S_raw,
                               float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D, float scale, float p_drop,
-                              unsigned long long seed, void* stream, const int* fmap = nullptr) {
+                              unsigned long long seed, void* stream, const int* fmap = nullptr, const int* cq = nullptr) {
     if (D != RD || Lr > 32 || (long)NA * Lqa >= (1 << 22)) return 1;
     if ((long)N * NA * (Li + 1) * Lqa >= (1l << 24) || (long)Li * Lqa >= (1l << 24)) return 1;   // 24-bit row arithmetic (+1: the dump slots of the frame-compact layout)
     hipStream_t st = (hipStream_t)stream;
     const bool train = p_drop > 0.f;
-#define ARGS Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st, fmap
+#define ARGS Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, scale, p_drop, seed, st, fmap, cq
     if (Lr <= 16) return train ? launch_reg<1, true, TQ>(ARGS) : launch_reg<1, false, TQ>(ARGS);
     return train ? launch_reg<2, true, TQ>(ARGS) : launch_reg<2, false, TQ>(ARGS);
 #undef ARGS
@@ -571,8 +582,9 @@ static int str_attn_fwd_reg_t(const float* Cn, const TQ* Q, const float* c_mask,
 
 int stage_str_attn_fwd_reg(const float* Cn, const float* Q, const float* c_mask, const float* q_mask, float* A,
                            float* S_raw, float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D, float scale,
-                           float p_drop, unsigned long long seed, void* stream, const int* fmap) {
-    return str_attn_fwd_reg_t<float>(Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, D, scale, p_drop, seed, stream, fmap);
+                           float p_drop, unsigned long long seed, void* stream, const int* fmap, const int* cq) {
+    if (cq && !fmap) return STAGE_ERR_SHAPE;
+    return str_attn_fwd_reg_t<float>(Cn, Q, c_mask, q_mask, A, S_raw, S_norm, N, NA, Li, Lqa, Lr, D, scale, p_drop, seed, stream, fmap, cq);
 }
 int stage_str_attn_fwd_reg_bf16(const float* Cn, const void* Q, const float* c_mask, const float* q_mask, void* A, float* S_raw,
                                 float* S_norm, int N, int NA, int Li, int Lqa, int Lr, int D, float scale, float p_drop,

@@ -313,13 +313,16 @@ def qa_ctx_rag_supported(N, NA, Li, Lqa, Lr, D, lay) -> bool:
 
 class _QaCtxRag(torch.autograd.Function):
     @_on_device
-    def forward(ctx, qa, cx, qa_mask, cx_mask, lay, scale: float, p: float, seeds, *params):
+    def forward(ctx, qa, cx, qa_mask, cx_mask, lay, clay, scale: float, p: float, seeds, *params):
         qa, cx = _chk(qa, "qa"), _chk(cx, "ctx")
         qa_mask, cx_mask = _chk(qa_mask, "qa_mask"), _chk(cx_mask, "ctx_mask")
         ctx.sinks = _sinks(params)
         params = _params(params)
         N, NA, Lqa, D = qa.shape
-        _, Li, Lr, _ = cx.shape
+        _, Li, Lr = cx_mask.shape
+        Uc = cx.numel() // D                       # rows of the context stream: N * Li * Lr, or its compact rows (clay)
+        assert Uc == (clay.U if clay is not None else N * Li * Lr)
+        T5 = lay.tables5(clay)
         lib = _lib.load()
         ab = _size("stage_grp_qa_ctx_rag_arena_bytes", N, NA, Lqa, D, lay.Ucap, lay.Fc)
         arena = _buf(ab, qa.device)
@@ -328,12 +331,12 @@ class _QaCtxRag(torch.autograd.Function):
         Sn = torch.empty_like(S)
         flags = _flags()
         _rc(lib.stage_grp_qa_ctx_rag_fwd(qa.data_ptr(), cx.data_ptr(), qa_mask.data_ptr(), cx_mask.data_ptr(), _ptrs(params),
-                                         mixed.data_ptr(), S.data_ptr(), Sn.data_ptr(), lay.T, arena.data_ptr(), ab, flags, N, NA, Li, Lqa, Lr,
-                                         D, lay.U, lay.Ucap, lay.Fc, float(scale), float(p), _u64(seeds), _stream()),
+                                         mixed.data_ptr(), S.data_ptr(), Sn.data_ptr(), T5, arena.data_ptr(), ab, flags, N, NA, Li, Lqa, Lr,
+                                         D, lay.U, lay.Ucap, lay.Fc, Uc, float(scale), float(p), _u64(seeds), _stream()),
             "stage_grp_qa_ctx_rag_fwd")
         ctx.save_for_backward(qa, cx, cx_mask, mixed, Sn, arena, *params)
-        ctx.cfg = (N, NA, Li, Lqa, Lr, D, float(scale), float(p), tuple(seeds), flags, ab)
-        ctx.lay = lay
+        ctx.cfg = (N, NA, Li, Lqa, Lr, D, float(scale), float(p), tuple(seeds), flags, ab, Uc)
+        ctx.lay, ctx.clay = lay, clay
         ctx.spent = False
         ctx.set_materialize_grads(False)
         return mixed, S, Sn
@@ -346,7 +349,7 @@ class _QaCtxRag(torch.autograd.Function):
                                "(retain_graph + a second backward: set STAGE_NO_RAGGED=1)")
         ctx.spent = True
         qa, cx, cx_mask, mixed, Sn, arena, *params = ctx.saved_tensors
-        N, NA, Li, Lqa, Lr, D, scale, p, seeds, flags, ab = ctx.cfg
+        N, NA, Li, Lqa, Lr, D, scale, p, seeds, flags, ab, Uc = ctx.cfg
         lay = ctx.lay
         dS = _fold_dsn(dS, dSn, Sn, scale)
         d_mixed = _chk(d_mixed, "d_mixed") if d_mixed is not None else torch.zeros_like(mixed)
@@ -354,36 +357,42 @@ class _QaCtxRag(torch.autograd.Function):
         lib = _lib.load()
         grads = _grad_views(params)
         d_qa, d_cx = torch.empty_like(qa), torch.empty_like(cx)
-        tb = _size("stage_grp_qa_ctx_rag_bwd_tmp_bytes", N, NA, Li, Lqa, Lr, D, lay.Ucap)
+        cap = ctx.clay.Ucap if ctx.clay is not None else Uc
+        tb = _size("stage_grp_qa_ctx_rag_bwd_tmp_bytes", N, NA, Li, Lqa, Lr, D, lay.Ucap, cap)
         tmp = _buf(tb, qa.device)
         _rc(lib.stage_grp_qa_ctx_rag_bwd(d_mixed.data_ptr(), None if dS is None else dS.data_ptr(), qa.data_ptr(), cx.data_ptr(),
                                          cx_mask.data_ptr(), mixed.data_ptr(), Sn.data_ptr(), _ptrs(params), _ptrs(grads), d_qa.data_ptr(),
-                                         d_cx.data_ptr(), lay.T, arena.data_ptr(), ab, flags, tmp.data_ptr(), tb, N, NA, Li, Lqa, Lr, D,
-                                         lay.U, lay.Ucap, lay.Fc, scale, p, _u64(seeds), _stream()), "stage_grp_qa_ctx_rag_bwd")
-        return (d_qa, d_cx, None, None, None, None, None, None) + _deliver(ctx.sinks, grads)
+                                         d_cx.data_ptr(), lay.tables5(ctx.clay), arena.data_ptr(), ab, flags, tmp.data_ptr(), tb, N, NA, Li,
+                                         Lqa, Lr, D, lay.U, lay.Ucap, lay.Fc, Uc, scale, p, _u64(seeds), _stream()),
+            "stage_grp_qa_ctx_rag_bwd")
+        return (d_qa, d_cx, None, None, None, None, None, None, None) + _deliver(ctx.sinks, grads)
 
 
-def qa_ctx_rag(qa, cx, qa_mask, cx_mask, lay, scale: float, p: float, seeds, params):
-    """As ``qa_ctx``; ``mixed`` comes back as the (U, D) compact rows of ``lay`` (a ``ragged.RaggedLayout``), the score maps dense."""
-    return _QaCtxRag.apply(qa, cx, qa_mask, cx_mask, lay, scale, p, tuple(seeds), *params)
+def qa_ctx_rag(qa, cx, qa_mask, cx_mask, lay, clay, scale: float, p: float, seeds, params):
+    """As ``qa_ctx``; ``mixed`` comes back as the (U, D) compact rows of ``lay`` (a ``ragged.RaggedLayout``), the score maps dense.
+    ``clay`` (a ``ragged.CtxLayout`` or None): ``cx`` holds the compact rows of the context stream instead of (N, Li, Lr, D)."""
+    return _QaCtxRag.apply(qa, cx, qa_mask, cx_mask, lay, clay, scale, p, tuple(seeds), *params)
 
 
 class _EncoderRag(torch.autograd.Function):
     @_on_device
     def forward(ctx, x, pe, qa_mask, lay, k: int, p: float, seeds, *params):
         x = _chk(x, "x")                       # (U, D) compact
-        pe, qa_mask = _chk(pe, "pe"), _chk(qa_mask, "qa_mask")
+        pe = _chk(pe, "pe")
+        qa_mask = _chk(qa_mask, "qa_mask") if qa_mask is not None else None
         ctx.sinks = _sinks(params)
         params = _params(params)
         U, D = x.shape
+        assert U == lay.U
         n_conv = (len(params) - 2) // 6
-        Rd = lay.N * lay.NA * lay.Li
+        Rd = lay.out_rows if qa_mask is not None else 0
         lib = _lib.load()
         ab = _size("stage_grp_encoder_rag_arena_bytes", lay.Ucap, Rd, D, n_conv)
         arena = _buf(ab, x.device)
-        out = torch.empty(Rd, D, dtype=torch.float32, device=x.device)
+        out = torch.empty(Rd, D, dtype=torch.float32, device=x.device) if qa_mask is not None else _rows(U, D, x.device)
         flags = _flags()
-        _rc(lib.stage_grp_encoder_rag_fwd(x.data_ptr(), pe.data_ptr(), qa_mask.data_ptr(), _ptrs(params), out.data_ptr(), lay.T,
+        _rc(lib.stage_grp_encoder_rag_fwd(x.data_ptr(), pe.data_ptr(), None if qa_mask is None else qa_mask.data_ptr(), _ptrs(params),
+                                          out.data_ptr(), lay.T,
                                           arena.data_ptr(), ab, flags, lay.U, lay.Ucap, lay.S, Rd, lay.Lqa, D, n_conv, int(k), float(p),
                                           _u64(seeds), _stream()), "stage_grp_encoder_rag_fwd")
         ctx.save_for_backward(qa_mask, arena, *params)
@@ -402,7 +411,7 @@ class _EncoderRag(torch.autograd.Function):
         dx = torch.empty(lay.Ucap, D, dtype=torch.float32, device=dout.device)[:U] if ctx.needs_input_grad[0] else None
         tb = _size("stage_grp_encoder_rag_bwd_tmp_bytes", lay.Ucap, D, k)
         tmp = _buf(tb, dout.device)
-        _rc(lib.stage_grp_encoder_rag_bwd(dout.data_ptr(), qa_mask.data_ptr(), _ptrs(params), _ptrs(grads),
+        _rc(lib.stage_grp_encoder_rag_bwd(dout.data_ptr(), None if qa_mask is None else qa_mask.data_ptr(), _ptrs(params), _ptrs(grads),
                                           None if dx is None else dx.data_ptr(), lay.T, arena.data_ptr(), ab, flags, tmp.data_ptr(), tb,
                                           lay.U, lay.Ucap, lay.S, Rd, lay.Lqa, D, n_conv, k, p, _u64(seeds), _stream()),
             "stage_grp_encoder_rag_bwd")
@@ -411,8 +420,50 @@ class _EncoderRag(torch.autograd.Function):
 
 def encoder_block_rag(x, pe, qa_mask, lay, k: int, p: float, seeds, params):
     """x (U, D) compact rows of ``lay`` -> (N*NA*Li, D): the classifier encoder block + the masked max over the words of every
-    (example, candidate, frame) (model/stage.py:502-503); qa_mask (N*NA, Lqa)."""
+    (example, candidate, frame) (model/stage.py:502-503); qa_mask (N*NA, Lqa).  qa_mask None: no pooling, (U, D) comes back -- an
+    encoder block over the ragged sequences of a context stream (``lay`` a ``ragged.CtxLayout``)."""
     return _EncoderRag.apply(x, pe, qa_mask, lay, k, p, tuple(seeds), *params)
+
+
+class _InputMLPRag(torch.autograd.Function):
+    @_on_device
+    def forward(ctx, x, clay, l2: int, p: float, seeds, *params):
+        x = _chk(x, "x")                       # the padded feature tensor, (..., K0)
+        ctx.sinks = _sinks(params)
+        params = _params(params)
+        K0, H, D = x.shape[-1], params[2].shape[0], params[6].shape[0]
+        M = clay.U
+        lib = _lib.load()
+        ab = _size("stage_grp_input_mlp_arena_bytes", clay.Ucap, K0, H, D, int(l2))
+        arena = _buf(ab, x.device)
+        out = _rows(M, D, x.device)
+        flags = _flags()
+        _rc(lib.stage_grp_input_mlp_rag_fwd(x.data_ptr(), clay.src_rows.data_ptr(), _ptrs(params), out.data_ptr(), arena.data_ptr(), ab, flags,
+                                            M, K0, H, D, int(l2), float(p), _u64(seeds), _stream()), "stage_grp_input_mlp_rag_fwd")
+        ctx.save_for_backward(x, arena, *params)
+        ctx.cfg = (M, K0, H, D, int(l2), float(p), tuple(seeds), flags, ab)
+        ctx.clay = clay
+        return out
+
+    @_on_device
+    def backward(ctx, dout):
+        x, arena, *params = ctx.saved_tensors
+        M, K0, H, D, l2, p, seeds, flags, ab = ctx.cfg
+        dout = _chk(dout, "dout")
+        lib = _lib.load()
+        grads = _grad_views(params)
+        tb = _size("stage_grp_input_mlp_bwd_tmp_bytes", ctx.clay.Ucap, K0, H, D)
+        tmp = _buf(tb, x.device)
+        _rc(lib.stage_grp_input_mlp_rag_bwd(dout.data_ptr(), x.data_ptr(), ctx.clay.src_rows.data_ptr(), _ptrs(params), _ptrs(grads),
+                                            arena.data_ptr(), ab, flags, tmp.data_ptr(), tb, M, K0, H, D, l2, p, _u64(seeds), _stream()),
+            "stage_grp_input_mlp_rag_bwd")
+        return (None, None, None, None, None) + _deliver(ctx.sinks, grads)
+
+
+def input_mlp_rag(x, clay, l2: bool, p: float, seeds, params):
+    """As ``input_mlp`` on the compact rows of a ragged context stream: x the padded (..., K0) features, ``clay.src_rows`` the rows of it
+    that exist; -> (clay.U, D)."""
+    return _InputMLPRag.apply(x, clay, int(bool(l2)), p, tuple(seeds), *params)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -300,7 +300,7 @@ class CandidateLayout:
             elif k in _LIST_KEYS and isinstance(v, list):
                 out[k] = v[lo:hi]
             elif k == "mask_host" and isinstance(v, dict):
-                out[k] = {kk: (vv[lo:hi, k0:k1] if kk == "qas" else vv[lo:hi]) for kk, vv in v.items()}
+                out[k] = {kk: (vv[lo:hi, k0:k1] if kk == "qas" else vv[lo:hi]) for kk, vv in v.items()}   # qas (N, NA, Lqa); *_len (N, Li)
             else:
                 out[k] = v
         out["cand_offset"] = k0

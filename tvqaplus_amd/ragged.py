@@ -144,27 +144,128 @@ class RaggedLayout:
         self.T = (ctypes.c_void_p * 4)(self.fmap.data_ptr(), self.gdesc.data_ptr(), self.seq.data_ptr(), self.rowinfo.data_ptr())
 
     @property
+    def out_rows(self) -> int:
+        return self.N * self.NA * self.Li      # the pooled encoder group writes one row per (example, candidate, frame)
+
+    def tables5(self, ctx: Optional["CtxLayout"]):
+        """Table pointers of the attention group: fmap, gdesc, seq, rowinfo + the context stream's frame table (or NULL)."""
+        return (ctypes.c_void_p * 5)(self.fmap.data_ptr(), self.gdesc.data_ptr(), self.seq.data_ptr(), self.rowinfo.data_ptr(),
+                                     None if ctx is None else ctx.cq.data_ptr())
+
+    @property
     def live_fraction(self) -> float:
         return self.U / float(max(1, self.N * self.NA * self.Li * self.Lqa))
 
 
-def host_masks(batch, frame_stream: str) -> Optional[tuple]:
-    """(qa_valid, frame_live) as numpy bools from the host copies a loader attached to the batch (``batch.mask_host``: dict with
-    ``qas`` (N, NA, Lqa) and ``sub_frames`` / ``vid_frames`` (N, Li): tvqaplus_amd.synth.make_batch, tvqaplus_amd.prefetch), or None."""
+class CtxTables:
+    """Host side of a ragged CONTEXT stream (subtitle words / video regions in front of the attention, model/stage.py:235-270).
+    ``lens`` (N, Li): last valid word / region + 1 of every frame (0: none).  A frame keeps ``min(L, len + halo)`` rows --
+    ``halo = n_blocks * n_conv * (k // 2)`` of the INPUT encoder, whose unmasked convolutions let that many padded positions leak into
+    the valid ones; what lies behind never reaches a valid position, and the attention masks every padded position itself
+    (model/context_query_attention.py:58-61, 100), so nothing else reads it.  A frame without a valid position keeps no row."""
+
+    def __init__(self, lens: np.ndarray, L: int, halo: int):
+        lens = np.ascontiguousarray(lens, dtype=np.int64)
+        self.N, self.Li = lens.shape
+        self.L, self.halo = int(L), int(halo)
+        lv = lens.reshape(-1)
+        qlen = np.where(lv > 0, np.minimum(L, lv + int(halo)), 0)
+        qstart = np.concatenate([[0], np.cumsum(qlen)[:-1]])
+        self.U = int(qlen.sum())
+        live = qlen > 0
+        self.S = int(live.sum())
+        self.cq = np.stack([np.where(live, qstart, 0), qlen], axis=1).astype(np.int32)        # (frames, 2)
+        self.seq = np.stack([qstart[live], qlen[live], np.zeros(self.S, np.int64), np.zeros(self.S, np.int64)], axis=1).astype(np.int32)
+
+    def src_rows_host(self) -> np.ndarray:
+        """What stage_rag_ctx_rows computes on the device (tests)."""
+        out = np.empty(self.U, dtype=np.int32)
+        for f in range(self.cq.shape[0]):
+            s, n = int(self.cq[f, 0]), int(self.cq[f, 1])
+            out[s:s + n] = f * self.L + np.arange(n)
+        return out
+
+
+class CtxLayout:
+    """Device side of ``CtxTables``: the tables, the source-row table, and the table-pointer array the ragged encoder group takes."""
+    out_rows = 0          # (the encoder group does not pool over these sequences)
+
+    def __init__(self, tab: CtxTables, device, stage=None):
+        self.tab = tab
+        self.N, self.Li, self.Lqa = tab.N, tab.Li, tab.L       # Lqa: the longest sequence, under the name the encoder group uses
+        self.U, self.S = tab.U, tab.S
+        self.Ucap = max(CAP_STEP, _align(tab.U, CAP_STEP))
+        parts = [tab.cq.reshape(-1), tab.seq.reshape(-1)]
+        offs, total = [], 0
+        for p in parts:
+            offs.append(total)
+            total += _align(p.size, 4)
+        host = np.zeros(max(total, 4), dtype=np.int32)
+        for o, p in zip(offs, parts):
+            host[o:o + p.size] = p
+        if torch.device(device).type == "cuda":
+            if stage is None:
+                from .att_host import PinnedStage
+                stage = PinnedStage()
+            self.tables = stage.upload(host, device)
+        else:
+            self.tables = torch.from_numpy(host).to(device)
+        self.stage = stage
+        self.cq = self.tables[offs[0]: offs[0] + tab.cq.size]
+        self.seq = self.tables[offs[1]: offs[1] + tab.seq.size]
+        self.src_rows = torch.empty(max(self.U, 1), dtype=torch.int32, device=device)
+        if self.tables.is_cuda and self.U > 0:
+            from .ops import _stream
+            with torch.cuda.device(device):
+                _lib.check(_lib.load().stage_rag_ctx_rows(self.cq.data_ptr(), tab.N * tab.Li, tab.L, self.src_rows.data_ptr(), _stream()),
+                           "stage_rag_ctx_rows")
+        self.T = (ctypes.c_void_p * 4)(None, None, self.seq.data_ptr(), None)
+
+
+def mask_lens(mask: np.ndarray) -> np.ndarray:
+    """(..., L) 0/1 mask -> last non-zero position + 1 along the last axis (0: none); holes inside stay live."""
+    v = np.asarray(mask) != 0
+    L = v.shape[-1]
+    return np.where(v.any(-1), L - np.argmax(v[..., ::-1], axis=-1), 0).astype(np.int32)
+
+
+def host_info(batch) -> Optional[dict]:
+    """What the loader knows about the masks, as attached to the batch (``batch.mask_host``: ``qas`` (N, NA, Lqa) bool and the per-frame
+    lengths ``sub_len`` / ``vid_len`` (N, Li) = last valid word / region + 1: tvqaplus_amd.synth.make_batch; the collate function builds
+    the masks from exactly these numbers, tvqa_dataset.py:515-590), or None."""
     mh = batch.get("mask_host") if isinstance(batch, dict) else getattr(batch, "mask_host", None)
-    if not mh:
+    return mh if mh and mh.get("qas") is not None else None
+
+
+def host_masks(batch, frame_stream: str) -> Optional[tuple]:
+    """(qa_valid, frame_live) from ``batch.mask_host`` (see host_info), or None."""
+    mh = host_info(batch)
+    if mh is None or mh.get(frame_stream + "_len") is None:
         return None
-    fl = mh.get(frame_stream + "_frames")
-    qa = mh.get("qas")
-    if fl is None or qa is None:
-        return None
-    return np.asarray(qa, dtype=bool), np.asarray(fl, dtype=bool)
+    return np.asarray(mh["qas"], dtype=bool), np.asarray(mh[frame_stream + "_len"]) > 0
+
+
+def info_from_device(qas_mask: torch.Tensor, ctx_masks: dict) -> dict:
+    """The same from the device tensors: ONE small device -> host copy (it waits for the queue: batches that come with ``mask_host``
+    avoid it).  qas_mask (N, NA, Lqa); ctx_masks: {"sub" / "vid": (N, Li, L)}."""
+    N, NA, Lqa = qas_mask.shape
+    parts = [(qas_mask != 0).reshape(-1).to(torch.int32)]
+    keys = sorted(ctx_masks)
+    for k in keys:
+        m = ctx_masks[k]
+        pos = torch.arange(1, m.shape[-1] + 1, device=m.device, dtype=torch.int32)
+        parts.append(((m != 0).to(torch.int32) * pos).amax(-1).reshape(-1))
+    flat = torch.cat(parts).cpu().numpy()
+    out = {"qas": flat[:N * NA * Lqa].reshape(N, NA, Lqa).astype(bool)}
+    o = N * NA * Lqa
+    for k in keys:
+        n = ctx_masks[k].shape[0] * ctx_masks[k].shape[1]
+        out[k + "_len"] = flat[o:o + n].reshape(ctx_masks[k].shape[0], ctx_masks[k].shape[1]).astype(np.int32)
+        o += n
+    return out
 
 
 def masks_from_device(qas_mask: torch.Tensor, ctx_mask: torch.Tensor) -> tuple:
-    """The same from the device tensors: ONE small device -> host copy (it waits for the queue: batches that come with
-    ``mask_host`` avoid it).  qas_mask (N, NA, Lqa), ctx_mask (N, Li, Lr)."""
-    N, NA, Lqa = qas_mask.shape
-    Li = ctx_mask.shape[1]
-    flat = torch.cat([(qas_mask != 0).reshape(-1), (ctx_mask.sum(-1) != 0).reshape(-1)]).to(torch.uint8).cpu().numpy().astype(bool)
-    return flat[:N * NA * Lqa].reshape(N, NA, Lqa), flat[N * NA * Lqa:].reshape(N, Li)
+    """(qa_valid, frame_live) from the device masks (one read-back)."""
+    info = info_from_device(qas_mask, {"ctx": ctx_mask})
+    return info["qas"], info["ctx_len"] > 0

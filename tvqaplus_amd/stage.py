@@ -210,8 +210,13 @@ class STAGE(nn.Module):
         # row is computed, as the reference does.  Needs the K-group path at hsz = 128 (otherwise the dense path runs, silently: it is
         # the same function).  ``last_ragged``: the layout of the last forward (None = dense), for tests and the bench record.
         self.use_ragged = os.environ.get("STAGE_NO_RAGGED") is None
+        # ... and the context streams in front of the attention on their valid words / regions + the input encoder's halo
+        # (STAGE_NO_RAGGED_CTX=1: dense context streams, ragged statement rows)
+        self.use_ragged_ctx = os.environ.get("STAGE_NO_RAGGED_CTX") is None
         self.last_ragged: Optional[ragged.RaggedLayout] = None
+        self.last_ragged_ctx: Dict[str, ragged.CtxLayout] = {}
         self._rag_stage = None
+        self._ctx_stage: Dict[str, object] = {}
         # storage type of the activations between kernels: fp32 (the reference's), or bf16 with ``opt.storage_dtype = "bf16"``
         # (BASELINE.json configs[4]: bf16 weights / activations, fp32 softmax / statistics / accumulation; parameters stay
         # fp32 master copies, a weight is rounded to bf16 when a GEMM stages it; scores, losses and logits are fp32)
@@ -327,9 +332,27 @@ class STAGE(nn.Module):
             x = self._encoder_block(x, mask, blk, pool_mask=pool_mask if j == len(blocks) - 1 else None)
         return x
 
-    def base_encoder(self, data, data_mask, init_encoder, downsize_encoder, input_encoder, l2_normalize=False):
+    def base_encoder(self, data, data_mask, init_encoder, downsize_encoder, input_encoder, l2_normalize=False, clay=None):
         """model/stage.py:350-363 (+ the F.normalize of :256 when l2_normalize)."""
         M, L, _ = data.shape
+        if clay is not None:
+            # ragged context rows (tvqaplus_amd/ragged.py: CtxLayout): the MLP reads the live rows of the padded features in place,
+            # everything behind it -- and the attention -- runs on the compact rows
+            params = [init_encoder[0].weight, init_encoder[0].bias, init_encoder[2].weight, init_encoder[2].bias,
+                      init_encoder[4].weight, init_encoder[4].bias, downsize_encoder[1].weight, downsize_encoder[1].bias,
+                      downsize_encoder[3].weight, downsize_encoder[3].bias]
+            y = groups.input_mlp_rag(data, clay, l2_normalize, self._p(), self._seeds(2), [self._g(w) for w in params])
+            for blk in input_encoder.stacked_encoderBlocks:
+                bp = []
+                for i in range(blk.n_conv):
+                    c = blk.conv[i]
+                    bp += [blk.layer_norm[i].weight, blk.layer_norm[i].bias, c.depthwise_conv.weight, c.depthwise_conv.bias,
+                           c.pointwise_conv.weight, c.pointwise_conv.bias]
+                bp += [blk.final_layer_norm.weight, blk.final_layer_norm.bias]
+                k = blk.conv[0].depthwise_conv.weight.shape[-1]
+                y = groups.encoder_block_rag(y, blk.position_encoding.rows(L), None, clay, k, self._p(),
+                                             self._seeds((blk.n_conv + 1) // 2), [self._g(w) for w in bp])
+            return y
         if data.dtype != self.storage:
             data = data.to(self.storage)      # bf16 storage: features are rounded once on entry
         if self._grouped() and not self.fuse_input_ln and data.dtype == torch.float32:
@@ -354,17 +377,17 @@ class STAGE(nn.Module):
         y, _ = self._ln(y, downsize_encoder[3])
         return self._stacked_encoder(y.view(M, L, -1), data_mask, input_encoder)
 
-    def qa_ctx_attention(self, qa_embed, ctx_embed, qa_mask, ctx_mask, lay=None):
+    def qa_ctx_attention(self, qa_embed, ctx_embed, qa_mask, ctx_mask, lay=None, clay=None):
         """model/stage.py:365-387.  qa_embed (N,5,Lqa,D), ctx_embed (N,Li,Lr,D), qa_mask (N,5,Lqa), ctx_mask (N,Li,Lr).
         ``lay`` (ragged.RaggedLayout): the mixed rows come back compact, (U, D)."""
         N, NA, Lqa, D = qa_embed.shape
-        Li = ctx_embed.shape[1]
+        Li = ctx_mask.shape[1]
         p = self._p()
         # (s_mask.sum(-1) != 0) with s_mask = qa_mask (x) ctx_mask
         mixed_mask = ((qa_mask != 0).view(N, NA, 1, Lqa) & (ctx_mask.sum(-1) != 0).view(N, 1, Li, 1)).float()
         if lay is not None:
             proj = self.c2q_down_projection
-            res = groups.qa_ctx_rag(qa_embed, ctx_embed, qa_mask, ctx_mask, lay, self.scale, p, self._seeds(3),
+            res = groups.qa_ctx_rag(qa_embed, ctx_embed, qa_mask, ctx_mask, lay, clay, self.scale, p, self._seeds(3),
                                     [self._g(w) for w in (proj[0].weight, proj[0].bias, proj[2].weight, proj[2].bias)])
             return res[0], mixed_mask, res[1], res[2]
         if self._grouped() and qa_embed.dtype == torch.float32 and ctx_embed.shape[2] <= 64:
@@ -597,45 +620,66 @@ class STAGE(nn.Module):
         """The ragged layout of this batch (tvqaplus_amd/ragged.py), or None when the dense path runs: switched off, a configuration
         the ragged kernels do not cover (decided BEFORE anything is launched: hsz = 128 on the K-group path, one classifier-encoder
         block without self-attention, <= 40 QA words, even region / word counts <= 64), or no live row at all."""
+        none = (None, {})
         if not (self.use_ragged and self._grouped() and self.fuse_ln_dwconv and self.fuse_ln_max and a_embed.is_cuda
                 and a_embed.dtype == torch.float32):
-            return None
+            return none
         N, NA, Lqa, D = a_embed.shape
         blocks = list(self.cls_encoder.stacked_encoderBlocks)
         if D != 128 or len(blocks) != 1 or blocks[0].num_heads != 0 or not (1 <= blocks[0].n_conv <= 8) or not (4 <= Lqa <= 40):
-            return None
+            return none
         k = blocks[0].conv[0].depthwise_conv.weight.shape[-1]
         if k % 2 == 0 or k > 9:
-            return None
+            return none
         streams = []
         if self.sub_flag:
             streams.append((batch.sub_mask, batch.sub_bert.shape[1], batch.sub_bert.shape[2]))
         if self.vfeat_flag:
             streams.append((batch.vid_mask, batch.vid.shape[1], batch.vid.shape[2]))
         if not streams or any(Li != streams[0][1] for _, Li, _ in streams):
-            return None
+            return none
         Li = streams[0][1]
         # the statement mask's frame side comes from the video stream when there is one (model/stage.py:283-289)
         frame_stream = "vid" if self.vfeat_flag else "sub"
-        hm = ragged.host_masks(batch, frame_stream)
-        if hm is not None and (hm[0].shape != (N, NA, Lqa) or hm[1].shape != (N, Li)):
-            hm = None                                    # stale host copies (a batch sliced by foreign code): read the masks
-        if hm is None:
-            ctx_m = batch.vid_mask if self.vfeat_flag else batch.sub_mask
-            hm = ragged.masks_from_device(batch.qas_mask.view(N, NA, Lqa), ctx_m.view(N, Li, -1))
-        qa_valid, frame_live = hm
-        if qa_valid.shape != (N, NA, Lqa) or frame_live.shape != (N, Li):
-            return None
-        tab = ragged.RaggedTables(qa_valid, frame_live, ragged.conv_halo(1, blocks[0].n_conv, k))
+        names = (["sub"] if self.sub_flag else []) + (["vid"] if self.vfeat_flag else [])
+        info = ragged.host_info(batch)
+        if info is not None and (info["qas"].shape != (N, NA, Lqa)
+                                 or any(info.get(k + "_len") is None or info[k + "_len"].shape != (N, Li) for k in names)):
+            info = None                                  # no / stale host copies (a batch sliced by foreign code): read the masks
+        if info is None:
+            info = ragged.info_from_device(batch.qas_mask.view(N, NA, Lqa),
+                                           {k: (batch.sub_mask if k == "sub" else batch.vid_mask).view(N, Li, -1) for k in names})
+        tab = ragged.RaggedTables(info["qas"], info[frame_stream + "_len"] > 0, ragged.conv_halo(1, blocks[0].n_conv, k))
         if tab.U == 0:
-            return None
+            return none
         lib_ok = all(bool(groups._lib.load().stage_grp_qa_ctx_rag_supported(N, NA, Li, Lqa, int(Lr), D, tab.U, tab.Fc))
                      for _, _, Lr in streams)
         if not lib_ok:
-            return None
+            return none
         lay = ragged.RaggedLayout(tab, a_embed.device, self._rag_stage)
         self._rag_stage = lay.stage
-        return lay
+        # the context streams themselves: valid words / regions + the halo of the INPUT encoder's convolutions (no self-attention there,
+        # feature widths the gathered LayerNorm takes)
+        clays = {}
+        iblocks = list(self.input_encoder.stacked_encoderBlocks)
+        ctx_ok = (self.use_ragged_ctx and len(iblocks) >= 1 and all(b.num_heads == 0 and 1 <= b.n_conv <= 8 for b in iblocks)
+                  and not self.fuse_input_ln)
+        if ctx_ok:
+            ik = iblocks[0].conv[0].depthwise_conv.weight.shape[-1]
+            ctx_ok = ik % 2 == 1 and ik <= 9 and all(b.conv[0].depthwise_conv.weight.shape[-1] == ik for b in iblocks)
+        if ctx_ok:
+            halo = sum(ragged.conv_halo(1, b.n_conv, ik) for b in iblocks)
+            for (mask, _, L), name in zip(streams, names):
+                feat = batch.sub_bert if name == "sub" else batch.vid
+                if feat.dtype != torch.float32 or feat.shape[-1] % 4 or feat.shape[-1] > 1024 or not feat.is_contiguous():
+                    continue
+                ct = ragged.CtxTables(info[name + "_len"], int(L), halo)
+                if ct.U == 0:
+                    continue
+                st = self._ctx_stage.get(name)
+                clays[name] = ragged.CtxLayout(ct, a_embed.device, st)
+                self._ctx_stage[name] = clays[name].stage
+        return lay, clays
 
     # ---- forward ----------------------------------------------------------------------------------------------
     def forward(self, batch):
@@ -690,22 +734,25 @@ class STAGE(nn.Module):
         a_embed = a_embed.view(N, NA, -1, D)
         attended_sub = attended_vid = attended_vid_mask = attended_sub_mask = None
         other_outputs: Dict[str, torch.Tensor] = {}
-        lay = self.last_ragged = self._ragged_layout(batch, qas_mask, a_embed)
+        lay, clays = self._ragged_layout(batch, qas_mask, a_embed)
+        self.last_ragged, self.last_ragged_ctx = lay, clays
         if self.sub_flag:
             Li, Lw = batch.sub_bert.shape[1:3]
             sub_mask = batch.sub_mask.view(N, Li, Lw).float()
+            cl = clays.get("sub")
             sub_embed = self.base_encoder(batch.sub_bert.view(N * Li, Lw, -1), sub_mask.view(N * Li, Lw),
-                                          self.bert_word_encoding_fc, self.input_embedding, self.input_encoder)
+                                          self.bert_word_encoding_fc, self.input_embedding, self.input_encoder, clay=cl)
             attended_sub, attended_sub_mask, raw, norm = self.qa_ctx_attention(
-                a_embed, sub_embed.view(N, Li, Lw, D), qas_mask, sub_mask, lay)
+                a_embed, sub_embed if cl is not None else sub_embed.view(N, Li, Lw, D), qas_mask, sub_mask, lay, cl)
             other_outputs["sub_normalized_s"], other_outputs["sub_raw_s"] = norm, raw
         if self.vfeat_flag:
             Li, Lr = batch.vid.shape[1:3]
             vid_mask = batch.vid_mask.view(N, Li, Lr).float()
+            cl = clays.get("vid")
             vid_embed = self.base_encoder(batch.vid.view(N * Li, Lr, -1), vid_mask.view(N * Li, Lr), self.vid_fc,
-                                          self.input_embedding, self.input_encoder, l2_normalize=True)
+                                          self.input_embedding, self.input_encoder, l2_normalize=True, clay=cl)
             attended_vid, attended_vid_mask, raw, norm = self.qa_ctx_attention(
-                a_embed, vid_embed.view(N, Li, Lr, D), qas_mask, vid_mask, lay)
+                a_embed, vid_embed if cl is not None else vid_embed.view(N, Li, Lr, D), qas_mask, vid_mask, lay, cl)
             other_outputs["vid_normalized_s"], other_outputs["vid_raw_s"] = norm, raw
         if self.flag_cnt == 2:
             fc = self.concat_fc

@@ -54,6 +54,14 @@ def _lengths(gen: torch.Generator, shape, lo: int, hi: int) -> torch.Tensor:
     return torch.randint(lo, hi + 1, shape, generator=gen)
 
 
+def _last_valid(mask: torch.Tensor):
+    """(..., L) 0/1 mask -> numpy int32 (...): last valid position + 1 (0: none) -- the lengths the collate function pads to."""
+    v = (mask != 0).numpy()
+    L = v.shape[-1]
+    import numpy as np
+    return np.where(v.any(-1), L - np.argmax(v[..., ::-1], axis=-1), 0).astype(np.int32)
+
+
 def _len_mask(lengths: torch.Tensor, L: int) -> torch.Tensor:
     return (torch.arange(L).view(*([1] * lengths.dim()), L) < lengths.unsqueeze(-1)).float()
 
@@ -108,8 +116,7 @@ def make_batch(N: int = 16, Li: int = 300, Lr: int = 20, Lw: int = 50, Lqa: int 
               # host copies of what the masks say about whole words / frames (the collate function builds the masks from
               # lengths on the host, tvqa_dataset.py:515-590): lets STAGE lay out its ragged token rows without reading the
               # device masks back (tvqaplus_amd/ragged.py: host_masks)
-              mask_host=dict(qas=(qas_mask != 0).numpy(), sub_frames=(sub_mask.sum(-1) != 0).numpy(),
-                             vid_frames=(vid_mask.sum(-1) != 0).numpy()),
+              mask_host=dict(qas=(qas_mask != 0).numpy(), sub_len=_last_valid(sub_mask), vid_len=_last_valid(vid_mask)),
               qid=list(range(N)), vid_name=["synthetic_%d" % i for i in range(N)],
               qas=torch.zeros(N, 5, Lqa, dtype=torch.long), att_labels=None, anno_st_idx=[0] * N, q_l=[1] * N,
               image_indices=[list(range(Li)) for _ in range(N)], boxes=[[] for _ in range(N)],
