@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("TVQA_GOLDEN_OUT", HERE)      # where the fixtures are written (tests/test_oracle_golden.py regenerates into a scratch directory)
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = os.environ.get("TVQA_REFERENCE", "/root/reference")
 sys.path.insert(0, ROOT)
@@ -92,7 +93,7 @@ def run_case(name, opt_kw, batch_kw, mode, seed):
     for k in ("sub_raw_s", "sub_normalized_s", "vid_raw_s", "vid_normalized_s"):
         if k in other:
             rec["out/" + k] = np32(other[k])
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **rec)
     print("%-28s %8.1f KB" % (name, os.path.getsize(path) / 1024))
 
@@ -116,7 +117,7 @@ def k1_case(name, N, Li, Lr, Lqa, D, seed, scale=10.0):
     rec = dict(C=np32(C), Q=np32(Q), c_mask=np32(c_mask), q_mask=np32(q_mask), scale=np.float32(scale),
                A=np32(A), S=np32(S), S_mask=np32(S_mask), S_norm=np32(S_), gA=np32(gA), gS=np32(gS), gSn=np32(gSn),
                dC=np32(C.grad), dQ=np32(Q.grad))
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **rec)
     print("%-28s %8.1f KB" % (name, os.path.getsize(path) / 1024))
 
@@ -140,7 +141,7 @@ def encoder_case(name, M, L, D, k, n_conv, nh, seed):
         rec["param/" + kk] = np32(v)
     for kk, p in enc.named_parameters():
         rec["grad/" + kk] = np32(p.grad)
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **rec)
     print("%-28s %8.1f KB" % (name, os.path.getsize(path) / 1024))
 
@@ -190,7 +191,7 @@ def att_case(name, seed, loss_type, hard, pool, num_hard, drop_topk, num_negativ
            "cfg": np.array(json.dumps(dict(seed=seed + 1, loss_type=loss_type, hard=hard, pool=pool, num_hard=num_hard,
                                            drop_topk=drop_topk, num_negatives=num_negatives, start=start, Li=Li))),
            "loss": np32(loss), "grad": np32(scores.grad), "preds": np.array(json.dumps(preds))}
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
     print("%-24s loss %.6f  preds %d" % (name, float(loss), sum(len(v) for q in preds for v in q.values())))
 
 
@@ -239,14 +240,32 @@ def att_main():
     att_case("att_hinge_pool", 34, "hinge", True, 4, 2, 1, num_negatives=3)
 
 
+def write_manifest():
+    """MANIFEST.json: the key set of every fixture as THIS generator writes it (tests/test_oracle_golden.py holds the committed files to it)."""
+    import glob
+    man = {os.path.basename(f)[:-4]: sorted(np.load(f, allow_pickle=False).files) for f in sorted(glob.glob(os.path.join(OUT, "*.npz")))}
+    with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
+        json.dump(man, f, indent=0, sort_keys=True)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "att":   # only the attention-loss / box-prediction fixtures
         att_main()
         att_model_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "emptyframe":
         emptyframe_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "only":   # selected whole-model cases (tests: bit-exact regeneration check)
+        cases = set(sys.argv[2:])
+        _run = run_case
+        run_case = lambda name, *a, **k: _run(name, *a, **k) if name in cases else None   # noqa: E731
+        main_names = [n for n in cases]
+        k1c, encc = k1_case, encoder_case
+        k1_case = lambda name, **k: k1c(name, **k) if name in cases else None              # noqa: E731
+        encoder_case = lambda name, **k: encc(name, **k) if name in cases else None        # noqa: E731
+        main()
     else:
         main()
         att_main()
         att_model_main()
         emptyframe_main()
+        write_manifest()

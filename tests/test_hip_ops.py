@@ -109,7 +109,10 @@ def test_cat3_layernorm(ops, G, rep, inner, D):
                                          # M >= 4096: the streaming kernels (ragged last row tile, partial column
                                          # tiles, several K chunks, ragged last K chunk, several column tiles)
                                          (5000, 300, 768, True), (4133, 128, 300, False), (8200, 384, 128, True),
-                                         (4097, 128, 384, True), (6000, 44, 132, False), (4096, 128, 64, True)])
+                                         (4097, 128, 384, True), (6000, 44, 132, False), (4096, 128, 64, True),
+                                         # row counts that are not multiples of 4 (ragged token rows): the ReLU bit mask's word rows are
+                                         # then only dword aligned in the weight-gradient kernels
+                                         (4099, 128, 128, True), (8191, 128, 384, True), (4102, 300, 768, True), (5001, 128, 300, True)])
 def test_linear(ops, M, N, K, relu):
     g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g)

@@ -120,3 +120,39 @@ def test_reference_fp32_gradients_are_off_fp64_by_more_than_the_output_tolerance
     G, G64 = fx.group("grad"), fp64_gradients(fx)
     worst = max(rel_err(G[k].double(), G64[k]) for k in G64)
     assert 1.5e-3 < worst < 6e-3, worst
+
+
+def test_committed_fixtures_have_the_generators_key_sets():
+    """tests/golden/MANIFEST.json is written by make_golden.py next to the fixtures: every committed .npz must carry exactly the keys the
+    current generator writes (a fixture that predates a generator change shows up here)."""
+    import glob
+    import json
+    import os
+    import numpy as np
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    man = json.load(open(os.path.join(here, "MANIFEST.json")))
+    files = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(here, "*.npz")))
+    assert files == sorted(man), set(files) ^ set(man)
+    for name in files:
+        assert sorted(np.load(os.path.join(here, name + ".npz"), allow_pickle=False).files) == man[name], name
+
+
+def test_fixtures_regenerate_bit_exactly_from_the_reference(tmp_path):
+    """Where the reference is importable (the build container: /root/reference), two fixtures are regenerated by the committed generator
+    and compared array by array.  The reference never travels: elsewhere this is skipped."""
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    ref = os.environ.get("TVQA_REFERENCE", "/root/reference")
+    if not os.path.exists(os.path.join(ref, "model", "stage.py")):
+        pytest.skip("reference not present")
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    env = dict(os.environ, TVQA_GOLDEN_OUT=str(tmp_path))
+    subprocess.check_call([sys.executable, os.path.join(here, "make_golden.py"), "only", "tiny_train", "k1_small"], env=env,
+                          stdout=subprocess.DEVNULL)
+    for name in ("tiny_train", "k1_small"):
+        a, b = np.load(os.path.join(str(tmp_path), name + ".npz")), np.load(os.path.join(here, name + ".npz"))
+        assert sorted(a.files) == sorted(b.files)
+        for k in a.files:
+            assert np.array_equal(a[k], b[k]), (name, k)

@@ -1418,8 +1418,9 @@ __global__ __launch_bounds__(128 * (1 + NXQ), 2) void gemm_tn_quad_kernel(const 
         for (int r = 0; r < 8; r++)
             va[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (int)((m0 + r) * ld * 4), 0);   // rows past the end read 0
         if (GATE == 2) {
-            // 16-byte alignment of the word row needs (word * M + m0 + 8 * ...) % 4 == 0: the host checks M % 4 == 0 and
-            // slabs start at multiples of 16
+            // word rows start at word * M: 16-byte aligned when M % 4 == 0 (the dense shapes), dword aligned otherwise (ragged row
+            // counts; buffer loads take any dword alignment -- round 4: falling back to the dword-load kernels for M % 4 != 0
+            // cost 0.4 ms per step).  Slabs start at multiples of 16
             gw[0] = __builtin_amdgcn_raw_buffer_load_b128(rg, moff, (int)(m0 * 4), 0);
             gw[1] = __builtin_amdgcn_raw_buffer_load_b128(rg, moff, (int)((m0 + 4) * 4), 0);
         }
@@ -1581,7 +1582,7 @@ int stage_gemm_tn_stream(const float* dY, const void* gate, int gate_kind, const
         dim3 gridw((N + 127) / 128, (K + 383) / 384, S);
         static const bool no_quad = getenv("STAGE_GEMM_TN_NOQUAD") != nullptr;
         if (STAGE_GEMM_TN_F16 && !no_quad && gate_kind != 1 && N % 4 == 0 && K % 4 == 0 && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0 &&
-            (gate_kind != 2 || (M % 4 == 0 && ((uintptr_t)gate & 15) == 0 && rows_per_split % 16 == 0))) {
+            (gate_kind != 2 || (((uintptr_t)gate & 15) == 0 && rows_per_split % 16 == 0))) {
             const int ldsq = 2 * 2 * 16 * 2 * 64 * (int)sizeof(uint4) + 2 * 16 * 32 * (int)sizeof(int);
 #define LAUNCH_TNQ(GT)                                                                                                 \
     do {                                                                                                               \
@@ -1621,7 +1622,7 @@ int stage_gemm_tn_stream(const float* dY, const void* gate, int gate_kind, const
     {   // K <= 128: the quad kernel with ONE X quad (row-wise 16-byte loads; same conditions as above)
         static const bool no_quad1 = getenv("STAGE_GEMM_TN_NOQUAD") != nullptr;
         if (STAGE_GEMM_TN_F16 && !no_quad1 && gate_kind != 1 && N % 4 == 0 && K % 4 == 0 && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0 &&
-            (gate_kind != 2 || (M % 4 == 0 && ((uintptr_t)gate & 15) == 0 && rows_per_split % 16 == 0))) {
+            (gate_kind != 2 || (((uintptr_t)gate & 15) == 0 && rows_per_split % 16 == 0))) {
             const int ldsq1 = 2 * 2 * 8 * 2 * 64 * (int)sizeof(uint4) + 2 * 8 * 32 * (int)sizeof(int);
 #define LAUNCH_TNQ1(GT)                                                                                                \
     do {                                                                                                               \

@@ -35,7 +35,7 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or ALWAYS_COLLECTIVE) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
@@ -44,6 +44,17 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+# True: the collectives below are ISSUED even in a one-rank group (where they are identities).  tests/test_parallel_hip.py uses it to
+# execute the RCCL calls of this module -- all-reduce of the flat gradient buffer, all-gather of the outputs, the loss-scale
+# all-reduce -- on device tensors on a box with a single GPU; production leaves it off (a one-rank job has nothing to exchange).
+ALWAYS_COLLECTIVE = False
+
+
+def _single() -> bool:
+    """No exchange needed: no process group, or one rank (unless ALWAYS_COLLECTIVE)."""
+    return not dist.is_initialized() or (dist.get_world_size() == 1 and not ALWAYS_COLLECTIVE)
 
 
 def _host_staged(t: torch.Tensor) -> bool:
@@ -106,7 +117,7 @@ def shard_batch(batch, rank: int, world: int):
 
 def all_gather_outputs(local: torch.Tensor, counts: Optional[Sequence[int]] = None) -> torch.Tensor:
     """Concatenate a per-example output over ranks (dim 0).  ``counts``: rows held by each rank when they differ."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return local
     world = dist.get_world_size()
     if counts is None or len(set(counts)) == 1:
@@ -189,7 +200,7 @@ class FlatGradBucket:
     def all_reduce(self) -> None:
         """Pack (always: ``flat`` is valid with one rank too), sum over ranks, drop the structurally absent gradients."""
         self.pack()
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if not _single():
             _all_reduce_sum(self.flat)
         self._drop_absent()
 
@@ -202,7 +213,7 @@ def global_loss_scale(n_examples_local: int, n_targets_local: int, device=None, 
     a candidate group that replicate the examples of the group's first rank.  ``as_tensor=True`` returns the ratio as a 0-dim
     tensor on ``device`` WITHOUT reading it back: the training step then has no host synchronisation between forward and backward
     (the collective is stream-ordered on RCCL)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         r = float(n_examples_local) / float(n_targets_local)
         return torch.tensor(r, dtype=torch.float32, device=device) if as_tensor else r
     if device is None:
