@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--no_pmc", action="store_true", help="do not measure `traffic` with rocprofv3 counter passes in this run")
     ap.add_argument("--cpu_seconds", type=float, default=20.0, help="CPU-baseline time budget")
     ap.add_argument("--cpu_all_threads", action="store_true", help="also time the CPU baseline on os.cpu_count() threads (minutes)")
+    ap.add_argument("--no_children", action="store_true", help="skip the side measurements run as child processes (exact-fp32 step, "
+                    "all-ones-mask step with its in-step K1 timing, the configs[4] stress step)")
     ap.add_argument("--h2d", action="store_true", help="developer mode: every step takes its batch from pinned host memory "
                     "through tvqaplus_amd.prefetch.BatchPrefetcher (PCIe-inclusive rate for DESIGN.md; never the headline value)")
     args = ap.parse_args()
@@ -241,7 +243,10 @@ def k1k2_roofline(args, device, model):
     tf = flops / (avg_ms * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": "K1 + K2 group forward (stage_grp_qa_ctx_fwd: str_attn_fwd + cff_fwd_kernel; the 1.47 GB normalised "
             "concat is still written once for the weight gradient)", "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s",
-            "frac": round(tf / 157.3, 4), "flops_fp32_equivalent": flops, "hbm_gbs_algorithmic": round(gbs, 1),
+            "frac": round(tf / 157.3, 4), "flops_fp32_equivalent": flops,
+            # the same time against the pipe the instructions actually issue on: three v_mfma_f32_32x32x16_f16 per fp32 product
+            "mfma_issued_tflops_f16": round(3.0 * tf, 1), "peak_f16": 2500.0, "frac_of_f16_peak": round(3.0 * tf / 2500.0, 4),
+            "hbm_gbs_algorithmic": round(gbs, 1),
             "hbm_frac_algorithmic": round(gbs / 8000.0, 4), "traffic": None, "algorithmic_bytes": alg,
             "avg_us": round(avg_ms * 1e3, 1), "min_us": round(ms[0] * 1e3, 1),
             "shape": {"N": N, "NA": NA, "Li": Li, "Lqa": Lqa, "Lr": Lr, "D": D}}
@@ -350,6 +355,50 @@ def device_time(step, n=3):
         return None, None
 
 
+def child_bench(extra, env=None, timeout=240):
+    """One more bench.py as a child process (its own HIP context: environment switches of the library are read once per process),
+    N = 1, without CPU baseline / counter passes / children of its own.  Returns its JSON record or {"error": ...}."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--no_cpu_baseline", "--no_pmc", "--no_children"] + list(extra)
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    try:
+        out = subprocess.run(cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, check=True).stdout.decode()
+        return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    except Exception as ex:   # noqa: BLE001 -- side measurements never fail the bench
+        return {"error": repr(ex)[:200]}
+
+
+def side_records(args):
+    """Measurements the headline line is read next to ("bench hygiene"), each a short child run at the headline shapes:
+    * exact_f32: the step with STAGE_GEMM_F32=1 -- every product on v_mfma_f32 (no fp16 pairs, dense rows: the ragged / fused kernels
+      are fp16-pair kernels), i.e. what the `dtype: f32` label costs when taken literally;
+    * dense: all-ones masks (nothing to skip for the ragged-row layout), with the K1 forward kernels timed inside its steps;
+    * stress: BASELINE.json configs[4] (bf16 storage, hsz 256, 512-word subtitle rows), three steps, with the long-row K1 forward."""
+    shp = ["--bsz", str(args.bsz), "--frames", str(args.frames), "--regions", str(args.regions), "--qa_words", str(args.qa_words)]
+    out = {}
+    r = child_bench(shp + ["--sub_words", str(args.sub_words), "--hsz", str(args.hsz), "--steps", "3", "--warmup", "2", "--no_roofline",
+                           "--no_device_time"], env={"STAGE_GEMM_F32": "1"})
+    out["exact_f32"] = ({"ms_per_step": r["ms_per_step"], "value": r["value"], "note": "STAGE_GEMM_F32=1: v_mfma_f32 products, dense rows"}
+                        if "ms_per_step" in r else r)
+    r = child_bench(shp + ["--sub_words", str(args.sub_words), "--hsz", str(args.hsz), "--steps", "6", "--warmup", "3", "--dense",
+                           "--no_device_time"])
+    if "ms_per_step" in r:
+        out["dense"] = {"ms_per_step": r["ms_per_step"], "value": r["value"]}
+        for k_src, k_dst in (("roofline", "roofline_dense"), ("roofline_sub", "roofline_sub_dense")):
+            if k_src in r:
+                out[k_dst] = {k: r[k_src].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_us", "min_us", "timed",
+                                                            "isolated_avg_us", "isolated_frac", "algorithmic_bytes", "masks", "traffic")}
+    else:
+        out["dense"] = r
+    r = child_bench(shp + ["--config", "stress", "--steps", "3", "--warmup", "2", "--no_device_time"], timeout=300)
+    out["stress"] = ({"ms_per_step": r["ms_per_step"], "value": r["value"], "dtype": r.get("dtype"), "workload": r["config"]["workload"],
+                      "peak_hbm_gib": r["config"].get("peak_hbm_gib"), "roofline": r.get("roofline")} if "ms_per_step" in r else r)
+    return out
+
+
 def cpu_baseline(args, opt):
     """The oracle (CPU port of the reference path, plain torch fp32) on the host cores: same step, bounded sample."""
     from oracle import stage_oracle as O
@@ -367,7 +416,7 @@ def cpu_baseline(args, opt):
                     break
     except OSError:
         pass
-    B = 1
+    B = args.bsz if args.cpu_seconds >= 15 else 1      # the bench batch itself when the budget allows one step of it (~20 s)
     sup = not args.no_sup_att
     batch = make_batch(N=B, Li=args.frames, Lr=args.regions, Lw=args.sub_words, Lqa=args.qa_words, seed=2018,
                        ragged=not args.dense, att_imgs=args.att_imgs if sup else 0, att_words=args.att_words)
@@ -383,7 +432,7 @@ def cpu_baseline(args, opt):
     def step():
         optim.zero_grad(set_to_none=True)
         out = O.stage_forward(P, opt, batch, training=True)
-        loss = O.training_loss(out, n_examples=B)
+        loss = O.training_loss(out, n_examples=len(batch.qid))
         if sup:   # the supervised attention term on the oracle's own attention map (host index building is shared code)
             from tvqaplus_amd import att_host
             loss = loss + 0.1 * att_host.get_att_loss(opt, out["vid_raw_s"].squeeze(2) if out["vid_raw_s"].dim() == 6 else out["vid_raw_s"], batch)[0]
@@ -391,9 +440,10 @@ def cpu_baseline(args, opt):
         torch.nn.utils.clip_grad_norm_(params, 10.0)
         optim.step()
 
-    def sample(threads, seconds):
+    def sample(threads, seconds, warm=True):
         torch.set_num_threads(threads)
-        step()  # warm-up (allocator, thread pool)
+        if warm:
+            step()  # warm-up (allocator, thread pool)
         t0 = time.time()
         n = 0
         while n < 1 or (time.time() - t0 < seconds and n < 50):
@@ -401,7 +451,21 @@ def cpu_baseline(args, opt):
             n += 1
         return n, time.time() - t0
 
-    n, dt = sample(cores, 0.7 * args.cpu_seconds)
+    # which thread count: MEASURED here on a short version of the same step (1 example x 24 frames), `cores` threads against every
+    # hardware thread of the host -- torch's CPU kernels thrash far below a 256-thread width (round 3: one full step took 95.7 s on 256
+    # threads against 1.1 s on 32), so the wide sample must stay small to keep the run bounded
+    probe = {}
+    host_threads = os.cpu_count() or 1
+    if host_threads > cores:
+        full_batch = batch
+        batch = make_batch(N=1, Li=24, Lr=args.regions, Lw=args.sub_words, Lqa=args.qa_words, seed=2018, ragged=not args.dense,
+                           att_imgs=min(args.att_imgs, 2) if sup else 0, att_words=args.att_words)
+        Bp, B = B, 1
+        for th in (cores, host_threads):
+            n_p, dt_p = sample(th, 1.5)
+            probe[str(th)] = round(dt_p / n_p, 4)
+        batch, B = full_batch, Bp
+    n, dt = sample(cores, 0.7 * args.cpu_seconds, warm=B == 1)
     rec = {"value": round(B * n / dt, 4), "unit": "QA-examples/s", "cores": cores, "host_cores": os.cpu_count(),
            "cpu_model": cpu_model, "kind": "port",
            "sample": "%d full training steps of B=%d x %d frames (same per-example shapes, dropout 0.1) in %.1f s"
@@ -410,7 +474,8 @@ def cpu_baseline(args, opt):
     # SURVEY 8d asks for os.cpu_count() threads.  Measured (round 3, EPYC 9575F, 256 hardware threads): ONE step took 95.7 s on
     # 256 threads against 1.1 s on 32 -- torch's CPU kernels thrash far below that width -- so the all-threads sample is
     # opt-in (it alone would take minutes) and 32 threads is the reported baseline
-    rec["all_threads_note"] = "256 threads measured 0.0104 QA-examples/s (1 step in 95.7 s) vs 0.91 on 32: --cpu_all_threads repeats it"
+    if probe:
+        rec["thread_probe_s_per_step"] = dict(probe, shape="1 example x 24 frames, same per-frame shapes, measured in this run")
     if host > cores and args.cpu_all_threads:
         n2, dt2 = sample(host, 0.3 * args.cpu_seconds)
         rec["all_threads"] = {"cores": host, "value": round(B * n2 / dt2, 4),
@@ -639,6 +704,35 @@ def main():
                         rec[name]["traffic"] = meas[key]
                         rec[name]["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes in this run "
                                                        "(WRITE_SIZE + 2 x FETCH_SIZE, KiB; MI355X_MICROARCH.md)")
+        # ragged token rows of this batch (tvqaplus_amd/ragged.py): what the step computed instead of every padded row
+        lay = getattr(model, "last_ragged", None)
+        if lay is not None:
+            dense_rows = lay.N * lay.NA * lay.Li * lay.Lqa
+            rr = {"statement_rows": lay.U, "of_padded": dense_rows, "fraction": round(lay.U / dense_rows, 4),
+                  "attention_output_rows": lay.Fc, "halo_words": lay.tab.halo}
+            for name, cl in getattr(model, "last_ragged_ctx", {}).items():
+                rr[name + "_rows"] = {"rows": cl.U, "of_padded": cl.tab.N * cl.tab.Li * cl.tab.L,
+                                      "fraction": round(cl.U / float(cl.tab.N * cl.tab.Li * cl.tab.L), 4), "halo": cl.tab.halo}
+            rec["config"]["ragged_rows"] = rr
+            # the K1 forward kernels inside the step write A for the live frames only and read compact region rows: their bytes in THIS
+            # layout next to the SURVEY 8d figure `achieved` / `frac` are quoted on (which counts every padded row)
+            for name, key, lr in (("roofline", "vid", args.regions), ("roofline_sub", "sub", args.sub_words)):
+                r = rec.get(name)
+                cl = getattr(model, "last_ragged_ctx", {}).get(key)
+                if r and r.get("timed"):
+                    qrows = cl.U if cl is not None else lay.N * lay.Li * lr
+                    b_here = 4 * (lay.N * lay.NA * lay.Lqa * args.hsz + qrows * args.hsz + lay.N * lay.NA * lay.Lqa + lay.N * lay.Li * lr
+                                  + (lay.Fc - lay.N * lay.NA * lay.Lqa) * args.hsz + 2 * dense_rows * lr)
+                    r["bytes_this_layout"] = b_here
+                    r["achieved_this_layout"] = round(b_here / (r["avg_us"] * 1e-6) / 1e9, 1)
+                    r["frac_this_layout"] = round(r["achieved_this_layout"] / 8000.0, 4)
+        rec["config"]["harness"] = {"gc": args.gc, "adam": args.adam, "ragged_rows": lay is not None}
+        if (world == 1 and not args.no_children and args.config == "default" and not args.dense and args.storage == "fp32" and not args.heads
+                and not args.h2d):
+            side = side_records(args)
+            if "roofline_dense" in side and "roofline_dense" in rec:          # in-step timing replaces the isolated sequence
+                side["roofline_dense"]["shape"] = rec["roofline_dense"].get("shape")
+            rec.update(side)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args, opt)
         print(json.dumps(rec))
