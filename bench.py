@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--no_pmc", action="store_true", help="do not measure `traffic` with rocprofv3 counter passes in this run")
     ap.add_argument("--cpu_seconds", type=float, default=20.0, help="CPU-baseline time budget")
     ap.add_argument("--cpu_all_threads", action="store_true", help="also time the CPU baseline on os.cpu_count() threads (minutes)")
+    ap.add_argument("--cpu_probe_threads", type=int, default=0, help="internal: time a short CPU-oracle step at this thread count and exit")
     ap.add_argument("--no_children", action="store_true", help="skip the side measurements run as child processes (exact-fp32 step, "
                     "all-ones-mask step with its in-step K1 timing, the configs[4] stress step)")
     ap.add_argument("--h2d", action="store_true", help="developer mode: every step takes its batch from pinned host memory "
@@ -456,15 +457,25 @@ def cpu_baseline(args, opt):
     # threads against 1.1 s on 32), so the wide sample must stay small to keep the run bounded
     probe = {}
     host_threads = os.cpu_count() or 1
-    if host_threads > cores:
-        full_batch = batch
+    if host_threads > cores and args.cpu_probe_threads == 0:
+        # each width in its own child process under a wall-clock limit: the all-threads run of even this short step took 94 s here
+        import subprocess
+        for th in (cores, host_threads):
+            cmd = [sys.executable, os.path.abspath(__file__), "--cpu_probe_threads", str(th), "--regions", str(args.regions), "--sub_words",
+                   str(args.sub_words), "--qa_words", str(args.qa_words), "--hsz", str(args.hsz)] + (["--no_sup_att"] if not sup else [])
+            try:
+                out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=20, check=True).stdout.decode()
+                probe[str(th)] = float(out.strip().splitlines()[-1])
+            except subprocess.TimeoutExpired:
+                probe[str(th)] = "> 20 (killed)"
+            except Exception:   # noqa: BLE001
+                probe[str(th)] = None
+    if args.cpu_probe_threads > 0:       # child mode: seconds per step of the short shape at the given width, printed
         batch = make_batch(N=1, Li=24, Lr=args.regions, Lw=args.sub_words, Lqa=args.qa_words, seed=2018, ragged=not args.dense,
                            att_imgs=min(args.att_imgs, 2) if sup else 0, att_words=args.att_words)
-        Bp, B = B, 1
-        for th in (cores, host_threads):
-            n_p, dt_p = sample(th, 1.5)
-            probe[str(th)] = round(dt_p / n_p, 4)
-        batch, B = full_batch, Bp
+        n_p, dt_p = sample(args.cpu_probe_threads, 1.5)
+        print("%.4f" % (dt_p / n_p))
+        return None
     n, dt = sample(cores, 0.7 * args.cpu_seconds, warm=B == 1)
     rec = {"value": round(B * n / dt, 4), "unit": "QA-examples/s", "cores": cores, "host_cores": os.cpu_count(),
            "cpu_model": cpu_model, "kind": "port",
@@ -475,7 +486,8 @@ def cpu_baseline(args, opt):
     # 256 threads against 1.1 s on 32 -- torch's CPU kernels thrash far below that width -- so the all-threads sample is
     # opt-in (it alone would take minutes) and 32 threads is the reported baseline
     if probe:
-        rec["thread_probe_s_per_step"] = dict(probe, shape="1 example x 24 frames, same per-frame shapes, measured in this run")
+        rec["thread_probe_s_per_step"] = dict(probe, shape="1 example x 24 frames, same per-frame shapes, measured in this run "
+                                                           "(one child process per width, 20 s limit)")
     if host > cores and args.cpu_all_threads:
         n2, dt2 = sample(host, 0.3 * args.cpu_seconds)
         rec["all_threads"] = {"cores": host, "value": round(B * n2 / dt2, 4),
@@ -498,6 +510,10 @@ def main():
     rank, local, world = parallel.init_from_env(backend="gloo" if shared else None)
     if shared:
         local = 0
+    if args.cpu_probe_threads > 0:      # CPU-only child of cpu_baseline()
+        from tvqaplus_amd.synth import make_opt as _mo
+        cpu_baseline(args, _mo(hsz=args.hsz, add_local=True, dropout=0.1, use_sup_att=not args.no_sup_att))
+        return
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)

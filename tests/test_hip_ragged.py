@@ -141,6 +141,7 @@ def _pair(opt_kw, batch_kw, device, seed=21):
         for p in model.parameters():
             p.add_(0.05 * torch.randn_like(p))
     model = model.to(device)
+    model.mha_dropout_override = 0.0           # (the reference's self-attention dropout is a fixed 0.1 whatever opt.dropout says)
     batch = make_batch(wd_size=96, vfeat_size=64, **batch_kw)
     return model, batch
 
@@ -164,6 +165,9 @@ def _train_step(model, batch, n_ex, att=False):
     dict(opt=dict(add_local=False, dropout=0.0, vfeat_flag=False), batch=dict(N=2, Li=10, Lr=20, Lw=24, Lqa=33, seed=33)),
     dict(opt=dict(add_local=True, dropout=0.0, sub_flag=False), batch=dict(N=3, Li=9, Lr=12, Lw=8, Lqa=40, seed=34, empty_frames=True)),
     dict(opt=dict(add_local=True, dropout=0.0, cls_encoder_kernel_size=3, cls_encoder_n_conv=3), batch=dict(N=2, Li=8, Lr=20, Lw=20, Lqa=29, seed=35)),
+    # self-attention in both encoders (BASELINE configs[2]): nothing inside a live frame can be dropped, dead frames still are
+    dict(opt=dict(add_local=True, dropout=0.0, input_encoder_n_heads=4, cls_encoder_n_heads=4), batch=dict(N=3, Li=10, Lr=20, Lw=18, Lqa=40, seed=36, empty_frames=True)),
+    dict(opt=dict(add_local=True, dropout=0.0, cls_encoder_n_blocks=2), batch=dict(N=2, Li=9, Lr=12, Lw=14, Lqa=24, seed=37)),
 ])
 def test_ragged_model_equals_dense_model(hip_device, cfg):
     """Whole training step, ragged against dense (the reference's semantics): identical proposals, outputs / maps / loss to fp32

@@ -174,6 +174,8 @@ class CtxTables:
         self.U = int(qlen.sum())
         live = qlen > 0
         self.S = int(live.sum())
+        self.live_frames = np.nonzero(live)[0].astype(np.int32)                                   # frames that keep rows, in order
+        self.regular = bool(self.S == 0 or (qlen[live] == self.L).all())                        # every live frame keeps all L rows
         self.cq = np.stack([np.where(live, qstart, 0), qlen], axis=1).astype(np.int32)        # (frames, 2)
         self.seq = np.stack([qstart[live], qlen[live], np.zeros(self.S, np.int64), np.zeros(self.S, np.int64)], axis=1).astype(np.int32)
 
@@ -195,7 +197,7 @@ class CtxLayout:
         self.N, self.Li, self.Lqa = tab.N, tab.Li, tab.L       # Lqa: the longest sequence, under the name the encoder group uses
         self.U, self.S = tab.U, tab.S
         self.Ucap = max(CAP_STEP, _align(tab.U, CAP_STEP))
-        parts = [tab.cq.reshape(-1), tab.seq.reshape(-1)]
+        parts = [tab.cq.reshape(-1), tab.seq.reshape(-1), tab.live_frames]
         offs, total = [], 0
         for p in parts:
             offs.append(total)
@@ -213,6 +215,8 @@ class CtxLayout:
         self.stage = stage
         self.cq = self.tables[offs[0]: offs[0] + tab.cq.size]
         self.seq = self.tables[offs[1]: offs[1] + tab.seq.size]
+        self.live_frames = self.tables[offs[2]: offs[2] + tab.live_frames.size]     # (S,) frame index of every sequence
+        self.regular = tab.regular
         self.src_rows = torch.empty(max(self.U, 1), dtype=torch.int32, device=device)
         if self.tables.is_cuda and self.U > 0:
             from .ops import _stream

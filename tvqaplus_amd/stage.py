@@ -342,6 +342,10 @@ class STAGE(nn.Module):
                       init_encoder[4].weight, init_encoder[4].bias, downsize_encoder[1].weight, downsize_encoder[1].bias,
                       downsize_encoder[3].weight, downsize_encoder[3].bias]
             y = groups.input_mlp_rag(data, clay, l2_normalize, self._p(), self._seeds(2), [self._g(w) for w in params])
+            if clay.tab.halo >= L:
+                # whole frames (self-attention in the input encoder): S sequences of L positions, the ordinary encoder path
+                mc = data_mask.index_select(0, clay.live_frames.long()).contiguous()
+                return self._stacked_encoder(y.view(clay.S, L, -1), mc, input_encoder).reshape(clay.U, -1)
             for blk in input_encoder.stacked_encoderBlocks:
                 bp = []
                 for i in range(blk.n_conv):
@@ -483,7 +487,15 @@ class STAGE(nn.Module):
         N, NA, Li, Lqa = statement_mask.shape
         D = statement.shape[-1]
         m = statement_mask.reshape(N * NA * Li, Lqa).contiguous()
-        if lay is not None:
+        if lay is not None and lay.tab.halo >= Lqa:
+            # every word of a live frame is kept (self-attention in the classifier encoder mixes all of them, or several blocks): the
+            # compact rows are S whole sequences of Lqa words -- the ordinary encoder path on (S, Lqa, D), dead frames filled in behind
+            seq = lay.seq.view(-1, 4)
+            seq_g, seq_out = seq[:, 2].long(), seq[:, 3].long()
+            ms = qa_mask.reshape(N * NA, Lqa).index_select(0, seq_g).contiguous()
+            mx_c = self._stacked_encoder(statement.view(lay.S, Lqa, D), ms, self.cls_encoder, pool_mask=ms)
+            mx = torch.full((N * NA * Li, D), NEG, dtype=mx_c.dtype, device=mx_c.device).index_copy(0, seq_out, mx_c)
+        elif lay is not None:
             blk = self.cls_encoder.stacked_encoderBlocks[0]
             params = []
             for i in range(blk.n_conv):
@@ -626,11 +638,15 @@ class STAGE(nn.Module):
             return none
         N, NA, Lqa, D = a_embed.shape
         blocks = list(self.cls_encoder.stacked_encoderBlocks)
-        if D != 128 or len(blocks) != 1 or blocks[0].num_heads != 0 or not (1 <= blocks[0].n_conv <= 8) or not (4 <= Lqa <= 40):
+        if D != 128 or not (4 <= Lqa <= 40):
             return none
-        k = blocks[0].conv[0].depthwise_conv.weight.shape[-1]
-        if k % 2 == 0 or k > 9:
-            return none
+        # words kept behind the last valid one: the classifier encoder's convolution halo -- or every word of a live frame when that
+        # encoder is not a single conv-only block (self-attention mixes all words; the frames that are dead are still skipped)
+        cls_halo = Lqa
+        if len(blocks) == 1 and blocks[0].num_heads == 0 and 1 <= blocks[0].n_conv <= 8:
+            k = blocks[0].conv[0].depthwise_conv.weight.shape[-1]
+            if k % 2 == 1 and k <= 9:
+                cls_halo = min(Lqa, ragged.conv_halo(1, blocks[0].n_conv, k))
         streams = []
         if self.sub_flag:
             streams.append((batch.sub_mask, batch.sub_bert.shape[1], batch.sub_bert.shape[2]))
@@ -649,7 +665,7 @@ class STAGE(nn.Module):
         if info is None:
             info = ragged.info_from_device(batch.qas_mask.view(N, NA, Lqa),
                                            {k: (batch.sub_mask if k == "sub" else batch.vid_mask).view(N, Li, -1) for k in names})
-        tab = ragged.RaggedTables(info["qas"], info[frame_stream + "_len"] > 0, ragged.conv_halo(1, blocks[0].n_conv, k))
+        tab = ragged.RaggedTables(info["qas"], info[frame_stream + "_len"] > 0, cls_halo)
         if tab.U == 0:
             return none
         lib_ok = all(bool(groups._lib.load().stage_grp_qa_ctx_rag_supported(N, NA, Li, Lqa, int(Lr), D, tab.U, tab.Fc))
@@ -662,13 +678,14 @@ class STAGE(nn.Module):
         # feature widths the gathered LayerNorm takes)
         clays = {}
         iblocks = list(self.input_encoder.stacked_encoderBlocks)
-        ctx_ok = (self.use_ragged_ctx and len(iblocks) >= 1 and all(b.num_heads == 0 and 1 <= b.n_conv <= 8 for b in iblocks)
-                  and not self.fuse_input_ln)
-        if ctx_ok:
+        ctx_ok = self.use_ragged_ctx and not self.fuse_input_ln
+        conv_only = len(iblocks) >= 1 and all(b.num_heads == 0 and 1 <= b.n_conv <= 8 for b in iblocks)
+        if conv_only:
             ik = iblocks[0].conv[0].depthwise_conv.weight.shape[-1]
-            ctx_ok = ik % 2 == 1 and ik <= 9 and all(b.conv[0].depthwise_conv.weight.shape[-1] == ik for b in iblocks)
+            conv_only = ik % 2 == 1 and ik <= 9 and all(b.conv[0].depthwise_conv.weight.shape[-1] == ik for b in iblocks)
         if ctx_ok:
-            halo = sum(ragged.conv_halo(1, b.n_conv, ik) for b in iblocks)
+            # conv-only input encoder: valid positions + its halo; otherwise (self-attention) whole frames, dead frames skipped
+            halo = sum(ragged.conv_halo(1, b.n_conv, ik) for b in iblocks) if conv_only else 1 << 20
             for (mask, _, L), name in zip(streams, names):
                 feat = batch.sub_bert if name == "sub" else batch.vid
                 if feat.dtype != torch.float32 or feat.shape[-1] % 4 or feat.shape[-1] > 1024 or not feat.is_contiguous():
