@@ -21,7 +21,10 @@ def _layout(batch, halo, stream, device):
     return ragged.RaggedLayout(ragged.RaggedTables(qa, fl, halo), device)
 
 
-@pytest.mark.parametrize("Lr,train", [(20, False), (20, True), (50, True), (12, False), (34, True)])
+@pytest.mark.parametrize("Lr,train", [(20, False), (20, True), (50, True), (12, False), (34, True),
+                                      # every tail shape of the two forward kernels (last region tile of 1..4 quads, full tiles)
+                                      (8, False), (14, False), (14, True), (16, False), (24, True), (28, False), (32, True), (40, False),
+                                      (48, True), (64, False)])
 def test_k1_frame_compact_equals_dense(hip_device, Lr, train):
     """stage_str_attn_fwd_fc / stage_str_attn_bwd_fused_fc against the dense entry points: same score maps, the rows of A of every live
     frame bit-identical, dead frames untouched, and the three gradients equal when dA is the dense gradient restricted to live frames."""

@@ -231,6 +231,14 @@ __device__ __forceinline__ void h_split2(float a, float b, float sc, unsigned& h
     hi = h_cvt_pk(as, bs);
     lo = h_cvt_pk(as - h_lo_f32(hi), bs - h_hi_f32(hi));
 }
+// h_cvt_pk is INLINE ASM: the compiler's hazard recogniser does not see a VALU write in it, so when its result goes straight into a
+// matrix instruction as an A / B operand nothing guarantees the wait states between the two (round 4: one schedule of the K1 forward
+// put the conversion one s_nop in front of the MFMA that read it -- the first product of a tile then used a stale low-half word, errors
+// of 5e-4 .. 10 in one output column, in one template instantiation only).  Call this on every register of a freshly split operand
+// before the first matrix instruction that reads it: all of them are then written, and five wait states follow.
+__device__ __forceinline__ void h_operands_ready(unsigned& a, unsigned& b, unsigned& c, unsigned& d) {
+    asm volatile("s_nop 4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
 // biased fp32 exponent of a magnitude -> the exponent field of the power of two that maps it into [2^11, 2^12)
 __device__ __forceinline__ int h_up_field(int eb) { return min(265 - eb, 254); }
 // max(|a|, |b|, |c|) in ONE instruction (the compiler builds |x| as max(|x|, |x|) and then a tree of two-input maxima: 17

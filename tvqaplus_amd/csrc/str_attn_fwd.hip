@@ -406,6 +406,8 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
                     h_split2(cf[0][2 * j][2], cf[0][2 * j][3], csc, bh[1], bl[1]);
                     h_split2(cf[0][2 * j + 1][0], cf[0][2 * j + 1][1], csc, bh[2], bl[2]);
                     h_split2(cf[0][2 * j + 1][2], cf[0][2 * j + 1][3], csc, bh[3], bl[3]);
+                    h_operands_ready(bh[0], bh[1], bh[2], bh[3]);       // (common.h: inline-asm conversions feeding matrix instructions)
+                    h_operands_ready(bl[0], bl[1], bl[2], bl[3]);
                     const sf16x8 vbh = __builtin_bit_cast(sf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
                     const sf16x8 vbl = __builtin_bit_cast(sf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
 #pragma unroll
@@ -531,6 +533,8 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_d128_kernel(
                         h_split2(pv[0][2 * s2 + 1][0], pv[0][2 * s2 + 1][1], 2048.f, wh[s2][2], wl[s2][2]);
                         h_split2(pv[0][2 * s2 + 1][2], pv[0][2 * s2 + 1][3], 2048.f, wh[s2][3], wl[s2][3]);
                     } else wh[s2][2] = wh[s2][3] = wl[s2][2] = wl[s2][3] = 0u;
+                    h_operands_ready(wh[s2][0], wh[s2][1], wh[s2][2], wh[s2][3]);
+                    h_operands_ready(wl[s2][0], wl[s2][1], wl[s2][2], wl[s2][3]);
                 }
 #pragma unroll
                 for (int dt = 0; dt < NCH; dt++) {

@@ -345,6 +345,8 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
                     h_split2(cf[2 * j][2], cf[2 * j][3], csc, bh[1], bl[1]);
                     h_split2(cf[2 * j + 1][0], cf[2 * j + 1][1], csc, bh[2], bl[2]);
                     h_split2(cf[2 * j + 1][2], cf[2 * j + 1][3], csc, bh[3], bl[3]);
+                    h_operands_ready(bh[0], bh[1], bh[2], bh[3]);
+                    h_operands_ready(bl[0], bl[1], bl[2], bl[3]);
                     const sf16x8 vbh = __builtin_bit_cast(sf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
                     const sf16x8 vbl = __builtin_bit_cast(sf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
 #pragma unroll
@@ -454,6 +456,8 @@ __global__ __launch_bounds__(256, 2) void str_attn_fwd_reg_kernel(
                 if (NK2 > 2) h_split2(w8[2], w8[3], 2048.f, wh4.y, wl4.y);
                 if (NK2 > 4) h_split2(w8[4], w8[5], 2048.f, wh4.z, wl4.z);
                 if (NK2 > 6) h_split2(w8[6], w8[7], 2048.f, wh4.w, wl4.w);
+                h_operands_ready(wh4.x, wh4.y, wh4.z, wh4.w);
+                h_operands_ready(wl4.x, wl4.y, wl4.z, wl4.w);
             }
 #pragma unroll
             for (int b = 0; b < 2; b++) {
