@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--cpu_seconds", type=float, default=20.0, help="CPU-baseline time budget")
     ap.add_argument("--cpu_all_threads", action="store_true", help="also time the CPU baseline on os.cpu_count() threads (minutes)")
     ap.add_argument("--cpu_probe_threads", type=int, default=0, help="internal: time a short CPU-oracle step at this thread count and exit")
+    ap.add_argument("--no_mask_host", action="store_true", help="developer: strip the loader's host copies of the mask lengths from the batch, "
+                    "as a batch from the reference's own prepare_inputs looks: the ragged layout then costs one mask read-back per step")
     ap.add_argument("--no_children", action="store_true", help="skip the side measurements run as child processes (exact-fp32 step, "
                     "all-ones-mask step with its in-step K1 timing, the configs[4] stress step)")
     ap.add_argument("--h2d", action="store_true", help="developer mode: every step takes its batch from pinned host memory "
@@ -558,6 +560,8 @@ def main():
                            att_words=args.att_words).to(device)
         n_local = args.bsz
     n_global = args.bsz if args.scaling == "strong" else world * args.bsz
+    if args.no_mask_host:
+        batch.pop("mask_host", None)
 
     def sync():
         if world > 1:

@@ -271,3 +271,47 @@ def test_candidate_layout_partitions():
                     assert (e, k) not in seen
                     seen[(e, k)] = r
         assert len(seen) == 5 * n, (n, w)        # every (example, candidate) pair exactly once
+
+
+def _absent_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from tvqaplus_amd import parallel
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ps = [torch.nn.Parameter(torch.zeros(3)) for _ in range(3)]
+    bucket = parallel.FlatGradBucket(ps)
+    out = []
+    for step in range(3):
+        bucket.zero()
+        ps[0].grad = torch.ones(3)
+        if rank == 0:
+            ps[1].grad = torch.ones(3)
+        if step >= 1 and rank == 1:
+            ps[2].grad = torch.ones(3)          # a branch that only rank 1 switches on after the first step
+        try:
+            bucket.all_reduce()
+            out.append([p.grad is None for p in ps])
+        except RuntimeError as e:
+            out.append("raised: " + str(e)[:60])
+            break
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_changed_gradient_set_raises_on_every_rank():
+    """a rank whose set of gradient-carrying parameters changes after the agreement must not raise alone (its peers would hang
+    in their next collective): the change travels with the gradient all-reduce, the step applies the old agreement on every rank, and
+    the NEXT step raises everywhere."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_absent_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    for r in (0, 1):
+        assert res[r][0] == [False, False, True]          # step 0: parameter 2 has no gradient anywhere
+        assert res[r][1] == [False, False, True]          # step 1: rank 1 has one now -- the old agreement still holds, on both ranks
+        assert isinstance(res[r][2], str) and res[r][2].startswith("raised"), res[r]

@@ -154,6 +154,8 @@ class AttPairs:
     def __init__(self, pos: np.ndarray, neg: np.ndarray, shape, device, stage: Optional[PinnedStage] = None):
         both = np.concatenate([pos, neg], axis=0)
         _, NA, Li, Lqa, Lr = shape
+        if both.size and ((both < 0).any() or (both >= np.asarray([shape[0], NA, Li, Lqa, Lr])).any()):
+            raise IndexError("attention-loss pair outside the (N, NA, Li, Lqa, Lr) score tensor")    # (the kernels gather / scatter unchecked)
         flat = (((both[:, 0] * NA + both[:, 1]) * Li + both[:, 2]) * Lqa + both[:, 3]) * Lr + both[:, 4]
         self.m = pos.shape[0]
         self.shape = tuple(shape)

@@ -924,7 +924,9 @@ __global__ __launch_bounds__(256) void span_kernel(const float* __restrict__ t_s
     __shared__ float bv[256];
     __shared__ int bi[256];
     const int n = blockIdx.x, tid = threadIdx.x;
-    const float* x = t_scores + ((long)n * NA + (int)target[n]) * Li * 2;
+    // (a target outside [0, NA) is an input error -- the reference's indexing raises; here the read is clamped and the temporal loss of
+    // that example comes out as NaN, ts_loss_kernel below, so the step fails loudly instead of reading out of bounds)
+    const float* x = t_scores + ((long)n * NA + min(max((int)target[n], 0), NA - 1)) * Li * 2;
     float m0 = -INFINITY, m1 = -INFINITY;
     for (int i = tid; i < Li; i += 256) {
         const float2 v = reinterpret_cast<const float2*>(x)[i];
@@ -1079,7 +1081,8 @@ __global__ __launch_bounds__(256) void ts_loss_kernel(const float* __restrict__ 
     const int local = (int)target[n] - cand_offset;
     if (a != local) {
         for (int i = tid; i < Li; i += 256) reinterpret_cast<float2*>(g)[i] = make_float2(0.f, 0.f);
-        if (tid == 0 && a == 0 && (local < 0 || local >= NA)) part[n] = 0.f;
+        // not among the local candidates: nothing here (candidate-sharded batches) -- unless no rank can hold it
+        if (tid == 0 && a == 0 && (local < 0 || local >= NA)) part[n] = (cand_offset == 0 && NA == 5) ? NAN : 0.f;
         return;
     }
     float m0 = -INFINITY, m1 = -INFINITY;
@@ -1100,13 +1103,14 @@ __global__ __launch_bounds__(256) void ts_loss_kernel(const float* __restrict__ 
     s1 = block_sum256(s1, sh);
     const float l0 = logf(s0), l1 = logf(s1);
     const int st = (int)lab_st[n], ed = (int)lab_ed[n];
+    const bool lab_ok = st >= 0 && st < Li && ed >= 0 && ed < Li;      // nn.CrossEntropyLoss raises on such a label: NaN here, no read
     for (int i = tid; i < Li; i += 256) {
         const float2 v = reinterpret_cast<const float2*>(x)[i];
         const float p0 = expf(v.x - m0 - l0), p1 = expf(v.y - m1 - l1);
         reinterpret_cast<float2*>(g)[i] = make_float2(0.5f * (p0 - (i == st ? 1.f : 0.f)), 0.5f * (p1 - (i == ed ? 1.f : 0.f)));
     }
     if (tid == 0) {
-        const float lp0 = x[2 * st] - m0 - l0, lp1 = x[2 * ed + 1] - m1 - l1;
+        const float lp0 = lab_ok ? x[2 * st] - m0 - l0 : NAN, lp1 = lab_ok ? x[2 * ed + 1] - m1 - l1 : NAN;
         part[n] = -0.5f * (lp0 + lp1);
     }
 }

@@ -141,7 +141,11 @@ class FlatGradBucket:
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         total = sum(p.numel() for p in self.params)
         ref = self.params[0]
-        self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
+        # one trailing element travels with the gradients: the number of ranks whose set of gradient-carrying parameters changed in
+        # this step (_drop_absent)
+        self._buf = torch.zeros(total + 1, dtype=ref.dtype, device=ref.device)
+        self.flat = self._buf[:total]          # the gradients (what callers and tests see)
+        self._changed_pending = None
         self.views: List[torch.Tensor] = []
         off = 0
         for p in self.params:
@@ -179,13 +183,11 @@ class FlatGradBucket:
         LOCAL presence vector it was derived from.  When that vector changes later (a branch enabled after warm-up, a first
         step that skipped a path) the cached decision would silently drop a real gradient: with one rank the decision is
         simply remade (host-only comparison, no device read); with several ranks a one-sided extra collective would
-        desynchronise them, so the change raises and the caller re-agrees with ``reset_absent()`` on every rank."""
+        desynchronise them (and a one-sided exception leaves the peers hanging in their next collective), so the change is REPORTED
+        through the gradient all-reduce itself -- one extra element of the flat buffer -- and EVERY rank raises at its next step (the
+        step in between applied the old agreement everywhere: the replicas have not diverged)."""
         world = dist.get_world_size() if dist.is_initialized() else 1
-        if getattr(self, "_absent", None) is not None and self._present_local != self._absent_basis:
-            if world > 1:
-                raise RuntimeError("FlatGradBucket: the set of parameters that receive a gradient changed on rank %d after the "
-                                   "first step; call bucket.reset_absent() on every rank when enabling / disabling a model "
-                                   "branch" % dist.get_rank())
+        if world == 1 and getattr(self, "_absent", None) is not None and self._present_local != self._absent_basis:
             self._absent = None
         if getattr(self, "_absent", None) is None:
             flags = torch.tensor([1.0 if f else 0.0 for f in self._present_local], device=self.flat.device)
@@ -199,9 +201,30 @@ class FlatGradBucket:
 
     def all_reduce(self) -> None:
         """Pack (always: ``flat`` is valid with one rank too), sum over ranks, drop the structurally absent gradients."""
+        if self._changed_pending is not None:
+            # what the PREVIOUS step's all-reduce said (its read-back has long arrived): some rank's set changed -> every rank sees the
+            # same count here, before this step's collective, and raises together
+            host, ev = self._changed_pending
+            if ev is not None:
+                ev.synchronize()
+            self._changed_pending = None
+            if float(host[0]) > 0.0:
+                raise RuntimeError("FlatGradBucket: the set of parameters that receive a gradient changed on %d rank(s) in the previous "
+                                   "step (which applied the old agreement on every rank, so the replicas are still identical); call "
+                                   "bucket.reset_absent() on every rank when enabling / disabling a model branch" % int(round(float(host[0]))))
         self.pack()
         if not _single():
-            _all_reduce_sum(self.flat)
+            changed = getattr(self, "_absent", None) is not None and self._present_local != self._absent_basis
+            self._buf[-1:].fill_(1.0 if changed else 0.0)
+            _all_reduce_sum(self._buf)
+            if self._buf.is_cuda:
+                host = torch.empty(1, dtype=self._buf.dtype, pin_memory=True)
+                host.copy_(self._buf[-1:], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self._buf.device))
+                self._changed_pending = (host, ev)
+            else:
+                self._changed_pending = (self._buf[-1:].clone(), None)
         self._drop_absent()
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -231,7 +254,12 @@ def global_loss_scale(n_examples_local: int, n_targets_local: int, device=None, 
 # candidate x batch layout (more ranks than examples)
 # ---------------------------------------------------------------------------------------------------------------
 NUM_CANDIDATES = 5   # model/stage.py:79
-_GROUP_CACHE = {}    # (E, C, world) -> the candidate groups of the default process group (communicators are never rebuilt)
+_GROUP_CACHE = {}    # (E, C, world, id of the default group) -> its candidate groups (communicators are never rebuilt)
+
+
+def reset_groups() -> None:
+    """Forget the cached candidate groups (after ``dist.destroy_process_group()``: they belong to the process group that is gone)."""
+    _GROUP_CACHE.clear()
 
 
 class _GroupCE(torch.autograd.Function):
@@ -288,7 +316,7 @@ class CandidateLayout:
         if dist.is_initialized() and world > 1 and self.C > 1:
             # new_group is collective over the world: every rank creates every block's group -- ONCE per (E, C) shape of the
             # process group (a layout built per batch, e.g. for a smaller last batch, reuses the communicators)
-            key = (self.E, self.C, world)
+            key = (self.E, self.C, world, id(dist.group.WORLD))
             groups = _GROUP_CACHE.get(key)
             if groups is None:
                 groups = [dist.new_group(ranks=list(range(b * self.C, (b + 1) * self.C))) for b in range(self.E)]

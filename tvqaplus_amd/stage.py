@@ -743,8 +743,13 @@ class STAGE(nn.Module):
         NA = batch.qas_bert.shape[1]          # 5 (self.num_a), or the local candidates of a candidate-sharded batch
         cand_offset = int(_opt(batch, "cand_offset", 0) or 0)
         gt_scores_fn = _opt(batch, "gt_scores_fn", None)
-        if self._seed_state is None and _opt(batch, "dropout_rank", None) is not None:
-            self._dropout_rank = int(_opt(batch, "dropout_rank"))
+        dr = _opt(batch, "dropout_rank", None)
+        if dr is not None and (self._seed_state is None or int(dr) != self._dropout_rank):
+            # the example block of this rank (parallel.CandidateLayout) -- it may change when the layout is rebuilt for another batch
+            # size: the ranks that now share a block must share a dropout stream again, so the stream is re-derived from the seed
+            if self._seed_state is not None:
+                self._seed_state = None
+            self._dropout_rank = int(dr)
         qas_mask = batch.qas_mask.view(N, NA, -1).float()
         a_embed = self.base_encoder(batch.qas_bert.view(N * NA, -1, self.wd_size), qas_mask.view(N * NA, -1),
                                     self.bert_word_encoding_fc, self.input_embedding, self.input_encoder)
