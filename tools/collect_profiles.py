@@ -2,7 +2,7 @@
 (bench.py: _profile_traffic, the judge) expect.  python tools/collect_profiles.py r02"""
 import os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 HEAD = ("# round %s: rocprofv3 PMC passes (counters only + kernel trace; tools/pmc_run.sh), averages per dispatch; FETCH_SIZE / WRITE_SIZE in KiB\n"
         "# FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950 counts the 128-byte requests of wide loads as 64 B)\n" % TAG[1:].lstrip("0"))
@@ -20,7 +20,7 @@ def put(name, text):
 
 
 for n in ("bench_line.json", "bench_line_dense.json", "bench_line_stress.json", "bench_kernel_trace_stats.txt", "bf16_storage_bench_line.json",
-          "bf16_storage_bench_kernel_trace_stats.txt"):
+          "bf16_storage_bench_kernel_trace_stats.txt", "bench_line_dense_rows.json", "bench_line_heads4.json", "heads4_bench_kernel_trace_stats.txt"):
     src = os.path.join(G, "%s_%s" % (TAG, n))
     if os.path.exists(src):
         shutil.copy(src, os.path.join(P, "%s_%s" % (TAG, n)))
@@ -46,3 +46,11 @@ for k, what in (("rep", "c2q_down_projection shape: a broadcast over 300 frames,
         t = "".join("#   " + l for l in lines("%s_cat3_fused_times_%s.txt" % (TAG, k))[-8:])
         put("%s_cat3_fused_pmc_%s.txt" % (TAG, k), HEAD + "# command: %sbash tools/pmc_run.sh %s_cat3_fused_%s cf python tools/cat3_fused_time.py   (%s; cf_bwd_kernel = fused backward, "
             "cff_fwd_kernel = fused forward, csrc/cat3_fused.hip)\n# event-timed, same run:\n%s" % ("REP=1 " if k == "flat" else "", TAG, k, what, t) + "".join(lines(name)))
+
+for k, what in (("cat3_ragged_instep", "the [a,b,a*b] kernels on ragged token rows INSIDE the bench step (cff_fwd_kernel<.., true> = gathered rows, cf_bwd_kernel<.., 3> = "
+                "per-group live words; <.., 0> / <.., false> = the concat_fc instance on compact rows)"),
+                ("k1_instep", "the attention kernels inside the bench step (frame-compact A, compact region rows)")):
+    name = "pmc_%s_%s.txt" % (TAG, k)
+    if os.path.exists(os.path.join(G, name)):
+        put("%s_%s_pmc.txt" % (TAG, k), HEAD + "# command: bash tools/pmc_run.sh %s_%s ... python bench.py --steps 3 --warmup 2 --no_cpu_baseline --no_pmc --no_children --no_roofline "
+            "--no_device_time   (%s)\n" % (TAG, k, what) + "".join(lines(name)))

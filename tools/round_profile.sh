@@ -1,12 +1,18 @@
 #!/bin/bash
 # Round profile set -> gpurun_out/${TAG}_*: bench line, kernel trace of the bench command, PMC passes of the K1 forward (video and
 # subtitle shapes), of the fused K1 backward and of the 960000 x 384 -> 128 GEMMs (forward, weight gradient).  bash tools/round_profile.sh r02
-TAG=${1:-r03}
+TAG=${1:-r04}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 600 python bench.py > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench.err
-timeout 300 python bench.py --no_cpu_baseline --dense > gpurun_out/${TAG}_bench_line_dense.json 2>> gpurun_out/${TAG}_bench.err
-timeout 300 bash tools/trace_bench.sh ${TAG}_bench > /dev/null 2>&1
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench.err
+timeout 300 python bench.py --no_cpu_baseline --no_children --dense > gpurun_out/${TAG}_bench_line_dense.json 2>> gpurun_out/${TAG}_bench.err
+# round 4: the same step with every padded row computed (STAGE_NO_RAGGED=1), and the ragged kernels' counters inside the step
+STAGE_NO_RAGGED=1 timeout 300 python bench.py --no_cpu_baseline --no_children --no_pmc --no_roofline > gpurun_out/${TAG}_bench_line_dense_rows.json 2>> gpurun_out/${TAG}_bench.err
+timeout 300 python bench.py --no_cpu_baseline --no_children --no_pmc --no_roofline --heads 4 > gpurun_out/${TAG}_bench_line_heads4.json 2>> gpurun_out/${TAG}_bench.err
+timeout 300 bash tools/trace_bench.sh ${TAG}_heads4_bench --heads 4 --no_children --no_pmc > /dev/null 2>&1
+timeout 500 bash tools/pmc_run.sh ${TAG}_cat3_ragged_instep cf python bench.py --steps 3 --warmup 2 --no_cpu_baseline --no_pmc --no_children --no_roofline --no_device_time > /dev/null 2>&1
+timeout 500 bash tools/pmc_run.sh ${TAG}_k1_instep str_attn python bench.py --steps 3 --warmup 2 --no_cpu_baseline --no_pmc --no_children --no_roofline --no_device_time > /dev/null 2>&1
+timeout 300 bash tools/trace_bench.sh ${TAG}_bench --no_children --no_pmc > /dev/null 2>&1
 # K1 forward PMC: bench.py --only_roofline launches the video shape then the subtitle shape
 timeout 400 bash tools/pmc_run.sh ${TAG}_k1_fwd str_attn_fwd python bench.py --only_roofline > /dev/null 2>&1
 timeout 400 bash tools/pmc_run.sh ${TAG}_k1_bwd_vid str_attn_bwd_fused python tools/k1_bwd_times.py > /dev/null 2>&1
@@ -18,7 +24,7 @@ timeout 400 bash tools/pmc_run.sh ${TAG}_cat3_fused_rep cf python tools/cat3_fus
 REP=1 timeout 400 bash tools/pmc_run.sh ${TAG}_cat3_fused_flat cf python tools/cat3_fused_time.py > /dev/null 2>&1
 timeout 200 python tools/cat3_fused_time.py > gpurun_out/${TAG}_cat3_fused_times_rep.txt 2>&1
 REP=1 timeout 200 python tools/cat3_fused_time.py > gpurun_out/${TAG}_cat3_fused_times_flat.txt 2>&1
-timeout 300 python bench.py --config stress --steps 5 --warmup 2 --no_cpu_baseline > gpurun_out/${TAG}_bench_line_stress.json 2>> gpurun_out/${TAG}_bench.err
+timeout 300 python bench.py --config stress --steps 5 --warmup 2 --no_cpu_baseline --no_children > gpurun_out/${TAG}_bench_line_stress.json 2>> gpurun_out/${TAG}_bench.err
 timeout 200 python tools/k1_bwd_times.py > gpurun_out/${TAG}_k1_bwd_times_vid.txt 2>&1
 LR=50 timeout 200 python tools/k1_bwd_times.py > gpurun_out/${TAG}_k1_bwd_times_sub.txt 2>&1
 ls gpurun_out | grep ${TAG}
