@@ -81,6 +81,16 @@ int stage_str_attn_long_bwd(const void* dA, const void* A, const float* dS_raw_e
                             int NA, int Li, int Lqa, int Lr, int D, float scale, int storage_bf16, void* ws, size_t ws_bytes,
                             void* stream);
 
+/* The backward with the region mask at hand (round 4): region blocks behind a frame's last valid region are skipped -- there S_ = 0,
+ * so dS, their share of dCn and the dQ rows are exact zeros (model/context_query_attention.py:58-61: masked scores are cos - 1e10) --
+ * unless dS_raw_ext is non-zero in them (then the frame is processed in full).  The forward skips the same blocks on its own (it has
+ * q_mask): raw scores -1e10 and weights 0 are stored as constants.  ws from stage_str_attn_long_bwd_qm_ws_bytes.                   */
+size_t stage_str_attn_long_bwd_qm_ws_bytes(int N, int NA, int Li, int Lqa, int D);
+int stage_str_attn_long_bwd_qm(const void* dA, const void* A, const float* dS_raw_ext, const void* Cn, const void* Q, const void* Qn,
+                               const float* S_norm, const float* q_mask, float* dS_ws, float* dQraw, float* dQn, float* dCn, int N,
+                               int NA, int Li, int Lqa, int Lr, int D, float scale, int storage_bf16, void* ws, size_t ws_bytes,
+                               void* stream);
+
 /* ---- F.normalize(p=2, eps) (+dropout)  (model/stage.py:256, model/context_query_attention.py:95-96) ----------- */
 int stage_l2norm_fwd(const float* x, float* y, float* norm_out /*may be NULL*/, long long rows, int K, float eps,
                      float p_drop, unsigned long long seed, void* stream);

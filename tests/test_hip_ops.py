@@ -712,12 +712,15 @@ def test_torch_ops_namespace_runs_the_hip_kernels(ops):
 # ---------------------------------------------------------------------------------------------------------------
 # BASELINE configs[4]: long region rows, D = 256, bf16 storage with fp32 softmax accumulation
 # ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ext", ["dense", "valid", "none"])
 @pytest.mark.parametrize("N,Li,Lr,Lqa,D", [(1, 3, 100, 13, 32), (1, 2, 512, 40, 256), (2, 3, 77, 40, 128), (1, 2, 50, 40, 128),
-                                            (1, 2, 20, 23, 16)])
-def test_k1_long_rows_fp32_vs_oracle(ops, N, Li, Lr, Lqa, D):
+                                            (1, 2, 20, 23, 16), (2, 5, 200, 24, 64)])
+def test_k1_long_rows_fp32_vs_oracle(ops, N, Li, Lr, Lqa, D, ext):
     """csrc/str_attn_long.hip in fp32 storage: any Lr (16-region blocks, two-pass softmax; the backward's row term <P, dP> is
     taken as <dA, A>), ragged masks with empty frames, gradient on raw_s included.  Same tolerances as the specialised
-    kernels; for Lr <= 64 it must also agree with them."""
+    kernels; for Lr <= 64 it must also agree with them.  Region blocks behind a frame's last valid region are skipped by the
+    forward always and by the backward unless the gradient on raw_s reaches into them: ``ext`` = that gradient everywhere
+    (nothing may be skipped), on valid regions only (the supervised attention loss), or absent."""
     from tvqaplus_amd.synth import make_batch
     g = torch.Generator().manual_seed(Lr * 3 + D)
     b = make_batch(N=N, Li=Li, Lr=Lr, Lw=2, Lqa=Lqa, wd_size=4, vfeat_size=4, seed=Lr + 1, empty_frames=True)
@@ -726,12 +729,14 @@ def test_k1_long_rows_fp32_vs_oracle(ops, N, Li, Lr, Lqa, D):
     cm, qm = b.qas_mask.view(N, 5, 1, Lqa), b.vid_mask.view(N, 1, Li, Lr)
     gA = torch.randn(N, 5, Li, Lqa, D, generator=g)
     gS = torch.randn(N, 5, Li, Lqa, Lr, generator=g) * 0.1
+    if ext == "valid":
+        gS = gS * qm.view(N, 1, Li, 1, Lr)
     Cc, Qc = C.clone().requires_grad_(), Q.clone().requires_grad_()
     Ao, So, _, Sno = O.structured_attention(Cc, Qc, cm, qm, 10.0)
-    ((Ao * gA).sum() + (So * gS).sum()).backward()
+    ((Ao * gA).sum() + ((So * gS).sum() if ext != "none" else 0.0)).backward()
     Cd, Qd = dev(C.view(N, 5, Lqa, D), True), dev(Q.view(N, Li, Lr, D), True)
     A, S, Sn = ops.structured_attention_long(Cd, Qd, cm.view(N, 5, Lqa).cuda(), qm.view(N, Li, Lr).cuda(), 10.0)
-    ((A * gA.cuda()).sum() + (S * gS.cuda()).sum()).backward()
+    ((A * gA.cuda()).sum() + ((S * gS.cuda()).sum() if ext != "none" else 0.0)).backward()
     check("A", A, Ao)
     check("S", S, So)
     check("S_norm", Sn, Sno)
@@ -740,7 +745,7 @@ def test_k1_long_rows_fp32_vs_oracle(ops, N, Li, Lr, Lqa, D):
     if Lr <= 64 and D % 16 == 0 and Lr % 2 == 0:
         C2, Q2 = dev(C.view(N, 5, Lqa, D), True), dev(Q.view(N, Li, Lr, D), True)
         A2, S2, Sn2 = ops.structured_attention(C2, Q2, cm.view(N, 5, Lqa).cuda(), qm.view(N, Li, Lr).cuda(), 10.0)
-        ((A2 * gA.cuda()).sum() + (S2 * gS.cuda()).sum()).backward()
+        ((A2 * gA.cuda()).sum() + ((S2 * gS.cuda()).sum() if ext != "none" else 0.0)).backward()
         check("A vs specialised", A, A2.cpu(), 1e-5)
         check("dQ vs specialised", Qd.grad, Q2.grad.cpu(), 1e-4)
 

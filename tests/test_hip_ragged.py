@@ -268,3 +268,28 @@ def test_ragged_attention_group_refuses_a_second_backward(hip_device):
     loss.backward(retain_graph=True)
     with pytest.raises(RuntimeError, match="once per forward"):
         loss.backward()
+
+
+@pytest.mark.parametrize("storage,Lw", [("fp32", 96), ("fp32", 200), ("bf16", 96)])
+def test_context_length_buckets_equal_one_dense_batch(hip_device, storage, Lw):
+    """Rows longer than 64 (the long-row attention kernels; bf16 storage): the context stream runs as length buckets
+    (ragged.bucket_plan, STAGE._base_encoder_buckets) -- same outputs and gradients as the one dense (frames, L, .) batch."""
+    model, batch = _pair(dict(add_local=True, dropout=0.0, storage_dtype=storage), dict(N=2, Li=9, Lr=20, Lw=Lw, Lqa=24, seed=41,
+                                                                                       empty_frames=True), hip_device)
+    batch = batch.to(hip_device)
+    n_ex = len(batch.qid)
+    model.train()
+    r = _train_step(model, batch, n_ex)
+    plan = model.last_buckets.get("sub")
+    assert plan and len(plan) >= 2 and "vid" not in model.last_buckets, model.last_buckets
+    assert sum(n * lb for n, lb in plan) < 2 * 9 * Lw
+    model.use_ctx_buckets = False
+    d = _train_step(model, batch, n_ex)
+    assert not model.last_buckets
+    tol_o, tol_g = (2e-5, 3e-4) if storage == "fp32" else (2e-2, 5e-2)
+    assert torch.equal(r[1], d[1])
+    assert rel_err(r[0], d[0]) < tol_o and rel_err(r[2], d[2]) < tol_o
+    for k in d[4]:
+        assert rel_err(r[4][k].float(), d[4][k].float()) < tol_o, k
+    worst = max((rel_err(r[5][k], d[5][k]), k) for k in d[5])
+    assert worst[0] < tol_g, worst

@@ -225,3 +225,19 @@ def test_context_rows_are_all_the_attention_needs(k, n_conv):
     assert torch.allclose(gxd, gxr, rtol=1e-10, atol=1e-12)
     for n in names:
         assert torch.allclose(gpd[n], gpr[n], rtol=1e-9, atol=1e-11), n
+
+
+def test_bucket_plan_covers_every_live_frame_once():
+    from tvqaplus_amd.ragged import bucket_plan
+    rng = np.random.default_rng(5)
+    L, halo, step = 512, 6, 64
+    lens = rng.integers(0, L + 1, size=300)
+    lens[:7] = [0, 1, 58, 59, 506, 507, 512]
+    plan = bucket_plan(lens, L, halo, step)
+    seen = np.concatenate([ix for ix, _ in plan])
+    assert sorted(seen.tolist()) == np.nonzero(lens > 0)[0].tolist()
+    for ix, lb in plan:
+        assert lb % step == 0 or lb == L
+        assert (np.minimum(L, lens[ix] + halo) <= lb).all() and (np.minimum(L, lens[ix] + halo) > lb - step).all()
+    assert [lb for _, lb in plan] == sorted(lb for _, lb in plan)
+    assert bucket_plan(np.zeros(4, int), L, halo, step) == []

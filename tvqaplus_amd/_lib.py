@@ -32,6 +32,8 @@ SIGNATURES = {
     "stage_str_attn_long_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, I, P]),
     "stage_str_attn_long_bwd_ws_bytes": (SZ, [I, I, I, I]),
     "stage_str_attn_long_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, I, P, SZ, P]),
+    "stage_str_attn_long_bwd_qm_ws_bytes": (SZ, [I, I, I, I, I]),
+    "stage_str_attn_long_bwd_qm": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, I, P, SZ, P]),
     "stage_l2norm_fwd": (I, [P, P, P, LL, I, F, F, U64, P]),
     "stage_l2norm_bwd": (I, [P, P, P, LL, I, F, F, U64, I, P]),
     "stage_layernorm_fwd": (I, [P, P, I, P, P, P, P, P, P, LL, I, F, F, U64, P]),

@@ -113,15 +113,24 @@ __global__ __launch_bounds__(256) void str_attn_long_fwd_kernel(const T* __restr
     const float* qm = qmask + frame * Lr;
     const int nb = (Lr + 15) >> 4;
     const bool vec4 = (Lr & 3) == 0;
+    // Region blocks behind the frame's last valid region are not computed: their raw scores are cos - 1e10 = -1e10 exactly (|cos| <= 1
+    // is below half an ulp of 1e10), their weights exp(-1e11 - max) * mask = 0, they add nothing to A -- the constants are stored.
+    // (A row without any unmasked region comes out 0 * uniform = 0 either way; a frame without a valid region computes nothing.)
+    int nv = 0;
+    for (int r0 = 0; r0 < Lr; r0 += 64) {
+        const unsigned long long bal = __ballot(r0 + lane < Lr && qm[min(r0 + lane, Lr - 1)] != 0.f);
+        if (bal) nv = r0 + 64 - __builtin_clzll(bal);
+    }
+    const int nvb = (nv + 15) >> 4;                   // blocks to compute (wave-uniform)
     // ---- pass 1: raw scores, online max / sum of exp(scale * raw) over the row ----
     float mx = -INFINITY, sum = 0.f;
     LngRowB<D> qnext;                    // bf16 path: the next block's Qn fragments are requested before this block is scored
     if constexpr (USEB) lng_rowb<D>(qnext, qn + (long)min(c15, Lr - 1) * D, g);
-    for (int rb = 0; rb < nb; rb++) {
+    for (int rb = 0; rb < nvb; rb++) {
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
         if constexpr (USEB) {
             const LngRowB<D> qfb = qnext;
-            lng_rowb<D>(qnext, qn + (long)min((rb + 1 < nb ? rb + 1 : rb) * 16 + c15, Lr - 1) * D, g);
+            lng_rowb<D>(qnext, qn + (long)min((rb + 1 < nvb ? rb + 1 : rb) * 16 + c15, Lr - 1) * D, g);
             acc = lng_dotb<D>(qfb, cfb);
         } else {
             float qf[DQ];
@@ -157,6 +166,26 @@ __global__ __launch_bounds__(256) void str_attn_long_fwd_kernel(const T* __restr
         sum = sum * expf(mx - nmx) + bs;         // mx = -inf at the first block: exp(-inf) = 0
         mx = nmx;
     }
+    // the blocks that are not computed: raw score -1e10, weight 0 (pass 2 of the bf16 path may still read the raw scores of the odd
+    // block behind nvb: the same lane wrote them here)
+    if (cvalid) {
+        for (int rb = nvb; rb < nb; rb++) {
+            const int b0 = rb * 16 + 4 * g;
+            if (vec4) {
+                if (b0 < Lr) {
+                    st4(S + orow * Lr + b0, make_float4(-1e10f, -1e10f, -1e10f, -1e10f));
+                    if (rb >= ((nvb + 1) & ~1)) st4(Sn + orow * Lr + b0, f4zero());
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (b0 + k < Lr) {
+                        S[orow * Lr + b0 + k] = -1e10f;
+                        if (rb >= ((nvb + 1) & ~1)) Sn[orow * Lr + b0 + k] = 0.f;
+                    }
+            }
+        }
+    }
     // ---- pass 2: normalised scores, A^T (d x ctx) += Qraw^T . S_^T ----
     f32x4 o[DT];
 #pragma unroll
@@ -169,7 +198,7 @@ __global__ __launch_bounds__(256) void str_attn_long_fwd_kernel(const T* __restr
     // Q is bf16 in HBM, so the product is exact.  A operand of d tile dt: element DT c15 + dt of the lane's eight Q rows, picked out of
     // the rows' 16-byte words with one v_perm per row pair.  32 MFMAs of ~16 cycles per step instead of 128 fp32 ones of 32.
     if constexpr (PF) {
-        for (int rb = 0; rb < nb; rb += 2) {
+        for (int rb = 0; rb < nvb; rb += 2) {
             uint4 q8[8][NW4];      // (requesting the next step's rows ahead -- 64 more registers -- measured the same)
 #pragma unroll
             for (int e = 0; e < 8; e++)
@@ -222,7 +251,7 @@ __global__ __launch_bounds__(256) void str_attn_long_fwd_kernel(const T* __restr
             }
         }
     } else
-    for (int rb = 0; rb < nb; rb++) {
+    for (int rb = 0; rb < ((nvb + 1) & ~1) && rb < nb; rb++) {
         float p[4];
         const bool blk = rb * 16 + 4 * g < Lr;
         float4 rv = make_float4(-1e10f, -1e10f, -1e10f, -1e10f);
@@ -268,7 +297,8 @@ __global__ __launch_bounds__(256) void str_attn_long_bwd_ds_kernel(const T* __re
                                                                    const float* __restrict__ ext, const T* __restrict__ Q,
                                                                    const T* __restrict__ Qn, const float* __restrict__ Sn,
                                                                    float* __restrict__ dS, float* __restrict__ part, int N,
-                                                                   int NA, int Li, int Lqa, int Lr, float scale, int nchunks) {
+                                                                   int NA, int Li, int Lqa, int Lr, float scale, int nchunks,
+                                                                   const int* __restrict__ fnv) {
     constexpr int D = 4 * DQ, DT = (D + 15) / 16;
     const int lane = threadIdx.x & 63, c15 = lane & 15, g = lane >> 4;
     const int CR = NA * Lqa, CT = (CR + 15) >> 4;
@@ -286,6 +316,10 @@ __global__ __launch_bounds__(256) void str_attn_long_bwd_ds_kernel(const T* __re
     for (int dt = 0; dt < DT; dt++) dcn[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int i = chunk; i < Li; i += nchunks) {
         const long frame = (long)n * Li + i;
+        // fnv: regions of the frame that can carry a gradient (lng_frame_nv_kernel); the blocks behind them have P = 0 and no external
+        // gradient: dS = 0 there, nothing is added to dCn, and B2 does not read them
+        const int nvb = fnv ? (__builtin_amdgcn_readfirstlane(fnv[frame]) + 15) >> 4 : nb;
+        if (nvb == 0) continue;
         const long orow = ((long)(n * NA + cc / Lqa) * Li + i) * Lqa + cc % Lqa;
         float gf[LngUseB<T, D>::value ? 1 : DQ];
         LngRowB<D> gfb;                                       // bf16 storage: the row as packed bf16 matrix-core fragments
@@ -312,7 +346,7 @@ __global__ __launch_bounds__(256) void str_attn_long_bwd_ds_kernel(const T* __re
         dot = cross_row_sum(dot);
         const T* qr = Q + frame * Lr * (long)D;
         const T* qn = Qn + frame * Lr * (long)D;
-        for (int rb = 0; rb < nb; rb++) {
+        for (int rb = 0; rb < nvb; rb++) {
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
             if constexpr (LngUseB<T, D>::value) {
                 LngRowB<D> qfb;
@@ -398,7 +432,7 @@ template <typename T, int DT, int DTW>   // DTW <= 8 d tiles per wave: 2 x DTW a
 __global__ __launch_bounds__(256) void str_attn_long_bwd_dq_kernel(const T* __restrict__ dA, const float* __restrict__ Sn,
                                                                    const float* __restrict__ dS, const T* __restrict__ Cn,
                                                                    float* __restrict__ dQraw, float* __restrict__ dQn, int N,
-                                                                   int NA, int Li, int Lqa, int Lr) {
+                                                                   int NA, int Li, int Lqa, int Lr, const int* __restrict__ fnv) {
     constexpr int D = 16 * DT;
     const int lane = threadIdx.x & 63, c15 = lane & 15, g = lane >> 4;
     const int CR = NA * Lqa, nb = (Lr + 15) >> 4;
@@ -411,6 +445,20 @@ __global__ __launch_bounds__(256) void str_attn_long_bwd_dq_kernel(const T* __re
     const int n = (int)(frame / Li), i = (int)(frame % Li);
     const int r = rb * 16 + c15, rc = min(r, Lr - 1);
     const int dofs = DT * c15 + DTW * hh;                    // this lane's DTW consecutive columns
+    if (fnv && rb * 16 >= __builtin_amdgcn_readfirstlane(fnv[frame])) {
+        // a block behind the last region that can carry a gradient (P = 0, dS = 0): both gradients are exact zeros
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int rr = rb * 16 + 4 * g + k;
+            if (rr < Lr) {
+                float* o1 = dQraw + (frame * Lr + rr) * D + dofs;
+                float* o2 = dQn + (frame * Lr + rr) * D + dofs;
+#pragma unroll
+                for (int dt = 0; dt < DTW; dt++) { o1[dt] = 0.f; o2[dt] = 0.f; }
+            }
+        }
+        return;
+    }
     f32x4 ar[DTW], an[DTW];
 #pragma unroll
     for (int dt = 0; dt < DTW; dt++) ar[dt] = an[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -459,10 +507,40 @@ __global__ __launch_bounds__(256) void lng_slab_sum_kernel(const float* __restri
     out[e] = acc;
 }
 
+// fnv[frame] = number of leading regions of the frame that can carry a gradient: last valid region + 1, or Lr when the external
+// gradient on the raw scores is non-zero somewhere behind the blocks that hold valid regions (then nothing may be skipped: the
+// scores of padded regions are cos - 1e10, d/dcos = 1).  One workgroup per frame; wave w scans the tails of context rows w, w + 4, ...
+__global__ __launch_bounds__(256) void lng_frame_nv_kernel(const float* __restrict__ qmask, const float* __restrict__ ext,
+                                                           int* __restrict__ fnv, int NA, int Li, int Lqa, int Lr) {
+    const long frame = blockIdx.x;
+    const int n = (int)(frame / Li), i = (int)(frame % Li), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, CR = NA * Lqa;
+    __shared__ int nv_sh[4];
+    int nv = 0;
+    for (int r = tid; r < Lr; r += 256)
+        if (qmask[frame * Lr + r] != 0.f) nv = r + 1;            // ascending r per thread: the last hit is the largest
+    nv = (int)wave_max((float)nv);
+    if (lane == 0) nv_sh[wave] = nv;
+    __syncthreads();
+    nv = max(max(nv_sh[0], nv_sh[1]), max(nv_sh[2], nv_sh[3]));
+    const int thr = ((nv + 15) >> 4) << 4;
+    int hit = 0;
+    if (ext && thr < Lr) {
+        for (int c = wave; c < CR; c += 4) {
+            const float* er = ext + ((((long)n * NA + c / Lqa) * Li + i) * Lqa + c % Lqa) * Lr;
+            for (int col = thr + lane; col < Lr; col += 64) hit |= er[col] != 0.f;
+        }
+    }
+    hit = __syncthreads_or(hit);
+    if (tid == 0) fnv[frame] = hit ? Lr : nv;
+}
+
 #define LNG_CHUNKS 8
 
 extern "C" size_t stage_str_attn_long_bwd_ws_bytes(int N, int NA, int Lqa, int D) {
     return (size_t)LNG_CHUNKS * N * NA * Lqa * D * sizeof(float);
+}
+extern "C" size_t stage_str_attn_long_bwd_qm_ws_bytes(int N, int NA, int Li, int Lqa, int D) {
+    return stage_str_attn_long_bwd_ws_bytes(N, NA, Lqa, D) + (((size_t)N * Li * sizeof(int) + 255) & ~(size_t)255);
 }
 
 template <typename T>
@@ -490,15 +568,21 @@ static int lng_fwd(const void* Cn, const void* Q, const void* Qn, const float* c
 template <typename T>
 static int lng_bwd(const void* dA, const void* A, const float* ext, const void* Cn, const void* Q, const void* Qn, const float* Sn,
                    float* dS, float* dQraw, float* dQn, float* dCn, int N, int NA, int Li, int Lqa, int Lr, int D, float scale,
-                   float* part, hipStream_t st) {
+                   float* part, hipStream_t st, const float* qmask = nullptr, int* fnv = nullptr) {
     const int CR = NA * Lqa, CT = (CR + 15) / 16;
+    if (qmask && fnv) {
+        hipLaunchKernelGGL(lng_frame_nv_kernel, dim3((unsigned)(N * Li)), dim3(256), 0, st, qmask, ext, fnv, NA, Li, Lqa, Lr);
+        STAGE_LAUNCH_CHECK();
+    } else {
+        fnv = nullptr;
+    }
     int nchunks = LNG_CHUNKS;
     if (nchunks > Li) nchunks = Li;
     const long items = (long)N * CT * nchunks;
     const dim3 grid((unsigned)((items + 3) / 4)), block(256);
 #define LNG_B(DQV)                                                                                                         \
     hipLaunchKernelGGL((str_attn_long_bwd_ds_kernel<T, DQV>), grid, block, 0, st, (const T*)dA, (const T*)A, ext, (const T*)Q, \
-                       (const T*)Qn, Sn, dS, part, N, NA, Li, Lqa, Lr, scale, nchunks)
+                       (const T*)Qn, Sn, dS, part, N, NA, Li, Lqa, Lr, scale, nchunks, (const int*)fnv)
     switch (D) {
         case 16: LNG_B(4); break;
         case 32: LNG_B(8); break;
@@ -516,7 +600,7 @@ static int lng_bwd(const void* dA, const void* A, const float* ext, const void* 
     const long items2 = (long)N * Li * ((Lr + 15) / 16) * (dq_split ? D / 128 : 1);
 #define LNG_Q(DTV, DTWV)                                                                                                   \
     hipLaunchKernelGGL((str_attn_long_bwd_dq_kernel<T, DTV, DTWV>), dim3((unsigned)((items2 + 3) / 4)), dim3(256), 0, st, (const T*)dA, Sn, \
-                       (const float*)dS, (const T*)Cn, dQraw, dQn, N, NA, Li, Lqa, Lr)
+                       (const float*)dS, (const T*)Cn, dQraw, dQn, N, NA, Li, Lqa, Lr, (const int*)fnv)
     switch (D) {
         case 16: LNG_Q(1, 1); break;
         case 32: LNG_Q(2, 2); break;
@@ -553,4 +637,21 @@ extern "C" int stage_str_attn_long_bwd(const void* dA, const void* A, const floa
                                                   scale, (float*)ws, st)
                         : lng_bwd<float>(dA, A, dS_raw_ext, Cn, Q, Qn, S_norm, dS_ws, dQraw, dQn, dCn, N, NA, Li, Lqa, Lr, D, scale,
                                          (float*)ws, st);
+}
+
+// The same with the region mask at hand: region blocks behind a frame's last valid region are skipped (exact zeros) unless the external
+// gradient touches them (lng_frame_nv_kernel).  ws from stage_str_attn_long_bwd_qm_ws_bytes.
+extern "C" int stage_str_attn_long_bwd_qm(const void* dA, const void* A, const float* dS_raw_ext, const void* Cn, const void* Q,
+                                          const void* Qn, const float* S_norm, const float* q_mask, float* dS_ws, float* dQraw,
+                                          float* dQn, float* dCn, int N, int NA, int Li, int Lqa, int Lr, int D, float scale,
+                                          int storage_bf16, void* ws, size_t ws_bytes, void* stream) {
+    if (N <= 0 || Li <= 0) return 0;
+    if (Lr < 1 || Lqa < 1 || NA < 1 || !q_mask) return STAGE_ERR_SHAPE;
+    if (ws_bytes < stage_str_attn_long_bwd_qm_ws_bytes(N, NA, Li, Lqa, D)) return STAGE_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int* fnv = (int*)((char*)ws + stage_str_attn_long_bwd_ws_bytes(N, NA, Lqa, D));
+    return storage_bf16 ? lng_bwd<__hip_bfloat16>(dA, A, dS_raw_ext, Cn, Q, Qn, S_norm, dS_ws, dQraw, dQn, dCn, N, NA, Li, Lqa, Lr, D,
+                                                  scale, (float*)ws, st, q_mask, fnv)
+                        : lng_bwd<float>(dA, A, dS_raw_ext, Cn, Q, Qn, S_norm, dS_ws, dQraw, dQn, dCn, N, NA, Li, Lqa, Lr, D, scale,
+                                         (float*)ws, st, q_mask, fnv);
 }

@@ -676,14 +676,14 @@ class _StrAttnLong(torch.autograd.Function):
         Sn = torch.empty_like(S)
         _call("stage_str_attn_long_fwd", _ptr(Cn), _ptr(Q), _ptr(Qn), _ptr(c_mask), _ptr(q_mask), _ptr(A), _ptr(S), _ptr(Sn),
               N, NA, Li, Lqa, Lr, D, float(scale), int(dt == torch.bfloat16), _stream())
-        ctx.save_for_backward(C, Q, Cn, Qn, Sn, A)
+        ctx.save_for_backward(C, Q, Cn, Qn, Sn, A, q_mask)
         ctx.cfg = (float(scale), float(p), int(seed_c), int(seed_q))
         ctx.set_materialize_grads(False)
         return A, S, Sn
 
     @_on_device
     def backward(ctx, dA, dS, dSn):
-        C, Q, Cn, Qn, Sn, A = ctx.saved_tensors
+        C, Q, Cn, Qn, Sn, A, q_mask = ctx.saved_tensors
         scale, p, seed_c, seed_q = ctx.cfg
         dS = _fold_dsn(dS, dSn, Sn, scale)
         dt = C.dtype
@@ -695,10 +695,12 @@ class _StrAttnLong(torch.autograd.Function):
         dQ = torch.empty(Q.shape, dtype=torch.float32, device=Q.device)
         dQn, dCn = torch.empty_like(dQ), torch.empty(C.shape, dtype=torch.float32, device=C.device)
         lib = _lib.load()
-        wsb = lib.stage_str_attn_long_bwd_ws_bytes(N, NA, Lqa, D)
+        # region blocks behind a frame's last valid region are exact zeros and skipped (unless dS_ext reaches into them)
+        wsb = lib.stage_str_attn_long_bwd_qm_ws_bytes(N, NA, Li, Lqa, D)
         ws = _workspace(wsb, C.device)
-        _call("stage_str_attn_long_bwd", _ptr(dA), _ptr(A), _ptr(dS_ext), _ptr(Cn), _ptr(Q), _ptr(Qn), _ptr(Sn), _ptr(dS_ws),
-              _ptr(dQ), _ptr(dQn), _ptr(dCn), N, NA, Li, Lqa, Lr, D, scale, int(dt == torch.bfloat16), _ptr(ws), wsb, _stream())
+        _call("stage_str_attn_long_bwd_qm", _ptr(dA), _ptr(A), _ptr(dS_ext), _ptr(Cn), _ptr(Q), _ptr(Qn), _ptr(Sn), _ptr(q_mask),
+              _ptr(dS_ws), _ptr(dQ), _ptr(dQn), _ptr(dCn), N, NA, Li, Lqa, Lr, D, scale, int(dt == torch.bfloat16), _ptr(ws), wsb,
+              _stream())
         if dt == _BF16:
             dQb, dCb = torch.empty_like(Q), torch.empty_like(C)
             _call("stage_l2norm_bwd_mixed_bf16", _ptr(dQn), _ptr(Q), _ptr(dQ), _ptr(dQb), N * Li * Lr, D, EPS_L2, p, seed_q, _stream())

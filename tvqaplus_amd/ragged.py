@@ -273,3 +273,17 @@ def masks_from_device(qas_mask: torch.Tensor, ctx_mask: torch.Tensor) -> tuple:
     """(qa_valid, frame_live) from the device masks (one read-back)."""
     info = info_from_device(qas_mask, {"ctx": ctx_mask})
     return info["qas"], info["ctx_len"] > 0
+
+
+def bucket_plan(lens: np.ndarray, L: int, halo: int, step: int) -> list:
+    """Length buckets of a context stream for the paths that keep dense (frames, L, .) tensors (long rows, bf16 storage: everything
+    the ``*_rag`` group entry points decline).  ``lens`` (frames,) = last valid position + 1 (0: none).  A frame needs the positions
+    below ``len + halo`` (the input encoder's convolutions reach no further: module docstring); it goes into the bucket of the
+    smallest multiple of ``step`` that holds them (capped at L), frames without a valid position into none.  Returns
+    ``[(frame indices int64, Lb), ...]`` by ascending Lb -- each bucket is an ordinary dense ``(len(idx), Lb, .)`` batch whose rows
+    behind ``Lb`` are never computed."""
+    lens = np.asarray(lens).reshape(-1).astype(np.int64)
+    need = np.minimum(L, lens + int(halo))
+    Lb = np.minimum(L, -(-need // int(step)) * int(step))
+    Lb = np.where(lens > 0, Lb, 0)
+    return [(np.nonzero(Lb == v)[0].astype(np.int64), int(v)) for v in np.unique(Lb) if v > 0]

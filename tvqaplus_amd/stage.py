@@ -36,6 +36,23 @@ def _opt(batch, key, default=None):
 # ---------------------------------------------------------------------------------------------------------------
 # parameter containers (names mirror the reference's attribute names -> identical state_dict keys)
 # ---------------------------------------------------------------------------------------------------------------
+class _ScatterBuckets(torch.autograd.Function):
+    """(frames_b, Lb, D) bucket outputs -> one zero-filled (M, L, D) tensor; the backward hands every bucket its slice of the
+    gradient.  (Plain in-place index_copy_ on views would make autograd clone the whole (M, L, D) gradient once per bucket.)"""
+
+    @staticmethod
+    def forward(ctx, M, L, idxs, *ys):
+        out = torch.zeros(M, L, ys[0].shape[-1], device=ys[0].device, dtype=ys[0].dtype)
+        for ix, y in zip(idxs, ys):
+            out[:, :y.shape[1]].index_copy_(0, ix, y)
+        ctx.idxs, ctx.lens = idxs, [y.shape[1] for y in ys]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, None, None) + tuple(g[:, :lb].index_select(0, ix) for ix, lb in zip(ctx.idxs, ctx.lens))
+
+
 class _PositionTable(nn.Module):
     """model/position_encoding.py:19-31: fixed sinusoid table registered as buffer ``pe`` (max_len, D)."""
 
@@ -213,6 +230,13 @@ class STAGE(nn.Module):
         # ... and the context streams in front of the attention on their valid words / regions + the input encoder's halo
         # (STAGE_NO_RAGGED_CTX=1: dense context streams, ragged statement rows)
         self.use_ragged_ctx = os.environ.get("STAGE_NO_RAGGED_CTX") is None
+        # context streams the ragged group path does not take (rows longer than 64, bf16 storage, hsz != 128): length BUCKETS -- the
+        # frames are sorted into a few dense (frames, Lb, .) batches by valid length + halo and every bucket runs the ordinary path on
+        # its Lb positions; dead frames run nowhere (ragged.bucket_plan).  ``last_buckets``: {stream: [(frames, Lb), ...]} of the
+        # last forward.  STAGE_NO_CTX_BUCKETS=1 / use_ctx_buckets = False: one dense (frames, L, .) batch, as the reference.
+        self.use_ctx_buckets = os.environ.get("STAGE_NO_CTX_BUCKETS") is None
+        self.last_buckets: Dict[str, list] = {}
+        self._mask_info = None
         self.last_ragged: Optional[ragged.RaggedLayout] = None
         self.last_ragged_ctx: Dict[str, ragged.CtxLayout] = {}
         self._rag_stage = None
@@ -628,6 +652,54 @@ class STAGE(nn.Module):
         return (per * here.to(per.dtype)).sum() / 2.
 
     # ---- ragged token rows --------------------------------------------------------------------------------------
+    def _get_mask_info(self, batch, N, NA, Lqa, Li, names):
+        """{"qas": (N, NA, Lqa) bool, "<stream>_len": (N, Li) last valid position + 1} of this batch: the loader's host copies
+        (batch.mask_host) or ONE read-back of the device masks; cached for the forward."""
+        if self._mask_info is not None:
+            return self._mask_info
+        info = ragged.host_info(batch)
+        if info is not None and (info["qas"].shape != (N, NA, Lqa)
+                                 or any(info.get(k + "_len") is None or info[k + "_len"].shape != (N, Li) for k in names)):
+            info = None                                  # no / stale host copies (a batch sliced by foreign code): read the masks
+        if info is None:
+            info = ragged.info_from_device(batch.qas_mask.view(N, NA, Lqa),
+                                           {k: (batch.sub_mask if k == "sub" else batch.vid_mask).view(N, Li, -1) for k in names})
+        self._mask_info = info
+        return info
+
+    def _ctx_buckets(self, batch, name, N, NA, Lqa, Li, L):
+        """Length buckets of context stream ``name`` (ragged.bucket_plan) for the dense paths, or None: switched off, short rows
+        (<= 64: the ragged group path's territory, and too few positions to sort), an input encoder with self-attention."""
+        if not (self.use_ragged_ctx and self.use_ctx_buckets) or L <= 64:
+            return None
+        iblocks = list(self.input_encoder.stacked_encoderBlocks)
+        if not iblocks or any(b.num_heads != 0 or b.n_conv < 1 for b in iblocks):
+            return None
+        halo = sum(ragged.conv_halo(1, b.n_conv, b.conv[0].depthwise_conv.weight.shape[-1]) for b in iblocks)
+        names = (["sub"] if self.sub_flag else []) + (["vid"] if self.vfeat_flag else [])
+        info = self._get_mask_info(batch, N, NA, Lqa, Li, names)
+        step = 64 if L >= 256 else 32
+        plan = ragged.bucket_plan(info[name + "_len"], int(L), halo, step)
+        if not plan or (len(plan) == 1 and plan[0][1] == L and len(plan[0][0]) == N * Li):
+            return None if plan else []
+        return plan
+
+    def _base_encoder_buckets(self, plan, data, data_mask, init_encoder, downsize_encoder, input_encoder, l2_normalize):
+        """base_encoder over the length buckets of ``plan``: (M, L, D) with zeros where nothing is computed (rows behind a frame's
+        bucket length, frames without a valid position -- the attention masks every one of them, and no gradient comes back)."""
+        M, L, _ = data.shape
+        idxs, ys = [], []
+        for idx, Lb in plan:
+            idx_d = torch.from_numpy(idx).to(data.device, non_blocking=True)
+            xb = data[:, :Lb].index_select(0, idx_d)                # (Mb, Lb, F): only these positions are read
+            mb = data_mask[:, :Lb].index_select(0, idx_d)
+            yb = self.base_encoder(xb, mb, init_encoder, downsize_encoder, input_encoder, l2_normalize=l2_normalize)
+            idxs.append(idx_d)
+            ys.append(yb.view(len(idx), Lb, -1))
+        if not ys:
+            return torch.zeros(M, L, self.hsz, device=data.device, dtype=self.storage)
+        return _ScatterBuckets.apply(M, L, idxs, *ys)
+
     def _ragged_layout(self, batch, qas_mask, a_embed):
         """The ragged layout of this batch (tvqaplus_amd/ragged.py), or None when the dense path runs: switched off, a configuration
         the ragged kernels do not cover (decided BEFORE anything is launched: hsz = 128 on the K-group path, one classifier-encoder
@@ -658,13 +730,7 @@ class STAGE(nn.Module):
         # the statement mask's frame side comes from the video stream when there is one (model/stage.py:283-289)
         frame_stream = "vid" if self.vfeat_flag else "sub"
         names = (["sub"] if self.sub_flag else []) + (["vid"] if self.vfeat_flag else [])
-        info = ragged.host_info(batch)
-        if info is not None and (info["qas"].shape != (N, NA, Lqa)
-                                 or any(info.get(k + "_len") is None or info[k + "_len"].shape != (N, Li) for k in names)):
-            info = None                                  # no / stale host copies (a batch sliced by foreign code): read the masks
-        if info is None:
-            info = ragged.info_from_device(batch.qas_mask.view(N, NA, Lqa),
-                                           {k: (batch.sub_mask if k == "sub" else batch.vid_mask).view(N, Li, -1) for k in names})
+        info = self._get_mask_info(batch, N, NA, Lqa, Li, names)
         tab = ragged.RaggedTables(info["qas"], info[frame_stream + "_len"] > 0, cls_halo)
         if tab.U == 0:
             return none
@@ -756,14 +822,22 @@ class STAGE(nn.Module):
         a_embed = a_embed.view(N, NA, -1, D)
         attended_sub = attended_vid = attended_vid_mask = attended_sub_mask = None
         other_outputs: Dict[str, torch.Tensor] = {}
+        self._mask_info = None
         lay, clays = self._ragged_layout(batch, qas_mask, a_embed)
         self.last_ragged, self.last_ragged_ctx = lay, clays
+        self.last_buckets = {}
         if self.sub_flag:
             Li, Lw = batch.sub_bert.shape[1:3]
             sub_mask = batch.sub_mask.view(N, Li, Lw).float()
             cl = clays.get("sub")
-            sub_embed = self.base_encoder(batch.sub_bert.view(N * Li, Lw, -1), sub_mask.view(N * Li, Lw),
-                                          self.bert_word_encoding_fc, self.input_embedding, self.input_encoder, clay=cl)
+            plan = self._ctx_buckets(batch, "sub", N, NA, qas_mask.shape[-1], Li, Lw) if cl is None else None
+            if plan is not None:
+                self.last_buckets["sub"] = [(len(ix), lb) for ix, lb in plan]
+                sub_embed = self._base_encoder_buckets(plan, batch.sub_bert.view(N * Li, Lw, -1), sub_mask.view(N * Li, Lw),
+                                                       self.bert_word_encoding_fc, self.input_embedding, self.input_encoder, False)
+            else:
+                sub_embed = self.base_encoder(batch.sub_bert.view(N * Li, Lw, -1), sub_mask.view(N * Li, Lw),
+                                              self.bert_word_encoding_fc, self.input_embedding, self.input_encoder, clay=cl)
             attended_sub, attended_sub_mask, raw, norm = self.qa_ctx_attention(
                 a_embed, sub_embed if cl is not None else sub_embed.view(N, Li, Lw, D), qas_mask, sub_mask, lay, cl)
             other_outputs["sub_normalized_s"], other_outputs["sub_raw_s"] = norm, raw
@@ -771,8 +845,14 @@ class STAGE(nn.Module):
             Li, Lr = batch.vid.shape[1:3]
             vid_mask = batch.vid_mask.view(N, Li, Lr).float()
             cl = clays.get("vid")
-            vid_embed = self.base_encoder(batch.vid.view(N * Li, Lr, -1), vid_mask.view(N * Li, Lr), self.vid_fc,
-                                          self.input_embedding, self.input_encoder, l2_normalize=True, clay=cl)
+            plan = self._ctx_buckets(batch, "vid", N, NA, qas_mask.shape[-1], Li, Lr) if cl is None else None
+            if plan is not None:
+                self.last_buckets["vid"] = [(len(ix), lb) for ix, lb in plan]
+                vid_embed = self._base_encoder_buckets(plan, batch.vid.view(N * Li, Lr, -1), vid_mask.view(N * Li, Lr), self.vid_fc,
+                                                       self.input_embedding, self.input_encoder, True)
+            else:
+                vid_embed = self.base_encoder(batch.vid.view(N * Li, Lr, -1), vid_mask.view(N * Li, Lr), self.vid_fc,
+                                              self.input_embedding, self.input_encoder, l2_normalize=True, clay=cl)
             attended_vid, attended_vid_mask, raw, norm = self.qa_ctx_attention(
                 a_embed, vid_embed if cl is not None else vid_embed.view(N, Li, Lr, D), qas_mask, vid_mask, lay, cl)
             other_outputs["vid_normalized_s"], other_outputs["vid_raw_s"] = norm, raw
