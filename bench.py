@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--storage", choices=["fp32", "bf16"], default="fp32",
                     help="bf16: the bf16 storage mode (BASELINE configs[4]); the headline line is the fp32 default")
+    ap.add_argument("--fp32_inputs", action="store_true", help="--storage bf16: keep the resident feature tensors fp32 (the model then rounds them "
+                    "to bf16 inside every step); default: resident as bf16, the way prefetch.BatchPrefetcher(stage_dtype=bf16) delivers them")
     ap.add_argument("--config", choices=("default", "stress"), default="default",
                     help="stress = BASELINE.json configs[4]: bf16 weights / activations with fp32 softmax accumulate, hsz = 256, 512 "
                          "subtitle words per frame (sets --hsz 256 --sub_words 512 --storage bf16; the roofline line is the long-row "
@@ -560,6 +562,12 @@ def main():
                            att_words=args.att_words).to(device)
         n_local = args.bsz
     n_global = args.bsz if args.scaling == "strong" else world * args.bsz
+    if args.storage == "bf16" and not args.fp32_inputs:
+        # bf16 storage mode: the features are rounded to bf16 ONCE on entry (stage.py: base_encoder); a loader for that mode stages them
+        # as bf16 (tvqaplus_amd/prefetch.py, bit-identical), so the resident batch of the timed region holds them as bf16
+        for k in ("vid", "sub_bert"):
+            if getattr(batch, k, None) is not None and getattr(batch, k).dtype == torch.float32:
+                setattr(batch, k, getattr(batch, k).to(torch.bfloat16))
     if args.no_mask_host:
         batch.pop("mask_host", None)
 
@@ -747,6 +755,8 @@ def main():
                     r["achieved_this_layout"] = round(b_here / (r["avg_us"] * 1e-6) / 1e9, 1)
                     r["frac_this_layout"] = round(r["achieved_this_layout"] / 8000.0, 4)
         rec["config"]["harness"] = {"gc": args.gc, "adam": args.adam, "ragged_rows": lay is not None}
+        if args.storage == "bf16":
+            rec["config"]["harness"]["resident_features"] = "fp32" if args.fp32_inputs else "bf16 (as the bf16-staging prefetcher delivers them)"
         if (world == 1 and not args.no_children and args.config == "default" and not args.dense and args.storage == "fp32" and not args.heads
                 and not args.h2d):
             side = side_records(args)
