@@ -483,10 +483,14 @@ int stage_cat3_ln_gemm_fwd_rag(const float* a, const float* b, const float* gamm
                                float p_drop, unsigned long long seed, void* ws, size_t ws_bytes, void* stream);
 int stage_cat3_dx_ln_bwd_rag_supported(long long rows, long long fc_rows, int D, int groups, int max_frames, int Lqa);
 size_t stage_cat3_dx_ln_bwd_rag_ws_bytes(int groups, int max_frames, int Lqa);
+/* wtab (may be NULL): balanced work table for stage_cat3_rag_work_groups() persistent workgroups (tvqaplus_amd/ragged.py:
+ * RaggedTables.work_table -- [first segment of every workgroup, W + 1 ints padded to 4][(first slab, slabs) per group][segments
+ * (group, first frame, end frame, workgroup)]): equal tile counts per workgroup; NULL: one workgroup per (group, chunk of max_frames) */
+int stage_cat3_rag_work_groups(void);
 int stage_cat3_dx_ln_bwd_rag(const float* dy, const unsigned* relu_mask, const float* W, const float* a, const float* b_fc,
                              const float* mean, const float* rstd, const float* gamma, float* da, float* db_fc, float* dgamma,
-                             float* dbeta, const int* gdesc, long long rows, long long fc_rows, int D, int groups, int max_frames,
-                             int Lqa, float p_drop, unsigned long long seed, void* ws, size_t ws_bytes, void* stream);
+                             float* dbeta, const int* gdesc, const int* wtab, long long rows, long long fc_rows, int D, int groups,
+                             int max_frames, int Lqa, float p_drop, unsigned long long seed, void* ws, size_t ws_bytes, void* stream);
 /* encoder block pieces on ragged sequences (model/encoder.py:35-52; model/stage.py:503 for the pooled LayerNorm) */
 int stage_ln_dwconv_rag_fwd(const float* x, const float* res, const float* pe, float* sum_out, const float* gamma,
                             const float* beta, const float* w, const float* bias, float* h, float* mean, float* rstd,
@@ -503,7 +507,8 @@ int stage_ln_masked_max_rag_bwd(const float* dout, const int* argmax, const floa
                                 const float* rstd, const float* gamma, float* dx, float* dgamma, float* dbeta,
                                 const int* rowinfo, long long rows, int K, void* ws, size_t ws_bytes, void* stream);
 /* K-groups on ragged rows (csrc/groups.hip "RAGGED TOKEN ROWS"): T = host array of the device tables fmap, gdesc, seq, rowinfo, cq
- * (cq NULL: dense context stream; Uc = rows of ctx / d_ctx).  The encoder group pools when qa_mask != NULL, else returns (U, D). */
+ * (cq NULL: dense context stream; Uc = rows of ctx / d_ctx) and -- the qa_ctx group, 6 entries -- wtab (the balanced work table of
+ * stage_cat3_dx_ln_bwd_rag, or NULL).  The encoder group pools when qa_mask != NULL, else returns (U, D). */
 int stage_grp_qa_ctx_rag_supported(int N, int NA, int Li, int Lqa, int Lr, int D, long long U, long long Fc);
 size_t stage_grp_qa_ctx_rag_arena_bytes(int N, int NA, int Lqa, int D, long long Ucap, long long Fc);
 size_t stage_grp_qa_ctx_rag_bwd_tmp_bytes(int N, int NA, int Li, int Lqa, int Lr, int D, long long Ucap, long long Uc);

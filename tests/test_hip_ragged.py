@@ -293,3 +293,49 @@ def test_context_length_buckets_equal_one_dense_batch(hip_device, storage, Lw):
         assert rel_err(r[4][k].float(), d[4][k].float()) < tol_o, k
     worst = max((rel_err(r[5][k], d[5][k]), k) for k in d[5])
     assert worst[0] < tol_g, worst
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_fused_cat3_backward_balanced_launch_equals_the_chunk_grid(hip_device, p):
+    """stage_cat3_dx_ln_bwd_rag with the balanced work table (persistent workgroups walking segments of equal tile counts,
+    ragged.RaggedTables.work_table) against the (group, chunk) grid (wtab = NULL): db bit for bit (each row is computed by the same
+    code), da / d gamma / d beta to summation order."""
+    from tvqaplus_amd import _lib, ragged
+    from tvqaplus_amd.ops import _stream
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    N, NA, Li, Lqa, D = 5, 5, 37, 40, 128
+    qa = np.zeros((N, NA, Lqa), bool)
+    for n in range(N):
+        for a in range(NA):
+            qa[n, a, :rng.integers(0, Lqa + 1)] = True
+    qa[0, 0, :] = True
+    fl = rng.random((N, Li)) < 0.8
+    tab = ragged.RaggedTables(qa, fl, 4)
+    lay = ragged.RaggedLayout(tab, hip_device)
+    assert lay.wtab is not None and lay.n_wg == lib.stage_cat3_rag_work_groups()
+    U, Fc, G = lay.U, lay.Fc, N * NA
+    g = torch.Generator().manual_seed(5)
+    dy = torch.randn(U, D, generator=g).cuda()
+    mask = torch.randint(-2 ** 31, 2 ** 31 - 1, (D // 32, U), generator=g, dtype=torch.int64).to(torch.int32).cuda()
+    W = (0.08 * torch.randn(D, 3 * D, generator=g)).cuda()
+    a = torch.randn(G * Lqa, D, generator=g).cuda()
+    b_fc = torch.randn(Fc, D, generator=g).cuda()
+    mean = (0.1 * torch.randn(U, generator=g)).cuda(); rstd = (1 + 0.1 * torch.rand(U, generator=g)).cuda()
+    gamma = (1 + 0.1 * torch.randn(3 * D, generator=g)).cuda()
+    wsb = lib.stage_cat3_dx_ln_bwd_rag_ws_bytes(G, Li, Lqa)
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    outs = []
+    for wt in (None, lay.wtab.data_ptr()):
+        da = torch.full((G * Lqa, D), float("nan"), device="cuda"); db = torch.zeros(Fc, D, device="cuda")
+        dg = torch.empty(3 * D, device="cuda"); dbt = torch.empty(3 * D, device="cuda")
+        _lib.check(lib.stage_cat3_dx_ln_bwd_rag(dy.data_ptr(), mask.data_ptr(), W.data_ptr(), a.data_ptr(), b_fc.data_ptr(), mean.data_ptr(),
+                                                rstd.data_ptr(), gamma.data_ptr(), da.data_ptr(), db.data_ptr(), dg.data_ptr(), dbt.data_ptr(),
+                                                lay.gdesc.data_ptr(), wt, U, Fc, D, G, Li, Lqa, p, 4321, ws.data_ptr(), wsb, _stream()), "cf rag")
+        torch.cuda.synchronize()
+        outs.append((da, db, dg, dbt))
+    assert torch.equal(outs[0][1], outs[1][1])
+    for x, y, nm in zip(outs[0], outs[1], ("da", "db", "dgamma", "dbeta")):
+        assert torch.isfinite(y).all(), nm
+        assert float((x - y).abs().max()) <= 2e-5 * float(x.abs().max()) + 1e-6, nm
+    assert float(outs[1][0].abs().max()) > 0

@@ -241,3 +241,41 @@ def test_bucket_plan_covers_every_live_frame_once():
         assert (np.minimum(L, lens[ix] + halo) <= lb).all() and (np.minimum(L, lens[ix] + halo) > lb - step).all()
     assert [lb for _, lb in plan] == sorted(lb for _, lb in plan)
     assert bucket_plan(np.zeros(4, int), L, halo, step) == []
+
+
+def test_work_table_covers_every_atom_once():
+    """RaggedTables.work_table (the balanced launch of the fused [a, b, a*b] backward): every live frame of every group in exactly one
+    segment, quads of frames intact for groups of more than 32 words, segments ordered by workgroup AND by group, per-workgroup tile
+    counts within one atom (<= 5 tiles) of each other."""
+    rng = np.random.default_rng(0)
+    for trial in range(120):
+        N, NA, Li, Lqa = int(rng.integers(1, 6)), int(rng.integers(1, 6)), int(rng.integers(1, 60)), int(rng.integers(4, 41))
+        qa = np.zeros((N, NA, Lqa), bool)
+        for n in range(N):
+            for a in range(NA):
+                qa[n, a, :rng.integers(0, Lqa + 1)] = True
+        fl = rng.random((N, Li)) < rng.random()
+        tab = ragged.RaggedTables(qa, fl, 4)
+        n_wg = int(rng.choice([1, 3, 16, 512]))
+        wt = tab.work_table(n_wg)
+        G = N * NA
+        o1 = ((n_wg + 1) + 3) & ~3
+        o2 = o1 + ((2 * G + 3) & ~3)
+        wf, gseg, seg = wt[:n_wg + 1], wt[o1:o1 + 2 * G].reshape(G, 2), wt[o2:].reshape(-1, 4)
+        assert wf[0] == 0 and wf[-1] == len(seg) and np.all(np.diff(wf) >= 0)
+        frames = np.where(tab.Lc > 0, np.repeat(tab.nlive, NA), 0)
+        cover = [np.zeros(f, int) for f in frames]
+        work = np.zeros(n_wg)
+        for si, (g, f0, f1, w) in enumerate(seg):
+            assert wf[w] <= si < wf[w + 1] and gseg[g, 0] <= si < gseg[g, 0] + gseg[g, 1]
+            assert 0 <= f0 < f1 <= frames[g]
+            if tab.Lc[g] > 32:
+                assert f0 % 4 == 0
+            cover[g][f0:f1] += 1
+            work[w] += (f1 - f0) if tab.Lc[g] <= 32 else 5 * ((f1 - f0 + 3) // 4)
+        for g in range(G):
+            assert np.all(cover[g] == 1)
+            assert gseg[g, 1] == int((seg[:, 0] == g).sum())
+        if len(seg) and n_wg > 1:
+            busy = work[:max(1, int(np.ceil(work.sum() / max(work.max(), 1))))]
+            assert work.max() - work.sum() / n_wg <= 5 + 1e-9

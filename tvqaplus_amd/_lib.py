@@ -148,7 +148,8 @@ SIGNATURES = {
     "stage_cat3_ln_gemm_fwd_rag": (I, [P, P, P, P, P, P, P, P, P, P, P, P, LL, LL, LL, I, F, F, U64, P, SZ, P]),
     "stage_cat3_dx_ln_bwd_rag_supported": (I, [LL, LL, I, I, I, I]),
     "stage_cat3_dx_ln_bwd_rag_ws_bytes": (SZ, [I, I, I]),
-    "stage_cat3_dx_ln_bwd_rag": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, LL, LL, I, I, I, I, F, U64, P, SZ, P]),
+    "stage_cat3_rag_work_groups": (I, []),
+    "stage_cat3_dx_ln_bwd_rag": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, LL, LL, I, I, I, I, F, U64, P, SZ, P]),
     "stage_ln_dwconv_rag_fwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, F, U64, P]),
     "stage_ln_dwconv_rag_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, U64, P, SZ, P]),
     "stage_ln_masked_max_rag_fwd": (I, [P, P, P, P, P, P, P, P, P, P, P, LL, I, I, F, P]),

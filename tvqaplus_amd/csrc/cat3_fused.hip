@@ -29,6 +29,11 @@ namespace {
 constexpr int CF_D = 128;            // the kernel is specialised to hsz = 128 (3D = 384 columns = 12 MFMA tiles)
 constexpr int CF_KS = CF_D / 16;     // k-steps of the 32x32x16 MFMA
 constexpr int CF_WFRAG = 2 * 12 * CF_KS * 64;   // uint4 fragments of the pre-split weight image
+constexpr int CF_RAG_WGS = 512;                 // persistent workgroups of the balanced ragged launch (2 per CU on 256 CUs)
+// work table (int32, tvqaplus_amd/ragged.py: RaggedTables.work_table): [first segment of workgroup w: W + 1 entries, padded to a multiple
+// of 4] [(first slab, slabs) of every group: 2 G] [segments (group, first frame, end frame, workgroup): 4 each]
+#define CF_WTAB_GSEG(W) ((((W) + 1) + 3) & ~3)
+#define CF_WTAB_SEG(W, G) (CF_WTAB_GSEG(W) + ((2 * (G) + 3) & ~3))
 
 // Weight image: Wimg[plane][column tile ct < 12][k-step ks < 8][lane] = the 8 fp16 of B-operand lane (col = 32 ct + (lane & 31),
 // k = 16 ks + 8 (lane >> 5) + e) of W[k][col]  (W = the Linear's (D, 3D) weight: dz = dy_gated . W).  One workgroup.
@@ -89,7 +94,8 @@ __global__ __launch_bounds__(256, 2) void cf_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ gamma, float* __restrict__ da,
                                                         float* __restrict__ db, float* __restrict__ part, long M, int rep, int inner,
                                                         int CH, int frames_per_chunk, uint64_t seed, uint32_t th, float inv_keep,
-                                                        const int4* __restrict__ gdesc, long b_rows, long a_rows) {
+                                                        const int4* __restrict__ gdesc, long b_rows, long a_rows,
+                                                        const int* __restrict__ wtab = nullptr) {
     constexpr bool REP = MODE > 0;
     constexpr bool RAG = MODE == 3;
     // LDS: A planes [ks][plane][lane] uint4 (16 KB) | row scale exponent fields [32] | row mean / rstd [32][2] | partial row
@@ -114,31 +120,22 @@ __global__ __launch_bounds__(256, 2) void cf_bwd_kernel(const float* __restrict_
     const __amdgpu_buffer_rsrc_t rs_db = __builtin_amdgcn_make_buffer_rsrc((void*)db, 0, (int)((RAG ? b_rows : M) * CF_D * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_da = __builtin_amdgcn_make_buffer_rsrc((void*)da, 0, REP ? 0 : (int)(M * CF_D * 4), 0x00020000);
     // work of this workgroup.  REP: frames [f_beg, f_end) of group g; else tiles blockIdx.x, + gridDim.x, ...
+    // RAG with a work table (wtab, tvqaplus_amd/ragged.py: RaggedTables.work_table): the workgroup is one of CF_RAG_WGS persistent
+    // ones and walks its SEGMENTS seg[s_beg .. s_end) = (group, first frame, end frame, .) -- equal tile counts per workgroup whatever
+    // the groups' live frames and word counts are (the (group, chunk) grid left 23 % of the kernel to the last round of workgroups)
     const long GR = REP ? (long)rep * inner : 0;
     int g = 0, f_beg = 0, f_end = 0;
-    long n_tiles;
+    long n_tiles = 0;
     long rg_row0 = 0, rg_seq0 = 0;                        // RAG: first compact row / first frame-compact sequence of the group
     int rg_lc = 0;                                        //      live words per frame
     bool rg_big = false;
-    if (REP) {
-        g = blockIdx.x / CH;
-        const int ch = blockIdx.x % CH;
-        f_beg = ch * frames_per_chunk;
-        int frames = rep;
-        if (RAG) {
-            const int4 gd = gdesc[g];
-            rg_row0 = __builtin_amdgcn_readfirstlane(gd.x);
-            rg_lc = __builtin_amdgcn_readfirstlane(gd.y);
-            frames = rg_lc > 0 ? __builtin_amdgcn_readfirstlane(gd.z) - 1 : 0;
-            rg_seq0 = __builtin_amdgcn_readfirstlane(gd.w);
-            rg_big = rg_lc > 32;
-        }
-        f_end = min(frames, f_beg + frames_per_chunk);
-        const int nf = max(f_end - f_beg, 0);
-        n_tiles = (MODE == 1 || (RAG && !rg_big)) ? nf : 5l * ((nf + 3) / 4);
-    } else {
-        const long all = (M + 31) / 32;
-        n_tiles = all > (long)blockIdx.x ? (all - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const bool persistent = RAG && wtab != nullptr;
+    int s_beg = 0, s_end = 1;
+    const int4* segs = nullptr;
+    if (persistent) {
+        s_beg = __builtin_amdgcn_readfirstlane(wtab[blockIdx.x]);
+        s_end = __builtin_amdgcn_readfirstlane(wtab[blockIdx.x + 1]);
+        segs = reinterpret_cast<const int4*>(wtab + CF_WTAB_SEG(gridDim.x, (int)(a_rows / inner)));
     }
     const int c = 32 * wave + l31;                        // this lane's column inside each third
     float gm[3], ag[3] = {0.f, 0.f, 0.f}, ab[3] = {0.f, 0.f, 0.f};
@@ -159,7 +156,67 @@ __global__ __launch_bounds__(256, 2) void cf_bwd_kernel(const float* __restrict_
 #pragma unroll
     for (int r = 0; r < 16; r++) dacc[r] = 0.f;
 
-    for (long it = 0; it < n_tiles; it++) {
+    // One loop over the tiles of all segments (a nested segment / tile loop made the allocator spill 39 registers): the segment
+    // switch -- slab of the finished segment out, descriptors of the next one in -- is a uniform branch at the head of an iteration,
+    // where only the persistent accumulators are live
+    auto write_slab = [&](int slab) {                     // da slab [inner][D] of a (group, chunk of frames) / segment
+        float* dst = da + (size_t)slab * inner * CF_D;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int pos = 8 * (r >> 2) + (r & 3) + h4;
+            if (pos < min(inner, 32)) dst[pos * CF_D + c] = dacc[r];
+        }
+        if (MODE == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) dst[(32 + r + h4) * CF_D + c] = dacc_rest[r];
+        }
+        if (RAG) {                                        // every one of the Lqa (<= 40) positions is written: zeros past the live words
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (32 + r + h4 < inner) dst[(32 + r + h4) * CF_D + c] = dacc_rest[r];
+        }
+    };
+    int sg = s_beg - 1;                                   // current segment (persistent) -- s_beg - 1: none yet
+    long it = 0;
+    for (;;) {
+        if (it >= n_tiles) {                              // (uniform) next segment
+            if (REP && sg >= s_beg) {
+                write_slab(persistent ? sg : (int)blockIdx.x);
+#pragma unroll
+                for (int r = 0; r < 16; r++) dacc[r] = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; r++) dacc_rest[r] = 0.f;
+            }
+            if (++sg >= s_end) break;
+            it = 0;
+            if (REP) {
+                int frames = rep;
+                if (persistent) {
+                    const int4 sd = segs[sg];
+                    g = __builtin_amdgcn_readfirstlane(sd.x);
+                    f_beg = __builtin_amdgcn_readfirstlane(sd.y);
+                    f_end = __builtin_amdgcn_readfirstlane(sd.z);
+                } else {
+                    g = blockIdx.x / CH;
+                    f_beg = (blockIdx.x % CH) * frames_per_chunk;
+                }
+                if (RAG) {
+                    const int4 gd = gdesc[g];
+                    rg_row0 = __builtin_amdgcn_readfirstlane(gd.x);
+                    rg_lc = __builtin_amdgcn_readfirstlane(gd.y);
+                    frames = rg_lc > 0 ? __builtin_amdgcn_readfirstlane(gd.z) - 1 : 0;
+                    rg_seq0 = __builtin_amdgcn_readfirstlane(gd.w);
+                    rg_big = rg_lc > 32;
+                }
+                if (!persistent) f_end = min(frames, f_beg + frames_per_chunk);
+                const int nf = max(f_end - f_beg, 0);
+                n_tiles = (MODE == 1 || (RAG && !rg_big)) ? nf : 5l * ((nf + 3) / 4);
+            } else {
+                const long all = (M + 31) / 32;
+                n_tiles = all > (long)blockIdx.x ? (all - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+            }
+            continue;
+        }
         // ---- the tile: four passes of 8 rows; pass p covers rows pb[p] .. pb[p] + nv[p] - 1 (uniform values) ----
         long pb[4];
         long pbB[4];                                      // the same passes in the rows of b / db (RAG: frame-compact rows)
@@ -423,33 +480,31 @@ __global__ __launch_bounds__(256, 2) void cf_bwd_kernel(const float* __restrict_
                 if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
+        it++;
     }
     // ---- column partials of d gamma / d beta: the two lane halves hold different rows of the same columns ----
     float* prow = part + (size_t)blockIdx.x * 2 * K3;
 #pragma unroll
     for (int t = 0; t < 3; t++) {
-        const float sg = xsum32(ag[t], ag[t]), sb = xsum32(ab[t], ab[t]);
+        const float sg2 = xsum32(ag[t], ag[t]), sb = xsum32(ab[t], ab[t]);
         if (h == 0) {
-            prow[t * CF_D + c] = sg;
+            prow[t * CF_D + c] = sg2;
             prow[K3 + t * CF_D + c] = sb;
         }
     }
-    if (REP) {                                            // da slab [G][CH][inner][D] of this (group, chunk of frames)
-        float* dst = da + (size_t)blockIdx.x * inner * CF_D;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int pos = 8 * (r >> 2) + (r & 3) + h4;
-            if (pos < min(inner, 32)) dst[pos * CF_D + c] = dacc[r];
-        }
-        if (MODE == 2) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) dst[(32 + r + h4) * CF_D + c] = dacc_rest[r];
-        }
-        if (RAG) {                                        // every one of the Lqa (<= 40) positions is written: zeros past the live words
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-                if (32 + r + h4 < inner) dst[(32 + r + h4) * CF_D + c] = dacc_rest[r];
-        }
+}
+
+// out[g][e] = sum of the slabs gseg[g] = (first, count) in order (zeros for a group without a slab); e < inner_elems (multiple of 4)
+__global__ __launch_bounds__(256) void cf_reduce_seg_kernel(const float* __restrict__ in, float* __restrict__ out, const int2* __restrict__ gseg,
+                                                            long groups, long inner4) {
+    const long total = groups * inner4;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long g = e / inner4, q = e % inner4;
+        const int2 gs = gseg[g];
+        const float* p = in + ((long)gs.x * inner4 + q) * 4;
+        float4 acc = f4zero();
+        for (int r = 0; r < gs.y; r++) acc = f4add(acc, ld4(p + (long)r * inner4 * 4));
+        st4(out + e * 4, acc);
     }
 }
 
@@ -552,21 +607,27 @@ extern "C" int stage_cat3_dx_ln_bwd_rag_supported(long long rows, long long fc_r
 extern "C" size_t stage_cat3_dx_ln_bwd_rag_ws_bytes(int groups, int max_frames, int Lqa) {
     int CH, fpc;
     cf_chunks(groups, max_frames, 2, &CH, &fpc);
-    const size_t wg = (size_t)groups * CH;
+    size_t wg = (size_t)groups * CH;
+    if (wg < (size_t)CF_RAG_WGS + groups) wg = (size_t)CF_RAG_WGS + groups;      // the balanced launch: <= CF_RAG_WGS + groups slabs
     size_t b = cf_align((size_t)CF_WFRAG * sizeof(uint4)) + 256;
     b += cf_align(wg * 2 * 3 * CF_D * sizeof(float));
     b += cf_align(wg * (size_t)Lqa * CF_D * sizeof(float));
     return b;
 }
+extern "C" int stage_cat3_rag_work_groups(void) { return CF_RAG_WGS; }
 // As stage_cat3_dx_ln_bwd with a broadcast `a`, on ragged token rows: dy / relu_mask / mean / rstd are compact (rows), b_fc and db_fc
 // rows of the frame-compact tensor (fc_rows; db_fc may be b_fc itself), a and da (groups, Lqa, D); gdesc: see cf_bwd_kernel MODE 3.
+// wtab (may be NULL: one workgroup per (group, chunk of max_frames)): the balanced work table for stage_cat3_rag_work_groups()
+// workgroups (layout: CF_WTAB_* above; built by tvqaplus_amd/ragged.py from the same lengths as gdesc).
 extern "C" int stage_cat3_dx_ln_bwd_rag(const float* dy, const unsigned* relu_mask, const float* W, const float* a, const float* b_fc,
                                         const float* mean, const float* rstd, const float* gamma, float* da, float* db_fc,
-                                        float* dgamma, float* dbeta, const int* gdesc, long long rows, long long fc_rows, int D,
-                                        int groups, int max_frames, int Lqa, float p_drop, unsigned long long seed, void* ws,
+                                        float* dgamma, float* dbeta, const int* gdesc, const int* wtab, long long rows, long long fc_rows,
+                                        int D, int groups, int max_frames, int Lqa, float p_drop, unsigned long long seed, void* ws,
                                         size_t ws_bytes, void* stream) {
     if (!stage_cat3_dx_ln_bwd_rag_supported(rows, fc_rows, D, groups, max_frames, Lqa)) return STAGE_ERR_SHAPE;
     if (ws_bytes < stage_cat3_dx_ln_bwd_rag_ws_bytes(groups, max_frames, Lqa)) return STAGE_ERR_WORKSPACE;
+    static const bool no_balance = getenv("STAGE_CF_NO_BALANCE") != nullptr;     // developer switch: the (group, chunk) grid
+    if (no_balance) wtab = nullptr;
     hipStream_t st = (hipStream_t)stream;
     char* wsp = (char*)ws;
     uint4* img = (uint4*)wsp;
@@ -578,21 +639,27 @@ extern "C" int stage_cat3_dx_ln_bwd_rag(const float* dy, const unsigned* relu_ma
     const int K3 = 3 * CF_D;
     int CH, fpc;
     cf_chunks(groups, max_frames, 2, &CH, &fpc);
-    const int grid = groups * CH;
+    const int grid = wtab ? CF_RAG_WGS : groups * CH;
+    const size_t slabs = wtab ? (size_t)CF_RAG_WGS + groups : (size_t)grid;
     float* part = (float*)wsp;
-    wsp += cf_align((size_t)grid * 2 * K3 * sizeof(float));
-    float* da_out = (float*)wsp;                               // slabs [G][CH][Lqa][D]
+    wsp += cf_align(slabs * 2 * K3 * sizeof(float));
+    float* da_out = (float*)wsp;                               // slabs [G][CH][Lqa][D] / one per segment
     const size_t lds = (size_t)CF_KS * 2 * 64 * 16 + (size_t)32 * (4 + 8 + 32);
 #define CF_LAUNCH3(DR)                                                                                                                \
     hipLaunchKernelGGL((cf_bwd_kernel<DR, 3>), dim3(grid), dim3(256), lds, st, dy, relu_mask, img, w_up, a, b_fc, mean, rstd, gamma,    \
                        da_out, db_fc, part, (long)rows, max_frames, Lqa, CH, fpc, (uint64_t)seed, th, inv_keep, (const int4*)gdesc,    \
-                       (long)fc_rows, (long)groups * Lqa)
+                       (long)fc_rows, (long)groups * Lqa, wtab)
     if (p_drop > 0.f) CF_LAUNCH3(true); else CF_LAUNCH3(false);
 #undef CF_LAUNCH3
     STAGE_LAUNCH_CHECK();
     stage_colreduce2(part, dgamma, 2 * K3, K3, part + K3, dbeta, 2 * K3, K3, grid, st);
     STAGE_LAUNCH_CHECK();
-    return stage_reduce_rep(da_out, da, groups, CH, (long long)Lqa * CF_D, st);
+    if (!wtab) return stage_reduce_rep(da_out, da, groups, CH, (long long)Lqa * CF_D, st);
+    const long inner4 = (long)Lqa * CF_D / 4;
+    hipLaunchKernelGGL(cf_reduce_seg_kernel, dim3(stage_grid_for((long long)groups * inner4, 256, 4096)), dim3(256), 0, st, da_out, da,
+                       reinterpret_cast<const int2*>(wtab + CF_WTAB_GSEG(CF_RAG_WGS)), (long)groups, inner4);
+    STAGE_LAUNCH_CHECK();
+    return 0;
 }
 
 // =====================================================================================================================

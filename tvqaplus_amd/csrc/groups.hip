@@ -668,6 +668,7 @@ extern "C" int stage_grp_temporal_head_bwd(const float* d_first, const float* d_
 //     T[1] gdesc  (N*NA, 4): first compact row, live words Lc, slots, first frame-compact sequence
 //     T[2] seq    (S, 4): first compact row, length, group g, dense output row g*Li + i         (one per (group, live frame))
 //     T[3] rowinfo (U, 4) from stage_rag_rowinfo
+//     T[5] wtab   balanced work table of the fused [a, b, a*b] backward (stage_cat3_dx_ln_bwd_rag), or NULL
 //     T[4] cq     (N*Li, 2) or NULL: the context stream itself is ragged -- frame f = rows cq[f].x .. + cq[f].y - 1 of ctx / d_ctx
 //                 (Uc rows in all: its valid words / regions + the halo of the input encoder's convolutions); NULL: dense (N, Li, Lr, D)
 // G3r  as G3; `mixed` is (U, D) compact, S_raw / S_norm stay dense.  The backward overwrites the arena's copy of the attention
@@ -754,8 +755,8 @@ extern "C" int stage_grp_qa_ctx_rag_bwd(const float* d_mixed, const float* dS_ex
     // weight / bias gradient of the Linear (contracts over the saved normalised concat), then its input gradient fused with the
     // LayerNorm backward: da accumulated over the live frames, db written over the attention output it came from
     TRY(lin_bwd(d_mixed, a.z, mixed, a.mask, 1, 1, P[2], t.wt, nullptr, G[2], G[3], U, D, 3 * D, t.ws, t.wsb, st));
-    TRY(stage_cat3_dx_ln_bwd_rag(d_mixed, a.mask, P[2], qa, a.A, a.mean, a.rstd, P[0], d_qa, a.A, G[0], G[1], T[1], U, Fc, D, N * NA, Li, Lqa,
-                                 p, seeds[2], t.ws, stage_cat3_dx_ln_bwd_rag_ws_bytes(N * NA, Li, Lqa), st));
+    TRY(stage_cat3_dx_ln_bwd_rag(d_mixed, a.mask, P[2], qa, a.A, a.mean, a.rstd, P[0], d_qa, a.A, G[0], G[1], T[1], T[5], U, Fc, D, N * NA, Li,
+                                 Lqa, p, seeds[2], t.ws, stage_cat3_dx_ln_bwd_rag_ws_bytes(N * NA, Li, Lqa), st));
     TRY(stage_rag_zero_dump(a.A, T[0], N, NA, Li, Lqa, D, st));
     TRY(stage_l2norm_fwd(ctx, t.Qn, nullptr, Qrows, D, EPS_L2, p, seeds[1], st));
     TRY(stage_str_attn_bwd_fused_fc(a.A, dS_ext, a.Cn, ctx, t.Qn, S_norm, ctx_mask, d_ctx, t.dQn, t.dCn, T[0], T[4], N, NA, Li, Lqa, Lr, D, scale,

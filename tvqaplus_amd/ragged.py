@@ -81,6 +81,45 @@ class RaggedTables:
                              g_of_s * Li + frame_of_slot[n_of_g[g_of_s], li_of_s]], axis=1).astype(np.int32)
         self.seqfc = (fcseq0[g_of_s] + li_of_s).astype(np.int32)
 
+    def work_table(self, n_wg: int) -> np.ndarray:
+        """Balanced work table of the fused [a, b, a*b] backward (csrc/cat3_fused.hip: cf_bwd_kernel MODE 3 with ``wtab``) for
+        ``n_wg`` persistent workgroups: int32 [first segment of workgroup w: n_wg + 1 entries, padded to a multiple of 4]
+        [(first slab, slabs) of every group][segments (group, first frame, end frame, workgroup)].
+        The kernel walks a group frame by frame (Lc <= 32: one 32-row tile per frame) or in quads of frames (Lc > 32: five tiles per
+        four frames); an ATOM is one such step, its cost 4 / 20 quarter-tiles.  All atoms, in (group, frame) order, are cut into
+        n_wg runs of equal cost; a run that crosses a group boundary becomes several segments.  Every atom belongs to the run its
+        midpoint falls into, so each is computed exactly once and a run is within half an atom of the mean; segments are in (workgroup, group) = (group, workgroup) order:
+        the slabs of one group are consecutive."""
+        G = self.N * self.NA
+        frames = np.where(self.Lc > 0, np.repeat(self.nlive, self.NA), 0).astype(np.int64)
+        big = self.Lc > 32
+        step = np.where(big, 4, 1).astype(np.int64)
+        cost = np.where(big, 20, 4).astype(np.int64)
+        atoms = (frames + step - 1) // step
+        P = np.concatenate([[0], np.cumsum(atoms * cost)])
+        W = int(P[-1])
+        wg_first = np.zeros(n_wg + 1, dtype=np.int64)
+        gseg = np.zeros((G, 2), dtype=np.int64)
+        seg = np.zeros((0, 4), dtype=np.int64)
+        if W > 0:
+            T = (W + n_wg - 1) // n_wg
+            cuts = np.unique(np.concatenate([P[:-1][atoms > 0], np.arange(n_wg, dtype=np.int64) * T]))
+            cuts = cuts[cuts < W]
+            ends = np.concatenate([cuts[1:], [W]])
+            g = np.searchsorted(P, cuts, side="right") - 1
+            w = cuts // T
+            # atom k of group g covers the cost units [P_g + k c, P_g + (k + 1) c): it goes to the run that holds its MIDPOINT
+            k0 = np.maximum(0, (2 * (cuts - P[g]) - cost[g] + 2 * cost[g] - 1) // (2 * cost[g]))
+            k1 = np.minimum(atoms[g], np.maximum(0, (2 * (ends - P[g]) - cost[g] + 2 * cost[g] - 1) // (2 * cost[g])))
+            keep = k1 > k0
+            g, w, k0, k1 = g[keep], w[keep], k0[keep], k1[keep]
+            seg = np.stack([g, k0 * step[g], np.minimum(frames[g], k1 * step[g]), w], axis=1)
+            wg_first = np.searchsorted(w, np.arange(n_wg + 1), side="left")
+            gseg[:, 0] = np.searchsorted(g, np.arange(G), side="left")
+            gseg[:, 1] = np.searchsorted(g, np.arange(G), side="right") - gseg[:, 0]
+        pad4 = lambda a: np.concatenate([a, np.zeros((-a.size) % 4, dtype=a.dtype)])
+        return np.concatenate([pad4(wg_first), pad4(gseg.reshape(-1)), seg.reshape(-1)]).astype(np.int32)
+
     # ---- reference semantics of the layouts (tests; never on the product path) ------------------------------------
     def compact_index(self) -> np.ndarray:
         """(U, 4) int64: (n, a, i, w) of every compact row, in order."""
@@ -115,7 +154,12 @@ class RaggedLayout:
         self.N, self.NA, self.Li, self.Lqa = tab.N, tab.NA, tab.Li, tab.Lqa
         self.U, self.S, self.Fc = tab.U, tab.S, tab.Fc
         self.Ucap = max(CAP_STEP, _align(tab.U, CAP_STEP))
-        parts = [tab.fmap, tab.gdesc.reshape(-1), tab.seq.reshape(-1), tab.seqfc]
+        self.n_wg = 0
+        wtab = np.zeros(0, dtype=np.int32)
+        if torch.device(device).type == "cuda":
+            self.n_wg = int(_lib.load().stage_cat3_rag_work_groups())
+            wtab = tab.work_table(self.n_wg)
+        parts = [tab.fmap, tab.gdesc.reshape(-1), tab.seq.reshape(-1), tab.seqfc, wtab]
         offs, total = [], 0
         for p in parts:
             offs.append(total)
@@ -135,6 +179,7 @@ class RaggedLayout:
         self.gdesc = self.tables[offs[1]: offs[1] + tab.gdesc.size]
         self.seq = self.tables[offs[2]: offs[2] + tab.seq.size]
         self.seqfc = self.tables[offs[3]: offs[3] + tab.seqfc.size]
+        self.wtab = self.tables[offs[4]: offs[4] + wtab.size] if wtab.size else None
         self.rowinfo = torch.empty(max(self.U, 1) * 4, dtype=torch.int32, device=device)
         if self.tables.is_cuda and self.S > 0:
             from .ops import _stream
@@ -148,9 +193,10 @@ class RaggedLayout:
         return self.N * self.NA * self.Li      # the pooled encoder group writes one row per (example, candidate, frame)
 
     def tables5(self, ctx: Optional["CtxLayout"]):
-        """Table pointers of the attention group: fmap, gdesc, seq, rowinfo + the context stream's frame table (or NULL)."""
-        return (ctypes.c_void_p * 5)(self.fmap.data_ptr(), self.gdesc.data_ptr(), self.seq.data_ptr(), self.rowinfo.data_ptr(),
-                                     None if ctx is None else ctx.cq.data_ptr())
+        """Table pointers of the attention group: fmap, gdesc, seq, rowinfo, the context stream's frame table (or NULL), the balanced
+        work table of the fused [a, b, a*b] backward (or NULL)."""
+        return (ctypes.c_void_p * 6)(self.fmap.data_ptr(), self.gdesc.data_ptr(), self.seq.data_ptr(), self.rowinfo.data_ptr(),
+                                     None if ctx is None else ctx.cq.data_ptr(), None if self.wtab is None else self.wtab.data_ptr())
 
     @property
     def live_fraction(self) -> float:
