@@ -31,6 +31,17 @@
 #define FD 128          // row width (floats)
 #define FLDQ 132        // padded LDS row of the raw region tile
 #define FUS_MAX_WGS 1024
+// Phase 1 on fp16 pairs (round 4; finding 39): the two products of phase 1 -- dP^T = Q . dA^T and dCn^T += Qn^T . G^T -- run on
+// v_mfma_f32_16x16x32_f16 with every fp32 operand split into hi + lo (three products per fp32 product: 5.3 x the rate of the fp32
+// matrix instructions they replace).  Q / Qn^T sit in LDS as two fp16 planes each, written once per frame by the staging pass; dA and
+// G are split in registers by the lane that owns the context row.  Power-of-two scales: Q one per frame (largest magnitude through an
+// LDS atomic max between the two staging halves), Qn fixed 2^14 (its rows are unit vectors), dA one per context row and frame, G one
+// per context row that only ever grows over the frames of a workgroup (the dCn accumulators are rescaled when it does: TN-GEMM rule).
+#ifndef FUS_P1_F16
+#define FUS_P1_F16 1
+#endif
+#define FQLD 136        // halfs per row of a Q plane: 272 B -- the 16 rows of a ds_read_b128 lane group sit on 16 different 16-byte slots
+#define FUS_UP_QN 141   // scale field (biased exponent) of the Qn planes: 2^14
 #define FUS_TABLE_BYTES(G, N) ((((size_t)(G) * sizeof(int4) + (size_t)(N) * sizeof(int2)) + 255) & ~(size_t)255)
 #define FUS_FRAME_BYTES(N, Li) (((size_t)(N) * (size_t)(Li) + 255) & ~(size_t)255)   // one byte per frame (fus_ext_scan_kernel)
 #ifndef FUS_ABL
@@ -112,9 +123,158 @@ __device__ __forceinline__ void fus_p1_fetch(FusTile<NRT, HAS_EXT>& T, const TD*
         }
 }
 
+#if FUS_P1_F16
+// phase 1, one 16-row context tile, fp16-pair products.  Qp: the two Q planes [plane][Lr][FQLD] halfs; Tp: the two Qn^T planes
+// [plane][128][LT] halfs; upQ: scale field of this frame's Q planes; geb: running exponent of |G| of this lane's context row
+// (all four lanes of a row agree); dcn accumulates in units of 2^(FUS_UP_QN + field(geb) - 254).
 template <int RT, int NRT, bool HAS_EXT, int PT = NRT, bool LDSA = false>
 __device__ __forceinline__ void fus_p1_tile(const FusTile<PT, HAS_EXT>& T, const float* Qr, const float* QnT, float* Gs, int c,
-                                            bool cvalid, int Lr, float scale, f32x4 (&dcn)[8], int c15, int g,
+                                            bool cvalid, int Lr, float scale, f32x4 (&dcn)[8], int c15, int g, int upQ, int& geb,
+                                            float* dAs = nullptr, int CRr = 0) {
+    constexpr int LT = FusLay<RT>::LT, LG = FusLay<RT>::LG;
+    const char* Qp = reinterpret_cast<const char*>(Qr);
+    const char* Tp = reinterpret_cast<const char*>(QnT);
+    float4 gl[8];      // dA fragments: context row c15, floats 4*fchunk(g, m) .. +3 = this lane's 32 consecutive floats 32 sigma(g) ..
+    if (LDSA) {        // coalesced rows -> LDS copy (kept for phase 2) -> this wave's fragments; no barrier: its own rows
+        const int lane = c15 + 16 * g, tile0 = c - c15;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int row = tile0 + 2 * i + (lane >> 5);
+            if (row < CRr) st4(&dAs[row * FD + ((4 * (lane & 31)) ^ fswz(row))], T.gv[i]);
+        }
+        const int rr = min(c, CRr - 1);           // padded context rows alias the last one (their columns are discarded)
+#pragma unroll
+        for (int m = 0; m < 8; m++) gl[m] = ld4(&dAs[rr * FD + ((4 * fchunk(g, m)) ^ fswz(rr))]);
+    } else {
+#pragma unroll
+        for (int m = 0; m < 8; m++) gl[m] = T.gv[m];
+    }
+    // ---- dA row -> B operands: K-block kb = floats 8 kb .. 8 kb + 7 of the lane's 32 (k-slot (g, e) <-> d = 32 sigma(g) + 8 kb + e) ----
+    float am = 0.f;
+#pragma unroll
+    for (int m = 0; m < 8; m++) am = h_amax3(h_amax3(am, gl[m].x, gl[m].y), gl[m].z, gl[m].w);
+    am = cross_row_max(am);
+    const int up_c = h_up_field((int)(__float_as_uint(am) >> 23) & 0xff);
+    const float sc_c = __uint_as_float((unsigned)up_c << 23);
+    uint4 bh[4], bl[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) {
+        h_split2(gl[2 * kb].x, gl[2 * kb].y, sc_c, bh[kb].x, bl[kb].x);
+        h_split2(gl[2 * kb].z, gl[2 * kb].w, sc_c, bh[kb].y, bl[kb].y);
+        h_split2(gl[2 * kb + 1].x, gl[2 * kb + 1].y, sc_c, bh[kb].z, bl[kb].z);
+        h_split2(gl[2 * kb + 1].z, gl[2 * kb + 1].w, sc_c, bh[kb].w, bl[kb].w);
+    }
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) {
+        h_operands_ready(bh[kb].x, bh[kb].y, bh[kb].z, bh[kb].w);
+        h_operands_ready(bl[kb].x, bl[kb].y, bl[kb].z, bl[kb].w);
+    }
+    // ---- dP^T tile (regions x ctx) = Q . dA^T ----
+    f32x4 acc[NRT];
+    const int plq = Lr * FQLD * 2;                            // bytes of one Q plane
+    const int qoff = (4 * fchunk(g, 0)) * 2;                  // this lane group's 32-float slice of a Q row
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++) {
+        acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const char* qr = Qp + min(rt * 16 + c15, Lr - 1) * (FQLD * 2) + qoff;   // pad rows alias the last region (P = 0 there)
+#pragma unroll
+        for (int kb = 0; kb < 4; kb++) {
+            const sf16x8 ah = __builtin_bit_cast(sf16x8, *reinterpret_cast<const uint4*>(qr + 16 * kb));
+            const sf16x8 al = __builtin_bit_cast(sf16x8, *reinterpret_cast<const uint4*>(qr + plq + 16 * kb));
+            const sf16x8 vbh = __builtin_bit_cast(sf16x8, bh[kb]), vbl = __builtin_bit_cast(sf16x8, bl[kb]);
+            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, vbh, acc[rt], 0, 0, 0);
+            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, vbl, acc[rt], 0, 0, 0);
+            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, vbh, acc[rt], 0, 0, 0);
+        }
+    }
+    // dP[c][r = rt*16 + 4g + k] in true units
+    const int dpe = 254 - upQ - up_c;
+    float p[NRT][4], dp[NRT][4], dot = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++) {
+        const bool rok0 = rt * 16 + 4 * g < Lr, rok1 = rt * 16 + 4 * g + 2 < Lr;
+        p[rt][0] = rok0 ? T.pq[rt][0].x : 0.f;
+        p[rt][1] = rok0 ? T.pq[rt][0].y : 0.f;
+        p[rt][2] = rok1 ? T.pq[rt][1].x : 0.f;
+        p[rt][3] = rok1 ? T.pq[rt][1].y : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            dp[rt][k] = __builtin_ldexpf(acc[rt][k], dpe);
+            dot += p[rt][k] * dp[rt][k];
+        }
+    }
+    dot = cross_row_sum(dot);
+    f32x4 G[NRT];
+    float gm = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++) {
+        const bool rok0 = rt * 16 + 4 * g < Lr, rok1 = rt * 16 + 4 * g + 2 < Lr;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float v = scale * p[rt][k] * (dp[rt][k] - dot);
+            if (HAS_EXT) {
+                const float e = k == 0 ? T.eq[rt][0].x : (k == 1 ? T.eq[rt][0].y : (k == 2 ? T.eq[rt][1].x : T.eq[rt][1].y));
+                v += (k < 2 ? rok0 : rok1) ? e : 0.f;
+            }
+            G[rt][k] = v;
+        }
+        gm = h_amax3(h_amax3(gm, G[rt][0], G[rt][1]), G[rt][2], G[rt][3]);
+        if (cvalid) *reinterpret_cast<f32x4*>(&Gs[c * LG + gcol<RT>(c, rt * 16 + 4 * g)]) = G[rt];
+    }
+    // ---- G^T of the row -> B operands of dCn^T += Qn^T . G^T: K-block p = region tiles 2p, 2p + 1, k-slot (g, e) <-> region
+    // 16 (2p + (e >> 2)) + 4 g + (e & 3) -- exactly the values this lane holds.  Running scale of the row (TN-GEMM rule). ----
+    gm = cross_row_max(gm);
+    {
+        const int ec = (int)(__float_as_uint(gm) >> 23) & 0xff;
+        const int neb = ec > geb + 3 ? ec : geb;
+        const int d = h_up_field(neb) - h_up_field(geb);
+        geb = neb;
+        if (__any(d != 0)) {                                  // this row's scale moved: bring its accumulators along
+#pragma unroll
+            for (int dt = 0; dt < 8; dt++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) dcn[dt][k] = __builtin_ldexpf(dcn[dt][k], d);
+        }
+    }
+    const float sc_g = __uint_as_float((unsigned)h_up_field(geb) << 23);
+    constexpr int NKB = (NRT + 1) / 2;
+    uint4 gh[NKB], gq[NKB];
+#pragma unroll
+    for (int pb = 0; pb < NKB; pb++) {
+        h_split2(G[2 * pb][0], G[2 * pb][1], sc_g, gh[pb].x, gq[pb].x);
+        h_split2(G[2 * pb][2], G[2 * pb][3], sc_g, gh[pb].y, gq[pb].y);
+        if (2 * pb + 1 < NRT) {
+            h_split2(G[(2 * pb + 1) < NRT ? 2 * pb + 1 : 0][0], G[(2 * pb + 1) < NRT ? 2 * pb + 1 : 0][1], sc_g, gh[pb].z, gq[pb].z);
+            h_split2(G[(2 * pb + 1) < NRT ? 2 * pb + 1 : 0][2], G[(2 * pb + 1) < NRT ? 2 * pb + 1 : 0][3], sc_g, gh[pb].w, gq[pb].w);
+        } else {
+            gh[pb].z = gh[pb].w = gq[pb].z = gq[pb].w = 0u;   // odd tile count: the upper half of the last K-block is zero
+        }
+        h_operands_ready(gh[pb].x, gh[pb].y, gh[pb].z, gh[pb].w);
+        h_operands_ready(gq[pb].x, gq[pb].y, gq[pb].z, gq[pb].w);
+    }
+    const int plt = FD * LT * 2;                              // bytes of one Qn^T plane
+#pragma unroll
+    for (int pb = 0; pb < NKB; pb++) {
+        const sf16x8 vgh = __builtin_bit_cast(sf16x8, gh[pb]), vgl = __builtin_bit_cast(sf16x8, gq[pb]);
+#pragma unroll
+        for (int dt = 0; dt < 8; dt++) {
+            const char* tr = Tp + ((dt * 16 + c15) * LT + 32 * pb + 4 * g) * 2;
+            // (odd tile count: the upper half of the last K-block is not read -- behind the last row it would leave the plane)
+            const bool up = 2 * pb + 1 < NRT;
+            const uint2 h0 = *reinterpret_cast<const uint2*>(tr), h1 = up ? *reinterpret_cast<const uint2*>(tr + 32) : make_uint2(0u, 0u);
+            const uint2 l0 = *reinterpret_cast<const uint2*>(tr + plt), l1 = up ? *reinterpret_cast<const uint2*>(tr + plt + 32) : make_uint2(0u, 0u);
+            const sf16x8 ah = __builtin_bit_cast(sf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+            const sf16x8 al = __builtin_bit_cast(sf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+            dcn[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, vgh, dcn[dt], 0, 0, 0);
+            dcn[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, vgl, dcn[dt], 0, 0, 0);
+            dcn[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, vgh, dcn[dt], 0, 0, 0);
+        }
+    }
+}
+#else
+template <int RT, int NRT, bool HAS_EXT, int PT = NRT, bool LDSA = false>
+__device__ __forceinline__ void fus_p1_tile(const FusTile<PT, HAS_EXT>& T, const float* Qr, const float* QnT, float* Gs, int c,
+                                            bool cvalid, int Lr, float scale, f32x4 (&dcn)[8], int c15, int g, int upQ, int& geb,
                                             float* dAs = nullptr, int CRr = 0) {
     constexpr int LT = FusLay<RT>::LT, LG = FusLay<RT>::LG;
     float4 gl[8];      // dA fragments in MFMA layout: context row c15, floats 4*fchunk(g, m) .. +3
@@ -206,6 +366,8 @@ __device__ __forceinline__ void fus_p1_tile(const FusTile<PT, HAS_EXT>& T, const
                 }
         }
 }
+
+#endif   // FUS_P1_F16
 
 // ---------------------------------------------------------------------------------------------------------------------
 // phase 2: this wave's d block (E floats per lane: 64-wide for 4-wave workgroups, 32-wide for 8-wave ones) of dQraw (RAW)
@@ -429,7 +591,8 @@ __device__ __forceinline__ void fus_frame(const TD* __restrict__ dA, const float
                                           long frame, int n, int i, int NA, int Li, int Lqa, int Lr, float scale,
                                           const unsigned (&orel)[16 / NW], int ntiles, f32x4 (&dcn)[16 / NW][8], int wave, int lane,
                                           unsigned long long* tim, unsigned long long (&tacc)[6], unsigned long long& tlast,
-                                          const unsigned (&orelA)[16 / NW], long arow0, int LiA, long qrow0, int Lrs) {
+                                          const unsigned (&orelA)[16 / NW], long arow0, int LiA, long qrow0, int Lrs, int upQ,
+                                          int (&geb)[16 / NW]) {
     constexpr int TPW = 16 / NW, E = NW == 4 ? 4 : 2;
     const int CR = NA * Lqa;
     // c15 / g re-derived from an opaque copy of the lane id per frame: hoisted out of the frame loop, the address
@@ -450,10 +613,10 @@ __device__ __forceinline__ void fus_frame(const TD* __restrict__ dA, const float
                 const int c = (wave + NW * s) * 16 + c15;
                 if (s & 1) {
                     if (s + 1 < TPW && s + 1 < ntiles) fus_p1_fetch<NRT, HAS_EXT, LDSA, TD>(Ta, dAf, Snf, extf, orel[s + 1 < TPW ? s + 1 : 0], orelA[s + 1 < TPW ? s + 1 : 0], Lr, g, wave + NW * (s + 1), l, NA, LiA, Lqa);
-                    fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(Tb, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, dAs, CR);
+                    fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(Tb, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, upQ, geb[s], dAs, CR);
                 } else {
                     if (s + 1 < TPW && s + 1 < ntiles) fus_p1_fetch<NRT, HAS_EXT, LDSA, TD>(Tb, dAf, Snf, extf, orel[s + 1 < TPW ? s + 1 : 0], orelA[s + 1 < TPW ? s + 1 : 0], Lr, g, wave + NW * (s + 1), l, NA, LiA, Lqa);
-                    fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(Ta, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, dAs, CR);
+                    fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(Ta, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, upQ, geb[s], dAs, CR);
                 }
             }
         }
@@ -464,7 +627,7 @@ __device__ __forceinline__ void fus_frame(const TD* __restrict__ dA, const float
                 const int c = (wave + NW * s) * 16 + c15;
                 FusTile<NRT, HAS_EXT> T;
                 fus_p1_fetch<NRT, HAS_EXT, LDSA, TD>(T, dAf, Snf, extf, orel[s], orelA[s], Lr, g, wave + NW * s, l, NA, LiA, Lqa);
-                fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(T, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, dAs, CR);
+                fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(T, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, upQ, geb[s], dAs, CR);
             }
         }
     }
@@ -503,10 +666,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OC
     constexpr int LT = FusLay<RT>::LT, TPW = 16 / NW, NT = 64 * NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int CR = NA * Lqa, CT = (CR + 15) >> 4;
+#if FUS_P1_F16
+    float* Qr = lds;                                  // [2 planes][Lr][FQLD] halfs   raw regions, hi / lo (reads of pad rows are clamped to the last region)
+    float* QnT = Qr + Lr * FQLD;                      // [2 planes][128][LT] halfs    normalised regions, transposed, pad columns zero
+#else
     float* Qr = lds;                                  // [Lr][FLDQ]     raw regions (reads of pad rows are clamped to the last region)
     float* QnT = Qr + Lr * FLDQ;                      // [128][LT]      normalised regions, transposed, pad columns zero
+#endif
     float* Gs = QnT + FusLay<RT>::QT_FLOATS;          // [CR][LG]       dS of the frame
     float* dAs = Gs + CR * FusLay<RT>::LG;            // [CR][128]      dA of the frame (LDSA: phase 2 re-reads it from here)
+    // two words behind everything else: largest |Q| of the frame being staged (float bits, LDS atomic max), alternating per frame
+    unsigned* qmx = reinterpret_cast<unsigned*>(dAs + (LDSA ? CR * FD : 0));
     // work assignment from the schedule kernel: example n, frames chunk, chunk + nchunks, ... (workgroups are dealt to the
     // examples in proportion to their non-empty frames)
     const int4 job = sched[blockIdx.x];
@@ -514,7 +684,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OC
     if (n < 0) return;
 
     for (int e = tid; e < FusLay<RT>::QT_FLOATS; e += NT) QnT[e] = 0.f;
+#if FUS_P1_F16
+    for (int e = tid; e < Lr * FQLD; e += NT) Qr[e] = 0.f;            // rows a frame does not have keep what an earlier frame left: finite
+    if (tid < 2) qmx[tid] = 0u;
+    int geb[TPW];                                                     // running |G| exponent of this lane's context rows (fus_p1_tile)
+#pragma unroll
+    for (int s = 0; s < TPW; s++) geb[s] = 0;
+    int par = 0;
+#else
     if (cq) for (int e = tid; e < Lr * FLDQ; e += NT) Qr[e] = 0.f;    // rows a frame does not have keep what an earlier frame left: finite
+    int geb[TPW] = {};
+#endif
+    int upQ = 254;
 
     // this wave's context tiles (phase 1): slot s -> tile wave + NW*s
     unsigned orel[TPW], orelA[TPW];   // row offset of context row c inside a frame's row block: a*Li*Lqa + w (score maps) / a*LiA*Lqa + w (dA)
@@ -564,6 +745,56 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OC
             continue;
         }
         // ---- stage the frame's regions ----
+#if FUS_P1_F16
+        {
+            float4 vq[NST], vn[NST];
+            float qm = 0.f;
+#pragma unroll
+            for (int s = 0; s < NST; s++) {
+                const int u = wave + NW * s;
+                const int r = 8 * (u >> 2) + (lane & 7), q = 8 * (u & 3) + (lane >> 3);
+                if (u < UNITS && r < Lrs) {
+                    vq[s] = ldv4(Q + (qrow0 + r) * FD + 4 * q);
+                    vn[s] = ldv4(Qn + (qrow0 + r) * FD + 4 * q);
+                } else {
+                    vq[s] = vn[s] = f4zero();
+                }
+                qm = h_amax3(h_amax3(qm, vq[s].x, vq[s].y), vq[s].z, vq[s].w);
+            }
+            qm = wave_max(qm);
+            if (lane == 0) atomicMax(&qmx[par], __float_as_uint(qm));     // (non-negative floats order like their bit patterns)
+            __syncthreads();
+            upQ = h_up_field((int)(qmx[par] >> 23) & 0xff);
+            if (tid == 0) qmx[par ^ 1] = 0u;                               // the next frame's word: last read before the barrier above
+            par ^= 1;
+            const float sq = __uint_as_float((unsigned)upQ << 23), sn = __uint_as_float((unsigned)FUS_UP_QN << 23);
+            char* Qp = reinterpret_cast<char*>(Qr);
+            unsigned short* Th = reinterpret_cast<unsigned short*>(QnT);
+            unsigned short* Tl = Th + FD * LT;
+#pragma unroll
+            for (int s = 0; s < NST; s++) {
+                const int u = wave + NW * s;
+                const int r = 8 * (u >> 2) + (lane & 7), q = 8 * (u & 3) + (lane >> 3);
+                if (u < UNITS && r < Lrs) {
+                    uint2 qh, ql, nh, nl;
+                    h_split2(vq[s].x, vq[s].y, sq, qh.x, ql.x);
+                    h_split2(vq[s].z, vq[s].w, sq, qh.y, ql.y);
+                    h_split2(vn[s].x, vn[s].y, sn, nh.x, nl.x);
+                    h_split2(vn[s].z, vn[s].w, sn, nh.y, nl.y);
+                    *reinterpret_cast<uint2*>(Qp + (r * FQLD + 4 * q) * 2) = qh;
+                    *reinterpret_cast<uint2*>(Qp + (Lr * FQLD + r * FQLD + 4 * q) * 2) = ql;
+                    Th[(4 * q + 0) * LT + r] = (unsigned short)(nh.x & 0xffffu);
+                    Th[(4 * q + 1) * LT + r] = (unsigned short)(nh.x >> 16);
+                    Th[(4 * q + 2) * LT + r] = (unsigned short)(nh.y & 0xffffu);
+                    Th[(4 * q + 3) * LT + r] = (unsigned short)(nh.y >> 16);
+                    Tl[(4 * q + 0) * LT + r] = (unsigned short)(nl.x & 0xffffu);
+                    Tl[(4 * q + 1) * LT + r] = (unsigned short)(nl.x >> 16);
+                    Tl[(4 * q + 2) * LT + r] = (unsigned short)(nl.y & 0xffffu);
+                    Tl[(4 * q + 3) * LT + r] = (unsigned short)(nl.y >> 16);
+                }
+            }
+        }
+#else
 #pragma unroll
         for (int s = 0; s < NST; s++) {
             const int u = wave + NW * s;
@@ -578,6 +809,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OC
                 QnT[(4 * q + 3) * LT + r] = vn.w;
             }
         }
+#endif
         TICK(0);
         __syncthreads();
         TICK(1);
@@ -590,7 +822,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OC
         const long arow0 = (afirst + aslot) * Lqa;
 #define FUS_FRAME(NRTV)                                                                                                  \
     fus_frame<RT, (NRTV) <= RT ? (NRTV) : RT, NW, HAS_EXT, (OCC == 2 && NW == 8), LDSA, TD>(dA, ext, Cn, Sn, Qr, QnT, Gs, dAs, dQraw, dQn, frame, n, i, NA, Li, \
-                                                         Lqa, Lr, scale, orel, ntiles, dcn, wave, lane, tim, tacc, tlast, orelA, arow0, LiA, qrow0, Lrs)
+                                                         Lqa, Lr, scale, orel, ntiles, dcn, wave, lane, tim, tacc, tlast, orelA, arow0, LiA, qrow0, Lrs, upQ, geb)
         if (RT == 1 || nrt == 1) FUS_FRAME(1);
         else if (RT == 2 || nrt == 2) FUS_FRAME(2);
         else if (RT == 3 || nrt == 3) FUS_FRAME(3);
@@ -607,6 +839,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OC
         const int c = (wave + NW * s) * 16 + (lane & 15);
         if (s < ntiles && c < CR) {
             float* dst = part + ((size_t)blockIdx.x * CR + c) * FD + 4 * (lane >> 4);
+#if FUS_P1_F16
+            const int de = 254 - FUS_UP_QN - h_up_field(geb[s]);          // back to true units
+#pragma unroll
+            for (int dt = 0; dt < 8; dt++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) dcn[s][dt][k] = __builtin_ldexpf(dcn[s][dt][k], de);
+#endif
 #pragma unroll
             for (int dt = 0; dt < 8; dt++)
                 st4(dst + dt * 16, make_float4(dcn[s][dt][0], dcn[s][dt][1], dcn[s][dt][2], dcn[s][dt][3]));
@@ -768,7 +1007,7 @@ static int fus_launch(const TD* dA, const float* ext, const float* Cn, const TD*
     STAGE_LAUNCH_CHECK();
     hipLaunchKernelGGL(fus_schedule_kernel, dim3(1), dim3(256), (3 * N + 1) * sizeof(int), st, N, Li, G, sched, per_n);
     STAGE_LAUNCH_CHECK();
-    const size_t base = ((size_t)Lr * FLDQ + FusLay<RT>::QT_FLOATS + (size_t)CR * FusLay<RT>::LG) * sizeof(float);
+    const size_t base = ((size_t)Lr * (FUS_P1_F16 ? FQLD : FLDQ) + FusLay<RT>::QT_FLOATS + (size_t)CR * FusLay<RT>::LG) * sizeof(float) + 16;
     const size_t with_da = base + (size_t)CR * FD * sizeof(float);
     // dA of a frame stays in LDS between the phases when it fits (the video shape) and the uniform phase 2 applies
     static const bool no_ldsa = getenv("STAGE_K1_BWD_NOLDSA") != nullptr;   // developer switch
