@@ -938,3 +938,39 @@ def test_exact_fp32_gemm_fallback_runs_the_suite():
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout
+
+
+@pytest.mark.parametrize("Lr", [20, 50])
+def test_k1_backward_fp16_pairs_are_fp32_class(ops, Lr):
+    """The fused K1 backward runs all four products as fp16 pairs (hi + lo, three matrix instructions per fp32 product) under
+    power-of-two scales per context row / per frame; against an fp64 evaluation of the oracle its gradients must be as accurate as the
+    three-kernel fp32 path on the same inputs -- with output gradients whose rows differ by e^+-4 in magnitude (what the scales are for)."""
+    from tvqaplus_amd.synth import make_batch
+    N, Li, Lqa, D = 2, 12, 40, 128
+    g = torch.Generator().manual_seed(7 + Lr)
+    b = make_batch(N=N, Li=Li, Lr=Lr, Lw=2, Lqa=Lqa, wd_size=4, vfeat_size=4, seed=3)
+    C = torch.randn(N, 5, 1, Lqa, D, generator=g)
+    Q = torch.randn(N, 1, Li, Lr, D, generator=g) * 2
+    cm, qm = b.qas_mask.view(N, 5, 1, Lqa), b.vid_mask.view(N, 1, Li, Lr)
+    gA = torch.randn(N, 5, Li, Lqa, D, generator=g) * torch.exp(2 * torch.randn(N, 5, Li, Lqa, 1, generator=g))
+    Cc, Qc = C.double().requires_grad_(), Q.double().requires_grad_()
+    Ao, _, _, _ = O.structured_attention(Cc, Qc, cm.double(), qm.double(), 10.0)
+    (Ao * gA.double()).sum().backward()
+
+    def run(unfused):
+        old = ops._K1_BWD_UNFUSED
+        ops._K1_BWD_UNFUSED = unfused
+        try:
+            Cd, Qd = dev(C.view(N, 5, Lqa, D), True), dev(Q.view(N, Li, Lr, D), True)
+            A, _, _ = ops.structured_attention(Cd, Qd, cm.view(N, 5, Lqa).cuda(), qm.view(N, Li, Lr).cuda(), 10.0)
+            (A * gA.cuda()).sum().backward()
+            return Cd.grad.cpu().double().view_as(Cc.grad), Qd.grad.cpu().double().view_as(Qc.grad)
+        finally:
+            ops._K1_BWD_UNFUSED = old
+
+    err = {}
+    for name, unf in (("fused", False), ("three", True)):
+        dC, dQ = run(unf)
+        err[name] = (float((dC - Cc.grad).abs().max() / Cc.grad.abs().max()), float((dQ - Qc.grad).abs().max() / Qc.grad.abs().max()))
+    assert err["fused"][0] < 2e-6 and err["fused"][1] < 2e-6, err
+    assert err["fused"][0] <= 2 * err["three"][0] + 1e-7 and err["fused"][1] <= 2 * err["three"][1] + 1e-7, err

@@ -20,7 +20,7 @@ def put(name, text):
 
 
 for n in ("bench_line.json", "bench_line_dense.json", "bench_line_stress.json", "bench_kernel_trace_stats.txt", "bf16_storage_bench_line.json",
-          "bf16_storage_bench_kernel_trace_stats.txt", "bench_line_dense_rows.json", "bench_line_heads4.json", "heads4_bench_kernel_trace_stats.txt"):
+          "bf16_storage_bench_kernel_trace_stats.txt", "bench_line_dense_rows.json", "bench_line_heads4.json", "heads4_bench_kernel_trace_stats.txt", "stress_kernel_trace_stats.txt"):
     src = os.path.join(G, "%s_%s" % (TAG, n))
     if os.path.exists(src):
         shutil.copy(src, os.path.join(P, "%s_%s" % (TAG, n)))

@@ -40,6 +40,15 @@
 #ifndef FUS_P1_F16
 #define FUS_P1_F16 1
 #endif
+// Phase 2 on fp16 pairs as well (needs FUS_P1_F16; Lqa a multiple of 8, 8-wave workgroups): dQraw = P^T . dA and dQn = G^T . Cn contract
+// over the context rows, so a lane's 8-element operand is 8 consecutive context rows of one column -- eight strided loads, the same
+// number as the k-steps of 4 they replace -- and both operands carry ONE scale per frame: P <= 1 and |Cn| <= 1 / keep are fixed,
+// dA and G use the frame's largest magnitude, published by phase 1 through LDS atomic maxima.
+#ifndef FUS_P2_F16
+#define FUS_P2_F16 FUS_P1_F16
+#endif
+#define FUS_UP_P 141    // 2^14: P = S_ <= 1
+#define FUS_UP_CN 139   // 2^12: |Cn| <= 1 / (1 - p_drop) < 4
 #define FQLD 136        // halfs per row of a Q plane: 272 B -- the 16 rows of a ds_read_b128 lane group sit on 16 different 16-byte slots
 #define FUS_UP_QN 141   // scale field (biased exponent) of the Qn planes: 2^14
 #define FUS_TABLE_BYTES(G, N) ((((size_t)(G) * sizeof(int4) + (size_t)(N) * sizeof(int2)) + 255) & ~(size_t)255)
@@ -130,7 +139,7 @@ __device__ __forceinline__ void fus_p1_fetch(FusTile<NRT, HAS_EXT>& T, const TD*
 template <int RT, int NRT, bool HAS_EXT, int PT = NRT, bool LDSA = false>
 __device__ __forceinline__ void fus_p1_tile(const FusTile<PT, HAS_EXT>& T, const float* Qr, const float* QnT, float* Gs, int c,
                                             bool cvalid, int Lr, float scale, f32x4 (&dcn)[8], int c15, int g, int upQ, int& geb,
-                                            float* dAs = nullptr, int CRr = 0) {
+                                            float* dAs = nullptr, int CRr = 0, unsigned* fmx = nullptr) {
     constexpr int LT = FusLay<RT>::LT, LG = FusLay<RT>::LG;
     const char* Qp = reinterpret_cast<const char*>(Qr);
     const char* Tp = reinterpret_cast<const char*>(QnT);
@@ -154,6 +163,10 @@ __device__ __forceinline__ void fus_p1_tile(const FusTile<PT, HAS_EXT>& T, const
 #pragma unroll
     for (int m = 0; m < 8; m++) am = h_amax3(h_amax3(am, gl[m].x, gl[m].y), gl[m].z, gl[m].w);
     am = cross_row_max(am);
+    if (FUS_P2_F16 && fmx) {                                  // phase 2 splits dA under ONE scale per frame: its largest magnitude
+        const float wm = wave_max(am);
+        if (c15 == 0 && g == 0) atomicMax(&fmx[0], __float_as_uint(wm));
+    }
     const int up_c = h_up_field((int)(__float_as_uint(am) >> 23) & 0xff);
     const float sc_c = __uint_as_float((unsigned)up_c << 23);
     uint4 bh[4], bl[4];
@@ -224,6 +237,10 @@ __device__ __forceinline__ void fus_p1_tile(const FusTile<PT, HAS_EXT>& T, const
     // ---- G^T of the row -> B operands of dCn^T += Qn^T . G^T: K-block p = region tiles 2p, 2p + 1, k-slot (g, e) <-> region
     // 16 (2p + (e >> 2)) + 4 g + (e & 3) -- exactly the values this lane holds.  Running scale of the row (TN-GEMM rule). ----
     gm = cross_row_max(gm);
+    if (FUS_P2_F16 && fmx) {                                  // ... and G
+        const float wm = wave_max(gm);
+        if (c15 == 0 && g == 0) atomicMax(&fmx[1], __float_as_uint(wm));
+    }
     {
         const int ec = (int)(__float_as_uint(gm) >> 23) & 0xff;
         const int neb = ec > geb + 3 ? ec : geb;
@@ -275,7 +292,7 @@ __device__ __forceinline__ void fus_p1_tile(const FusTile<PT, HAS_EXT>& T, const
 template <int RT, int NRT, bool HAS_EXT, int PT = NRT, bool LDSA = false>
 __device__ __forceinline__ void fus_p1_tile(const FusTile<PT, HAS_EXT>& T, const float* Qr, const float* QnT, float* Gs, int c,
                                             bool cvalid, int Lr, float scale, f32x4 (&dcn)[8], int c15, int g, int upQ, int& geb,
-                                            float* dAs = nullptr, int CRr = 0) {
+                                            float* dAs = nullptr, int CRr = 0, unsigned* fmx = nullptr) {
     constexpr int LT = FusLay<RT>::LT, LG = FusLay<RT>::LG;
     float4 gl[8];      // dA fragments in MFMA layout: context row c15, floats 4*fchunk(g, m) .. +3
     if (LDSA) {        // coalesced rows -> LDS copy (kept for phase 2) -> this wave's MFMA fragments; no barrier: its own rows
@@ -583,6 +600,138 @@ __device__ __forceinline__ void fus_p2_unif(const TD* __restrict__ dAf, const fl
         }
 }
 
+#if FUS_P2_F16
+// phase 2, fp16 pairs: this wave's 32-wide d block (d = d0 + e, e < 2; d0 = 32 (wave % 4) + 2 c15) of dQraw (RAW: A = P from global,
+// B = dA from its LDS copy or global) or dQn (A = G from LDS, B = Cn), contraction over the context rows in K-blocks of 32
+// (k-slot (g, j) <-> row 32 kb + 8 g + j).  fA / fB: scale fields of the two operands.
+template <int RT, int NRT, bool RAW, bool LDSA, typename TD>
+__device__ __forceinline__ void fus_p2_f16(const TD* __restrict__ dAf, const float* __restrict__ Snf, const float* __restrict__ Cnn,
+                                           const float* Gs, float* __restrict__ outf, int NA, int Li, int Lqa, int Lr, int d0, int c15,
+                                           int g, const float* dAs, int LiA, int Lrs, int fA, int fB) {
+    constexpr int LG = FusLay<RT>::LG;
+    const int CR = NA * Lqa, nkb = (CR + 31) >> 5;
+    f32x4 acc[NRT][2];
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) acc[rt][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float sA = __uint_as_float((unsigned)fA << 23), sB = __uint_as_float((unsigned)fB << 23);
+    int colA[NRT];
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++) colA[rt] = min(rt * 16 + c15, Lr - 1);
+    // one K-block ahead: the B rows (8 x float2) and the row base of the A columns; the A values of a region tile are requested one
+    // tile ahead of their split (a full double buffer of A -- 8 NRT registers more -- spills)
+    struct RawB { float2 b[8]; };
+    auto rows = [&](int kb, bool& ok, int& cc, int& an, int& w) {
+        const int c0 = 32 * kb + 8 * g;                   // 8 rows of one answer (Lqa % 8 == 0): valid or past the end as a whole
+        ok = c0 < CR;
+        cc = ok ? c0 : 0;
+        an = cc / Lqa;
+        w = cc - an * Lqa;
+    };
+    auto fetch_b = [&](RawB& R, int kb) {
+        bool ok; int cc, an, w;
+        rows(kb, ok, cc, an, w);
+        if (RAW) {
+            if (LDSA) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) R.b[j] = ld2(&dAs[(cc + j) * FD + (d0 ^ fswz(cc + j))]);
+            } else {
+                const TD* pb = dAf + (long)(an * LiA * Lqa + w) * FD + d0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) R.b[j] = fus_ldv<2>(pb + j * FD);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) R.b[j] = ld2(Cnn + (long)(cc + j) * FD + d0);
+        }
+    };
+    auto fetch_a = [&](float (&a)[8], int kb, int rt) {
+        bool ok; int cc, an, w;
+        rows(kb, ok, cc, an, w);
+        if (RAW) {
+            const float* pa = Snf + (long)(an * Li * Lqa + w) * Lr + colA[rt < NRT ? rt : 0];
+#pragma unroll
+            for (int j = 0; j < 8; j++) a[j] = pa[j * Lr];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) a[j] = Gs[(cc + j) * LG + gcol<RT>(cc + j, (rt < NRT ? rt : 0) * 16 + c15)];
+        }
+    };
+    auto split_b = [&](const RawB& R, uint4 (&bh)[2], uint4 (&bl)[2]) {
+        h_split2(R.b[0].x, R.b[1].x, sB, bh[0].x, bl[0].x);
+        h_split2(R.b[2].x, R.b[3].x, sB, bh[0].y, bl[0].y);
+        h_split2(R.b[4].x, R.b[5].x, sB, bh[0].z, bl[0].z);
+        h_split2(R.b[6].x, R.b[7].x, sB, bh[0].w, bl[0].w);
+        h_split2(R.b[0].y, R.b[1].y, sB, bh[1].x, bl[1].x);
+        h_split2(R.b[2].y, R.b[3].y, sB, bh[1].y, bl[1].y);
+        h_split2(R.b[4].y, R.b[5].y, sB, bh[1].z, bl[1].z);
+        h_split2(R.b[6].y, R.b[7].y, sB, bh[1].w, bl[1].w);
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            h_operands_ready(bh[e].x, bh[e].y, bh[e].z, bh[e].w);
+            h_operands_ready(bl[e].x, bl[e].y, bl[e].z, bl[e].w);
+        }
+    };
+    {
+        RawB B0, B1;
+        float a0[8], a1[8];
+        fetch_b(B0, 0);
+        fetch_a(a0, 0, 0);
+#pragma unroll 1
+        for (int kb = 0; kb < nkb; kb++) {
+            const bool more = kb + 1 < nkb;
+            if (more) fetch_b(B1, kb + 1);
+            uint4 bh[2], bl[2];
+            split_b(B0, bh, bl);
+            const float sa = (32 * kb + 8 * g < CR) ? sA : 0.f;            // rows past the end: the A operand is zero
+#pragma unroll
+            for (int rt = 0; rt < NRT; rt++) {
+                // the A values of the next tile (or of tile 0 of the next K-block) are requested before this tile is multiplied
+                if (rt + 1 < NRT) fetch_a((rt & 1) ? a0 : a1, kb, rt + 1);
+                else if (more) fetch_a((rt & 1) ? a0 : a1, kb + 1, 0);
+                const float (&av)[8] = (rt & 1) ? a1 : a0;
+                uint4 ah, al;
+                h_split2(av[0], av[1], sa, ah.x, al.x);
+                h_split2(av[2], av[3], sa, ah.y, al.y);
+                h_split2(av[4], av[5], sa, ah.z, al.z);
+                h_split2(av[6], av[7], sa, ah.w, al.w);
+                h_operands_ready(ah.x, ah.y, ah.z, ah.w);
+                h_operands_ready(al.x, al.y, al.z, al.w);
+                const sf16x8 vah = __builtin_bit_cast(sf16x8, ah), val = __builtin_bit_cast(sf16x8, al);
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const sf16x8 vbh = __builtin_bit_cast(sf16x8, bh[e]), vbl = __builtin_bit_cast(sf16x8, bl[e]);
+                    acc[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(val, vbh, acc[rt][e], 0, 0, 0);
+                    acc[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vah, vbl, acc[rt][e], 0, 0, 0);
+                    acc[rt][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vah, vbh, acc[rt][e], 0, 0, 0);
+                }
+            }
+            // (NRT odd: tile 0 of the next block went into the other buffer -- keep the roles aligned)
+            if (NRT & 1) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) { const float t = a0[j]; a0[j] = a1[j]; a1[j] = t; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) B0.b[j] = B1.b[j];
+        }
+    }
+    const int de = 254 - fA - fB;                         // back to true units
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int r = rt * 16 + 4 * g + reg;
+            if (r < Lrs) {
+                constexpr int Z = 0;
+                const int ra = rt < NRT ? rt : Z;
+                st2(outf + r * FD + d0, rt < NRT ? make_float2(__builtin_ldexpf(acc[ra][0][reg], de), __builtin_ldexpf(acc[ra][1][reg], de))
+                                                 : make_float2(0.f, 0.f));
+            }
+        }
+}
+#endif
+
 // one frame: phase 1 over the wave's tiles (slot s -> tile wave + NW*s), barrier, phase 2
 template <int RT, int NRT, int NW, bool HAS_EXT, bool PIPE, bool LDSA, typename TD = float>
 __device__ __forceinline__ void fus_frame(const TD* __restrict__ dA, const float* __restrict__ ext,
@@ -592,7 +741,7 @@ __device__ __forceinline__ void fus_frame(const TD* __restrict__ dA, const float
                                           const unsigned (&orel)[16 / NW], int ntiles, f32x4 (&dcn)[16 / NW][8], int wave, int lane,
                                           unsigned long long* tim, unsigned long long (&tacc)[6], unsigned long long& tlast,
                                           const unsigned (&orelA)[16 / NW], long arow0, int LiA, long qrow0, int Lrs, int upQ,
-                                          int (&geb)[16 / NW]) {
+                                          int (&geb)[16 / NW], unsigned* fmx) {
     constexpr int TPW = 16 / NW, E = NW == 4 ? 4 : 2;
     const int CR = NA * Lqa;
     // c15 / g re-derived from an opaque copy of the lane id per frame: hoisted out of the frame loop, the address
@@ -613,10 +762,10 @@ __device__ __forceinline__ void fus_frame(const TD* __restrict__ dA, const float
                 const int c = (wave + NW * s) * 16 + c15;
                 if (s & 1) {
                     if (s + 1 < TPW && s + 1 < ntiles) fus_p1_fetch<NRT, HAS_EXT, LDSA, TD>(Ta, dAf, Snf, extf, orel[s + 1 < TPW ? s + 1 : 0], orelA[s + 1 < TPW ? s + 1 : 0], Lr, g, wave + NW * (s + 1), l, NA, LiA, Lqa);
-                    fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(Tb, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, upQ, geb[s], dAs, CR);
+                    fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(Tb, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, upQ, geb[s], dAs, CR, fmx);
                 } else {
                     if (s + 1 < TPW && s + 1 < ntiles) fus_p1_fetch<NRT, HAS_EXT, LDSA, TD>(Tb, dAf, Snf, extf, orel[s + 1 < TPW ? s + 1 : 0], orelA[s + 1 < TPW ? s + 1 : 0], Lr, g, wave + NW * (s + 1), l, NA, LiA, Lqa);
-                    fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(Ta, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, upQ, geb[s], dAs, CR);
+                    fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(Ta, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, upQ, geb[s], dAs, CR, fmx);
                 }
             }
         }
@@ -627,7 +776,7 @@ __device__ __forceinline__ void fus_frame(const TD* __restrict__ dA, const float
                 const int c = (wave + NW * s) * 16 + c15;
                 FusTile<NRT, HAS_EXT> T;
                 fus_p1_fetch<NRT, HAS_EXT, LDSA, TD>(T, dAf, Snf, extf, orel[s], orelA[s], Lr, g, wave + NW * s, l, NA, LiA, Lqa);
-                fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(T, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, upQ, geb[s], dAs, CR);
+                fus_p1_tile<RT, NRT, HAS_EXT, NRT, LDSA>(T, Qr, QnT, Gs, c, c < CR, Lr, scale, dcn[s], c15, g, upQ, geb[s], dAs, CR, fmx);
             }
         }
     }
@@ -639,6 +788,14 @@ __device__ __forceinline__ void fus_frame(const TD* __restrict__ dA, const float
     constexpr int UG = (PIPE && NRT == 1) ? 10 : FUS_U;
     const bool unif = (Lqa & 3) == 0 && ((CR >> 2) % UG) == 0;
     if (FUS_ABL & 1) return;
+#if FUS_P2_F16
+    if (E == 2 && (Lqa & 7) == 0) {
+        const int upD = h_up_field((int)(fmx[0] >> 23) & 0xff), upG = h_up_field((int)(fmx[1] >> 23) & 0xff);
+        if (wave < NW / 2) fus_p2_f16<RT, NRT, true, LDSA, TD>(dAf, Snf, nullptr, Gs, dQraw + qrow0 * FD, NA, Li, Lqa, Lr, d0, c15, g, dAs, LiA, Lrs, FUS_UP_P, upD);
+        else fus_p2_f16<RT, NRT, false, false, TD>(dAf, Snf, Cn + (long)n * CR * FD, Gs, dQn + qrow0 * FD, NA, Li, Lqa, Lr, d0, c15, g, nullptr, LiA, Lrs, upG, FUS_UP_CN);
+        return;
+    }
+#endif
     if (unif) {
         if (wave < NW / 2) fus_p2_unif<RT, NRT, E, true, PIPE, LDSA, UG, TD>(dAf, Snf, nullptr, Gs, dQraw + qrow0 * FD, NA, Li, Lqa, Lr, d0, c15, g, dAs, LiA, Lrs);
         else fus_p2_unif<RT, NRT, E, false, PIPE, false, UG, TD>(dAf, Snf, Cn + (long)n * CR * FD, Gs, dQn + qrow0 * FD, NA, Li, Lqa, Lr, d0, c15, g, nullptr, LiA, Lrs);
@@ -686,14 +843,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OC
     for (int e = tid; e < FusLay<RT>::QT_FLOATS; e += NT) QnT[e] = 0.f;
 #if FUS_P1_F16
     for (int e = tid; e < Lr * FQLD; e += NT) Qr[e] = 0.f;            // rows a frame does not have keep what an earlier frame left: finite
-    if (tid < 2) qmx[tid] = 0u;
+    if (tid < 6) qmx[tid] = 0u;                                       // qmx[0..1]: |Q|; qmx[2 + 2 par + k]: |dA| (k = 0), |G| (k = 1) of a frame
     int geb[TPW];                                                     // running |G| exponent of this lane's context rows (fus_p1_tile)
 #pragma unroll
     for (int s = 0; s < TPW; s++) geb[s] = 0;
-    int par = 0;
+    int par = 0, fpar = 0;
 #else
     if (cq) for (int e = tid; e < Lr * FLDQ; e += NT) Qr[e] = 0.f;    // rows a frame does not have keep what an earlier frame left: finite
     int geb[TPW] = {};
+    int fpar = 0;
 #endif
     int upQ = 254;
 
@@ -765,7 +923,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OC
             if (lane == 0) atomicMax(&qmx[par], __float_as_uint(qm));     // (non-negative floats order like their bit patterns)
             __syncthreads();
             upQ = h_up_field((int)(qmx[par] >> 23) & 0xff);
-            if (tid == 0) qmx[par ^ 1] = 0u;                               // the next frame's word: last read before the barrier above
+            if (tid == 0) {                                                // the next frame's words: last read before the barrier above
+                qmx[par ^ 1] = 0u;
+                qmx[2 + 2 * (par ^ 1)] = 0u;
+                qmx[3 + 2 * (par ^ 1)] = 0u;
+            }
+            fpar = par;
             par ^= 1;
             const float sq = __uint_as_float((unsigned)upQ << 23), sn = __uint_as_float((unsigned)FUS_UP_QN << 23);
             char* Qp = reinterpret_cast<char*>(Qr);
@@ -822,7 +985,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(OCC, OC
         const long arow0 = (afirst + aslot) * Lqa;
 #define FUS_FRAME(NRTV)                                                                                                  \
     fus_frame<RT, (NRTV) <= RT ? (NRTV) : RT, NW, HAS_EXT, (OCC == 2 && NW == 8), LDSA, TD>(dA, ext, Cn, Sn, Qr, QnT, Gs, dAs, dQraw, dQn, frame, n, i, NA, Li, \
-                                                         Lqa, Lr, scale, orel, ntiles, dcn, wave, lane, tim, tacc, tlast, orelA, arow0, LiA, qrow0, Lrs, upQ, geb)
+                                                         Lqa, Lr, scale, orel, ntiles, dcn, wave, lane, tim, tacc, tlast, orelA, arow0, LiA, qrow0, Lrs, upQ, geb, qmx + 2 + 2 * fpar)
         if (RT == 1 || nrt == 1) FUS_FRAME(1);
         else if (RT == 2 || nrt == 2) FUS_FRAME(2);
         else if (RT == 3 || nrt == 3) FUS_FRAME(3);
@@ -1007,7 +1170,7 @@ static int fus_launch(const TD* dA, const float* ext, const float* Cn, const TD*
     STAGE_LAUNCH_CHECK();
     hipLaunchKernelGGL(fus_schedule_kernel, dim3(1), dim3(256), (3 * N + 1) * sizeof(int), st, N, Li, G, sched, per_n);
     STAGE_LAUNCH_CHECK();
-    const size_t base = ((size_t)Lr * (FUS_P1_F16 ? FQLD : FLDQ) + FusLay<RT>::QT_FLOATS + (size_t)CR * FusLay<RT>::LG) * sizeof(float) + 16;
+    const size_t base = ((size_t)Lr * (FUS_P1_F16 ? FQLD : FLDQ) + FusLay<RT>::QT_FLOATS + (size_t)CR * FusLay<RT>::LG) * sizeof(float) + 32;
     const size_t with_da = base + (size_t)CR * FD * sizeof(float);
     // dA of a frame stays in LDS between the phases when it fits (the video shape) and the uniform phase 2 applies
     static const bool no_ldsa = getenv("STAGE_K1_BWD_NOLDSA") != nullptr;   // developer switch
