@@ -30,7 +30,7 @@ int main() {
     CK(hipMemcpy(dcm, cm.data(), cm.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dqm, qm.data(), qm.size() * 4, hipMemcpyHostToDevice));
     hipStream_t st;
     CK(hipStreamCreate(&st));
-    if (stage_hip_abi_version() != 3) { std::fprintf(stderr, "ABI version\n"); return 3; }
+    if (stage_hip_abi_version() != STAGE_HIP_ABI_VERSION) { std::fprintf(stderr, "ABI version\n"); return 3; }
     int rc = stage_l2norm_fwd(dC, dCn, nullptr, (long long)N * NA * Lqa, D, 1e-12f, 0.f, 0ull, st);     // the context side, normalised
     if (rc == 0) rc = stage_str_attn_fwd(dCn, dQ, dcm, dqm, dA, dS, dSn, N, NA, Li, Lqa, Lr, D, 10.0f, 0.f, 0ull, st);
     if (rc != 0) { std::fprintf(stderr, "stage_hip: %s\n", stage_hip_error_string(rc)); return 4; }

@@ -27,6 +27,7 @@ extern "C" {
 #define STAGE_ERR_WORKSPACE (-2)  /* workspace too small */
 
 /* ---- library info -------------------------------------------------------------------------------------------- */
+#define STAGE_HIP_ABI_VERSION 3   /* what stage_hip_abi_version() of a matching library returns; bumped whenever a symbol or a signature changes */
 int stage_hip_abi_version(void);
 const char* stage_hip_error_string(int code);
 /* Measurement helpers (bench.py; no reference counterpart): events for hosts without a HIP binding, and a one-shot hook that makes the

@@ -34,7 +34,7 @@ def check(name, got, exp, tol=TOL):
 def ops(hip_device):
     from tvqaplus_amd import ops as _ops
     from tvqaplus_amd import _lib
-    assert _lib.load().stage_hip_abi_version() == 3
+    assert _lib.load().stage_hip_abi_version() == _lib.ABI_VERSION
     return _ops
 
 

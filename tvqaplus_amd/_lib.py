@@ -165,6 +165,8 @@ SIGNATURES = {
     "stage_grp_encoder_rag_bwd": (I, [P, P, P, P, P, P, P, SZ, P, P, SZ, LL, LL, LL, LL, I, I, I, I, F, P, P]),
 }
 
+ABI_VERSION = 3    # include/stage_hip.h: STAGE_HIP_ABI_VERSION (tests/test_abi.py holds the two together)
+
 _lib = None
 
 
@@ -193,6 +195,9 @@ def load() -> ctypes.CDLL:
             raise StageHipError("tvqaplus_amd: symbol %s missing from %s" % (name, LIB_PATH)) from e
         fn.restype = res
         fn.argtypes = args
+    if lib.stage_hip_abi_version() != ABI_VERSION:
+        raise StageHipError("tvqaplus_amd: %s has ABI version %d, this package binds version %d -- rebuild with `make`"
+                            % (LIB_PATH, lib.stage_hip_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 
