@@ -322,7 +322,7 @@ class _QaCtxRag(torch.autograd.Function):
         _, Li, Lr = cx_mask.shape
         Uc = cx.numel() // D                       # rows of the context stream: N * Li * Lr, or its compact rows (clay)
         assert Uc == (clay.U if clay is not None else N * Li * Lr)
-        T5 = lay.tables5(clay)
+        T5 = lay.attention_tables(clay)
         lib = _lib.load()
         ab = _size("stage_grp_qa_ctx_rag_arena_bytes", N, NA, Lqa, D, lay.Ucap, lay.Fc)
         arena = _buf(ab, qa.device)
@@ -362,7 +362,7 @@ class _QaCtxRag(torch.autograd.Function):
         tmp = _buf(tb, qa.device)
         _rc(lib.stage_grp_qa_ctx_rag_bwd(d_mixed.data_ptr(), None if dS is None else dS.data_ptr(), qa.data_ptr(), cx.data_ptr(),
                                          cx_mask.data_ptr(), mixed.data_ptr(), Sn.data_ptr(), _ptrs(params), _ptrs(grads), d_qa.data_ptr(),
-                                         d_cx.data_ptr(), lay.tables5(ctx.clay), arena.data_ptr(), ab, flags, tmp.data_ptr(), tb, N, NA, Li,
+                                         d_cx.data_ptr(), lay.attention_tables(ctx.clay), arena.data_ptr(), ab, flags, tmp.data_ptr(), tb, N, NA, Li,
                                          Lqa, Lr, D, lay.U, lay.Ucap, lay.Fc, Uc, scale, p, _u64(seeds), _stream()),
             "stage_grp_qa_ctx_rag_bwd")
         return (d_qa, d_cx, None, None, None, None, None, None, None) + _deliver(ctx.sinks, grads)

@@ -192,7 +192,7 @@ class RaggedLayout:
     def out_rows(self) -> int:
         return self.N * self.NA * self.Li      # the pooled encoder group writes one row per (example, candidate, frame)
 
-    def tables5(self, ctx: Optional["CtxLayout"]):
+    def attention_tables(self, ctx: Optional["CtxLayout"]):
         """Table pointers of the attention group: fmap, gdesc, seq, rowinfo, the context stream's frame table (or NULL), the balanced
         work table of the fused [a, b, a*b] backward (or NULL)."""
         return (ctypes.c_void_p * 6)(self.fmap.data_ptr(), self.gdesc.data_ptr(), self.seq.data_ptr(), self.rowinfo.data_ptr(),
