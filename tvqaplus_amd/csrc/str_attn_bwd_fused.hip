@@ -35,7 +35,7 @@
 // v_mfma_f32_16x16x32_f16 with every fp32 operand split into hi + lo (three products per fp32 product: 5.3 x the rate of the fp32
 // matrix instructions they replace).  Q / Qn^T sit in LDS as two fp16 planes each, written once per frame by the staging pass; dA and
 // G are split in registers by the lane that owns the context row.  Power-of-two scales: Q one per frame (largest magnitude through an
-// LDS atomic max between the two staging halves), Qn fixed 2^14 (its rows are unit vectors), dA one per context row and frame, G one
+// LDS atomic max between the two staging halves), Qn fixed 2^12 (its rows are unit vectors times the dropout scale), dA one per context row and frame, G one
 // per context row that only ever grows over the frames of a workgroup (the dCn accumulators are rescaled when it does: TN-GEMM rule).
 #ifndef FUS_P1_F16
 #define FUS_P1_F16 1
@@ -50,7 +50,7 @@
 #define FUS_UP_P 141    // 2^14: P = S_ <= 1
 #define FUS_UP_CN 139   // 2^12: |Cn| <= 1 / (1 - p_drop) < 4
 #define FQLD 136        // halfs per row of a Q plane: 272 B -- the 16 rows of a ds_read_b128 lane group sit on 16 different 16-byte slots
-#define FUS_UP_QN 141   // scale field (biased exponent) of the Qn planes: 2^14
+#define FUS_UP_QN 139   // scale field (biased exponent) of the Qn planes: 2^12 (|Qn| <= 1 / (1 - p_drop): room up to p = 0.93)
 #define FUS_TABLE_BYTES(G, N) ((((size_t)(G) * sizeof(int4) + (size_t)(N) * sizeof(int2)) + 255) & ~(size_t)255)
 #define FUS_FRAME_BYTES(N, Li) (((size_t)(N) * (size_t)(Li) + 255) & ~(size_t)255)   // one byte per frame (fus_ext_scan_kernel)
 #ifndef FUS_ABL
