@@ -49,6 +49,10 @@ def parse():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--storage", choices=["fp32", "bf16"], default="fp32",
                     help="bf16: the bf16 storage mode (BASELINE configs[4]); the headline line is the fp32 default")
+    ap.add_argument("--streams", type=int, default=-1, choices=(-1, 0, 1, 2, 3),
+                    help="branch streams of the model (stage.py: use_streams; -1 = its default, 2): 0 one stream, 1 the statement branch on a "
+                         "side stream, 2 + the video input MLP / encoder, 3 + the video attention (fastest; the K1 forward kernels then run "
+                         "next to another branch and their in-step timings stop being a statement about the kernel)")
     ap.add_argument("--fp32_inputs", action="store_true", help="--storage bf16: keep the resident feature tensors fp32 (the model then rounds them "
                     "to bf16 inside every step); default: resident as bf16, the way prefetch.BatchPrefetcher(stage_dtype=bf16) delivers them")
     ap.add_argument("--config", choices=("default", "stress"), default="default",
@@ -381,7 +385,9 @@ def side_records(args):
     * exact_f32: the step with STAGE_GEMM_F32=1 -- every product on v_mfma_f32 (no fp16 pairs, dense rows: the ragged / fused kernels
       are fp16-pair kernels), i.e. what the `dtype: f32` label costs when taken literally;
     * dense: all-ones masks (nothing to skip for the ragged-row layout), with the K1 forward kernels timed inside its steps;
-    * stress: BASELINE.json configs[4] (bf16 storage, hsz 256, 512-word subtitle rows), three steps, with the long-row K1 forward."""
+    * stress: BASELINE.json configs[4] (bf16 storage, hsz 256, 512-word subtitle rows), three steps, with the long-row K1 forward;
+    * one_stream / all_branches: the same step with the model's branch streams off (--streams 0: every kernel on one stream, what
+      rounds 1-3 and the first half of round 4 measured) and fully on (--streams 3: the video attention on its side stream too)."""
     shp = ["--bsz", str(args.bsz), "--frames", str(args.frames), "--regions", str(args.regions), "--qa_words", str(args.qa_words)]
     out = {}
     r = child_bench(shp + ["--sub_words", str(args.sub_words), "--hsz", str(args.hsz), "--steps", "3", "--warmup", "2", "--no_roofline",
@@ -398,6 +404,10 @@ def side_records(args):
                                                             "isolated_avg_us", "isolated_frac", "algorithmic_bytes", "masks", "traffic")}
     else:
         out["dense"] = r
+    for key, lv in (("one_stream", "0"), ("all_branches", "3")):
+        r = child_bench(shp + ["--sub_words", str(args.sub_words), "--hsz", str(args.hsz), "--steps", "10", "--warmup", "4", "--no_roofline",
+                               "--no_device_time", "--streams", lv])
+        out[key] = {"ms_per_step": r["ms_per_step"], "value": r["value"], "streams": int(lv)} if "ms_per_step" in r else r
     r = child_bench(shp + ["--config", "stress", "--steps", "3", "--warmup", "2", "--no_device_time"], timeout=300)
     out["stress"] = ({"ms_per_step": r["ms_per_step"], "value": r["value"], "dtype": r.get("dtype"), "workload": r["config"]["workload"],
                       "peak_hbm_gib": r["config"].get("peak_hbm_gib"), "roofline": r.get("roofline")} if "ms_per_step" in r else r)
@@ -538,6 +548,8 @@ def main():
     with contextlib.redirect_stdout(open(os.devnull, "w")):
         model = STAGE(opt)
     model = model.to(device).train()
+    if args.streams >= 0:
+        model.use_streams = args.streams
     params = [p for p in model.parameters() if p.requires_grad]
     bucket = parallel.FlatGradBucket(params)
     # torch.optim.Adam, as main.py:209; fused=True is the same update as ONE multi-tensor kernel instead of ~10 (--adam foreach =
@@ -698,6 +710,8 @@ def main():
             rec["step_ms_all"] = [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(args.steps)]
         if dev_ms is not None:
             rec["device_ms_per_step"], rec["launches_per_step"] = dev_ms
+            if int(model.use_streams) > 0:
+                rec["device_ms_note"] = "sum of kernel durations: kernels of different branch streams overlap, the sum may exceed the step"
         if not args.no_roofline and args.config == "stress":
             rec["roofline"] = k1_long_roofline(args, device)
         elif not args.no_roofline:   # rank 0's GPU, after the timed region (the other ranks wait at the final barrier)
@@ -754,7 +768,8 @@ def main():
                     r["bytes_this_layout"] = b_here
                     r["achieved_this_layout"] = round(b_here / (r["avg_us"] * 1e-6) / 1e9, 1)
                     r["frac_this_layout"] = round(r["achieved_this_layout"] / 8000.0, 4)
-        rec["config"]["harness"] = {"gc": args.gc, "adam": args.adam, "ragged_rows": lay is not None}
+        rec["config"]["harness"] = {"gc": args.gc, "adam": args.adam, "ragged_rows": lay is not None,
+                                    "branch_streams": int(model.use_streams)}
         if args.storage == "bf16":
             rec["config"]["harness"]["resident_features"] = "fp32" if args.fp32_inputs else "bf16 (as the bf16-staging prefetcher delivers them)"
         if (world == 1 and not args.no_children and args.config == "default" and not args.dense and args.storage == "fp32" and not args.heads

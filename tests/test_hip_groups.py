@@ -285,3 +285,30 @@ def test_fused_cat3_forward_equals_layernorm_plus_gemm(hip_device, rep, inner, G
     bits = lambda k: ((k.unsqueeze(-1) >> torch.arange(32, device="cuda", dtype=torch.int32)) & 1).permute(1, 0, 2).reshape(U, D).bool()
     assert torch.equal(bits(k1), y1 > 0)
     assert float((bits(k0) != bits(k1)).float().mean()) < 1e-4
+
+
+def test_gradient_sink_orders_contributions_across_streams(hip_device):
+    """groups._Sink / _ParamGate (the gradients of modules applied to several branches leave the graph once, summed OUTSIDE autograd's
+    edges): with branch streams the contributions are produced on different streams.  Three streams, each kept busy by a large product in
+    front of its contribution, then the gate's backward on the main stream: the totals must be exact (the unordered version added into
+    accumulators that were still being written)."""
+    import types
+    from tvqaplus_amd import groups
+    big = torch.randn(4096, 4096, device="cuda")
+    for trial in range(8):              # (the unordered version got 3 of 8 trials wrong)
+        sink = groups._Sink(2)
+        streams = [torch.cuda.Stream() for _ in range(3)]
+        main = torch.cuda.current_stream()
+        for k, s in enumerate(streams):
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                x = big @ big                                 # the contribution below is ready late
+                g0 = x[:256, :256] * 0.0 + float(k + 1)
+                g1 = x[:128, :512] * 0.0 + float(10 * (k + 1))
+                sink.add([0, 1], [g0, g1])
+        res = groups._ParamGate.backward(types.SimpleNamespace(sink=sink), None, None)
+        assert res[0] is None
+        torch.cuda.synchronize()
+        assert float(res[1].min()) == float(res[1].max()) == 6.0, (trial, float(res[1].min()), float(res[1].max()))
+        assert float(res[2].min()) == float(res[2].max()) == 60.0, (trial, float(res[2].min()), float(res[2].max()))
+        assert sink.acc == [None, None]

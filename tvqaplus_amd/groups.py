@@ -102,10 +102,34 @@ def _params(params) -> List[torch.Tensor]:
 # ones are added with ONE multi-tensor add per group call) and returns None for it; the gate's own backward -- which autograd
 # runs after every consumer, whatever they returned -- hands the totals to the parameters.
 class _Sink:
+    """The contributions arrive OUTSIDE autograd's graph edges, so autograd does not order them: with branch streams (stage.py:
+    use_streams) the three applications of a shared module run their backward on three streams.  Every access to ``acc`` therefore
+    waits for the event of the previous one on the stream it runs on, records its own, and tells the allocator that the accumulators
+    are in use on that stream (an unordered first version failed one model test in ten)."""
+
     def __init__(self, n: int):
         self.acc: List[Optional[torch.Tensor]] = [None] * n
+        self.ev = None
+
+    def _enter(self, tensors):
+        if not tensors or not tensors[0].is_cuda:
+            return None
+        cur = torch.cuda.current_stream(tensors[0].device)
+        if self.ev is not None:
+            cur.wait_event(self.ev)
+        return cur
+
+    def _leave(self, cur, tensors):
+        if cur is None:
+            return
+        for t in tensors:
+            if t is not None:
+                t.record_stream(cur)
+        self.ev = torch.cuda.Event()
+        self.ev.record(cur)
 
     def add(self, idx: Sequence[int], grads: Sequence[torch.Tensor]):
+        cur = self._enter(list(grads))
         accs, news = [], []
         for i, g in zip(idx, grads):
             if self.acc[i] is None:
@@ -115,6 +139,7 @@ class _Sink:
                 news.append(g)
         if accs:
             torch._foreach_add_(accs, news)
+        self._leave(cur, [self.acc[i] for i in idx])
 
 
 class _ParamGate(torch.autograd.Function):
@@ -129,10 +154,15 @@ class _ParamGate(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gouts):
+        sink = ctx.sink
+        live = [a for a in sink.acc if a is not None]
+        cur = sink._enter(live)
         res = []
-        for a, g in zip(ctx.sink.acc, gouts):     # g: whatever reached the alias through ordinary autograd (a per-kernel fallback)
+        for a, g in zip(sink.acc, gouts):         # g: whatever reached the alias through ordinary autograd (a per-kernel fallback)
             res.append(a if g is None else (g if a is None else a + g))
-        ctx.sink.acc = [None] * len(res)
+        sink._leave(cur, live)
+        sink.acc = [None] * len(res)
+        sink.ev = None
         return (None,) + tuple(res)
 
 

@@ -262,7 +262,7 @@ def cat3_layernorm(a, b, gamma, beta, rep: int = 1, inner: int = 1, p: float = 0
 # ---------------------------------------------------------------------------------------------------------------
 # Linear (+bias, +ReLU) on the matrix cores
 # ---------------------------------------------------------------------------------------------------------------
-_WT_CACHE = {}   # id(weight) -> (data_ptr, version, transposed copy, weakref, epoch); entries die with their weight
+_WT_CACHE = {}   # (id(weight), stream) -> (data_ptr, version, transposed copy, weakref, epoch); entries die with their weight
 _WT_EPOCH = 0
 
 
@@ -283,7 +283,9 @@ def invalidate_weight_cache() -> None:
 def _transposed_weight(w, w2):
     """(K, N) copy of the (N, K) weight for the dX GEMM, cached per weight object for the current step (see ``new_step``)."""
     import weakref
-    key = id(w)
+    # one copy per stream: a shared module's backward runs on the stream of each of its applications (stage.py: branch streams), and a
+    # copy made on one stream is not ordered against a reader on another
+    key = (id(w), torch.cuda.current_stream(w2.device).cuda_stream if w2.is_cuda else 0)
     hit = _WT_CACHE.get(key)
     if (hit is not None and hit[4] == _WT_EPOCH and hit[0] == w2.data_ptr() and hit[1] == w._version
             and hit[2].shape == (w2.shape[1], w2.shape[0])):

@@ -14,6 +14,7 @@ from __future__ import annotations
 import copy
 
 import math
+import contextlib
 import os
 from typing import Dict, List, Optional, Tuple
 
@@ -235,6 +236,15 @@ class STAGE(nn.Module):
         # its Lb positions; dead frames run nowhere (ragged.bucket_plan).  ``last_buckets``: {stream: [(frames, Lb), ...]} of the
         # last forward.  STAGE_NO_CTX_BUCKETS=1 / use_ctx_buckets = False: one dense (frames, L, .) batch, as the reference.
         self.use_ctx_buckets = os.environ.get("STAGE_NO_CTX_BUCKETS") is None
+        # Branch streams (STAGE_STREAMS=0..3 / use_streams; default 2): the three branches of the forward -- statements, subtitles,
+        # video -- are independent up to the attention (statements <-> context) and the fusion (subtitles <-> video).  Level 1 runs the
+        # statement branch (input MLP + encoder over N*5 statements: ~90 latency-bound launches forward + backward, 0.66 ms of device
+        # time that uses a few CUs) on a side stream next to the subtitle branch; level 2 also the video input MLP / encoder; level 3
+        # the video attention as well (two saturating kernels side by side: fastest step, but a kernel's duration is then no statement
+        # about that kernel).  The backward of every op runs on its forward's stream (autograd), so the branches overlap there too.
+        # Joins: events in front of the attention / the fusion; tensors that cross streams are registered with the allocator.
+        self.use_streams = int(os.environ.get("STAGE_STREAMS", "2") or 0)
+        self._side_streams = {}
         self.last_buckets: Dict[str, list] = {}
         self._mask_info = None
         self.last_ragged: Optional[ragged.RaggedLayout] = None
@@ -817,15 +827,27 @@ class STAGE(nn.Module):
                 self._seed_state = None
             self._dropout_rank = int(dr)
         qas_mask = batch.qas_mask.view(N, NA, -1).float()
-        a_embed = self.base_encoder(batch.qas_bert.view(N * NA, -1, self.wd_size), qas_mask.view(N * NA, -1),
-                                    self.bert_word_encoding_fc, self.input_embedding, self.input_encoder)
-        a_embed = a_embed.view(N, NA, -1, D)
+        dev = batch.qas_bert.device
+        streams = int(self.use_streams) if dev.type == "cuda" else 0
+        main = s_qa = s_vid = None
+        if streams:
+            main = torch.cuda.current_stream(dev)
+            if dev not in self._side_streams:
+                self._side_streams[dev] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+            s_qa, s_vid = self._side_streams[dev]
+            s_qa.wait_stream(main)                 # the batch (and last step's parameter update) is ready on the main stream
+        with (torch.cuda.stream(s_qa) if streams else contextlib.nullcontext()):
+            a_embed = self.base_encoder(batch.qas_bert.view(N * NA, -1, self.wd_size), qas_mask.view(N * NA, -1),
+                                        self.bert_word_encoding_fc, self.input_embedding, self.input_encoder)
+            a_embed = a_embed.view(N, NA, -1, D)
         attended_sub = attended_vid = attended_vid_mask = attended_sub_mask = None
         other_outputs: Dict[str, torch.Tensor] = {}
         self._mask_info = None
         lay, clays = self._ragged_layout(batch, qas_mask, a_embed)
         self.last_ragged, self.last_ragged_ctx = lay, clays
         self.last_buckets = {}
+        if streams:
+            s_vid.wait_stream(main)                # the layouts' tables are uploaded / expanded on the main stream
         if self.sub_flag:
             Li, Lw = batch.sub_bert.shape[1:3]
             sub_mask = batch.sub_mask.view(N, Li, Lw).float()
@@ -838,6 +860,9 @@ class STAGE(nn.Module):
             else:
                 sub_embed = self.base_encoder(batch.sub_bert.view(N * Li, Lw, -1), sub_mask.view(N * Li, Lw),
                                               self.bert_word_encoding_fc, self.input_embedding, self.input_encoder, clay=cl)
+            if streams:
+                main.wait_stream(s_qa)             # the statement embedding
+                a_embed.record_stream(main)
             attended_sub, attended_sub_mask, raw, norm = self.qa_ctx_attention(
                 a_embed, sub_embed if cl is not None else sub_embed.view(N, Li, Lw, D), qas_mask, sub_mask, lay, cl)
             other_outputs["sub_normalized_s"], other_outputs["sub_raw_s"] = norm, raw
@@ -846,16 +871,36 @@ class STAGE(nn.Module):
             vid_mask = batch.vid_mask.view(N, Li, Lr).float()
             cl = clays.get("vid")
             plan = self._ctx_buckets(batch, "vid", N, NA, qas_mask.shape[-1], Li, Lr) if cl is None else None
-            if plan is not None:
-                self.last_buckets["vid"] = [(len(ix), lb) for ix, lb in plan]
-                vid_embed = self._base_encoder_buckets(plan, batch.vid.view(N * Li, Lr, -1), vid_mask.view(N * Li, Lr), self.vid_fc,
-                                                       self.input_embedding, self.input_encoder, True)
+            with (torch.cuda.stream(s_vid) if streams >= 2 else contextlib.nullcontext()):
+                if plan is not None:
+                    self.last_buckets["vid"] = [(len(ix), lb) for ix, lb in plan]
+                    vid_embed = self._base_encoder_buckets(plan, batch.vid.view(N * Li, Lr, -1), vid_mask.view(N * Li, Lr), self.vid_fc,
+                                                           self.input_embedding, self.input_encoder, True)
+                else:
+                    vid_embed = self.base_encoder(batch.vid.view(N * Li, Lr, -1), vid_mask.view(N * Li, Lr), self.vid_fc,
+                                                  self.input_embedding, self.input_encoder, l2_normalize=True, clay=cl)
+                if streams >= 3:
+                    s_vid.wait_stream(s_qa)
+                    a_embed.record_stream(s_vid)
+                    attended_vid, attended_vid_mask, raw, norm = self.qa_ctx_attention(
+                        a_embed, vid_embed if cl is not None else vid_embed.view(N, Li, Lr, D), qas_mask, vid_mask, lay, cl)
+            if streams >= 2:
+                main.wait_stream(s_vid)
+            if streams:
+                main.wait_stream(s_qa)
+                a_embed.record_stream(main)
+            if streams >= 3:
+                for t in (attended_vid, attended_vid_mask, raw, norm):
+                    if torch.is_tensor(t):
+                        t.record_stream(main)
             else:
-                vid_embed = self.base_encoder(batch.vid.view(N * Li, Lr, -1), vid_mask.view(N * Li, Lr), self.vid_fc,
-                                              self.input_embedding, self.input_encoder, l2_normalize=True, clay=cl)
-            attended_vid, attended_vid_mask, raw, norm = self.qa_ctx_attention(
-                a_embed, vid_embed if cl is not None else vid_embed.view(N, Li, Lr, D), qas_mask, vid_mask, lay, cl)
+                if streams == 2:
+                    vid_embed.record_stream(main)
+                attended_vid, attended_vid_mask, raw, norm = self.qa_ctx_attention(
+                    a_embed, vid_embed if cl is not None else vid_embed.view(N, Li, Lr, D), qas_mask, vid_mask, lay, cl)
             other_outputs["vid_normalized_s"], other_outputs["vid_raw_s"] = norm, raw
+        elif streams:
+            pass
         if self.flag_cnt == 2:
             fc = self.concat_fc
             z = None
