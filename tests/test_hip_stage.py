@@ -543,3 +543,41 @@ def test_training_trajectory_vs_oracle(hip_device, path):
         assert abs(float(loss) - float(ref_loss)) < TOL * (1 + abs(float(ref_loss))), (step, float(loss), float(ref_loss))
     worst = max((rel_err(p, P[k]), k) for k, p in model.named_parameters())
     assert worst[0] < GTOL, worst
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_branch_streams_change_nothing_but_the_schedule(hip_device, train):
+    """stage.py: use_streams (statement branch / video branch on side streams, DESIGN.md finding 45).  The streams decide WHEN kernels
+    run, never what they compute: repeated steps at levels 0, 1, 2, 3 -- evaluation mode (no autograd graph keeps intermediates alive:
+    the allocator may hand a freed block to another stream at once) and training mode (gradients of the shared modules leave the graph
+    through groups._Sink) -- must reproduce level 0 bit for bit."""
+    from tvqaplus_amd.stage import STAGE
+    from tvqaplus_amd.synth import make_batch, make_opt
+    torch.manual_seed(11)
+    opt = make_opt(hsz=128, embedding_size=96, vfeat_size=64, dropout=0.1 if train else 0.0, add_local=True, use_sup_att=True)
+    model = STAGE(opt).to(hip_device)
+    model.train(train)
+    batch = make_batch(N=4, Li=48, Lr=20, Lw=30, Lqa=40, wd_size=96, vfeat_size=64, seed=3, att_imgs=3, att_words=2).to(hip_device)
+
+    def run(level):
+        model.use_streams = level
+        model._seed_state = None
+        for p in model.parameters():
+            p.grad = None
+        torch.manual_seed(5)
+        if not train:
+            with torch.no_grad():
+                out, _, _, t_loss, t_scores, other = model.forward_main(batch)
+            return [out.clone(), t_scores.clone()] + [other[k].clone() for k in sorted(other) if torch.is_tensor(other[k])]
+        (out, targets), att_loss, _, t_loss, t_scores, other = model.forward_main(batch)
+        loss = F.cross_entropy(out, targets, reduction="sum") + 0.5 * t_loss + 0.1 * att_loss
+        loss.backward()
+        return [out.detach().clone(), loss.detach().clone()] + [p.grad.clone() for p in model.parameters() if p.grad is not None]
+
+    ref = run(0)
+    for rep in range(3):
+        for level in (2, 3, 1, 0):
+            cur = run(level)
+            assert len(cur) == len(ref)
+            for i, (a, b) in enumerate(zip(cur, ref)):
+                assert torch.equal(a, b), (rep, level, i)

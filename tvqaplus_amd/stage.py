@@ -827,6 +827,10 @@ class STAGE(nn.Module):
                 self._seed_state = None
             self._dropout_rank = int(dr)
         qas_mask = batch.qas_mask.view(N, NA, -1).float()
+        # (all masks converted HERE, on the caller's stream and in front of the first join: a cast issued later on the main stream would
+        # not be ordered against a branch stream that reads it)
+        sub_mask_f = batch.sub_mask.float() if self.sub_flag else None
+        vid_mask_f = batch.vid_mask.float() if self.vfeat_flag else None
         dev = batch.qas_bert.device
         streams = int(self.use_streams) if dev.type == "cuda" else 0
         main = s_qa = s_vid = None
@@ -850,7 +854,7 @@ class STAGE(nn.Module):
             s_vid.wait_stream(main)                # the layouts' tables are uploaded / expanded on the main stream
         if self.sub_flag:
             Li, Lw = batch.sub_bert.shape[1:3]
-            sub_mask = batch.sub_mask.view(N, Li, Lw).float()
+            sub_mask = sub_mask_f.view(N, Li, Lw)
             cl = clays.get("sub")
             plan = self._ctx_buckets(batch, "sub", N, NA, qas_mask.shape[-1], Li, Lw) if cl is None else None
             if plan is not None:
@@ -868,7 +872,7 @@ class STAGE(nn.Module):
             other_outputs["sub_normalized_s"], other_outputs["sub_raw_s"] = norm, raw
         if self.vfeat_flag:
             Li, Lr = batch.vid.shape[1:3]
-            vid_mask = batch.vid_mask.view(N, Li, Lr).float()
+            vid_mask = vid_mask_f.view(N, Li, Lr)
             cl = clays.get("vid")
             plan = self._ctx_buckets(batch, "vid", N, NA, qas_mask.shape[-1], Li, Lr) if cl is None else None
             with (torch.cuda.stream(s_vid) if streams >= 2 else contextlib.nullcontext()):
