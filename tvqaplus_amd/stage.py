@@ -37,6 +37,9 @@ def _opt(batch, key, default=None):
 # ---------------------------------------------------------------------------------------------------------------
 # parameter containers (names mirror the reference's attribute names -> identical state_dict keys)
 # ---------------------------------------------------------------------------------------------------------------
+_SIDE_STREAMS: Dict[torch.device, Tuple[torch.cuda.Stream, torch.cuda.Stream]] = {}    # branch streams (STAGE.use_streams), per device
+
+
 class _ScatterBuckets(torch.autograd.Function):
     """(frames_b, Lb, D) bucket outputs -> one zero-filled (M, L, D) tensor; the backward hands every bucket its slice of the
     gradient.  (Plain in-place index_copy_ on views would make autograd clone the whole (M, L, D) gradient once per bucket.)"""
@@ -244,7 +247,6 @@ class STAGE(nn.Module):
         # about that kernel).  The backward of every op runs on its forward's stream (autograd), so the branches overlap there too.
         # Joins: events in front of the attention / the fusion; tensors that cross streams are registered with the allocator.
         self.use_streams = int(os.environ.get("STAGE_STREAMS", "2") or 0)
-        self._side_streams = {}
         self.last_buckets: Dict[str, list] = {}
         self._mask_info = None
         self.last_ragged: Optional[ragged.RaggedLayout] = None
@@ -836,9 +838,9 @@ class STAGE(nn.Module):
         main = s_qa = s_vid = None
         if streams:
             main = torch.cuda.current_stream(dev)
-            if dev not in self._side_streams:
-                self._side_streams[dev] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
-            s_qa, s_vid = self._side_streams[dev]
+            if dev not in _SIDE_STREAMS:      # (per device, not per model: a Stream object inside the module would not survive copy.deepcopy)
+                _SIDE_STREAMS[dev] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+            s_qa, s_vid = _SIDE_STREAMS[dev]
             s_qa.wait_stream(main)                 # the batch (and last step's parameter update) is ready on the main stream
         with (torch.cuda.stream(s_qa) if streams else contextlib.nullcontext()):
             a_embed = self.base_encoder(batch.qas_bert.view(N * NA, -1, self.wd_size), qas_mask.view(N * NA, -1),
@@ -903,8 +905,6 @@ class STAGE(nn.Module):
                 attended_vid, attended_vid_mask, raw, norm = self.qa_ctx_attention(
                     a_embed, vid_embed if cl is not None else vid_embed.view(N, Li, Lr, D), qas_mask, vid_mask, lay, cl)
             other_outputs["vid_normalized_s"], other_outputs["vid_raw_s"] = norm, raw
-        elif streams:
-            pass
         if self.flag_cnt == 2:
             fc = self.concat_fc
             z = None
