@@ -49,10 +49,11 @@ def parse():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--storage", choices=["fp32", "bf16"], default="fp32",
                     help="bf16: the bf16 storage mode (BASELINE configs[4]); the headline line is the fp32 default")
-    ap.add_argument("--streams", type=int, default=-1, choices=(-1, 0, 1, 2, 3),
+    ap.add_argument("--streams", type=int, default=-1, choices=(-1, 0, 1, 2, 3, 4),
                     help="branch streams of the model (stage.py: use_streams; -1 = its default, 2): 0 one stream, 1 the statement branch on a "
-                         "side stream, 2 + the video input MLP / encoder, 3 + the video attention (fastest; the K1 forward kernels then run "
-                         "next to another branch and their in-step timings stop being a statement about the kernel)")
+                         "side stream, 2 + the video input MLP / encoder, 3 + the video attention with its forward fenced behind the subtitle "
+                         "attention, 4 without the fence (fastest; the K1 forward kernels then run next to another branch and their in-step "
+                         "timings stop being a statement about the kernel)")
     ap.add_argument("--fp32_inputs", action="store_true", help="--storage bf16: keep the resident feature tensors fp32 (the model then rounds them "
                     "to bf16 inside every step); default: resident as bf16, the way prefetch.BatchPrefetcher(stage_dtype=bf16) delivers them")
     ap.add_argument("--config", choices=("default", "stress"), default="default",
@@ -387,7 +388,7 @@ def side_records(args):
     * dense: all-ones masks (nothing to skip for the ragged-row layout), with the K1 forward kernels timed inside its steps;
     * stress: BASELINE.json configs[4] (bf16 storage, hsz 256, 512-word subtitle rows), three steps, with the long-row K1 forward;
     * one_stream / all_branches: the same step with the model's branch streams off (--streams 0: every kernel on one stream, what
-      rounds 1-3 and the first half of round 4 measured) and fully on (--streams 3: the video attention on its side stream too)."""
+      rounds 1-3 and the first half of round 4 measured) and fully on (--streams 4: the video attention on its side stream too, unfenced)."""
     shp = ["--bsz", str(args.bsz), "--frames", str(args.frames), "--regions", str(args.regions), "--qa_words", str(args.qa_words)]
     out = {}
     r = child_bench(shp + ["--sub_words", str(args.sub_words), "--hsz", str(args.hsz), "--steps", "3", "--warmup", "2", "--no_roofline",
@@ -404,7 +405,7 @@ def side_records(args):
                                                             "isolated_avg_us", "isolated_frac", "algorithmic_bytes", "masks", "traffic")}
     else:
         out["dense"] = r
-    for key, lv in (("one_stream", "0"), ("all_branches", "3")):
+    for key, lv in (("one_stream", "0"), ("all_branches", "4")):
         r = child_bench(shp + ["--sub_words", str(args.sub_words), "--hsz", str(args.hsz), "--steps", "10", "--warmup", "4", "--no_roofline",
                                "--no_device_time", "--streams", lv])
         out[key] = {"ms_per_step": r["ms_per_step"], "value": r["value"], "streams": int(lv)} if "ms_per_step" in r else r

@@ -548,7 +548,7 @@ def test_training_trajectory_vs_oracle(hip_device, path):
 @pytest.mark.parametrize("train", [False, True])
 def test_branch_streams_change_nothing_but_the_schedule(hip_device, train):
     """stage.py: use_streams (statement branch / video branch on side streams, DESIGN.md finding 45).  The streams decide WHEN kernels
-    run, never what they compute: repeated steps at levels 0, 1, 2, 3 -- evaluation mode (no autograd graph keeps intermediates alive:
+    run, never what they compute: repeated steps at levels 0 .. 4 -- evaluation mode (no autograd graph keeps intermediates alive:
     the allocator may hand a freed block to another stream at once) and training mode (gradients of the shared modules leave the graph
     through groups._Sink) -- must reproduce level 0 bit for bit."""
     from tvqaplus_amd.stage import STAGE
@@ -576,7 +576,7 @@ def test_branch_streams_change_nothing_but_the_schedule(hip_device, train):
 
     ref = run(0)
     for rep in range(3):
-        for level in (2, 3, 1, 0):
+        for level in (2, 4, 3, 1, 0):
             cur = run(level)
             assert len(cur) == len(ref)
             for i, (a, b) in enumerate(zip(cur, ref)):

@@ -10,7 +10,7 @@ with contextlib.redirect_stdout(open(os.devnull, "w")):
     model = STAGE(opt).cuda().train()
 b = make_batch(N=16, Li=int(os.environ.get("LI", 300)), Lr=20, Lw=50, Lqa=40, seed=2018, att_imgs=4, att_words=3).to("cuda")
 res = {}
-for lv in (0, 2, 3, 2, 0):
+for lv in (0, 2, 4, 3, 2, 0):
     model.use_streams = lv
     model._seed_state = None
     for p in model.parameters(): p.grad = None
