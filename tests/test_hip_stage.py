@@ -545,8 +545,9 @@ def test_training_trajectory_vs_oracle(hip_device, path):
     assert worst[0] < GTOL, worst
 
 
+@pytest.mark.parametrize("variant", ["groups", "per_op", "heads", "bf16"])
 @pytest.mark.parametrize("train", [False, True])
-def test_branch_streams_change_nothing_but_the_schedule(hip_device, train):
+def test_branch_streams_change_nothing_but_the_schedule(hip_device, train, variant):
     """stage.py: use_streams (statement branch / video branch on side streams, DESIGN.md finding 45).  The streams decide WHEN kernels
     run, never what they compute: repeated steps at levels 0 .. 4 -- evaluation mode (no autograd graph keeps intermediates alive:
     the allocator may hand a freed block to another stream at once) and training mode (gradients of the shared modules leave the graph
@@ -554,10 +555,18 @@ def test_branch_streams_change_nothing_but_the_schedule(hip_device, train):
     from tvqaplus_amd.stage import STAGE
     from tvqaplus_amd.synth import make_batch, make_opt
     torch.manual_seed(11)
-    opt = make_opt(hsz=128, embedding_size=96, vfeat_size=64, dropout=0.1 if train else 0.0, add_local=True, use_sup_att=True)
+    kw = {}
+    if variant == "heads":
+        kw = dict(input_encoder_n_heads=4, cls_encoder_n_heads=4)
+    elif variant == "bf16":
+        kw = dict(storage_dtype="bf16")
+    opt = make_opt(hsz=128, embedding_size=96, vfeat_size=64, dropout=0.1 if train else 0.0, add_local=True, use_sup_att=True, **kw)
     model = STAGE(opt).to(hip_device)
     model.train(train)
-    batch = make_batch(N=4, Li=48, Lr=20, Lw=30, Lqa=40, wd_size=96, vfeat_size=64, seed=3, att_imgs=3, att_words=2).to(hip_device)
+    if variant == "per_op":
+        model.use_groups = False
+    batch = make_batch(N=4, Li=48, Lr=20, Lw=30 if variant != "bf16" else 96, Lqa=40, wd_size=96, vfeat_size=64, seed=3, att_imgs=3,
+                       att_words=2).to(hip_device)
 
     def run(level):
         model.use_streams = level

@@ -836,6 +836,11 @@ class STAGE(nn.Module):
         vid_mask_f = batch.vid_mask.float() if self.vfeat_flag else None
         dev = batch.qas_bert.device
         streams = int(self.use_streams) if dev.type == "cuda" else 0
+        if streams > 3 and os.environ.get("STAGE_STREAMS_UNSAFE4") is None and not (self._grouped() and self.storage == torch.float32 and self.input_encoder.stacked_encoderBlocks[0].num_heads == 0):
+            # level 4 (two attention forwards side by side) only on the fp32 K-group path, where steps reproduce level 0 bit for bit; on the
+            # per-kernel path the stress config's loss differed from run to run at level 4 (an ordering problem that was not found), while
+            # levels <= 3 reproduce level 0 there
+            streams = 3
         main = s_qa = s_vid = None
         if streams:
             main = torch.cuda.current_stream(dev)
