@@ -427,6 +427,9 @@ extern "C" int stage_gemm_nt_bf16(const void* X, const void* gate, const float* 
 }
 
 size_t stage_gemm_tn_bf16_stream_ws_bytes(long long M, int N, int K);                       // gemm_bf16_stream.hip
+size_t stage_gemm_tn_bf16_oct_ws_bytes(long long M, int N, int K);                          // gemm_bf16_oct.hip
+int stage_gemm_tn_bf16_oct(const void* dY, const void* gate, const void* X, float* dW, float* db, long long M, int N, int K, void* ws,
+                           size_t ws_bytes, void* stream);
 int stage_gemm_tn_bf16_stream(const void* dY, const void* gate, const void* X, float* part, float* part_b, long long M, int N,
                               int K, int* slabs, void* stream);                             // 1 = shape not handled there
 
@@ -434,7 +437,9 @@ extern "C" size_t stage_gemm_tn_bf16_ws_bytes(long long M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const size_t tiled = (size_t)tn_splits_b(M, N, K) * ((size_t)N * K + N) * sizeof(float);
     const size_t strm = stage_gemm_tn_bf16_stream_ws_bytes(M, N, K);
-    return tiled > strm ? tiled : strm;
+    const size_t oct = stage_gemm_tn_bf16_oct_ws_bytes(M, N, K);
+    const size_t m = tiled > strm ? tiled : strm;
+    return m > oct ? m : oct;
 }
 
 // workspace: stage_gemm_tn_bf16_ws_bytes(M, N, K)
@@ -446,6 +451,10 @@ extern "C" int stage_gemm_tn_bf16(const void* dY, const void* gate, const void* 
         (void)hipMemsetAsync(dW, 0, sizeof(float) * (size_t)N * K, st);
         if (db) (void)hipMemsetAsync(db, 0, sizeof(float) * N, st);
         return 0;
+    }
+    {   // wide layers (128 < N <= 256): row-wise 16-byte loads, 256 x 256 tiles (gemm_bf16_oct.hip)
+        const int rc = stage_gemm_tn_bf16_oct(dY, gate, X, dW, db, M, N, K, ws, ws_bytes, stream);
+        if (rc != 1) return rc;
     }
     {   // streaming kernel (gemm_bf16_stream.hip) when the shape allows it and the workspace holds its partials
         const size_t need = stage_gemm_tn_bf16_stream_ws_bytes(M, N, K);
