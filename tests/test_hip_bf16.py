@@ -113,11 +113,15 @@ def test_cat3_layernorm_bf16(ops, G, rep, inner, D):
                                          (4097, 256, 256, False), (6000, 128, 200, True), (8200, 128, 72, True),
                                          # its 64-column variant: wide K, N % 128 != 0, 8-byte-aligned rows (K = 300)
                                          (4500, 300, 128, True), (4300, 44, 768, True), (4200, 192, 100, False),
-                                         # weight gradient of wide layers (csrc/gemm_bf16_oct.hip: M >= 8192, 128 < N <= 256,
-                                         # N, K % 8 == 0): 1 / 3 column blocks of X, ragged last block, ragged N, slabs that end
+                                         # weight gradient of wide layers (csrc/gemm_bf16_oct.hip: M >= 8192, N > 128,
+                                         # N, K % 4 == 0): 1 / 3 column blocks of X, ragged last block, ragged N, slabs that end
                                          # inside a 64-row super-step, gate on / off
                                          (8200, 256, 256, True), (9001, 256, 768, True), (20011, 200, 304, False),
-                                         (8192, 136, 64, True), (33333, 256, 520, False)])
+                                         (8192, 136, 64, True), (33333, 256, 520, False),
+                                         # ... two 256-column blocks of dY, rows of 8 q + 4 elements on either side (the stress config's
+                                         # 768 -> 300 -> 256 input layers)
+                                         (20011, 300, 768, True), (9000, 256, 300, False), (8200, 300, 300, True),
+                                         (9000, 516, 132, True)])
 def test_linear_bf16(ops, M, N, K, relu):
     g = torch.Generator().manual_seed(M + N + K)
     x = rb(torch.randn(M, K, generator=g))

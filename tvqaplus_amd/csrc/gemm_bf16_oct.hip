@@ -1,5 +1,6 @@
-// Weight gradients of the bf16 storage mode for wide layers (128 < N <= 256 output features, any K % 8 == 0): dW = dY^T . X with the
-// contraction over the ROWS of two row-major bf16 tensors that are streamed exactly once per 256-column block of X.
+// Weight gradients of the bf16 storage mode for wide layers (N > 128 output features, N and K multiples of 4): dW = dY^T . X with the
+// contraction over the ROWS of two row-major bf16 tensors, streamed from HBM once (256-column blocks of either operand that share a
+// slab of rows run side by side on one XCD and meet in its L2).
 //
 // The tiled kernel of gemm_bf16x3.hip (the only one that took these shapes: hsz = 256 has 16 / 48 patches of 64 x 64, the streaming
 // kernel of gemm_bf16_stream.hip stops at 12) ran at 1.0-1.8 TB/s of algorithmic bytes (tools/experiments/tn_bf16_time.py: 2.7 ms for
@@ -40,29 +41,32 @@ template <bool HAS_GATE>
 __global__ __launch_bounds__(512) void gemm_tn_bf16_oct_kernel(const stage_bf16* __restrict__ dY, const stage_bf16* __restrict__ G,
                                                                const stage_bf16* __restrict__ X, float* __restrict__ part,
                                                                float* __restrict__ part_b, long M, int N, int K, int Kp, int KB,
-                                                               int S, long rows_per_slab) {
+                                                               int NB, int S, long rows_per_slab) {
     extern __shared__ __attribute__((aligned(16))) uint4 ex[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     // workgroup -> (slab, column block): the KB blocks of a slab sit on one XCD (workgroup ids go round the 8 XCDs)
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int slab = (idx / KB) * 8 + xcd, kb = idx % KB;
+    const int NBK = NB * KB, blk = idx % NBK;
+    const int slab = (idx / NBK) * 8 + xcd, kb = blk % KB, nb = blk / KB;
     if (slab >= S) return;
-    const int k0 = kb * 256;
+    const int k0 = kb * 256, n0 = nb * 256;
     const long mbeg = (long)slab * rows_per_slab, mend = min(M, mbeg + rows_per_slab);
     if (mbeg >= mend) return;
     // ---- producer role ----
     const bool is_y = (wave & 1) == 0;                  // wave-uniform
     const int sub = wave >> 1;                          // the 16-row step of a super-step this wave prepares
     const int ld = is_y ? N : K;
-    const int col = is_y ? 8 * l31 : k0 + 8 * l31;
-    const bool col_ok = col < ld;                       // N, K are multiples of 8: a column group is inside or outside as a whole
-    const bool all_cols = __all(col_ok);
+    const int col = is_y ? n0 + 8 * l31 : k0 + 8 * l31;
+    // columns of this group inside the operand: 8, 0, or 4 (N or K = 8 q + 4: the last group is loaded four columns early -- a load
+    // that runs past the end of the slab would be dropped as a whole -- and shifted down afterwards)
+    const int vc = min(max(ld - col, 0), 8);
+    const bool all_cols = __all(vc == 8);
     const unsigned slab_bytes = (unsigned)((mend - mbeg) * (long)ld * 2);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((is_y ? dY : X) + mbeg * ld), 0, (int)slab_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)((HAS_GATE ? G : dY) + mbeg * N), 0,
                                                                          (int)((unsigned)((mend - mbeg) * (long)N * 2)), 0x00020000);
-    const int voff = ((16 * sub + 8 * h) * ld + (col_ok ? col : 0)) * 2;
+    const int voff = ((16 * sub + 8 * h) * ld + (vc == 8 ? col : vc == 4 ? col - 4 : 0)) * 2;
     const bool want_b = part_b != nullptr && kb == 0 && is_y;
     float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     go_u4 va[8], vg[8];
@@ -86,7 +90,10 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_oct_kernel(const stage_bf16*
 #pragma unroll
             for (int r = 0; r < 8; r++)
 #pragma unroll
-                for (int d = 0; d < 4; d++) va[r][d] = col_ok ? va[r][d] : 0u;
+                for (int d = 0; d < 4; d++) {
+                    const unsigned shifted = d < 2 ? va[r][d + 2] : 0u;
+                    va[r][d] = vc == 8 ? va[r][d] : vc == 4 ? shifted : 0u;
+                }
         }
         if (want_b) {
 #pragma unroll
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_oct_kernel(const stage_bf16*
             const int pos = k0 + 32 * (2 * pk + j) + l31;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int n = 8 * ((r & 3) + 8 * (r >> 2) + 4 * h) + 4 * pn + i;
+                const int n = n0 + 8 * ((r & 3) + 8 * (r >> 2) + 4 * h) + 4 * pn + i;
                 if (n < N) po[(size_t)n * Kp + pos] = acc[i][j][r];
             }
         }
@@ -169,11 +176,11 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_oct_kernel(const stage_bf16*
             for (int t = 0; t < 8; t++) red[(sub * 2 + h) * 256 + 8 * l31 + t] = bs[t];
         }
         __syncthreads();
-        if (threadIdx.x < 256 && (int)threadIdx.x < N) {
+        if (threadIdx.x < 256 && n0 + (int)threadIdx.x < N) {
             float s = 0.f;
 #pragma unroll
             for (int q = 0; q < 8; q++) s += red[q * 256 + threadIdx.x];
-            part_b[(size_t)slab * N + threadIdx.x] = s;
+            part_b[(size_t)slab * N + n0 + threadIdx.x] = s;
         }
     }
 }
@@ -198,13 +205,14 @@ __global__ void oct_reduce_b_kernel(const float* __restrict__ part_b, float* __r
 }
 
 // slabs of the octet kernel for a shape (0: not handled here)
-static int go_plan(long long M, int N, int K, int* KB, int* Kp, long* rps) {
+static int go_plan(long long M, int N, int K, int* KB, int* NB, int* Kp, long* rps) {
     static const bool off = getenv("STAGE_GEMM_BF16_NO_OCT") != nullptr;
-    if (off || M < 8192 || N % 8 != 0 || K % 8 != 0 || N <= 128 || N > 256 || K < 64) return 0;
+    if (off || M < 8192 || N % 4 != 0 || K % 4 != 0 || N <= 128 || K < 64) return 0;
     *KB = (K + 255) / 256;
+    *NB = (N + 255) / 256;
     *Kp = *KB * 256;
-    if (*KB > 32) return 0;
-    int S = 8 * (32 / *KB);                              // one workgroup per CU, the KB blocks of a slab on one XCD
+    if (*KB * *NB > 32) return 0;
+    int S = 8 * (32 / (*KB * *NB));                      // one workgroup per CU, the blocks of a slab on one XCD
     long r = (long)((M + S - 1) / S);
     r = (r + 63) / 64 * 64;
     if (r < 1024) r = 1024;                              // (short slabs: the partials would outweigh the operands)
@@ -214,17 +222,17 @@ static int go_plan(long long M, int N, int K, int* KB, int* Kp, long* rps) {
 }
 
 size_t stage_gemm_tn_bf16_oct_ws_bytes(long long M, int N, int K) {
-    int KB, Kp; long rps;
-    const int S = go_plan(M, N, K, &KB, &Kp, &rps);
+    int KB, NB, Kp; long rps;
+    const int S = go_plan(M, N, K, &KB, &NB, &Kp, &rps);
     return (size_t)S * ((size_t)N * Kp + N) * sizeof(float);
 }
 
 // returns 1 if the shape / alignment is not handled here, 0 after writing dW (and db)
 int stage_gemm_tn_bf16_oct(const void* dY, const void* gate, const void* X, float* dW, float* db, long long M, int N, int K, void* ws,
                            size_t ws_bytes, void* stream) {
-    int KB, Kp; long rps;
-    const int S = go_plan(M, N, K, &KB, &Kp, &rps);
-    if (S == 0 || ((uintptr_t)dY & 15) || ((uintptr_t)X & 15) || (gate && ((uintptr_t)gate & 15))) return 1;
+    int KB, NB, Kp; long rps;
+    const int S = go_plan(M, N, K, &KB, &NB, &Kp, &rps);
+    if (S == 0 || ((uintptr_t)dY & 7) || ((uintptr_t)X & 7) || (gate && ((uintptr_t)gate & 7))) return 1;
     if (ws_bytes < (size_t)S * ((size_t)N * Kp + N) * sizeof(float)) return 1;
     hipStream_t st = (hipStream_t)stream;
     typedef stage_bf16 B;
@@ -237,13 +245,13 @@ int stage_gemm_tn_bf16_oct(const void* dY, const void* gate, const void* X, floa
         (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_oct_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr = true;
     }
-    const unsigned grid = 8u * (unsigned)((S + 7) / 8) * (unsigned)KB;
+    const unsigned grid = 8u * (unsigned)((S + 7) / 8) * (unsigned)(KB * NB);
     if (gate)
         hipLaunchKernelGGL(gemm_tn_bf16_oct_kernel<true>, dim3(grid), dim3(512), lds, st, (const B*)dY, (const B*)gate, (const B*)X, part,
-                           db ? part_b : (float*)nullptr, (long)M, N, K, Kp, KB, S, rps);
+                           db ? part_b : (float*)nullptr, (long)M, N, K, Kp, KB, NB, S, rps);
     else
         hipLaunchKernelGGL(gemm_tn_bf16_oct_kernel<false>, dim3(grid), dim3(512), lds, st, (const B*)dY, (const B*)gate, (const B*)X, part,
-                           db ? part_b : (float*)nullptr, (long)M, N, K, Kp, KB, S, rps);
+                           db ? part_b : (float*)nullptr, (long)M, N, K, Kp, KB, NB, S, rps);
     const long C = (long)N * Kp;
     hipLaunchKernelGGL(oct_reduce_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, part, dW, S, N, K, Kp);
     if (db) hipLaunchKernelGGL(oct_reduce_b_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part_b, db, S, N);
