@@ -185,23 +185,41 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_oct_kernel(const stage_bf16*
     }
 }
 
-// dW[n][k] = sum over slabs of the permuted partials (fixed order)
+// dW[n][k] = sum over slabs of the permuted partials (fixed order); four consecutive positions per thread
 __global__ void oct_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int S, int N, int K, int Kp) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)N * Kp) return;
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const long C = (long)N * Kp;
+    if (i >= C) return;
     const int n = (int)(i / Kp), p = (int)(i - (long)n * Kp);
-    const int k = (p & ~255) + 8 * (p & 31) + ((p & 255) >> 5);
-    if (k >= K) return;
-    float s = 0.f;
-    for (int q = 0; q < S; q++) s += part[(size_t)q * N * Kp + i];
-    dW[(size_t)n * K + k] = s;
+    float4 s = f4zero();
+#pragma unroll 8
+    for (int q = 0; q < S; q++) s = f4add(s, ld4(part + (size_t)q * C + i));
+    const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int pe = p + e;
+        const int k = (pe & ~255) + 8 * (pe & 31) + ((pe & 255) >> 5);
+        if (k < K) dW[(size_t)n * K + k] = v[e];
+    }
 }
-__global__ void oct_reduce_b_kernel(const float* __restrict__ part_b, float* __restrict__ db, int S, int N) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+// db[n] = sum over slabs, 8 slab groups per column side by side, combined in a fixed order
+__global__ __launch_bounds__(256) void oct_reduce_b_kernel(const float* __restrict__ part_b, float* __restrict__ db, int S, int N) {
+    __shared__ float red[8][32];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + c;
     float s = 0.f;
-    for (int q = 0; q < S; q++) s += part_b[(size_t)q * N + n];
-    db[n] = s;
+    if (n < N) {
+#pragma unroll 4
+        for (int q = g; q < S; q += 8) s += part_b[(size_t)q * N + n];
+    }
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; q++) t += red[q][c];
+        db[n] = t;
+    }
 }
 
 // slabs of the octet kernel for a shape (0: not handled here)
@@ -253,8 +271,8 @@ int stage_gemm_tn_bf16_oct(const void* dY, const void* gate, const void* X, floa
         hipLaunchKernelGGL(gemm_tn_bf16_oct_kernel<false>, dim3(grid), dim3(512), lds, st, (const B*)dY, (const B*)gate, (const B*)X, part,
                            db ? part_b : (float*)nullptr, (long)M, N, K, Kp, KB, NB, S, rps);
     const long C = (long)N * Kp;
-    hipLaunchKernelGGL(oct_reduce_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, part, dW, S, N, K, Kp);
-    if (db) hipLaunchKernelGGL(oct_reduce_b_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part_b, db, S, N);
+    hipLaunchKernelGGL(oct_reduce_kernel, dim3((unsigned)((C / 4 + 255) / 256)), dim3(256), 0, st, part, dW, S, N, K, Kp);
+    if (db) hipLaunchKernelGGL(oct_reduce_b_kernel, dim3((N + 31) / 32), dim3(256), 0, st, part_b, db, S, N);
     STAGE_LAUNCH_CHECK();
     return 0;
 }

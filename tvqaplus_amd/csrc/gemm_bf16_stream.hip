@@ -42,14 +42,18 @@ struct __attribute__((aligned(8))) GbU4 { unsigned x, y, z, w; };
 template <bool HAS_GATE, int NKC>
 __global__ __launch_bounds__(64 * GB_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_bf16_stream_kernel(
     const stage_bf16* __restrict__ X, const stage_bf16* __restrict__ G, const float* __restrict__ W,
-    const float* __restrict__ bias, stage_bf16* __restrict__ Y, long M, int N, int K, int Kp, int relu) {
+    const float* __restrict__ bias, stage_bf16* __restrict__ Y, long M, int N, int K, int Kp, int relu, int gx, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
     unsigned short* Wl = lds;                                            // [GB_BN][Kp] bf16, natural k order, zero padded
     unsigned short* stg = Wl + GB_BN * Kp;                               // [GB_WAVES][32][GB_STG]
     float* bias_s = reinterpret_cast<float*>(stg + GB_WAVES * 32 * GB_STG);   // [GB_BN]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.y * GB_BN;
+    // 1-D grid, XCD-aware (as the 64-column kernel below): the n_tiles column tiles of a row group get consecutive slots of ONE XCD
+    // (workgroup ids go round the 8 XCDs), so their re-reads of X (and the gate) meet in that XCD's L2
+    const int r8 = blockIdx.x & 7, tq = blockIdx.x >> 3;
+    const int by = tq % n_tiles, bx = (tq / n_tiles) * 8 + r8;
+    const int n0 = by * GB_BN;
     // ---- weight tile -> LDS (rounded to bf16 once) ----
     const int K4p = Kp >> 2;
     for (int e = tid; e < GB_BN * K4p; e += 64 * GB_WAVES) {
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(64 * GB_WAVES) __attribute__((amdgpu_waves_per_eu(2
     __syncthreads();
 
     const long MT = (M + 31) >> 5;
-    const long nw = (long)gridDim.x * GB_WAVES;
+    const long nw = (long)gx * GB_WAVES;
     unsigned short* my_stg = stg + wave * 32 * GB_STG;
     // this lane's 32 elements of chunk c of row `row`: k = 64 c + 32 h + 8 s .. +7  (s = MFMA step; the same permutation of
     // the contraction index on the weight side)
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(64 * GB_WAVES) __attribute__((amdgpu_waves_per_eu(2
             if (HAS_GATE) b.g[s] = *reinterpret_cast<const uint4*>(G + off);
         }
     };
-    long t = (long)blockIdx.x * GB_WAVES + wave;
+    long t = (long)bx * GB_WAVES + wave;
     GbBuf b0, b1, bn;
     if (t < MT) fetch(b0, t * 32 + l31, 0);
     for (; t < MT; t += nw) {
@@ -293,17 +297,18 @@ int stage_gemm_nt_bf16_stream(const void* X, const void* gate, const float* W, c
     const size_t lds = (size_t)GB_BN * Kp * 2 + (size_t)GB_WAVES * 32 * GB_STG * 2 + GB_BN * sizeof(float);
     if (lds > 160 * 1024) return 1;
     const long MT = (M + 31) / 32;
-    long gx = (MT + GB_WAVES - 1) / GB_WAVES;
     const int n_tiles = N / GB_BN;
-    const long cap = 256 / n_tiles > 0 ? 256 / n_tiles : 1;
-    if (gx > cap) gx = cap;
-    dim3 grid((unsigned)gx, (unsigned)n_tiles), block(64 * GB_WAVES);
+    long gx = (256 / n_tiles) / 8 * 8;              // row groups: a multiple of 8 (one per XCD slot), one workgroup per CU
+    if (gx < 8) gx = 8;
+    const long need = ((MT + GB_WAVES - 1) / GB_WAVES + 7) / 8 * 8;
+    if (gx > need) gx = need;
+    dim3 grid((unsigned)(gx * n_tiles)), block(64 * GB_WAVES);
     typedef stage_bf16 B;
 #define GB_GO(GT, NK)                                                                                                          \
     do {                                                                                                                       \
         (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_stream_kernel<GT, NK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((gemm_nt_bf16_stream_kernel<GT, NK>), grid, block, lds, (hipStream_t)stream, (const B*)X, (const B*)gate, W, \
-                           bias, (B*)Y, (long)M, N, K, Kp, relu);                                                              \
+                           bias, (B*)Y, (long)M, N, K, Kp, relu, (int)gx, n_tiles);                                            \
     } while (0)
 #define GB_NK(NK) do { if (gate) GB_GO(true, NK); else GB_GO(false, NK); } while (0)
     switch (nkc) {
