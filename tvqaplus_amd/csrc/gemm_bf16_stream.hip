@@ -68,23 +68,32 @@ __global__ __launch_bounds__(64 * GB_WAVES) __attribute__((amdgpu_waves_per_eu(2
     const long MT = (M + 31) >> 5;
     const long nw = (long)gx * GB_WAVES;
     unsigned short* my_stg = stg + wave * 32 * GB_STG;
-    // this lane's 32 elements of chunk c of row `row`: k = 64 c + 32 h + 8 s .. +7  (s = MFMA step; the same permutation of
-    // the contraction index on the weight side)
-    auto fetch = [&](GbBuf& b, long row, int c) {
-        const long rc = row < M ? row : M - 1;
+    // chunk c (64 k = 128 bytes per row) of row tile `tile`, COALESCED: load j covers rows 8 j .. 8 j + 7, eight lanes per row, 16 bytes
+    // each (8 cache lines per instruction).  Round 4: the former scheme -- every lane reading 64 contiguous bytes of ITS row, i.e. the
+    // MFMA operand layout straight from memory -- touched 32 lines per instruction and ran at ~2.5 us per chunk and CU whatever the
+    // prefetch depth, the column-tile placement or the HBM traffic (PMC: every byte fetched once, 72 % of the wave cycles waiting):
+    // the vector memory pipeline's line rate was the limit.  The operand layout is now made by a pass through the wave's staging rows.
+    auto fetch = [&](GbBuf& b, long tile, int c) {
+        const int k = c * GB_KC + 8 * (lane & 7);
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            const int k = c * GB_KC + 32 * h + 8 * s;
-            const long off = rc * K + (k < K ? k : 0);                   // past K: any valid address, zeroed at use
-            b.x[s] = *reinterpret_cast<const uint4*>(X + off);
-            if (HAS_GATE) b.g[s] = *reinterpret_cast<const uint4*>(G + off);
+        for (int j = 0; j < 4; j++) {
+            const long row = tile * 32 + 8 * j + (lane >> 3);
+            const long off = (row < M ? row : M - 1) * K + (k < K ? k : 0);      // past M / K: any valid address, zeroed at use / unused
+            b.x[j] = *reinterpret_cast<const uint4*>(X + off);
+            if (HAS_GATE) b.g[j] = *reinterpret_cast<const uint4*>(G + off);
         }
     };
     long t = (long)bx * GB_WAVES + wave;
-    GbBuf b0, b1, bn;
-    if (t < MT) fetch(b0, t * 32 + l31, 0);
+    // A WHOLE row tile ahead: chunk c of the next tile is requested the moment chunk c of this one has been multiplied (its buffer is
+    // free), so DEPTH chunks per wave are always in flight.  (Round 4: with one chunk ahead a wave waited out one memory latency per
+    // 16 MFMAs -- 72 % of the wave cycles waiting, 2.1 TB/s at 960000 x 256 -> 768 with every byte fetched from HBM once.)
+    constexpr int DEPTH = NKC == 6 ? 3 : NKC;            // chunks in flight (divides NKC; six gated chunks would not fit the registers)
+    GbBuf buf[DEPTH];
+    if (t < MT) {
+#pragma unroll
+        for (int c = 0; c < DEPTH; c++) fetch(buf[c], t, c);
+    }
     for (; t < MT; t += nw) {
-        const long row = t * 32 + l31;
         f32x16 acc[4];
 #pragma unroll
         for (int nt = 0; nt < 4; nt++)
@@ -92,23 +101,32 @@ __global__ __launch_bounds__(64 * GB_WAVES) __attribute__((amdgpu_waves_per_eu(2
             for (int r = 0; r < 16; r++) acc[nt][r] = 0.f;
 #pragma unroll
         for (int c = 0; c < NKC; c++) {
-            GbBuf& cur = (c & 1) ? b1 : b0;
-            GbBuf& nxt = (c & 1) ? b0 : b1;
-            if (c + 1 < NKC) fetch(nxt, row, c + 1);
-            else fetch(bn, (t + nw) * 32 + l31, 0);      // first chunk of the next tile, ahead of this tile's stores (clamped row)
+            GbBuf& cur = buf[c % DEPTH];
+            // gate, zero the K tail, and turn the coalesced pieces into MFMA operands through the wave's own staging rows (144-byte row
+            // stride: both the 16-byte writes and the reads are conflict free; the LDS operations of one wave complete in order)
+            const bool k_ok = c * GB_KC + 8 * (lane & 7) < K;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint4 xv = cur.x[j];
+                if (HAS_GATE) xv = gb_gate(xv, cur.g[j]);
+                if (!k_ok) xv = make_uint4(0u, 0u, 0u, 0u);
+                *reinterpret_cast<uint4*>(&my_stg[(8 * j + (lane >> 3)) * GB_STG + 8 * (lane & 7)]) = xv;
+            }
+            uint4 xf[4];
+#pragma unroll
+            for (int s = 0; s < 4; s++) xf[s] = *reinterpret_cast<const uint4*>(&my_stg[l31 * GB_STG + 32 * h + 8 * s]);
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 const int k = c * GB_KC + 32 * h + 8 * s;
-                uint4 xv = cur.x[s];
-                if (HAS_GATE) xv = gb_gate(xv, cur.g[s]);
-                if (k >= K) xv = make_uint4(0u, 0u, 0u, 0u);
-                const gb_bf16x8 b = __builtin_bit_cast(gb_bf16x8, xv);
+                const gb_bf16x8 b = __builtin_bit_cast(gb_bf16x8, xf[s]);
 #pragma unroll
                 for (int nt = 0; nt < 4; nt++) {
                     const gb_bf16x8 a = __builtin_bit_cast(gb_bf16x8, *reinterpret_cast<const uint4*>(&Wl[(nt * 32 + l31) * Kp + k]));
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nt], 0, 0, 0);   // D[n][m]
                 }
             }
+            if (c + DEPTH < NKC) fetch(cur, t, c + DEPTH);
+            else fetch(cur, t + nw, c + DEPTH - NKC);                   // ... of the next tile (clamped rows)
         }
         // ---- epilogue: D[n][m], lane = row m (l31), registers = columns 8 (r >> 2) + 4 h + (r & 3) of n-tile nt ----
 #pragma unroll
@@ -135,7 +153,6 @@ __global__ __launch_bounds__(64 * GB_WAVES) __attribute__((amdgpu_waves_per_eu(2
                 if (m < M) *reinterpret_cast<uint4*>(Y + m * N + n0 + 64 * p + c8) = v;
             }
         }
-        b0 = bn;
     }
 }
 
