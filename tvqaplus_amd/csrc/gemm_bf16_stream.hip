@@ -200,23 +200,32 @@ __global__ __launch_bounds__(64 * GB_WAVES) __attribute__((amdgpu_waves_per_eu(2
         }
         return make_uint4(0u, 0u, 0u, 0u);
     };
-    auto fetch = [&](GbBuf& b, long row, int c) {
-        const long ro = (row < M ? row : M - 1) * K;
+    // coalesced, as in the 128-column kernel: load j = rows 8 j .. 8 j + 7 of the tile, eight lanes per row
+    auto fetch = [&](GbBuf& b, long tile, int c) {
+        const int k = c * GB_KC + 8 * (lane & 7);
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            const int k = c * GB_KC + 32 * h + 8 * s;
-            b.x[s] = ld8(X, ro, k);
-            if (HAS_GATE) b.g[s] = ld8(G, ro, k);
+        for (int j = 0; j < 4; j++) {
+            const long row = tile * 32 + 8 * j + (lane >> 3);
+            const long ro = (row < M ? row : M - 1) * K;
+            b.x[j] = ld8(X, ro, k);
+            if (HAS_GATE) b.g[j] = ld8(G, ro, k);
         }
     };
     f32x16 acc[2];
     auto mul = [&](GbBuf& cur, int c) {
 #pragma unroll
+        for (int j = 0; j < 4; j++) {                    // gate, then through the wave's staging rows into the MFMA operand layout
+            uint4 xv = cur.x[j];
+            if (HAS_GATE) xv = gb_gate(xv, cur.g[j]);
+            *reinterpret_cast<uint4*>(&my_stg[(8 * j + (lane >> 3)) * GB_STG + 8 * (lane & 7)]) = xv;
+        }
+        uint4 xf[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) xf[s] = *reinterpret_cast<const uint4*>(&my_stg[l31 * GB_STG + 32 * h + 8 * s]);
+#pragma unroll
         for (int s = 0; s < 4; s++) {
             const int k = c * GB_KC + 32 * h + 8 * s;
-            uint4 xv = cur.x[s];
-            if (HAS_GATE) xv = gb_gate(xv, cur.g[s]);
-            const gb_bf16x8 b = __builtin_bit_cast(gb_bf16x8, xv);
+            const gb_bf16x8 b = __builtin_bit_cast(gb_bf16x8, xf[s]);
 #pragma unroll
             for (int nt = 0; nt < 2; nt++) {
                 const gb_bf16x8 a = __builtin_bit_cast(gb_bf16x8, *reinterpret_cast<const uint4*>(&Wl[(nt * 32 + l31) * Kp + k]));
@@ -226,9 +235,9 @@ __global__ __launch_bounds__(64 * GB_WAVES) __attribute__((amdgpu_waves_per_eu(2
     };
     long t = (long)bx * GB_WAVES + wave;
     GbBuf b0, b1, bn;
-    if (t < MT) fetch(b0, t * 32 + l31, 0);
+    if (t < MT) fetch(b0, t, 0);
     for (; t < MT; t += nw) {
-        const long row = t * 32 + l31;
+        const long row = t;
 #pragma unroll
         for (int nt = 0; nt < 2; nt++)
 #pragma unroll
@@ -237,11 +246,11 @@ __global__ __launch_bounds__(64 * GB_WAVES) __attribute__((amdgpu_waves_per_eu(2
         for (int c = 0; c < nkc; c += 2) {
             const bool has1 = c + 1 < nkc;
             if (has1) fetch(b1, row, c + 1);
-            else fetch(bn, (t + nw) * 32 + l31, 0);
+            else fetch(bn, t + nw, 0);
             mul(b0, c);
             if (has1) {
                 if (c + 2 < nkc) fetch(b0, row, c + 2);
-                else fetch(bn, (t + nw) * 32 + l31, 0);
+                else fetch(bn, t + nw, 0);
                 mul(b1, c + 1);
             }
         }
@@ -280,7 +289,8 @@ static int gb_launch64(const void* X, const void* gate, const float* W, const fl
     if (lds > 160 * 1024) return 1;
     // a gated operand in half-aligned rows with many column tiles: measured slower than the tiled kernel (2.46 M rows,
     // 300 -> 768: 12.7 vs 9.1 ms; 240 k rows: 1.04 vs 0.88 ms)
-    if (gate && K % 8 != 0 && N > 256) return 1;
+    static const bool tiled_gated = getenv("STAGE_GEMM_BF16_TILED_GATED") != nullptr;    // (developer switch: the rule of round 3)
+    if (tiled_gated && gate && K % 8 != 0 && N > 256) return 1;
     const long MT = (M + 31) / 32;
     const int n_tiles = (N + 63) / 64;
     long gx = (256 / n_tiles) / 8 * 8;
