@@ -11,7 +11,7 @@
 // multiplied.  The product is accumulated TRANSPOSED (weight fragment = A operand): a lane then owns four consecutive output
 // columns of one row, packs them to 8 bytes, and the tile leaves through a per-wave LDS staging area as full 128-byte lines
 // (a direct store would write 8-byte pieces of 32 different lines per instruction -- what the memory system handles worst).
-// Shapes outside (K % 8 == 0, K <= 384, N % 128 == 0, M >= 4096, 8-byte aligned operands) take the tiled kernel of
+// Shapes outside (K % 4 == 0, K <= 384, N % 128 == 0, M >= 4096, 8-byte aligned operands) take the 64-column variant below or the tiled kernel of
 // gemm_bf16x3.hip.
 #include <stdlib.h>
 #include "common.h"
@@ -78,9 +78,19 @@ __global__ __launch_bounds__(64 * GB_WAVES) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const long row = tile * 32 + 8 * j + (lane >> 3);
-            const long off = (row < M ? row : M - 1) * K + (k < K ? k : 0);      // past M / K: any valid address, zeroed at use / unused
-            b.x[j] = *reinterpret_cast<const uint4*>(X + off);
-            if (HAS_GATE) b.g[j] = *reinterpret_cast<const uint4*>(G + off);
+            const long ro = (row < M ? row : M - 1) * K;
+            if (k + 8 <= K) {                            // (rows of K = 8 q + 4 elements are 8-byte aligned: GbU4)
+                const GbU4 v = *reinterpret_cast<const GbU4*>(X + ro + k);
+                b.x[j] = make_uint4(v.x, v.y, v.z, v.w);
+                if (HAS_GATE) { const GbU4 g4 = *reinterpret_cast<const GbU4*>(G + ro + k); b.g[j] = make_uint4(g4.x, g4.y, g4.z, g4.w); }
+            } else if (k < K) {                          // K % 8 == 4: half a group at the end of the row
+                const uint2 v = *reinterpret_cast<const uint2*>(X + ro + k);
+                b.x[j] = make_uint4(v.x, v.y, 0u, 0u);
+                if (HAS_GATE) { const uint2 g2 = *reinterpret_cast<const uint2*>(G + ro + k); b.g[j] = make_uint4(g2.x, g2.y, 0u, 0u); }
+            } else {
+                b.x[j] = make_uint4(0u, 0u, 0u, 0u);
+                if (HAS_GATE) b.g[j] = make_uint4(0u, 0u, 0u, 0u);
+            }
         }
     };
     long t = (long)bx * GB_WAVES + wave;
@@ -104,12 +114,10 @@ __global__ __launch_bounds__(64 * GB_WAVES) __attribute__((amdgpu_waves_per_eu(2
             GbBuf& cur = buf[c % DEPTH];
             // gate, zero the K tail, and turn the coalesced pieces into MFMA operands through the wave's own staging rows (144-byte row
             // stride: both the 16-byte writes and the reads are conflict free; the LDS operations of one wave complete in order)
-            const bool k_ok = c * GB_KC + 8 * (lane & 7) < K;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                uint4 xv = cur.x[j];
+                uint4 xv = cur.x[j];                     // (zero past K: fetch)
                 if (HAS_GATE) xv = gb_gate(xv, cur.g[j]);
-                if (!k_ok) xv = make_uint4(0u, 0u, 0u, 0u);
                 *reinterpret_cast<uint4*>(&my_stg[(8 * j + (lane >> 3)) * GB_STG + 8 * (lane & 7)]) = xv;
             }
             uint4 xf[4];
@@ -315,10 +323,11 @@ int stage_gemm_nt_bf16_stream(const void* X, const void* gate, const float* W, c
                               int K, int relu, void* stream) {
     static const bool off = getenv("STAGE_GEMM_BF16_TILED") != nullptr;   // developer switch: tiled kernel everywhere
     if (off) return 1;
-    if (M < 4096 || K % 8 != 0 || K < 64 || K > 384 || N % GB_BN != 0 ||
-        ((uintptr_t)X & 15) || ((uintptr_t)Y & 15) || ((uintptr_t)W & 15) || (gate && ((uintptr_t)gate & 15)))
+    if (M < 4096 || K % 4 != 0 || K < 64 || K > 384 || N % GB_BN != 0 ||
+        ((uintptr_t)X & 7) || ((uintptr_t)Y & 15) || ((uintptr_t)W & 15) || (gate && ((uintptr_t)gate & 7)))
         return gb_launch64(X, gate, W, bias, Y, M, N, K, relu, stream);   // wide K / ragged N / 8-byte rows
-    const int nkc = (K + GB_KC - 1) / GB_KC;
+    int nkc = (K + GB_KC - 1) / GB_KC;
+    if (gate && nkc == 5) nkc = 6;                  // five gated chunks in flight spill; six run three deep (the sixth is all zeros: no loads)
     int Kp = nkc * GB_KC;                           // whole chunks, zero padded
     Kp += ((Kp / 8) % 2 == 0) ? 8 : 16;             // odd number of 16-byte slots per row: conflict-free ds_read_b128
     const size_t lds = (size_t)GB_BN * Kp * 2 + (size_t)GB_WAVES * 32 * GB_STG * 2 + GB_BN * sizeof(float);
