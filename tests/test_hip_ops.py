@@ -974,3 +974,47 @@ def test_k1_backward_fp16_pairs_are_fp32_class(ops, Lr):
         err[name] = (float((dC - Cc.grad).abs().max() / Cc.grad.abs().max()), float((dQ - Qc.grad).abs().max() / Qc.grad.abs().max()))
     assert err["fused"][0] < 2e-6 and err["fused"][1] < 2e-6, err
     assert err["fused"][0] <= 2 * err["three"][0] + 1e-7 and err["fused"][1] <= 2 * err["three"][1] + 1e-7, err
+
+
+@pytest.mark.parametrize("Lr,Lqa", [(100, 12), (512, 40), (33, 7)])
+def test_long_attention_bf16_dq_blocks_of_32_regions(ops, Lr, Lqa):
+    """csrc/str_attn_long.hip: str_attn_long_bwd_dq32_kernel (bf16 storage, D = 256: 32 regions per wave on the bf16 matrix cores,
+    weights as hi + lo pairs).  Through the C ABI with the dS workspace PRE-FILLED with NaN: the first backward kernel writes dS only for
+    the 16-region blocks that can carry a gradient, so a 32-region block that straddles that limit must not read what lies behind it.
+    dQraw = P^T dA and dQn = dS^T Cn against fp64 products of the same operands."""
+    from tvqaplus_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    N, Li, NA, D = 2, 3, 5, 256
+    g = torch.Generator().manual_seed(Lr + Lqa)
+    bf = torch.bfloat16
+    dA = torch.randn(N, NA, Li, Lqa, D, generator=g).to(bf).cuda()
+    A = torch.randn(N, NA, Li, Lqa, D, generator=g).to(bf).cuda()
+    Cn = torch.randn(N, NA, Lqa, D, generator=g).to(bf).cuda()
+    Q = torch.randn(N, Li, Lr, D, generator=g).to(bf).cuda()
+    Qn = torch.randn(N, Li, Lr, D, generator=g).to(bf).cuda()
+    lens = torch.tensor([[1, 17, Lr], [min(Lr, 40), 0, min(Lr, 33)]])        # 0: a frame without a valid region
+    qm = (torch.arange(Lr).view(1, 1, Lr) < lens.unsqueeze(-1)).float()
+    logits = torch.randn(N, NA, Li, Lqa, Lr, generator=g) - 1e10 * (1 - qm.view(N, 1, Li, 1, Lr))
+    Sn = (torch.softmax(logits, -1) * qm.view(N, 1, Li, 1, Lr)).cuda()
+    qm = qm.cuda()
+    dS_ws = torch.full_like(Sn, float("nan"))
+    dQ = torch.full((N, Li, Lr, D), float("nan"), device="cuda")
+    dQn = torch.full_like(dQ, float("nan"))
+    dCn = torch.empty(N, NA, Lqa, D, device="cuda")
+    wsb = lib.stage_str_attn_long_bwd_qm_ws_bytes(N, NA, Li, Lqa, D)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device="cuda")
+    rc = lib.stage_str_attn_long_bwd_qm(dA.data_ptr(), A.data_ptr(), None, Cn.data_ptr(), Q.data_ptr(), Qn.data_ptr(), Sn.data_ptr(),
+                                        qm.data_ptr(), dS_ws.data_ptr(), dQ.data_ptr(), dQn.data_ptr(), dCn.data_ptr(), N, NA, Li, Lqa, Lr, D,
+                                        1.0, 1, ws.data_ptr(), wsb, st)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(dQ).all() and torch.isfinite(dQn).all()
+    dS = torch.nan_to_num(dS_ws, nan=0.0)                                    # what was not written is an exact zero of the gradient
+    ref_raw = torch.einsum("nailr,naild->nird", Sn.double(), dA.double())
+    ref_n = torch.einsum("nailr,nald->nird", dS.double(), Cn.double())
+    for name, got, ref in (("dQraw", dQ, ref_raw), ("dQn", dQn, ref_n)):
+        err = float((got.double() - ref).abs().max())
+        assert err <= 2e-5 * (1.0 + float(ref.abs().max())), (name, err, float(ref.abs().max()))   # bf16 hi + lo weights: 2^-16 per term
+    dead = (qm == 0).view(N, Li, Lr, 1).expand_as(dQ)
+    assert float(dQ[dead].abs().max()) == 0.0                                # padded regions: P = 0 exactly

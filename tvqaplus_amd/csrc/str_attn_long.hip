@@ -499,6 +499,117 @@ __global__ __launch_bounds__(256) void str_attn_long_bwd_dq_kernel(const T* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// backward B2 on bf16 storage with D = 256 (BASELINE configs[4]): the kernel above spends its time on the fp32 matrix cores
+// (0.5 TFLOP per call on v_mfma_f32_16x16x4_f32 = 3.2 ms at the stress shape) and every 16-region block re-reads the frame's dA and
+// Cn rows.  Here a wave owns 32 regions and ONE of the two products (dQraw = P^T dA or dQn = dS^T Cn: 8 accumulator tiles of
+// v_mfma_f32_32x32x16_bf16), so each row of dA / Cn is read once per 32 regions and product.  The contraction runs over the context
+// rows: k-slot (h, e) = row c0 + 8h + e.  The weights (P or dS, fp32) go in as bf16 pairs hi + lo (error 2^-16 of a weight); dA / Cn ARE
+// bf16.  d tile dt = columns 8 l + dt (l = lane position): a lane loads the 16 bytes at columns 8l..8l+7 of its eight rows -- two full
+// 512-byte rows per instruction -- and an 8 x 8 transpose of 16-bit values (32 v_perm_b32, as in gemm_bf16_oct.hip) gives the B
+// operand of every tile; the lane ends up owning 8 consecutive output columns of each of its 16 regions (full-row stores).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void str_attn_long_bwd_dq32_kernel(const __hip_bfloat16* __restrict__ dA, const float* __restrict__ Sn,
+                                                                     const float* __restrict__ dS, const __hip_bfloat16* __restrict__ Cn,
+                                                                     float* __restrict__ dQraw, float* __restrict__ dQn, int N, int NA,
+                                                                     int Li, int Lqa, int Lr, const int* __restrict__ fnv) {
+    constexpr int D = 256;
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+    const int CR = NA * Lqa, nb = (Lr + 31) >> 5;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (long)N * Li * nb * 2) return;
+    const int prod = (int)(item & 1);                        // wave-uniform: 0 = dQraw (P, dA), 1 = dQn (dS, Cn)
+    const int rb = (int)((item >> 1) % nb);
+    const long frame = (item >> 1) / nb;
+    const int n = (int)(frame / Li), i = (int)(frame % Li);
+    float* __restrict__ out = prod ? dQn : dQraw;
+    const float* __restrict__ wsrc = prod ? dS : Sn;
+    const int rc = min(rb * 32 + l31, Lr - 1);
+    const int nvf = fnv ? __builtin_amdgcn_readfirstlane(fnv[frame]) : Lr;
+    // B1 writes dS for the 16-region blocks that can carry a gradient only: a region behind them has weight 0 (not whatever the
+    // workspace holds)
+    const bool reg_live = rb * 32 + l31 < ((nvf + 15) & ~15);
+    if (rb * 32 >= nvf) {
+        // regions behind the last one that can carry a gradient (P = 0, dS = 0): exact zeros
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) {
+            const int reg = rb * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+            if (reg < Lr) {
+                float* o = out + (frame * Lr + reg) * D + 8 * l31;
+                st4(o, f4zero());
+                st4(o + 4, f4zero());
+            }
+        }
+        return;
+    }
+    f32x16 acc[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; dt++)
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) acc[dt][rr] = 0.f;
+    struct Step { float w[8]; uint4 q[8]; };
+    auto fetch = [&](Step& s, int c0) {
+        int c = c0 + 8 * h;
+        int qa = c / Lqa, ma = c - qa * Lqa;                 // (candidate, word) of the lane's first row; the next seven follow
+#pragma unroll
+        for (int e = 0; e < 8; e++, c++) {
+            const bool ok = c < CR;
+            const int qq = ok ? qa : NA - 1, mm = ok ? ma : Lqa - 1;
+            const long orow = ((long)(n * NA + qq) * Li + i) * Lqa + mm;
+            s.w[e] = (ok && reg_live) ? wsrc[orow * Lr + rc] : 0.f;   // rows past CR: zero weights (the clamped rows are finite)
+            s.q[e] = prod ? *reinterpret_cast<const uint4*>(Cn + ((long)n * CR + qq * Lqa + mm) * D + 8 * l31)
+                          : *reinterpret_cast<const uint4*>(dA + orow * D + 8 * l31);
+            if (++ma == Lqa) { ma = 0; qa++; }
+        }
+    };
+    auto mul = [&](const Step& s) {
+        unsigned bh[4], bl[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            bh[j] = stage_pk_bf16(s.w[2 * j], s.w[2 * j + 1]);
+            bl[j] = stage_pk_bf16(s.w[2 * j] - __uint_as_float(bh[j] << 16), s.w[2 * j + 1] - __uint_as_float(bh[j] & 0xFFFF0000u));
+        }
+        typedef __bf16 dq_bf16x8 __attribute__((ext_vector_type(8)));
+        const dq_bf16x8 vah = __builtin_bit_cast(dq_bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+        const dq_bf16x8 val = __builtin_bit_cast(dq_bf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+#pragma unroll
+        for (int dt = 0; dt < 8; dt++) {
+            unsigned aw[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint4 w0 = s.q[2 * j], w1 = s.q[2 * j + 1];
+                const int wi = dt >> 1;
+                const unsigned x0 = wi == 0 ? w0.x : (wi == 1 ? w0.y : (wi == 2 ? w0.z : w0.w));
+                const unsigned x1 = wi == 0 ? w1.x : (wi == 1 ? w1.y : (wi == 2 ? w1.z : w1.w));
+                aw[j] = __builtin_amdgcn_perm(x1, x0, (dt & 1) ? 0x07060302u : 0x05040100u);
+            }
+            const dq_bf16x8 vb = __builtin_bit_cast(dq_bf16x8, make_uint4(aw[0], aw[1], aw[2], aw[3]));
+            acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(val, vb, acc[dt], 0, 0, 0);
+            acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah, vb, acc[dt], 0, 0, 0);
+        }
+    };
+    Step s0, s1;
+    fetch(s0, 0);
+    for (int c0 = 0; c0 < CR; c0 += 32) {
+        if (c0 + 16 < CR) fetch(s1, c0 + 16);
+        mul(s0);
+        if (c0 + 16 < CR) {
+            if (c0 + 32 < CR) fetch(s0, c0 + 32);
+            mul(s1);
+        }
+    }
+    // C/D layout: row (rr & 3) + 8 (rr >> 2) + 4 h = region inside the block, column l31 -> d = 8 l31 + dt
+#pragma unroll
+    for (int rr = 0; rr < 16; rr++) {
+        const int reg = rb * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+        if (reg < Lr) {
+            float* o = out + (frame * Lr + reg) * D + 8 * l31;
+            st4(o, make_float4(acc[0][rr], acc[1][rr], acc[2][rr], acc[3][rr]));
+            st4(o + 4, make_float4(acc[4][rr], acc[5][rr], acc[6][rr], acc[7][rr]));
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void lng_slab_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int nb, long C) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= C) return;
@@ -596,6 +707,16 @@ static int lng_bwd(const void* dA, const void* A, const float* ext, const void* 
     const long C = (long)N * CR * D;
     hipLaunchKernelGGL(lng_slab_sum_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, (const float*)part, dCn, nchunks, C);
     STAGE_LAUNCH_CHECK();
+    if constexpr (sizeof(T) == 2) {
+        static const bool dq16 = getenv("STAGE_LONG_DQ16") != nullptr;      // developer switch: the 16-region fp32-MFMA kernel
+        if (D == 256 && !dq16) {
+            const long items32 = (long)N * Li * ((Lr + 31) / 32) * 2;
+            hipLaunchKernelGGL(str_attn_long_bwd_dq32_kernel, dim3((unsigned)((items32 + 3) / 4)), dim3(256), 0, st, (const __hip_bfloat16*)dA, Sn,
+                               (const float*)dS, (const __hip_bfloat16*)Cn, dQraw, dQn, N, NA, Li, Lqa, Lr, (const int*)fnv);
+            STAGE_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const bool dq_split = D > 128 && !(sizeof(T) == 2 && !getenv("STAGE_LONG_DQ_SPLIT"));
     const long items2 = (long)N * Li * ((Lr + 15) / 16) * (dq_split ? D / 128 : 1);
 #define LNG_Q(DTV, DTWV)                                                                                                   \
