@@ -1013,7 +1013,8 @@ def test_long_attention_bf16_dq_blocks_of_32_regions(ops, Lr, Lqa):
     dS = torch.nan_to_num(dS_ws, nan=0.0)                                    # what was not written is an exact zero of the gradient
     ref_raw = torch.einsum("nailr,naild->nird", Sn.double(), dA.double())
     ref_n = torch.einsum("nailr,nald->nird", dS.double(), Cn.double())
-    for name, got, ref in (("dQraw", dQ, ref_raw), ("dQn", dQn, ref_n)):
+    ref_c = torch.einsum("nailr,nird->nald", dS.double(), Qn.double())        # dCn: the same hi + lo scheme in str_attn_long_bwd_ds_kernel
+    for name, got, ref in (("dQraw", dQ, ref_raw), ("dQn", dQn, ref_n), ("dCn", dCn, ref_c)):
         err = float((got.double() - ref).abs().max())
         assert err <= 2e-5 * (1.0 + float(ref.abs().max())), (name, err, float(ref.abs().max()))   # bf16 hi + lo weights: 2^-16 per term
     dead = (qm == 0).view(N, Li, Lr, 1).expand_as(dQ)

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void str_attn_long_bwd_ds_kernel(const T* __re
         dot = cross_row_sum(dot);
         const T* qr = Q + frame * Lr * (long)D;
         const T* qn = Qn + frame * Lr * (long)D;
-        for (int rb = 0; rb < nvb; rb++) {
+        auto ds_block = [&](int rb) -> f32x4 {      // dP, dS (stored) of one 16-region block; returns the lane's four dS values
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
             if constexpr (LngUseB<T, D>::value) {
                 LngRowB<D> qfb;
@@ -384,25 +384,52 @@ __global__ __launch_bounds__(256) void str_attn_long_bwd_ds_kernel(const T* __re
                     G[k] = v;
                 }
             }
-            if constexpr (LngUseB<T, D>::value && (DT % 8 == 0)) {
-                // bf16 storage: the Qn rows stay packed (half the registers: two waves per SIMD at D = 256) and are
-                // converted where they feed the matrix cores
-                uint4 qw[4][DT / 8];
+            return G;
+        };
+        if constexpr (LngUseB<T, D>::value && (DT % 8 == 0)) {
+            // bf16 storage, D = 128 / 256: dCn^T (d x ctx) += Qn^T . dS^T on the bf16 matrix cores, 32 regions (two blocks) per step, exactly as
+            // the forward's A^T += Q^T . S_^T: K-slot (g, e) of the 16x16x32 MFMA = region (rb + (e >> 2)) * 16 + 4 g + (e & 3) = the eight dS
+            // values lane (c15, g) holds after two blocks; dS goes in as bf16 pairs hi + lo (2^-16 of a value), Qn is bf16 in HBM.  32 MFMAs of
+            // ~16 cycles per step instead of 128 fp32 ones of 32 (round 4: this product was 1.6 of the kernel's 2.7 ms at the stress shape).
+            constexpr int NW4 = DT / 8;
+            for (int rb = 0; rb < nvb; rb += 2) {
+                uint4 q8[8][NW4];
 #pragma unroll
-                for (int k = 0; k < 4; k++)
+                for (int e = 0; e < 8; e++)
 #pragma unroll
-                    for (int q = 0; q < DT / 8; q++)
-                        qw[k][q] = *reinterpret_cast<const uint4*>(qn + (long)min(rb * 16 + 4 * g + k, Lr - 1) * D + DT * c15 + 8 * q);
+                    for (int q = 0; q < NW4; q++)
+                        q8[e][q] = *reinterpret_cast<const uint4*>(qn + (long)min((rb + (e >> 2)) * 16 + 4 * g + (e & 3), Lr - 1) * D + DT * c15 + 8 * q);
+                const f32x4 G0 = ds_block(rb);
+                f32x4 G1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (rb + 1 < nvb) G1 = ds_block(rb + 1);               // (wave-uniform)
+                const float p[8] = {G0[0], G0[1], G0[2], G0[3], G1[0], G1[1], G1[2], G1[3]};
+                unsigned bh[4], bl[4];
 #pragma unroll
-                for (int dt = 0; dt < DT; dt++)
+                for (int j = 0; j < 4; j++) {
+                    bh[j] = stage_pk_bf16(p[2 * j], p[2 * j + 1]);
+                    bl[j] = stage_pk_bf16(p[2 * j] - __uint_as_float(bh[j] << 16), p[2 * j + 1] - __uint_as_float(bh[j] & 0xFFFF0000u));
+                }
+                const lng_bf16x8 vbh = __builtin_bit_cast(lng_bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+                const lng_bf16x8 vbl = __builtin_bit_cast(lng_bf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint4 w4 = qw[k][dt / 8];
-                        const unsigned w = (dt % 8) / 2 == 0 ? w4.x : ((dt % 8) / 2 == 1 ? w4.y : ((dt % 8) / 2 == 2 ? w4.z : w4.w));
-                        const float a = (dt & 1) ? __uint_as_float(w & 0xFFFF0000u) : __uint_as_float(w << 16);
-                        dcn[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, G[k], dcn[dt], 0, 0, 0);
+                for (int dt = 0; dt < DT; dt++) {
+                    unsigned aw[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint4 w0 = q8[2 * j][dt / 8], w1 = q8[2 * j + 1][dt / 8];
+                        const int wi = (dt % 8) / 2;
+                        const unsigned x0 = wi == 0 ? w0.x : (wi == 1 ? w0.y : (wi == 2 ? w0.z : w0.w));
+                        const unsigned x1 = wi == 0 ? w1.x : (wi == 1 ? w1.y : (wi == 2 ? w1.z : w1.w));
+                        aw[j] = __builtin_amdgcn_perm(x1, x0, (dt & 1) ? 0x07060302u : 0x05040100u);
                     }
-            } else {
+                    const lng_bf16x8 va = __builtin_bit_cast(lng_bf16x8, make_uint4(aw[0], aw[1], aw[2], aw[3]));
+                    dcn[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, vbl, dcn[dt], 0, 0, 0);
+                    dcn[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, vbh, dcn[dt], 0, 0, 0);
+                }
+            }
+        } else {
+            for (int rb = 0; rb < nvb; rb++) {
+                const f32x4 G = ds_block(rb);
                 float qd[4][DT];         // Qn[region][DT c15 .. + DT - 1] (d tiles permuted as in the forward)
 #pragma unroll
                 for (int k = 0; k < 4; k++) lng_ldn<DT>(qd[k], qn + (long)min(rb * 16 + 4 * g + k, Lr - 1) * D + DT * c15);   // G = 0 past Lr
