@@ -27,7 +27,7 @@ extern "C" {
 #define STAGE_ERR_WORKSPACE (-2)  /* workspace too small */
 
 /* ---- library info -------------------------------------------------------------------------------------------- */
-#define STAGE_HIP_ABI_VERSION 3   /* what stage_hip_abi_version() of a matching library returns; bumped whenever a symbol or a signature changes */
+#define STAGE_HIP_ABI_VERSION 4   /* what stage_hip_abi_version() of a matching library returns; bumped whenever a symbol or a signature changes */
 int stage_hip_abi_version(void);
 const char* stage_hip_error_string(int code);
 /* Measurement helpers (bench.py; no reference counterpart): events for hosts without a HIP binding, and a one-shot hook that makes the
@@ -408,9 +408,10 @@ int stage_tscores_bwd(const float* dout, const float* tm, float* d_st, float* d_
 int stage_gt_spans(const float* t_scores, const long long* target, const long long* lab_st, const long long* lab_ed,
                    float* spans, int N, int NA, int Li, void* stream);
 /* temporal loss (model/stage.py:539-555) and d loss / d t_scores in one pass; scratch: N floats; cand_offset: global index of
- * local candidate 0 (candidate-sharded batches: examples whose ground truth is not local contribute nothing)               */
+ * local candidate 0 (candidate-sharded batches: examples whose ground truth is not local contribute nothing); na_total: the
+ * model's candidate count over all ranks (a target outside [0, na_total) makes the loss NaN; <= 0: cand_offset + NA)        */
 int stage_ts_loss(const float* t_scores, const long long* target, const long long* lab_st, const long long* lab_ed, float* loss,
-                  float* grad, float* scratch, int N, int NA, int Li, int cand_offset, void* stream);
+                  float* grad, float* scratch, int N, int NA, int Li, int cand_offset, int na_total, void* stream);
 /* supervised attention loss (model/stage.py:738-745) over M (positive, negative) pairs: flat = 2M int64 indices into scores
  * (positives, then negatives); hinge != 0: max(0, margin + s_neg - s_pos), else log1p(exp(alpha (s_neg - s_pos))).  coef (M) is
  * kept for the backward, which zero-fills dS (n_scores floats) and scatters gout[0] * coef into it.                          */

@@ -64,3 +64,20 @@ def test_unknown_loss_type_raises():
     model.att_loss_type = "bce"
     with pytest.raises(NotImplementedError):
         att_host.get_att_loss(model, scores, batch)
+
+
+def test_placeholder_targets_plus_device_offset_equal_the_host_build():
+    """``build_att_pairs(placeholder_targets=True)`` + ``AttPairs(target_dev=...)`` (the answer's slice offset added next to the score
+    tensor instead of ``batch.target.tolist()``) index exactly the pairs the host-target build indexes, with the same random draws."""
+    fx, cfg, scores, batch, model = _load("att_lse_random")
+    shape = tuple(scores.shape)
+    torch.manual_seed(cfg["seed"])
+    pos, neg = att_host.build_att_pairs(model, batch, None)
+    torch.manual_seed(cfg["seed"])
+    pos0, neg0 = att_host.build_att_pairs(model, batch, None, placeholder_targets=True)
+    assert (pos0[:, 1] == 0).all() and (neg0[:, 1] == 0).all()
+    a = att_host.AttPairs(pos, neg, shape, "cpu")
+    b = att_host.AttPairs(pos0, neg0, shape, "cpu", target_dev=batch.target)
+    assert a.m == b.m and torch.equal(a.flat, b.flat)
+    # on the host nothing qualifies for the device path (the decision needs a device-resident target and no host copy)
+    assert not att_host.targets_on_device_ok(model, batch, None)

@@ -13,15 +13,16 @@ with contextlib.redirect_stdout(open(os.devnull, "w")):
     model = STAGE(opt).cuda().train()
 params = [p for p in model.parameters() if p.requires_grad]
 bucket = parallel.FlatGradBucket(params)
-optim = torch.optim.Adam(params, lr=1e-3, weight_decay=3e-7)
-batch = make_batch(N=16, seed=2018, att_imgs=4, att_words=3).to("cuda")
+optim = torch.optim.Adam(params, lr=1e-3, weight_decay=3e-7, fused=True)
+BSZ = int(os.environ.get("BSZ", "16"))
+batch = make_batch(N=BSZ, seed=2018, att_imgs=4, att_words=3).to("cuda")
 for _ in range(4):
-    bench.train_step(model, batch, bucket, params, optim, 16, 1)
+    bench.train_step(model, batch, bucket, params, optim, BSZ, 1)
 torch.cuda.synchronize()
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(steps):
-    bench.train_step(model, batch, bucket, params, optim, 16, 1)
+    bench.train_step(model, batch, bucket, params, optim, BSZ, 1)
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)

@@ -125,7 +125,7 @@ SIGNATURES = {
     "stage_tscores_fwd": (I, [P, P, P, P, I, I, I, P]),
     "stage_tscores_bwd": (I, [P, P, P, P, I, I, I, P]),
     "stage_gt_spans": (I, [P, P, P, P, P, I, I, I, P]),
-    "stage_ts_loss": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
+    "stage_ts_loss": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "stage_att_loss_fwd": (I, [P, P, LL, I, F, F, P, P, P]),
     "stage_att_loss_bwd": (I, [P, P, P, LL, P, LL, P]),
     "stage_grp_pool_cls_arena_bytes": (SZ, [LL, I, I]),
@@ -165,7 +165,7 @@ SIGNATURES = {
     "stage_grp_encoder_rag_bwd": (I, [P, P, P, P, P, P, P, SZ, P, P, SZ, LL, LL, LL, LL, I, I, I, I, F, P, P]),
 }
 
-ABI_VERSION = 3    # include/stage_hip.h: STAGE_HIP_ABI_VERSION (tests/test_abi.py holds the two together)
+ABI_VERSION = 4    # include/stage_hip.h: STAGE_HIP_ABI_VERSION (tests/test_abi.py holds the two together)
 
 _lib = None
 

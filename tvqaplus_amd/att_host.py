@@ -55,7 +55,24 @@ def _labels_to_host(att_labels) -> List[List[np.ndarray]]:
     return out
 
 
-def build_att_pairs(model, batch, scores: Optional[torch.Tensor] = None, n_local_candidates: Optional[int] = None):
+def targets_on_device_ok(model, batch, n_local_candidates: Optional[int]) -> bool:
+    """True when the pair lists can be built WITHOUT knowing the answer indices on the host: the batch carries no host copy of them
+    (``target_list``: a batch straight from the reference's prepare_inputs, tvqa_dataset.py:631-688, has only the device tensor), every
+    candidate is local (the answer index then only selects a slice of the score tensor, it filters nothing) and the negatives are drawn at
+    random (hard negatives read the scores of the answer's rows).  ``AttPairs(..., target_dev=batch.target)`` then adds the answer's
+    offset on the device -- instead of ``batch.target.tolist()``, which drains the whole queue (11-16 ms per step, DESIGN finding 18)."""
+    if getattr(batch, "target_list", None) is not None or bool(getattr(batch, "use_hard_negatives", False)):
+        return False
+    if int(getattr(batch, "cand_offset", 0) or 0) != 0:
+        return False
+    t = getattr(batch, "target", None)
+    if not (torch.is_tensor(t) and t.is_cuda):
+        return False
+    return n_local_candidates is None or int(n_local_candidates) == int(getattr(model, "num_a", n_local_candidates))
+
+
+def build_att_pairs(model, batch, scores: Optional[torch.Tensor] = None, n_local_candidates: Optional[int] = None,
+                    placeholder_targets: bool = False):
     """Host half of ``get_att_loss`` (model/stage.py:612-694): the (positive, sampled negative) index pairs of the batch as
     two (M, 5) int64 arrays of (batch, answer, image, word, region) rows, in the reference's order and with the reference's
     random draws.  Random-negative mode needs no scores (it can run ahead of the device, e.g. in the data loader);
@@ -64,7 +81,9 @@ def build_att_pairs(model, batch, scores: Optional[torch.Tensor] = None, n_local
     # host copy of the answer indices when the input pipeline kept one (`.tolist()` of a device tensor waits for the whole
     # queue: measured 11-16 ms inside the step -- a full host/device serialisation per batch, which the reference also pays)
     targets = getattr(batch, "target_list", None)
-    if targets is None:
+    if placeholder_targets:      # ``targets_on_device_ok``: candidate column 0 everywhere, the device adds the answer's offset
+        targets = [0] * len(batch.att_labels)
+    elif targets is None:
         targets = batch.target.tolist()
     targets = list(targets)
     hard = bool(getattr(batch, "use_hard_negatives", False))
@@ -151,7 +170,10 @@ class AttPairs:
     rows, resident on the device.  ``stage`` = a ``PinnedStage`` reused across steps (``pin_memory()`` per call registers
     a fresh page-locked allocation every time: ~0.5 ms of host time on the launch path)."""
 
-    def __init__(self, pos: np.ndarray, neg: np.ndarray, shape, device, stage: Optional[PinnedStage] = None):
+    def __init__(self, pos: np.ndarray, neg: np.ndarray, shape, device, stage: Optional[PinnedStage] = None,
+                 target_dev: Optional[torch.Tensor] = None):
+        """``target_dev`` (N,) int64 on the device: the pairs were built with candidate 0 as a placeholder
+        (``build_att_pairs(placeholder_targets=True)``); the answer's slice offset is added here, on the device, without a host read."""
         both = np.concatenate([pos, neg], axis=0)
         _, NA, Li, Lqa, Lr = shape
         if both.size and ((both < 0).any() or (both >= np.asarray([shape[0], NA, Li, Lqa, Lr])).any()):
@@ -159,6 +181,8 @@ class AttPairs:
         flat = (((both[:, 0] * NA + both[:, 1]) * Li + both[:, 2]) * Lqa + both[:, 3]) * Lr + both[:, 4]
         self.m = pos.shape[0]
         self.shape = tuple(shape)
+        if target_dev is not None:
+            flat = np.concatenate([flat, both[:, 0]])            # the example of every pair rides in the same upload
         t = torch.from_numpy(flat)
         if torch.device(device).type == "cuda":
             if stage is None:
@@ -166,6 +190,10 @@ class AttPairs:
             self.flat = stage.upload(t, device)
         else:
             self.flat = t
+        if target_dev is not None:
+            n2 = 2 * self.m
+            ca = target_dev.to(self.flat.device).clamp(0, NA - 1).index_select(0, self.flat[n2:])     # (the kernels gather unchecked)
+            self.flat = self.flat[:n2] + ca * (Li * Lqa * Lr)
         self.stage = stage
 
 

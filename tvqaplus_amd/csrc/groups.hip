@@ -1074,7 +1074,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void ts_loss_kernel(const float* __restrict__ t, const long long* __restrict__ target,
                                                       const long long* __restrict__ lab_st, const long long* __restrict__ lab_ed,
                                                       float* __restrict__ grad, float* __restrict__ part, int NA, int Li,
-                                                      int cand_offset) {
+                                                      int cand_offset, int na_total) {
     __shared__ float sh[4];
     const int n = blockIdx.x / NA, a = blockIdx.x % NA, tid = threadIdx.x;
     const float* x = t + (long)blockIdx.x * Li * 2;
@@ -1082,8 +1082,9 @@ __global__ __launch_bounds__(256) void ts_loss_kernel(const float* __restrict__ 
     const int local = (int)target[n] - cand_offset;
     if (a != local) {
         for (int i = tid; i < Li; i += 256) reinterpret_cast<float2*>(g)[i] = make_float2(0.f, 0.f);
-        // not among the local candidates: nothing here (candidate-sharded batches) -- unless no rank can hold it
-        if (tid == 0 && a == 0 && (local < 0 || local >= NA)) part[n] = (cand_offset == 0 && NA == 5) ? NAN : 0.f;
+        // not among the local candidates: nothing here (candidate-sharded batches) -- unless no rank can hold it (a target outside
+        // the na_total candidates of the model: NaN, what the reference's gather would fault on)
+        if (tid == 0 && a == 0 && (local < 0 || local >= NA)) part[n] = (local + cand_offset < 0 || local + cand_offset >= na_total) ? NAN : 0.f;
         return;
     }
     float m0 = -INFINITY, m1 = -INFINITY;
@@ -1187,10 +1188,10 @@ extern "C" int stage_gt_spans(const float* t_scores, const long long* target, co
 }
 // loss (1), grad (N, NA, Li, 2) = d loss / d t_scores; scratch: N floats
 extern "C" int stage_ts_loss(const float* t_scores, const long long* target, const long long* lab_st, const long long* lab_ed,
-                             float* loss, float* grad, float* scratch, int N, int NA, int Li, int cand_offset, void* st) {
+                             float* loss, float* grad, float* scratch, int N, int NA, int Li, int cand_offset, int na_total, void* st) {
     if (N <= 0 || NA <= 0 || Li <= 0) return STAGE_ERR_SHAPE;
     hipLaunchKernelGGL(ts_loss_kernel, dim3(N * NA), dim3(256), 0, (hipStream_t)st, t_scores, target, lab_st, lab_ed, grad, scratch, NA,
-                       Li, cand_offset);
+                       Li, cand_offset, na_total > 0 ? na_total : cand_offset + NA);
     hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(64), 0, (hipStream_t)st, scratch, N, loss);
     STAGE_LAUNCH_CHECK();
     return 0;

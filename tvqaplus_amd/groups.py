@@ -683,7 +683,7 @@ def pool_classifier(first, mask, glob, idx_g, meta, dims, p: float, seeds, param
 
 class _TsLoss(torch.autograd.Function):
     @_on_device
-    def forward(ctx, t_scores, target, lab_st, lab_ed, cand_offset: int):
+    def forward(ctx, t_scores, target, lab_st, lab_ed, cand_offset: int, na_total: int = 0):
         t = _chk(t_scores, "t_scores")
         N, NA, Li, _ = t.shape
         target, lab_st, lab_ed = (_chk(v, "labels", torch.int64) for v in (target, lab_st, lab_ed))
@@ -691,19 +691,19 @@ class _TsLoss(torch.autograd.Function):
         grad = torch.empty_like(t)
         scratch = torch.empty(N, dtype=torch.float32, device=t.device)
         _rc(_lib.load().stage_ts_loss(t.data_ptr(), target.data_ptr(), lab_st.data_ptr(), lab_ed.data_ptr(), loss.data_ptr(), grad.data_ptr(),
-                                      scratch.data_ptr(), N, NA, Li, int(cand_offset), _stream()), "stage_ts_loss")
+                                      scratch.data_ptr(), N, NA, Li, int(cand_offset), int(na_total), _stream()), "stage_ts_loss")
         ctx.save_for_backward(grad)
         return loss
 
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        return grad * g, None, None, None, None
+        return grad * g, None, None, None, None, None
 
 
-def ts_loss(t_scores, target, lab_st, lab_ed, cand_offset: int = 0):
+def ts_loss(t_scores, target, lab_st, lab_ed, cand_offset: int = 0, na_total: int = 0):
     """0.5 * (CE_sum(start scores of the ground-truth candidate, st) + CE_sum(end scores, ed))   (model/stage.py:539-555)."""
-    return _TsLoss.apply(t_scores, target, lab_st, lab_ed, cand_offset)
+    return _TsLoss.apply(t_scores, target, lab_st, lab_ed, cand_offset, na_total)
 
 
 class _AttLoss(torch.autograd.Function):

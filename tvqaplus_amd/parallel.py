@@ -199,8 +199,18 @@ class FlatGradBucket:
             if absent:
                 p.grad = None
 
+    def flush(self) -> None:
+        """Raise NOW if the last ``all_reduce`` reported a changed gradient set (otherwise the report of the LAST step of a run would
+        never be read: call after the training loop, on every rank)."""
+        self._raise_if_changed()
+
     def all_reduce(self) -> None:
         """Pack (always: ``flat`` is valid with one rank too), sum over ranks, drop the structurally absent gradients."""
+        self._raise_if_changed()
+        self.pack()
+        self._reduce_packed()
+
+    def _raise_if_changed(self) -> None:
         if self._changed_pending is not None:
             # what the PREVIOUS step's all-reduce said (its read-back has long arrived): some rank's set changed -> every rank sees the
             # same count here, before this step's collective, and raises together
@@ -212,13 +222,16 @@ class FlatGradBucket:
                 raise RuntimeError("FlatGradBucket: the set of parameters that receive a gradient changed on %d rank(s) in the previous "
                                    "step (which applied the old agreement on every rank, so the replicas are still identical); call "
                                    "bucket.reset_absent() on every rank when enabling / disabling a model branch" % int(round(float(host[0]))))
-        self.pack()
+
+    def _reduce_packed(self) -> None:
         if not _single():
             changed = getattr(self, "_absent", None) is not None and self._present_local != self._absent_basis
             self._buf[-1:].fill_(1.0 if changed else 0.0)
             _all_reduce_sum(self._buf)
             if self._buf.is_cuda:
-                host = torch.empty(1, dtype=self._buf.dtype, pin_memory=True)
+                host = getattr(self, "_changed_host", None)        # ONE pinned word, reused: the previous read was consumed above
+                if host is None or host.dtype != self._buf.dtype:
+                    host = self._changed_host = torch.empty(1, dtype=self._buf.dtype, pin_memory=True)
                 host.copy_(self._buf[-1:], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(self._buf.device))

@@ -188,6 +188,10 @@ class RaggedLayout:
                                                          self.rowinfo.data_ptr(), _stream()), "stage_rag_rowinfo")
         self.T = (ctypes.c_void_p * 4)(self.fmap.data_ptr(), self.gdesc.data_ptr(), self.seq.data_ptr(), self.rowinfo.data_ptr())
 
+    def device_tensors(self) -> list:
+        """The device allocations behind the table pointers (for ``record_stream`` when another stream reads them)."""
+        return [self.tables, self.rowinfo]
+
     @property
     def out_rows(self) -> int:
         return self.N * self.NA * self.Li      # the pooled encoder group writes one row per (example, candidate, frame)
@@ -270,6 +274,9 @@ class CtxLayout:
                 _lib.check(_lib.load().stage_rag_ctx_rows(self.cq.data_ptr(), tab.N * tab.Li, tab.L, self.src_rows.data_ptr(), _stream()),
                            "stage_rag_ctx_rows")
         self.T = (ctypes.c_void_p * 4)(None, None, self.seq.data_ptr(), None)
+
+    def device_tensors(self) -> list:
+        return [self.tables, self.src_rows]
 
 
 def mask_lens(mask: np.ndarray) -> np.ndarray:

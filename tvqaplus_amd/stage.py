@@ -648,7 +648,7 @@ class STAGE(nn.Module):
         if self._grouped() and temporal_scores.is_cuda and temporal_scores.dtype == torch.float32 and 1 <= Li <= 2048 and bsz > 0:
             # loss and its gradient in one pass (csrc/groups.hip: ts_loss_kernel) instead of gather + 2 x (log-softmax, nll) + add
             try:
-                return groups.ts_loss(temporal_scores, answer_indices, ts_labels["st"], ts_labels["ed"], cand_offset)
+                return groups.ts_loss(temporal_scores, answer_indices, ts_labels["st"], ts_labels["ed"], cand_offset, self.num_a)
             except groups.Unsupported:
                 pass
         local = answer_indices - cand_offset
@@ -723,8 +723,8 @@ class STAGE(nn.Module):
             return none
         N, NA, Lqa, D = a_embed.shape
         blocks = list(self.cls_encoder.stacked_encoderBlocks)
-        if D != 128 or not (4 <= Lqa <= 40):
-            return none
+        if D != 128 or not (4 <= Lqa <= 40) or self.bridge_hsz % 4 or self.bridge_hsz > 1024:
+            return none          # (the ragged input-MLP group's own limits: stage_grp_input_mlp_rag_fwd declines other widths)
         # words kept behind the last valid one: the classifier encoder's convolution halo -- or every word of a live frame when that
         # encoder is not a single conv-only block (self-attention mixes all words; the frames that are dead are still skipped)
         cls_halo = Lqa
@@ -860,6 +860,20 @@ class STAGE(nn.Module):
         self.last_buckets = {}
         if streams:
             s_vid.wait_stream(main)                # the layouts' tables are uploaded / expanded on the main stream
+            # Everything allocated on the main stream that a branch stream reads -- in the forward or, through saved tensors, in the
+            # backward (autograd runs a node on its forward's stream): the float masks and the layouts' device tables.  Registered with
+            # the allocator for both side streams, so that a block whose last reference is dropped by a side-stream node is not handed
+            # to the main stream's next allocation while that node's kernel still reads it (the statement / video
+            # embeddings and the level-3 outputs are registered where they cross).
+            shared = [qas_mask, sub_mask_f, vid_mask_f]
+            if lay is not None:
+                shared += lay.device_tensors()
+            for cl_ in clays.values():
+                shared += cl_.device_tensors()
+            for t in shared:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(s_qa)
+                    t.record_stream(s_vid)
         if self.sub_flag:
             Li, Lw = batch.sub_bert.shape[1:3]
             sub_mask = sub_mask_f.view(N, Li, Lw)
@@ -940,12 +954,13 @@ class STAGE(nn.Module):
         att_pairs = None
         if (self.use_sup_att and self.training and self.vfeat_flag and not self.inference_mode
                 and not bool(_opt(batch, "use_hard_negatives", False)) and _opt(batch, "att_pairs", None) is None):
-            from .att_host import AttPairs, build_att_pairs
-            pos, neg = build_att_pairs(self, batch, None, n_local_candidates=NA)
+            from .att_host import AttPairs, build_att_pairs, targets_on_device_ok
+            on_dev = targets_on_device_ok(self, batch, NA)       # no host copy of the answers: their offset is added on the device
+            pos, neg = build_att_pairs(self, batch, None, n_local_candidates=NA, placeholder_targets=on_dev)
             if pos is not None:
                 Li_v, Lr_v = batch.vid.shape[1:3]
                 att_pairs = AttPairs(pos, neg, (N, NA, Li_v, batch.qas_mask.shape[-1], Lr_v), batch.vid.device,
-                                     getattr(self, "_att_stage", None))
+                                     getattr(self, "_att_stage", None), target_dev=batch.target if on_dev else None)
                 self._att_stage = att_pairs.stage
         ctx_m = vid_mask if self.vfeat_flag else sub_mask       # the statement mask's context side (model/stage.py:386)
         factors = ((qas_mask != 0).any(-1), ctx_m.sum(-1) != 0)
