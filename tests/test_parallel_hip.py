@@ -163,8 +163,9 @@ def test_bench_two_ranks_sharing_one_gpu(hip_device):
     lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]                       # rank 0 prints the one line
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
-    assert rec["config"]["global_batch"] == 4 and rec["device_ms_per_step"] > 0
+    # (default --scaling strong: the --bsz examples are the GLOBAL batch, one example per rank here)
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
+    assert rec["config"]["global_batch"] == 2 and rec["device_ms_per_step"] > 0
 
 
 def _nccl_worker(port, q):

@@ -12,14 +12,15 @@ with contextlib.redirect_stdout(open(os.devnull, "w")):
     model = STAGE(opt).cuda().train()
 params = [p for p in model.parameters() if p.requires_grad]
 bucket = parallel.FlatGradBucket(params)
-optim = torch.optim.Adam(params, lr=1e-3, weight_decay=3e-7)
-batch = make_batch(N=16, seed=2018, att_imgs=4 if sup else 0, att_words=3).to("cuda")
+optim = torch.optim.Adam(params, lr=1e-3, weight_decay=3e-7, fused=True)
+BSZ = int(os.environ.get("BSZ", "16"))
+batch = make_batch(N=BSZ, seed=2018, att_imgs=4 if sup else 0, att_words=3).to("cuda")
 acc = [0.0] * 4
 def step(record):
     t0 = time.perf_counter()
     bucket.zero()
     (out, targets), att_loss, _, t_loss, _ = model(batch)
-    loss = F.cross_entropy(out, targets, reduction="sum") * (16.0 / len(targets)) + 0.1 * att_loss + 0.5 * t_loss
+    loss = F.cross_entropy(out, targets, reduction="sum") * (float(BSZ) / len(targets)) + 0.1 * att_loss + 0.5 * t_loss
     t1 = time.perf_counter()
     loss.backward()
     t2 = time.perf_counter()
@@ -43,6 +44,17 @@ def wrap(obj, name, key):
     setattr(obj, name, g)
 wrap(AH, "build_att_pairs", "build_att_pairs"); wrap(AH, "get_att_loss", "get_att_loss")
 wrap(torch.cuda.Event, "synchronize", "event.synchronize")
+for nm in ("_ragged_layout", "base_encoder", "qa_ctx_attention", "classfier_head_multi_proposal", "_proposals_grouped", "get_ts_loss", "_open_gates"):
+    wrap(STAGE, nm, "STAGE." + nm)
+import tvqaplus_amd.groups as GR
+for nm in ("concat_fc", "temporal_head", "pool_classifier", "encoder_block_rag", "encoder_block", "input_mlp", "input_mlp_rag", "qa_ctx_rag", "gate", "gt_spans", "masked_max_raw", "tscores", "att_loss", "ts_loss"):
+    if hasattr(GR, nm):
+        wrap(GR, nm, "groups." + nm)
+wrap(bucket, "all_reduce", "bucket.all_reduce"); wrap(optim, "step", "optim.step")
+_cg = torch.nn.utils.clip_grad_norm_
+def _cgt(*a, **k):
+    t = time.perf_counter(); r = _cg(*a, **k); tm["clip_grad_norm_"] = tm.get("clip_grad_norm_", 0.0) + time.perf_counter() - t; return r
+torch.nn.utils.clip_grad_norm_ = _cgt
 torch.cuda.synchronize()
 for _ in range(n): step(False)
 torch.cuda.synchronize()

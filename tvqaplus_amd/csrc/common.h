@@ -281,43 +281,8 @@ __global__ __launch_bounds__(1024) static void stage_colreduce_kernel(const floa
         } else out[c] = s;
     }
 }
-// First level of a large reduction, IN PLACE: row g*SG <- row g*SG + row g*SG+1 + ... (SG rows, fixed order).  A workgroup column is
-// 256 lanes x 16 bytes = 4 KB of contiguous row, a workgroup reads its SG rows with all loads independent: the split-M slabs of a
-// weight gradient (256..1024 rows of 64..900 KB, 30..200 MB) stream at HBM rate instead of 16 rows x 256 B per workgroup visit
-// (round 4: 0.35 TB/s, 1.6 ms of a 14 ms step).  The caller then reduces the ceil(nb/SG) folded rows (stride SG*stride).
-template <int SG>
-__global__ __launch_bounds__(256) static void stage_colfold_kernel(float* __restrict__ part, int nb, long stride, int C4) {
-    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
-    const int b0 = blockIdx.y * SG;
-    if (c4 >= C4) return;
-    float4* p = reinterpret_cast<float4*>(part + (size_t)b0 * stride) + c4;
-    const int n = min(SG, nb - b0);
-    float4 v[SG];
-#pragma unroll
-    for (int j = 0; j < SG; j++) {
-        const int jj = j < n ? j : 0;                       // (rows past the end: a repeated, unused load instead of a branch)
-        v[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + (size_t)jj * stride);
-    }
-    float4 acc = v[0];
-#pragma unroll
-    for (int j = 1; j < SG; j++)
-        if (j < n) acc = f4add(acc, v[j]);
-    *p = acc;
-}
-// rows / stride the final reduction sees after the optional fold (large inputs with 16-byte aligned rows only)
-static inline void stage_colfold(const float*& part, int& nb, long& stride, int C, hipStream_t st) {
-    constexpr int SG = 8;
-    if (nb < 4 * SG || (long)nb * C < (1l << 16) || (C & 3) || (stride & 3) || ((uintptr_t)part & 15)) return;
-    const int G = (nb + SG - 1) / SG;
-    const int C4 = C / 4;
-    const int bx = C4 >= 256 ? 256 : (C4 + 63) / 64 * 64;
-    hipLaunchKernelGGL(stage_colfold_kernel<SG>, dim3((C4 + bx - 1) / bx, G), dim3(bx), 0, st, const_cast<float*>(part), nb, stride, C4);
-    nb = G;
-    stride *= SG;
-}
 static inline void stage_colreduce(const float* part, float* out, float* out2, int nb, long stride, int C, int D, int k,
                                    hipStream_t st) {
-    stage_colfold(part, nb, stride, C, st);
     hipLaunchKernelGGL(stage_colreduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, part, out, out2, nb, stride, C, D, k);
 }
 
@@ -331,7 +296,7 @@ static inline int stage_chunk_len(int L) {
 // [0, ceil(CA/64)) reduce segment A, the rest segment B.  Same 16-way parallel, fixed-order scheme as above.
 __global__ __launch_bounds__(1024) static void stage_colreduce2_kernel(const float* __restrict__ partA, float* __restrict__ outA,
                                                                        long strideA, int CA, const float* __restrict__ partB,
-                                                                       float* __restrict__ outB, long strideB, int CB, int nbA, int nbB) {
+                                                                       float* __restrict__ outB, long strideB, int CB, int nb) {
     __shared__ float sm[16][64];
     const int x = threadIdx.x & 63, r = threadIdx.x >> 6;
     const int blocksA = (CA + 63) / 64;
@@ -341,7 +306,6 @@ __global__ __launch_bounds__(1024) static void stage_colreduce2_kernel(const flo
     const long stride = isA ? strideA : strideB;
     const int C = isA ? CA : CB;
     const int c = (isA ? blockIdx.x : blockIdx.x - blocksA) * 64 + x;
-    const int nb = isA ? nbA : nbB;
     float acc = 0.f;
     if (c < C) {
 #pragma unroll 4
@@ -358,10 +322,8 @@ __global__ __launch_bounds__(1024) static void stage_colreduce2_kernel(const flo
 }
 static inline void stage_colreduce2(const float* partA, float* outA, long strideA, int CA, const float* partB, float* outB,
                                     long strideB, int CB, int nb, hipStream_t st) {
-    int nbA = nb;
-    stage_colfold(partA, nbA, strideA, CA, st);
     hipLaunchKernelGGL(stage_colreduce2_kernel, dim3((CA + 63) / 64 + (CB + 63) / 64), dim3(1024), 0, st, partA, outA, strideA,
-                       CA, partB, outB, strideB, CB, nbA, nb);
+                       CA, partB, outB, strideB, CB, nb);
 }
 
 static inline int stage_pow2_ceil(int v) {
