@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--gc", choices=("freeze", "default", "off"), default="freeze",
                     help="cyclic garbage collector during the timed steps: freeze (default) = gc.freeze() after the warm-up")
     ap.add_argument("--adam", choices=["fused", "foreach"], default="fused", help="torch.optim.Adam implementation (same update)")
+    ap.add_argument("--clip", choices=["flat", "torch"], default="flat", help="clip_grad_norm_(10): on the packed gradient buffer "
+                    "(parallel.FlatGradBucket.clip_grad_norm_: one reduction + one multiply) or torch.nn.utils.clip_grad_norm_ (same update)")
     ap.add_argument("--dump_steps", action="store_true", help="developer: add every timed step's duration (ms) to the record")
     ap.add_argument("--no_device_time", action="store_true", help="skip the torch.profiler pass behind device_ms_per_step")
     ap.add_argument("--only_roofline", action="store_true")
@@ -90,6 +92,9 @@ def parse():
     return args
 
 
+CLIP_FLAT = True      # --clip flat|torch: clip_grad_norm_ on the flat gradient buffer (one norm + one multiply) or torch's per-tensor form
+
+
 def train_step(model, batch, bucket, params, optimizer, n_examples, world=1):
     from tvqaplus_amd import parallel
     bucket.zero()
@@ -99,7 +104,10 @@ def train_step(model, batch, bucket, params, optimizer, n_examples, world=1):
     loss = F.cross_entropy(out, targets, reduction="sum") * scale + 0.1 * att_loss + 0.5 * t_loss   # att_weight 0.1, ts_weight 0.5 (config.py)
     loss.backward()
     bucket.all_reduce()
-    torch.nn.utils.clip_grad_norm_(params, 10.0)
+    if CLIP_FLAT:
+        bucket.clip_grad_norm_(10.0)                         # the same clip on the packed buffer (parallel.FlatGradBucket)
+    else:
+        torch.nn.utils.clip_grad_norm_(params, 10.0)
     optimizer.step()
     return loss
 
@@ -544,6 +552,8 @@ def cpu_baseline(args, opt):
 
 def main():
     args = parse()
+    global CLIP_FLAT
+    CLIP_FLAT = args.clip == "flat"
     from tvqaplus_amd import parallel
     from tvqaplus_amd.stage import STAGE
     from tvqaplus_amd.synth import make_batch, make_opt
@@ -805,7 +815,7 @@ def main():
                     r["frac"] = r["frac_this_layout"] = round(r["achieved"] / 8000.0, 4)
                     r["bytes_note"] = ("algorithmic bytes of the ragged launch: A rows of live frames only, compact region rows; "
                                        "score maps dense (they are outputs)")
-        rec["config"]["harness"] = {"gc": args.gc, "adam": args.adam, "ragged_rows": lay is not None,
+        rec["config"]["harness"] = {"gc": args.gc, "adam": args.adam, "clip": args.clip, "ragged_rows": lay is not None,
                                     "branch_streams": int(model.use_streams)}
         if args.storage == "bf16":
             rec["config"]["harness"]["resident_features"] = "fp32" if args.fp32_inputs else "bf16 (as the bf16-staging prefetcher delivers them)"

@@ -10,6 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the product switches to the padded rows below 200 000 statement rows (stage.py: ragged_min_rows -- small batches are host-bound);
+# the tests are all small and must keep exercising the ragged layout
+os.environ.setdefault("STAGE_RAGGED_MIN_ROWS", "0")
 
 
 def pytest_configure(config):

@@ -315,3 +315,25 @@ def test_changed_gradient_set_raises_on_every_rank():
         assert res[r][0] == [False, False, True]          # step 0: parameter 2 has no gradient anywhere
         assert res[r][1] == [False, False, True]          # step 1: rank 1 has one now -- the old agreement still holds, on both ranks
         assert isinstance(res[r][2], str) and res[r][2].startswith("raised"), res[r]
+
+
+def test_flat_clip_equals_torch_clip_grad_norm():
+    """FlatGradBucket.clip_grad_norm_ (one norm + one multiply on the packed buffer) against torch.nn.utils.clip_grad_norm_ on the same
+    gradients: same norm, same clipped gradients -- with a parameter that received no gradient, above and below the threshold."""
+    from tvqaplus_amd import parallel
+    torch.manual_seed(3)
+    for scale in (0.01, 50.0):
+        ps = [torch.nn.Parameter(torch.randn(s)) for s in ((7, 5), (11,), (3, 4, 2), (6,))]
+        ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+        grads = [scale * torch.randn_like(p) for p in ps]
+        for i, (p, r) in enumerate(zip(ps, ref)):
+            if i != 3:                                   # the last parameter stays without a gradient
+                p.grad, r.grad = grads[i].clone(), grads[i].clone()
+        bucket = parallel.FlatGradBucket(ps)
+        bucket.all_reduce()
+        n_flat = bucket.clip_grad_norm_(10.0)
+        n_ref = torch.nn.utils.clip_grad_norm_([r for r in ref if r.grad is not None], 10.0)
+        assert abs(float(n_flat) - float(n_ref)) <= 1e-5 * float(n_ref)
+        for p, r in zip(ps[:3], ref[:3]):
+            assert torch.allclose(p.grad, r.grad, rtol=1e-5, atol=1e-7)
+        assert ps[3].grad is None

@@ -151,6 +151,25 @@ class _ConvLinearParams(nn.Module):
 # ---------------------------------------------------------------------------------------------------------------
 # the model
 # ---------------------------------------------------------------------------------------------------------------
+def _block_params(blk):
+    """[ln.w, ln.b, dw.w, dw.b, pw.w, pw.b] per conv layer + the final LayerNorm's pair of an encoder block, in the order the encoder
+    K-groups take them.  Cached on the block (plain attribute): the Parameter OBJECTS never change (``.to()`` / the optimizer update them
+    in place), and walking ``nn.Module.__getattr__`` / ``ModuleList.__getitem__`` for 14 parameters per call is host time the small-batch
+    step is bound by."""
+    ps = blk.__dict__.get("_stage_plist")
+    if ps is not None and ps[-1] is not blk.final_layer_norm._parameters["bias"]:
+        ps = None                                   # a parameter object was replaced (rare: surgery on the module) -> rebuild
+    if ps is None:
+        ps = []
+        for i in range(blk.n_conv):
+            c = blk.conv[i]
+            ps += [blk.layer_norm[i].weight, blk.layer_norm[i].bias, c.depthwise_conv.weight, c.depthwise_conv.bias,
+                   c.pointwise_conv.weight, c.pointwise_conv.bias]
+        ps += [blk.final_layer_norm.weight, blk.final_layer_norm.bias]
+        blk.__dict__["_stage_plist"] = ps
+    return ps
+
+
 class STAGE(nn.Module):
     def __init__(self, opt):
         super().__init__()
@@ -234,6 +253,8 @@ class STAGE(nn.Module):
         # ... and the context streams in front of the attention on their valid words / regions + the input encoder's halo
         # (STAGE_NO_RAGGED_CTX=1: dense context streams, ragged statement rows)
         self.use_ragged_ctx = os.environ.get("STAGE_NO_RAGGED_CTX") is None
+        # padded statement rows (N * 5 * Li * Lqa) below which the ragged layout is not worth its host work (_ragged_layout)
+        self.ragged_min_rows = int(os.environ.get("STAGE_RAGGED_MIN_ROWS", "200000"))
         # context streams the ragged group path does not take (rows longer than 64, bf16 storage, hsz != 128): length BUCKETS -- the
         # frames are sorted into a few dense (frames, Lb, .) batches by valid length + halo and every bucket runs the ordinary path on
         # its Lb positions; dead frames run nowhere (ragged.bucket_plan).  ``last_buckets``: {stream: [(frames, Lb), ...]} of the
@@ -317,13 +338,7 @@ class STAGE(nn.Module):
         if (self._grouped() and blk.num_heads == 0 and blk.n_conv >= 1 and x.dtype == torch.float32 and self.fuse_ln_dwconv
                 and self.fuse_ln_max):
             k = blk.conv[0].depthwise_conv.weight.shape[-1]
-            params = []
-            for i in range(blk.n_conv):
-                c = blk.conv[i]
-                params += [blk.layer_norm[i].weight, blk.layer_norm[i].bias, c.depthwise_conv.weight, c.depthwise_conv.bias,
-                           c.pointwise_conv.weight, c.pointwise_conv.bias]
-            params += [blk.final_layer_norm.weight, blk.final_layer_norm.bias]
-            params = [self._g(w) for w in params]
+            params = [self._g(w) for w in _block_params(blk)]
             y = self._try_group(lambda seeds: groups.encoder_block(x, blk.position_encoding.rows(L), pool_mask, k, self._p(), seeds,
                                                                    params), (blk.n_conv + 1) // 2)
             if y is not None:
@@ -384,12 +399,7 @@ class STAGE(nn.Module):
                 mc = data_mask.index_select(0, clay.live_frames.long()).contiguous()
                 return self._stacked_encoder(y.view(clay.S, L, -1), mc, input_encoder).reshape(clay.U, -1)
             for blk in input_encoder.stacked_encoderBlocks:
-                bp = []
-                for i in range(blk.n_conv):
-                    c = blk.conv[i]
-                    bp += [blk.layer_norm[i].weight, blk.layer_norm[i].bias, c.depthwise_conv.weight, c.depthwise_conv.bias,
-                           c.pointwise_conv.weight, c.pointwise_conv.bias]
-                bp += [blk.final_layer_norm.weight, blk.final_layer_norm.bias]
+                bp = _block_params(blk)
                 k = blk.conv[0].depthwise_conv.weight.shape[-1]
                 y = groups.encoder_block_rag(y, blk.position_encoding.rows(L), None, clay, k, self._p(),
                                              self._seeds((blk.n_conv + 1) // 2), [self._g(w) for w in bp])
@@ -534,12 +544,7 @@ class STAGE(nn.Module):
             mx = torch.full((N * NA * Li, D), NEG, dtype=mx_c.dtype, device=mx_c.device).index_copy(0, seq_out, mx_c)
         elif lay is not None:
             blk = self.cls_encoder.stacked_encoderBlocks[0]
-            params = []
-            for i in range(blk.n_conv):
-                c = blk.conv[i]
-                params += [blk.layer_norm[i].weight, blk.layer_norm[i].bias, c.depthwise_conv.weight, c.depthwise_conv.bias,
-                           c.pointwise_conv.weight, c.pointwise_conv.bias]
-            params += [blk.final_layer_norm.weight, blk.final_layer_norm.bias]
+            params = _block_params(blk)
             k = blk.conv[0].depthwise_conv.weight.shape[-1]
             mx = groups.encoder_block_rag(statement, blk.position_encoding.rows(Lqa), qa_mask.reshape(N * NA, Lqa).contiguous(), lay, k,
                                           self._p(), self._seeds((blk.n_conv + 1) // 2), [self._g(w) for w in params])
@@ -723,6 +728,12 @@ class STAGE(nn.Module):
             return none
         N, NA, Lqa, D = a_embed.shape
         blocks = list(self.cls_encoder.stacked_encoderBlocks)
+        # Small batches (a rank of a strong-scaled job holds 1-2 examples): the step is bound by the HOST there, and the ragged layout
+        # costs the host its tables, three uploads and six small launches (0.9 ms of a 5.4 ms step at 2 examples, measured) to save device
+        # time nobody waits for -- the padded rows run instead (the same function: tests hold the two paths equal).
+        li_any = batch.vid.shape[1] if self.vfeat_flag else batch.sub_bert.shape[1]
+        if N * NA * li_any * Lqa < self.ragged_min_rows:
+            return none
         if D != 128 or not (4 <= Lqa <= 40) or self.bridge_hsz % 4 or self.bridge_hsz > 1024:
             return none          # (the ragged input-MLP group's own limits: stage_grp_input_mlp_rag_fwd declines other widths)
         # words kept behind the last valid one: the classifier encoder's convolution halo -- or every word of a live frame when that
@@ -802,7 +813,9 @@ class STAGE(nn.Module):
         if self.flag_cnt == 2:
             mods.append(self.c2q_down_projection)
         for m in mods:
-            ps = [w for w in m.parameters() if w.requires_grad]
+            ps = m.__dict__.get("_stage_gated")        # (cached: m.parameters() walks named_modules() on every call)
+            if ps is None or any(not w.requires_grad for w in ps):
+                ps = m.__dict__["_stage_gated"] = [w for w in m.parameters() if w.requires_grad]
             if ps:
                 for w, a in zip(ps, groups.gate(ps)):
                     self._gate_map[id(w)] = a
