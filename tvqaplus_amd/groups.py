@@ -20,7 +20,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from .ops import _chk, _on_device, _stream
+from .ops import _chk, _deliver, _on_device, _sinks, _stream
 
 _U8 = torch.uint8
 
@@ -169,28 +169,6 @@ class _ParamGate(torch.autograd.Function):
 def gate(params: Sequence[torch.Tensor]) -> List[torch.Tensor]:
     """Aliases of ``params`` for ONE training step (see above); use them wherever the parameters go into a group call."""
     return list(_ParamGate.apply(_Sink(len(params)), *params))
-
-
-def _sinks(params) -> list:
-    return [getattr(w, "_stage_sink", None) for w in params]
-
-
-def _deliver(sinks, grads) -> tuple:
-    """Parameter gradients of a group call: into the sinks of gated parameters (returned as None), as they are otherwise."""
-    if not any(sinks):
-        return tuple(grads)
-    out, per = [], {}
-    for sk, g in zip(sinks, grads):
-        if sk is None:
-            out.append(g)
-        else:
-            e = per.setdefault(id(sk[0]), (sk[0], [], []))
-            e[1].append(sk[1])
-            e[2].append(g)
-            out.append(None)
-    for sink, idx, gs in per.values():
-        sink.add(idx, gs)
-    return tuple(out)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -110,6 +110,36 @@ def _call(name: str, *args):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# Parameter-gradient sinks (tvqaplus_amd/groups.py: gate): a parameter alias handed out by ``groups.gate`` carries ``_stage_sink``;
+# a backward that holds such an alias puts its gradient into the sink (first contribution kept, later ones added with one
+# multi-tensor add per call) and returns None for it -- the K-groups do this, and so do the per-kernel LayerNorm / Linear /
+# LayerNorm->dwconv ops below, so that a shared module applied once per stream and length bucket (the bf16 stress configuration:
+# 220 AccumulateGrad additions per step) costs one fused add per application instead of one kernel per parameter and application.
+# ---------------------------------------------------------------------------------------------------------------
+def _sinks(params) -> list:
+    return [getattr(w, "_stage_sink", None) for w in params]
+
+
+def _deliver(sinks, grads) -> tuple:
+    """Parameter gradients of a group call: into the sinks of gated parameters (returned as None), as they are otherwise."""
+    if not any(sinks):
+        return tuple(grads)
+    out, per = [], {}
+    for sk, g in zip(sinks, grads):
+        if sk is None:
+            out.append(g)
+        else:
+            e = per.setdefault(id(sk[0]), (sk[0], [], []))
+            e[1].append(sk[1])
+            e[2].append(g)
+            out.append(None)
+    for sink, idx, gs in per.values():
+        sink.add(idx, gs)
+    return tuple(out)
+
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # LayerNorm (+ fused residual add / position table, + fused dropout)
 # ---------------------------------------------------------------------------------------------------------------
 class _LayerNorm(torch.autograd.Function):
@@ -121,6 +151,7 @@ class _LayerNorm(torch.autograd.Function):
         if res is not None and res_period > 0 and res.dtype != x.dtype:
             res = res.to(x.dtype)          # the (L, D) position table follows the storage type
         res_c = None if res is None else _act(res, "res", x)
+        ctx.sinks = _sinks((gamma, beta))
         gamma, beta = _chk(gamma, "gamma"), _chk(beta, "beta")
         y = torch.empty_like(x)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
@@ -164,6 +195,7 @@ class _LayerNorm(torch.autograd.Function):
             dadd = _act(dsum, "dsum", xin)
         _call("stage_layernorm_bwd" + _sfx(xin), _ptr(dy), _ptr(xin), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dx), _ptr(dadd),
               _ptr(dgamma), _ptr(dbeta), rows, K, ctx.p, ctx.seed, _ptr(ws), wsb, _stream())
+        dgamma, dbeta = _deliver(ctx.sinks, (dgamma, dbeta))
         return (dx if x_needs else None), (dx if res_needs else None), dgamma, dbeta, None, None, None, None
 
 
@@ -304,6 +336,7 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, x, w, bias, relu: bool):
         x = _act(x, "x")
         bf = x.dtype == _BF16
+        ctx.sinks = _sinks((w, bias))
         w2 = _chk(w, "w").reshape(w.shape[0], -1)  # (N, K) ; pointwise Conv1d weights are (N, K, 1)
         N, K = w2.shape
         assert x.shape[-1] == K, (x.shape, w.shape)
@@ -353,7 +386,8 @@ class _Linear(torch.autograd.Function):
             wsb = lib.stage_gemm_tn_bf16_ws_bytes(M, N, K)
             ws = _workspace(wsb, x.device)
             _call("stage_gemm_tn_bf16", _ptr(dy), _ptr(gate), _ptr(x), _ptr(dw), _ptr(db), M, N, K, _ptr(ws), wsb, _stream())
-            return dx, dw.view(ctx.wshape), db, None
+            dwv, db = _deliver(ctx.sinks, (dw.view(ctx.wshape), db))
+            return dx, dwv, db, None
         use_mask = mask is not None and dy.data_ptr() % 16 == 0
         dx = None
         if ctx.needs_input_grad[0]:
@@ -379,7 +413,8 @@ class _Linear(torch.autograd.Function):
                 done = True
         if not done:
             _call("stage_gemm_tn", _ptr(dy), _ptr(gate), _ptr(x), _ptr(dw), _ptr(db), M, N, K, _ptr(ws), wsb, _stream())
-        return dx, dw.view(ctx.wshape), db, None
+        dwv, db = _deliver(ctx.sinks, (dw.view(ctx.wshape), db))
+        return dx, dwv, db, None
 
 
 def linear(x, w, bias=None, relu: bool = False):
@@ -501,6 +536,7 @@ class _LnDwConv(torch.autograd.Function):
         if res is not None and res_period > 0 and res.dtype != x.dtype:
             res = res.to(x.dtype)          # the (L, D) position table follows the storage type
         res_c = None if res is None else _act(res, "res", x)
+        ctx.sinks = _sinks((gamma, beta, w, bias))
         gamma, beta, w, bias = _chk(gamma, "gamma"), _chk(beta, "beta"), _chk(w, "w"), _chk(bias, "bias")
         k = w.shape[-1]
         h = torch.empty_like(x)
@@ -542,6 +578,7 @@ class _LnDwConv(torch.autograd.Function):
         _call("stage_ln_dwconv_bwd" + _sfx(xin), _ptr(dh), _ptr(xin), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(w),
               _ptr(dx), _ptr(dadd), _ptr(dgamma), _ptr(dbeta), _ptr(dw), _ptr(db), M, L, D, k, ctx.p, ctx.seed,
               _ptr(ws), wsb, _stream())
+        dgamma, dbeta, dw, db = _deliver(ctx.sinks, (dgamma, dbeta, dw, db))
         return (dx if x_needs else None), (dx if res_needs else None), dgamma, dbeta, dw, db, None, None, None
 
 

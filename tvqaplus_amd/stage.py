@@ -327,7 +327,7 @@ class STAGE(nn.Module):
 
     # ---- building blocks ---------------------------------------------------------------------------------------
     def _ln(self, x, ln: nn.LayerNorm, drop: bool = False, res=None, res_period: int = 0):
-        return ops.layernorm(x, ln.weight, ln.bias, p=self._p() if drop else 0.0, seed=self._seed() if drop else 0,
+        return ops.layernorm(x, self._g(ln.weight), self._g(ln.bias), p=self._p() if drop else 0.0, seed=self._seed() if drop else 0,
                              res=res, res_period=res_period)
 
     def _encoder_block(self, x, mask, blk: _EncoderBlockParams, pool_mask=None):
@@ -349,25 +349,26 @@ class STAGE(nn.Module):
             ln, drop = blk.layer_norm[i], (i % 2 == 0)
             if self.fuse_ln_dwconv and ops.ln_dwconv_supported(D, c.depthwise_conv.weight.shape[-1], pending.dtype):
                 # LayerNorm output only feeds the depthwise conv: one fused pass, never materialised
-                h, cur = ops.ln_dwconv(pending, ln.weight, ln.bias, c.depthwise_conv.weight, c.depthwise_conv.bias,
+                h, cur = ops.ln_dwconv(pending, self._g(ln.weight), self._g(ln.bias), self._g(c.depthwise_conv.weight),
+                                       self._g(c.depthwise_conv.bias),
                                        p=self._p() if drop else 0.0, seed=self._seed() if drop else 0, res=cur,
                                        res_period=period)
             else:
                 y, cur = self._ln(pending, ln, drop=drop, res=cur, res_period=period)
                 h = ops.dwconv(y, c.depthwise_conv.weight, c.depthwise_conv.bias)
             period = 0
-            pending = ops.linear(h, c.pointwise_conv.weight, c.pointwise_conv.bias, relu=True)
+            pending = ops.linear(h, self._g(c.pointwise_conv.weight), self._g(c.pointwise_conv.bias), relu=True)
         if blk.num_heads != 0:
             y, cur = self._ln(pending, blk.attn_layer_norm, res=cur, res_period=period)
             period = 0
             mha = blk.multi_head_attn
-            q = ops.linear(y, mha.linears[0].weight, mha.linears[0].bias)
-            k = ops.linear(y, mha.linears[1].weight, mha.linears[1].bias)
-            v = ops.linear(y, mha.linears[2].weight, mha.linears[2].bias)
+            q = ops.linear(y, self._g(mha.linears[0].weight), self._g(mha.linears[0].bias))
+            k = ops.linear(y, self._g(mha.linears[1].weight), self._g(mha.linears[1].bias))
+            v = ops.linear(y, self._g(mha.linears[2].weight), self._g(mha.linears[2].bias))
             p_attn = mha.p_attn_drop if self.mha_dropout_override is None else self.mha_dropout_override
             p_attn = p_attn if self.training else 0.0
             a = ops.mha_core(q, k, v, mask, mha.nh, p=p_attn, seed=self._seed() if p_attn > 0 else 0)
-            pending = ops.linear(a, mha.linears[3].weight, mha.linears[3].bias)
+            pending = ops.linear(a, self._g(mha.linears[3].weight), self._g(mha.linears[3].bias))
         if pool_mask is not None:
             if self.fuse_ln_max and period == 0 and ops.ln_masked_max_supported(pending, L, D):
                 return ops.ln_masked_max(pending, cur, blk.final_layer_norm.weight, blk.final_layer_norm.bias, pool_mask)
@@ -422,9 +423,9 @@ class STAGE(nn.Module):
                                     p=self._p(), seed=self._seed())
         else:
             y, _ = self._ln(data, init_encoder[0], drop=True)
-            y = ops.linear(y, init_encoder[2].weight, init_encoder[2].bias, relu=True)
+            y = ops.linear(y, self._g(init_encoder[2].weight), self._g(init_encoder[2].bias), relu=True)
         y, _ = self._ln(y, init_encoder[4], drop=True)            # LN(300) then input_embedding's Dropout
-        y = ops.linear(y, downsize_encoder[1].weight, downsize_encoder[1].bias, relu=True)
+        y = ops.linear(y, self._g(downsize_encoder[1].weight), self._g(downsize_encoder[1].bias), relu=True)
         y, _ = self._ln(y, downsize_encoder[3])
         return self._stacked_encoder(y.view(M, L, -1), data_mask, input_encoder)
 
@@ -807,7 +808,9 @@ class STAGE(nn.Module):
     def _open_gates(self):
         # modules applied to two or three streams (model/stage.py:226-269): their parameter gradients leave the graph once
         self._gate_map = {}
-        if not (self.gate_shared and self._grouped() and self.training and torch.is_grad_enabled()):
+        # (both paths: the K-groups deliver into the sinks, and so do the per-kernel LayerNorm / Linear / LayerNorm->dwconv ops --
+        # the bf16 storage mode runs the shared encoder once per stream and length bucket)
+        if not (self.gate_shared and self.training and torch.is_grad_enabled()):
             return
         mods = [self.bert_word_encoding_fc, self.input_embedding, self.input_encoder]
         if self.flag_cnt == 2:
