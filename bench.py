@@ -223,7 +223,7 @@ def k1_roofline(args, device, dense=None):
     # MI355X_MICROARCH.md); only quoted for the exact shapes those passes ran (`traffic_source` says which file)
     traffic = src = None
     if (N, NA, Li, Lqa, D) == (16, 5, 300, 40, 128) and not dense and Lr in (20, 50):
-        for rnd in ("r04", "r03", "r02"):
+        for rnd in ("r05", "r04", "r03", "r02"):
             src = "profiles/%s_k1_fwd_pmc_%s.txt" % (rnd, "vid" if Lr == 20 else "sub")
             traffic = _profile_traffic(os.path.basename(src), "str_attn_fwd")
             if traffic is not None:
@@ -345,7 +345,7 @@ def k1_bwd_roofline(args, device):
     achieved = alg / (avg_ms * 1e-3) / 1e9
     traffic = src = None
     if (N, NA, Li, Lqa, D) == (16, 5, 300, 40, 128) and not args.dense and Lr in (20, 50):
-        for rnd in ("r04", "r03", "r02"):
+        for rnd in ("r05", "r04", "r03", "r02"):
             src = "profiles/%s_k1_bwd_pmc_%s.txt" % (rnd, "vid" if Lr == 20 else "sub")
             traffic = _profile_traffic(os.path.basename(src), "str_attn_bwd_fused")
             if traffic is not None:

@@ -2,7 +2,7 @@
 (bench.py: _profile_traffic, the judge) expect.  python tools/collect_profiles.py r02"""
 import os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 HEAD = ("# round %s: rocprofv3 PMC passes (counters only + kernel trace; tools/pmc_run.sh), averages per dispatch; FETCH_SIZE / WRITE_SIZE in KiB\n"
         "# FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950 counts the 128-byte requests of wide loads as 64 B)\n" % TAG[1:].lstrip("0"))
@@ -20,7 +20,8 @@ def put(name, text):
 
 
 for n in ("bench_line.json", "bench_line_dense.json", "bench_line_stress.json", "bench_kernel_trace_stats.txt", "bf16_storage_bench_line.json",
-          "bf16_storage_bench_kernel_trace_stats.txt", "bench_line_dense_rows.json", "bench_line_heads4.json", "heads4_bench_kernel_trace_stats.txt", "stress_kernel_trace_stats.txt"):
+          "bf16_storage_bench_kernel_trace_stats.txt", "bench_line_dense_rows.json", "bench_line_heads4.json", "heads4_bench_kernel_trace_stats.txt", "stress_kernel_trace_stats.txt",
+          "one_stream_bench_kernel_trace_stats.txt", "bench_line_bsz2.json", "bench_line_reference_batch.json"):
     src = os.path.join(G, "%s_%s" % (TAG, n))
     if os.path.exists(src):
         shutil.copy(src, os.path.join(P, "%s_%s" % (TAG, n)))

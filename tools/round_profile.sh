@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile set -> gpurun_out/${TAG}_*: bench line, kernel trace of the bench command, PMC passes of the K1 forward (video and
 # subtitle shapes), of the fused K1 backward and of the 960000 x 384 -> 128 GEMMs (forward, weight gradient).  bash tools/round_profile.sh r02
-TAG=${1:-r04}
+TAG=${1:-r05}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench.err
@@ -13,6 +13,11 @@ timeout 300 bash tools/trace_bench.sh ${TAG}_heads4_bench --heads 4 --no_childre
 timeout 500 bash tools/pmc_run.sh ${TAG}_cat3_ragged_instep cf python bench.py --steps 3 --warmup 2 --no_cpu_baseline --no_pmc --no_children --no_roofline --no_device_time > /dev/null 2>&1
 timeout 500 bash tools/pmc_run.sh ${TAG}_k1_instep str_attn python bench.py --steps 3 --warmup 2 --no_cpu_baseline --no_pmc --no_children --no_roofline --no_device_time > /dev/null 2>&1
 timeout 300 bash tools/trace_bench.sh ${TAG}_bench --no_children --no_pmc > /dev/null 2>&1
+# round 5: the same trace on ONE stream (--streams 0): kernel durations that are statements about the kernels -- with branch streams a
+# small kernel's duration includes waiting for compute units a neighbour holds (the column reductions: 0.33 ms/step here, 1.6 in the default trace)
+TRACE_PAT=colreduce timeout 300 bash tools/trace_bench.sh ${TAG}_one_stream_bench --no_children --no_pmc --streams 0 > /dev/null 2>&1
+timeout 200 python bench.py --bsz 2 --steps 30 --warmup 5 --no_children --no_cpu_baseline --no_roofline > gpurun_out/${TAG}_bench_line_bsz2.json 2>> gpurun_out/${TAG}_bench.err
+timeout 300 python bench.py --steps 20 --warmup 5 --no_children --no_cpu_baseline --no_roofline --reference_batch > gpurun_out/${TAG}_bench_line_reference_batch.json 2>> gpurun_out/${TAG}_bench.err
 # K1 forward PMC: bench.py --only_roofline launches the video shape then the subtitle shape
 timeout 400 bash tools/pmc_run.sh ${TAG}_k1_fwd str_attn_fwd python bench.py --only_roofline > /dev/null 2>&1
 timeout 400 bash tools/pmc_run.sh ${TAG}_k1_bwd_vid str_attn_bwd_fused python tools/k1_bwd_times.py > /dev/null 2>&1
