@@ -48,6 +48,10 @@ for k, what in (("rep", "c2q_down_projection shape: a broadcast over 300 frames,
         put("%s_cat3_fused_pmc_%s.txt" % (TAG, k), HEAD + "# command: %sbash tools/pmc_run.sh %s_cat3_fused_%s cf python tools/cat3_fused_time.py   (%s; cf_bwd_kernel = fused backward, "
             "cff_fwd_kernel = fused forward, csrc/cat3_fused.hip)\n# event-timed, same run:\n%s" % ("REP=1 " if k == "flat" else "", TAG, k, what, t) + "".join(lines(name)))
 
+if os.path.exists(os.path.join(G, "pmc_%s_k1_long_fwd.txt" % TAG)):
+    put("%s_k1_long_fwd_pmc.txt" % TAG, HEAD + "# command: bash tools/pmc_run.sh %s_k1_long_fwd str_attn_long_fwd python bench.py --config stress --only_roofline   "
+        "(BASELINE configs[4]: N=16, Li=300, Lr=512, Lqa=40, D=256, bf16 storage, ragged masks)\n" % TAG + "".join(lines("pmc_%s_k1_long_fwd.txt" % TAG)))
+
 for k, what in (("cat3_ragged_instep", "the [a,b,a*b] kernels on ragged token rows INSIDE the bench step (cff_fwd_kernel<.., true> = gathered rows, cf_bwd_kernel<.., 3> = "
                 "per-group live words; <.., 0> / <.., false> = the concat_fc instance on compact rows)"),
                 ("k1_instep", "the attention kernels inside the bench step (frame-compact A, compact region rows)")):

@@ -31,6 +31,7 @@ timeout 200 python tools/cat3_fused_time.py > gpurun_out/${TAG}_cat3_fused_times
 REP=1 timeout 200 python tools/cat3_fused_time.py > gpurun_out/${TAG}_cat3_fused_times_flat.txt 2>&1
 timeout 300 python bench.py --config stress --steps 5 --warmup 2 --no_cpu_baseline --no_children > gpurun_out/${TAG}_bench_line_stress.json 2>> gpurun_out/${TAG}_bench.err
 timeout 300 bash tools/trace_bench.sh ${TAG}_stress --config stress --no_children --no_pmc --steps 5 --warmup 2 > /dev/null 2>&1
+timeout 500 bash tools/pmc_run.sh ${TAG}_k1_long_fwd str_attn_long_fwd python bench.py --config stress --only_roofline > /dev/null 2>&1
 timeout 200 python tools/k1_bwd_times.py > gpurun_out/${TAG}_k1_bwd_times_vid.txt 2>&1
 LR=50 timeout 200 python tools/k1_bwd_times.py > gpurun_out/${TAG}_k1_bwd_times_sub.txt 2>&1
 ls gpurun_out | grep ${TAG}
