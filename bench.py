@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--storage", choices=["fp32", "bf16"], default="fp32",
                     help="bf16: the bf16 storage mode (BASELINE configs[4]); the headline line is the fp32 default")
     ap.add_argument("--streams", type=int, default=-1, choices=(-1, 0, 1, 2, 3, 4),
-                    help="branch streams of the model (stage.py: use_streams; -1 = its default, 2): 0 one stream, 1 the statement branch on a "
+                    help="branch streams of the model (stage.py: use_streams; -1 = its default, 3): 0 one stream, 1 the statement branch on a "
                          "side stream, 2 + the video input MLP / encoder, 3 + the video attention with its forward fenced behind the subtitle "
                          "attention, 4 without the fence (fastest; the K1 forward kernels then run next to another branch and their in-step "
                          "timings stop being a statement about the kernel)")

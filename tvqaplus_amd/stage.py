@@ -260,15 +260,16 @@ class STAGE(nn.Module):
         # its Lb positions; dead frames run nowhere (ragged.bucket_plan).  ``last_buckets``: {stream: [(frames, Lb), ...]} of the
         # last forward.  STAGE_NO_CTX_BUCKETS=1 / use_ctx_buckets = False: one dense (frames, L, .) batch, as the reference.
         self.use_ctx_buckets = os.environ.get("STAGE_NO_CTX_BUCKETS") is None
-        # Branch streams (STAGE_STREAMS=0..4 / use_streams; default 2): the three branches of the forward -- statements, subtitles,
+        # Branch streams (STAGE_STREAMS=0..4 / use_streams; default 3 since round 5, 2 in round 4): the three branches of the forward -- statements, subtitles,
         # video -- are independent up to the attention (statements <-> context) and the fusion (subtitles <-> video).  Level 1 runs the
         # statement branch (input MLP + encoder over N*5 statements: ~90 latency-bound launches forward + backward, 0.66 ms of device
         # time that uses a few CUs) on a side stream next to the subtitle branch; level 2 also the video input MLP / encoder; level 3
-        # the video attention as well, its forward fenced behind the subtitle attention (only the backward overlaps: -0.6 % on level 2);
+        # the video attention as well, its forward fenced behind the subtitle attention (only the backward overlaps: -1..2 % on level 2 with the K1 forward kernels
+        # still alone on their streams -- round 5, two A/B runs on one box: 13.65 / 13.61 ms at level 2, 13.50 / 13.35 ms at level 3);
         # level 4 without the fence (two saturating kernels side by side: fastest step, -2..3 % on level 2, but a kernel's duration is
         # then no statement about that kernel).  The backward of every op runs on its forward's stream (autograd), so the branches overlap there too.
         # Joins: events in front of the attention / the fusion; tensors that cross streams are registered with the allocator.
-        self.use_streams = int(os.environ.get("STAGE_STREAMS", "2") or 0)
+        self.use_streams = int(os.environ.get("STAGE_STREAMS", "3") or 0)
         self.last_buckets: Dict[str, list] = {}
         self._mask_info = None
         self.last_ragged: Optional[ragged.RaggedLayout] = None
