@@ -690,7 +690,9 @@ def main():
     from tvqaplus_amd import _lib as _L
     lib = _L.load()
     k1_ev = {}
-    if rank == 0 and args.storage == "fp32" and args.hsz == 128 and not args.no_roofline:
+    # (only when this rank's step runs the full --bsz examples: under strong scaling with N > 1 a rank's kernels see bsz / N examples --
+    # their in-step durations say nothing about the published shape, and the roofline record keeps its isolated full-shape launches)
+    if rank == 0 and args.storage == "fp32" and args.hsz == 128 and not args.no_roofline and n_local == args.bsz:
         for lr in {args.regions, args.sub_words}:
             if lr <= 64:
                 k1_ev[lr] = [(lib.stage_timer_create(), lib.stage_timer_create()) for _ in range(args.steps)]
