@@ -296,6 +296,14 @@ int stage_mha_core_fwd_bf16(const void* q, const void* k, const void* v, const f
 int stage_mha_core_bwd_bf16(const void* dout, const void* q, const void* k, const void* v, const float* mask, void* dq,
                             void* dk, void* dv, long long M, int L, int D, int nh, float p_drop, unsigned long long seed,
                             void* stream);
+/* self-attention core on FUSED projections (round 5): qkv (M, L, 3D) = the output of ONE Linear(D -> 3D) with the weight
+ * [W_q; W_k; W_v] (model/self_attention.py:35-44: three Linears on the same input), thirds q | k | v of every row; dqkv (M, L, 3D)
+ * receives dq | dk | dv and IS that Linear's output gradient.  out / dout (M, L, D).  is_bf16: storage type of all four.  Matrix-core
+ * shapes only (stage_mha_core_recomputes == 1), same masking / dropout contract as stage_mha_core_fwd.                          */
+int stage_mha_core_qkv_fwd(const void* qkv, const float* mask, void* out, long long M, int L, int D, int nh, float p_drop,
+                           unsigned long long seed, int is_bf16, void* stream);
+int stage_mha_core_qkv_bwd(const void* dout, const void* qkv, const float* mask, void* dqkv, long long M, int L, int D, int nh,
+                           float p_drop, unsigned long long seed, int is_bf16, void* stream);
 int stage_masked_max_fwd_bf16(const void* x, const float* mask, const int* window, void* out, int* argmax, long long R,
                               int L, int D, void* stream);
 int stage_masked_max_bwd_bf16(const void* dout, const int* argmax, const float* mask, void* dx, long long R, int L, int D,

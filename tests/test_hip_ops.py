@@ -390,6 +390,30 @@ def test_mha_core(ops, M, L, D, nh):
     check("dv", vd.grad, vc.grad)
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("M,L,D,nh,p", [(5, 20, 128, 4, 0.0), (3, 50, 128, 4, 0.1), (4, 40, 128, 4, 0.1), (6, 13, 32, 4, 0.3), (2, 64, 64, 1, 0.1)])
+def test_mha_core_on_fused_projections_equals_separate_tensors(ops, M, L, D, nh, p, bf16):
+    """stage_mha_core_qkv_* (q | k | v as the thirds of ONE (M, L, 3D) tensor, row stride 3D; dq | dk | dv written into one gradient
+    tensor) against the same kernels on three separate tensors with the same dropout seed: bit for bit, both storage types."""
+    g = torch.Generator().manual_seed(M * 10 + L)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    qkv = torch.randn(M, L, 3 * D, generator=g).to(dt)
+    lens = torch.randint(1, L + 1, (M,), generator=g)
+    lens[0] = L
+    m = (torch.arange(L).unsqueeze(0) < lens.unsqueeze(1)).float().cuda()
+    go = torch.randn(M, L, D, generator=g).to(dt).cuda()
+    assert ops.mha_core_qkv_supported(L, D, nh)
+    x = qkv.cuda().requires_grad_()
+    o = ops.mha_core_qkv(x, m, nh, p=p, seed=77)
+    o.backward(go)
+    parts = [qkv[..., j * D:(j + 1) * D].contiguous().cuda().requires_grad_() for j in range(3)]
+    o2 = ops.mha_core(parts[0], parts[1], parts[2], m, nh, p=p, seed=77)
+    o2.backward(go)
+    assert torch.equal(o, o2)
+    for j in range(3):
+        assert torch.equal(x.grad[..., j * D:(j + 1) * D], parts[j].grad), j
+
+
 @pytest.mark.parametrize("M,L,D,nh,p", [(5, 20, 128, 4, 0.0), (3, 50, 128, 4, 0.1), (4, 40, 128, 4, 0.1), (2, 64, 64, 1, 0.1),
                                         (6, 13, 32, 4, 0.3), (3, 33, 32, 2, 0.1)])
 def test_mha_matrix_core_kernels_match_scalar(ops, M, L, D, nh, p):

@@ -89,6 +89,8 @@ SIGNATURES = {
     "stage_ln_dwconv_bwd_bf16": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, U64, P, SZ, P]),
     "stage_mha_core_fwd_bf16": (I, [P, P, P, P, P, LL, I, I, I, F, U64, P]),
     "stage_mha_core_bwd_bf16": (I, [P, P, P, P, P, P, P, P, LL, I, I, I, F, U64, P]),
+    "stage_mha_core_qkv_fwd": (I, [P, P, P, LL, I, I, I, F, U64, I, P]),
+    "stage_mha_core_qkv_bwd": (I, [P, P, P, P, LL, I, I, I, F, U64, I, P]),
     "stage_masked_max_fwd_bf16": (I, [P, P, P, P, P, LL, I, I, P]),
     "stage_masked_max_bwd_bf16": (I, [P, P, P, P, LL, I, I, I, P]),
     "stage_ln_masked_max_fwd_bf16": (I, [P, P, P, P, P, P, P, P, P, P, LL, I, I, F, P]),

@@ -55,24 +55,26 @@ template <int T, int KS, typename TS = float>   // TS: storage type of q, k, v, 
 __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const TS* __restrict__ q, const TS* __restrict__ k,
                                                            const TS* __restrict__ v, const float* __restrict__ mask,
                                                            TS* __restrict__ out, long items, int L, int D, int nh,
-                                                           uint64_t seed, uint32_t th, float inv_keep) {
+                                                           uint64_t seed, uint32_t th, float inv_keep, int ld) {
     constexpr int DK = 4 * KS, DT = (DK + 15) / 16;
     const int lane = threadIdx.x & 63, c15 = lane & 15, g = lane >> 4;
     const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= items) return;
     const long m = item / nh;
     const int h = (int)(item % nh);
-    const long base = m * L * (long)D + (long)h * DK, pbase = (m * nh + h) * (long)L;
+    // ld: row stride (elements) of q, k, v (and of dq, dk, dv): D for separate tensors, 3 D when they are the thirds of ONE fused
+    // projection output (M, L, 3 D) -- stage_mha_core_qkv_*; out / dout always have row stride D
+    const long base = m * L * (long)ld + (long)h * DK, obase = m * L * (long)D + (long)h * DK, pbase = (m * nh + h) * (long)L;
     const float rs = sqrtf((float)DK);
     float kf[T][KS];
 #pragma unroll
-    for (int jt = 0; jt < T; jt++) mha_row_frag<KS>(kf[jt], k + base + (long)min(jt * 16 + c15, L - 1) * D, g);
+    for (int jt = 0; jt < T; jt++) mha_row_frag<KS>(kf[jt], k + base + (long)min(jt * 16 + c15, L - 1) * ld, g);
 #pragma unroll
     for (int it = 0; it < T; it++) {
         if (it * 16 >= L) break;
         const int qi = it * 16 + c15, qc = min(qi, L - 1);
         float qf[KS];
-        mha_row_frag<KS>(qf, q + base + (long)qc * D, g);
+        mha_row_frag<KS>(qf, q + base + (long)qc * ld, g);
         const bool dead = mask[m * L + qc] == 0.f;
         f32x4 p[T];
         float mx = -INFINITY;
@@ -115,11 +117,11 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const TS* __restrict_
             for (int jt = 0; jt < T; jt++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const float a = ldv1(v + base + (long)min(jt * 16 + 4 * g + r, L - 1) * D + dcol);   // P = 0 for keys >= L
+                    const float a = ldv1(v + base + (long)min(jt * 16 + 4 * g + r, L - 1) * ld + dcol);   // P = 0 for keys >= L
                     o = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p[jt][r], o, 0, 0, 0);
                 }
             const int d0 = dt * 16 + 4 * g;
-            if (qi < L && d0 < DK) stv4(out + base + (long)qi * D + d0, make_float4(o[0], o[1], o[2], o[3]));
+            if (qi < L && d0 < DK) stv4(out + obase + (long)qi * D + d0, make_float4(o[0], o[1], o[2], o[3]));
         }
     }
 }
@@ -134,19 +136,21 @@ __global__ __launch_bounds__(256, ((T <= 3 && KS <= 8) || T == 1 ? 2 : 1)) void 
                                                            const TS* __restrict__ k, const TS* __restrict__ v,
                                                            const float* __restrict__ mask, TS* __restrict__ dq,
                                                            TS* __restrict__ dkk, TS* __restrict__ dv, long items, int L,
-                                                           int D, int nh, uint64_t seed, uint32_t th, float inv_keep) {
+                                                           int D, int nh, uint64_t seed, uint32_t th, float inv_keep, int ld) {
     constexpr int DK = 4 * KS, DT = (DK + 15) / 16;
     const int lane = threadIdx.x & 63, c15 = lane & 15, g = lane >> 4;
     const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= items) return;
     const long m = item / nh;
     const int h = (int)(item % nh);
-    const long base = m * L * (long)D + (long)h * DK, pbase = (m * nh + h) * (long)L;
+    // ld: row stride (elements) of q, k, v (and of dq, dk, dv): D for separate tensors, 3 D when they are the thirds of ONE fused
+    // projection output (M, L, 3 D) -- stage_mha_core_qkv_*; out / dout always have row stride D
+    const long base = m * L * (long)ld + (long)h * DK, obase = m * L * (long)D + (long)h * DK, pbase = (m * nh + h) * (long)L;
     const float rs = sqrtf((float)DK);
     float kf[T][KS], vf[T][KS];                      // row fragments of K and V (rows jt*16 + c15)
 #pragma unroll
     for (int jt = 0; jt < T; jt++) {
-        const long ro = (long)min(jt * 16 + c15, L - 1) * D;
+        const long ro = (long)min(jt * 16 + c15, L - 1) * ld;
         mha_row_frag<KS>(kf[jt], k + base + ro, g);
         mha_row_frag<KS>(vf[jt], v + base + ro, g);
     }
@@ -161,9 +165,9 @@ __global__ __launch_bounds__(256, ((T <= 3 && KS <= 8) || T == 1 ? 2 : 1)) void 
         if (it * 16 >= L) break;
         float qf[KS], gf[KS];                        // row fragments of Q and dout (rows it*16 + c15)
         {
-            const long ro = (long)min(it * 16 + c15, L - 1) * D;
-            mha_row_frag<KS>(qf, q + base + ro, g);
-            mha_row_frag<KS>(gf, dout + base + ro, g);
+            const int rr = min(it * 16 + c15, L - 1);
+            mha_row_frag<KS>(qf, q + base + (long)rr * ld, g);
+            mha_row_frag<KS>(gf, dout + obase + (long)rr * D, g);
         }
         // ---------------- transposed layout: lane = query it*16 + c15, registers = keys -> dQ ----------------
         {
@@ -218,11 +222,11 @@ __global__ __launch_bounds__(256, ((T <= 3 && KS <= 8) || T == 1 ? 2 : 1)) void 
                 for (int jt = 0; jt < T; jt++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const float a = ldv1(k + base + (long)min(jt * 16 + 4 * g + r, L - 1) * D + dcol);   // dS = 0 for keys >= L
+                        const float a = ldv1(k + base + (long)min(jt * 16 + 4 * g + r, L - 1) * ld + dcol);   // dS = 0 for keys >= L
                         o = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p[jt][r], o, 0, 0, 0);
                     }
                 const int d0 = dt * 16 + 4 * g;
-                if (qi < L && d0 < DK) stv4(dq + base + (long)qi * D + d0, make_float4(o[0] / rs, o[1] / rs, o[2] / rs, o[3] / rs));
+                if (qi < L && d0 < DK) stv4(dq + base + (long)qi * ld + d0, make_float4(o[0] / rs, o[1] / rs, o[2] / rs, o[3] / rs));
             }
         }
         // ---------------- normal layout: lane = key jt*16 + c15, registers = queries it*16 + 4g + reg -> dV, dK ----------------
@@ -286,9 +290,9 @@ __global__ __launch_bounds__(256, ((T <= 3 && KS <= 8) || T == 1 ? 2 : 1)) void 
                 float ga[4], qa[4];                        // dout^T / Q^T operands: rows d = dt*16 + c15, k = queries 4g + r
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const long ro = (long)min(it * 16 + 4 * g + r, L - 1) * D + dcol;
-                    ga[r] = ldv1(dout + base + ro);
-                    qa[r] = ldv1(q + base + ro);
+                    const int rr = min(it * 16 + 4 * g + r, L - 1);
+                    ga[r] = ldv1(dout + obase + (long)rr * D + dcol);
+                    qa[r] = ldv1(q + base + (long)rr * ld + dcol);
                 }
 #pragma unroll
                 for (int jt = 0; jt < T; jt++)
@@ -307,8 +311,8 @@ __global__ __launch_bounds__(256, ((T <= 3 && KS <= 8) || T == 1 ? 2 : 1)) void 
         for (int jt = 0; jt < T; jt++) {
             const int j = jt * 16 + c15, d0 = dt * 16 + 4 * g;
             if (j < L && d0 < DK) {
-                stv4(dv + base + (long)j * D + d0, make_float4(adv[dt][jt][0], adv[dt][jt][1], adv[dt][jt][2], adv[dt][jt][3]));
-                stv4(dkk + base + (long)j * D + d0,
+                stv4(dv + base + (long)j * ld + d0, make_float4(adv[dt][jt][0], adv[dt][jt][1], adv[dt][jt][2], adv[dt][jt][3]));
+                stv4(dkk + base + (long)j * ld + d0,
                     make_float4(adk[dt][jt][0] / rs, adk[dt][jt][1] / rs, adk[dt][jt][2] / rs, adk[dt][jt][3] / rs));
             }
         }
@@ -342,28 +346,28 @@ extern "C" int stage_mha_core_recomputes(int L, int D, int nh) {
 
 template <typename TS>
 static int mha_fwd_t(const TS* q, const TS* k, const TS* v, const float* mask, TS* out, long long M, int L, int D, int nh,
-                     float p_drop, unsigned long long seed, void* stream) {
+                     float p_drop, unsigned long long seed, void* stream, int ld = 0) {
     hipStream_t st = (hipStream_t)stream;
     const int dk = D / nh;
     const long items = (long)M * nh;
     uint32_t th = p_drop > 0.f ? drop_thresh16(p_drop) : 0u;
     if (p_drop > 0.f && th == 0u) th = 1u;
     const float ik = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
-    MHA_DISPATCH(mha_fwd_mfma_kernel, q, k, v, mask, out, items, L, D, nh, (uint64_t)seed, th, ik);
+    MHA_DISPATCH(mha_fwd_mfma_kernel, q, k, v, mask, out, items, L, D, nh, (uint64_t)seed, th, ik, ld > 0 ? ld : D);
     STAGE_LAUNCH_CHECK();
     return 0;
 }
 
 template <typename TS>
 static int mha_bwd_t(const TS* dout, const TS* q, const TS* k, const TS* v, const float* mask, TS* dq, TS* dk_out, TS* dv,
-                     long long M, int L, int D, int nh, float p_drop, unsigned long long seed, void* stream) {
+                     long long M, int L, int D, int nh, float p_drop, unsigned long long seed, void* stream, int ld = 0) {
     hipStream_t st = (hipStream_t)stream;
     const int dk = D / nh;
     const long items = (long)M * nh;
     uint32_t th = p_drop > 0.f ? drop_thresh16(p_drop) : 0u;
     if (p_drop > 0.f && th == 0u) th = 1u;
     const float ik = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
-    MHA_DISPATCH(mha_bwd_mfma_kernel, dout, q, k, v, mask, dq, dk_out, dv, items, L, D, nh, (uint64_t)seed, th, ik);
+    MHA_DISPATCH(mha_bwd_mfma_kernel, dout, q, k, v, mask, dq, dk_out, dv, items, L, D, nh, (uint64_t)seed, th, ik, ld > 0 ? ld : D);
     STAGE_LAUNCH_CHECK();
     return 0;
 }
@@ -395,4 +399,35 @@ extern "C" int stage_mha_core_bwd_bf16(const void* dout, const void* q, const vo
     typedef stage_bf16 B;
     return mha_bwd_t<B>((const B*)dout, (const B*)q, (const B*)k, (const B*)v, mask, (B*)dq, (B*)dk, (B*)dv, M, L, D, nh, p_drop,
                         seed, stream);
+}
+
+// Fused projections: q, k, v are the three thirds of ONE (M, L, 3 D) tensor -- the output of a single Linear(D -> 3 D) whose weight is
+// [W_q; W_k; W_v] (model/self_attention.py:35-44 applies three Linears to the same input) -- and dq, dk, dv the thirds of ONE gradient
+// tensor of that shape, which IS the output gradient of that Linear: one forward GEMM, one dX GEMM and one weight-gradient GEMM
+// instead of three each, and no summation of three input gradients.  fp32 and bf16 storage (is_bf16); matrix-core shapes only.
+extern "C" int stage_mha_core_qkv_fwd(const void* qkv, const float* mask, void* out, long long M, int L, int D, int nh, float p_drop,
+                                      unsigned long long seed, int is_bf16, void* stream) {
+    if (M <= 0) return 0;
+    if (!stage_mha_core_recomputes(L, D, nh)) return STAGE_ERR_SHAPE;
+    if (is_bf16) {
+        typedef stage_bf16 B;
+        const B* p = (const B*)qkv;
+        return mha_fwd_t<B>(p, p + D, p + 2 * D, mask, (B*)out, M, L, D, nh, p_drop, seed, stream, 3 * D);
+    }
+    const float* p = (const float*)qkv;
+    return mha_fwd_t<float>(p, p + D, p + 2 * D, mask, (float*)out, M, L, D, nh, p_drop, seed, stream, 3 * D);
+}
+extern "C" int stage_mha_core_qkv_bwd(const void* dout, const void* qkv, const float* mask, void* dqkv, long long M, int L, int D, int nh,
+                                      float p_drop, unsigned long long seed, int is_bf16, void* stream) {
+    if (M <= 0) return 0;
+    if (!stage_mha_core_recomputes(L, D, nh)) return STAGE_ERR_SHAPE;
+    if (is_bf16) {
+        typedef stage_bf16 B;
+        const B* p = (const B*)qkv;
+        B* g = (B*)dqkv;
+        return mha_bwd_t<B>((const B*)dout, p, p + D, p + 2 * D, mask, g, g + D, g + 2 * D, M, L, D, nh, p_drop, seed, stream, 3 * D);
+    }
+    const float* p = (const float*)qkv;
+    float* g = (float*)dqkv;
+    return mha_bwd_t<float>((const float*)dout, p, p + D, p + 2 * D, mask, g, g + D, g + 2 * D, M, L, D, nh, p_drop, seed, stream, 3 * D);
 }

@@ -883,3 +883,41 @@ class _MHACore(torch.autograd.Function):
 
 def mha_core(q, k, v, mask, nh: int, p: float = 0.0, seed: int = 0):
     return _MHACore.apply(q, k, v, mask, nh, p, seed)
+
+
+class _MHACoreQKV(torch.autograd.Function):
+    """The same core on the FUSED projections: qkv (M, L, 3D) = Linear(D -> 3D)(x) with the weight [W_q; W_k; W_v]; the backward
+    writes dq | dk | dv into one (M, L, 3D) tensor, the output gradient of that Linear (stage_mha_core_qkv_*)."""
+
+    @_on_device
+    def forward(ctx, qkv, mask, nh: int, p: float, seed: int):
+        qkv = _act(qkv, "qkv")
+        mask = _chk(mask, "mask")
+        M, L, D3 = qkv.shape
+        D = D3 // 3
+        out = torch.empty(M, L, D, dtype=qkv.dtype, device=qkv.device)
+        _call("stage_mha_core_qkv_fwd", _ptr(qkv), _ptr(mask), _ptr(out), M, L, D, nh, float(p), int(seed), int(qkv.dtype == _BF16),
+              _stream())
+        ctx.save_for_backward(qkv, mask)
+        ctx.cfg = (nh, float(p), int(seed), D)
+        return out
+
+    @_on_device
+    def backward(ctx, dout):
+        qkv, mask = ctx.saved_tensors
+        nh, p, seed, D = ctx.cfg
+        M, L, _ = qkv.shape
+        dout = _act(dout, "dout", qkv)
+        dqkv = torch.empty_like(qkv)
+        _call("stage_mha_core_qkv_bwd", _ptr(dout), _ptr(qkv), _ptr(mask), _ptr(dqkv), M, L, D, nh, p, seed, int(qkv.dtype == _BF16),
+              _stream())
+        return dqkv, None, None, None, None
+
+
+def mha_core_qkv_supported(L: int, D: int, nh: int) -> bool:
+    return _os.environ.get("STAGE_MHA_SCALAR") is None and _os.environ.get("STAGE_NO_FUSED_QKV") is None and \
+        bool(_lib.load().stage_mha_core_recomputes(L, D, nh)) and D % 8 == 0
+
+
+def mha_core_qkv(qkv, mask, nh: int, p: float = 0.0, seed: int = 0):
+    return _MHACoreQKV.apply(qkv, mask, nh, p, seed)

@@ -363,12 +363,22 @@ class STAGE(nn.Module):
             y, cur = self._ln(pending, blk.attn_layer_norm, res=cur, res_period=period)
             period = 0
             mha = blk.multi_head_attn
-            q = ops.linear(y, self._g(mha.linears[0].weight), self._g(mha.linears[0].bias))
-            k = ops.linear(y, self._g(mha.linears[1].weight), self._g(mha.linears[1].bias))
-            v = ops.linear(y, self._g(mha.linears[2].weight), self._g(mha.linears[2].bias))
             p_attn = mha.p_attn_drop if self.mha_dropout_override is None else self.mha_dropout_override
             p_attn = p_attn if self.training else 0.0
-            a = ops.mha_core(q, k, v, mask, mha.nh, p=p_attn, seed=self._seed() if p_attn > 0 else 0)
+            if ops.mha_core_qkv_supported(L, D, mha.nh):
+                # the three projections of model/self_attention.py:35-44 as ONE Linear(D -> 3D) on the stacked weight: one forward GEMM,
+                # one dX GEMM (no sum of three input gradients), one weight-gradient GEMM; the attention core reads / writes the thirds
+                # of the fused tensors in place (round 5; the stacked weight is a 192 KB torch.cat whose backward hands each
+                # Linear its slice of the gradient)
+                w_qkv = torch.cat([self._g(mha.linears[j].weight) for j in range(3)], dim=0)
+                b_qkv = torch.cat([self._g(mha.linears[j].bias) for j in range(3)], dim=0)
+                qkv = ops.linear(y, w_qkv, b_qkv)
+                a = ops.mha_core_qkv(qkv, mask, mha.nh, p=p_attn, seed=self._seed() if p_attn > 0 else 0)
+            else:
+                q = ops.linear(y, self._g(mha.linears[0].weight), self._g(mha.linears[0].bias))
+                k = ops.linear(y, self._g(mha.linears[1].weight), self._g(mha.linears[1].bias))
+                v = ops.linear(y, self._g(mha.linears[2].weight), self._g(mha.linears[2].bias))
+                a = ops.mha_core(q, k, v, mask, mha.nh, p=p_attn, seed=self._seed() if p_attn > 0 else 0)
             pending = ops.linear(a, self._g(mha.linears[3].weight), self._g(mha.linears[3].bias))
         if pool_mask is not None:
             if self.fuse_ln_max and period == 0 and ops.ln_masked_max_supported(pending, L, D):
