@@ -10,7 +10,8 @@ from torch.profiler import ProfilerActivity, profile
 
 dev = torch.device("cuda", 0)
 torch.manual_seed(2018)
-opt = make_opt(hsz=128, add_local=True, dropout=0.1, use_sup_att=True)
+HEADS = int(os.environ.get("HEADS", "0"))
+opt = make_opt(hsz=128, add_local=True, dropout=0.1, use_sup_att=True, input_encoder_n_heads=HEADS, cls_encoder_n_heads=HEADS)
 with contextlib.redirect_stdout(open(os.devnull, "w")):
     model = STAGE(opt).to(dev).train()
 params = [p for p in model.parameters() if p.requires_grad]
