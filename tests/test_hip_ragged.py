@@ -339,3 +339,23 @@ def test_fused_cat3_backward_balanced_launch_equals_the_chunk_grid(hip_device, p
         assert torch.isfinite(y).all(), nm
         assert float((x - y).abs().max()) <= 2e-5 * float(x.abs().max()) + 1e-6, nm
     assert float(outs[1][0].abs().max()) > 0
+
+
+def test_small_batches_run_the_padded_rows(hip_device):
+    """stage.py: ragged_min_rows -- below 200 000 padded statement rows (a rank of a strong-scaled job) the step is bound by the host and
+    the ragged layout is not built; the threshold is a property of the model, 0 forces the layout (what this suite runs with)."""
+    from tvqaplus_amd.stage import STAGE
+    from tvqaplus_amd.synth import make_batch, make_opt
+    torch.manual_seed(1)
+    model = STAGE(make_opt(hsz=128, embedding_size=64, vfeat_size=48, dropout=0.0, add_local=True)).to(hip_device).train()
+    batch = make_batch(N=2, Li=8, Lr=10, Lw=12, Lqa=14, wd_size=64, vfeat_size=48, seed=3).to(hip_device)
+    assert model.ragged_min_rows == 0                       # tests/conftest.py: STAGE_RAGGED_MIN_ROWS=0
+    model(batch)
+    assert model.last_ragged is not None
+    model.ragged_min_rows = 200000                          # the product default: 2 * 5 * 8 * 14 rows are far below it
+    (out_d, tgt_d), _, _, tl_d, ts_d = model(batch)
+    assert model.last_ragged is None and not model.last_ragged_ctx
+    model.ragged_min_rows = 0
+    (out_r, tgt_r), _, _, tl_r, ts_r = model(batch)
+    assert model.last_ragged is not None
+    assert torch.equal(tgt_d, tgt_r) and rel_err(out_d, out_r) < 2e-5 and rel_err(ts_d, ts_r) < 2e-5 and rel_err(tl_d, tl_r) < 2e-5
