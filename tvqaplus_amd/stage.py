@@ -770,8 +770,11 @@ class STAGE(nn.Module):
         tab = ragged.RaggedTables(info["qas"], info[frame_stream + "_len"] > 0, cls_halo)
         if tab.U == 0:
             return none
-        lib_ok = all(bool(groups._lib.load().stage_grp_qa_ctx_rag_supported(N, NA, Li, Lqa, int(Lr), D, tab.U, tab.Fc))
-                     for _, _, Lr in streams)
+        lib = groups._lib.load()
+        lib_ok = all(bool(lib.stage_grp_qa_ctx_rag_supported(N, NA, Li, Lqa, int(Lr), D, tab.U, tab.Fc)) for _, _, Lr in streams)
+        # ... and the fused [a, b, a*b] kernels on gathered rows, which the attention and the fusion groups of this layout are built on
+        # (switched off by STAGE_NO_CAT3_FUSED: the dense path then runs -- decided here, before anything is launched)
+        lib_ok = lib_ok and bool(lib.stage_cat3_ln_gemm_fwd_rag_supported(tab.U, N * NA * Lqa, tab.Fc, D))
         if not lib_ok:
             return none
         lay = ragged.RaggedLayout(tab, a_embed.device, self._rag_stage)
