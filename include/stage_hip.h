@@ -27,7 +27,7 @@ extern "C" {
 #define STAGE_ERR_WORKSPACE (-2)  /* workspace too small */
 
 /* ---- library info -------------------------------------------------------------------------------------------- */
-#define STAGE_HIP_ABI_VERSION 4   /* what stage_hip_abi_version() of a matching library returns; bumped whenever a symbol or a signature changes */
+#define STAGE_HIP_ABI_VERSION 5   /* what stage_hip_abi_version() of a matching library returns; bumped whenever a symbol or a signature changes */
 int stage_hip_abi_version(void);
 const char* stage_hip_error_string(int code);
 /* Measurement helpers (bench.py; no reference counterpart): events for hosts without a HIP binding, and a one-shot hook that makes the
@@ -337,6 +337,19 @@ int stage_cat3_ln_gemm_fwd(const float* a, const float* b, const float* gamma, c
                            float* z, float* mean, float* rstd, float* y, unsigned* relu_mask_out, long long rows, int D, int rep,
                            int inner, float eps, float p_drop, unsigned long long seed, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- the same backward WITH the Linear's own gradients, no saved z (csrc/cat3_bwd_dw.hip) -----------------------------------------
+ * (model/stage.py:381-385, :276-279, :107-113, :133-138.)  One persistent 8-wave workgroup per compute unit owns complete rows and
+ * the whole (D, 3D) weight gradient in matrix-core accumulators: dz = (dy .* relu') W never exists as a tensor (as above) AND
+ * dW[n][k] = sum_rows (dy .* relu')[row][n] z[row][k], dc[n] = sum_rows (dy .* relu')[row][n] are formed from z REBUILT in registers
+ * (a, b, the saved row statistics, gamma / beta, the dropout stream) -- the forward passes z = NULL to stage_cat3_ln_gemm_fwd* and
+ * no weight-gradient GEMM runs.  Arguments as stage_cat3_dx_ln_bwd plus beta (3D), dW (D, 3D), dc (D).                            */
+int stage_cat3_bwd_dw_supported(long long rows, int D, int rep, int inner);
+size_t stage_cat3_bwd_dw_ws_bytes(long long rows, int D, int rep, int inner);
+int stage_cat3_bwd_dw(const float* dy, const unsigned* relu_mask, const float* W, const float* a, const float* b, const float* mean,
+                      const float* rstd, const float* gamma, const float* beta, float* da, float* db, float* dgamma, float* dbeta,
+                      float* dW, float* dc, long long rows, int D, int rep, int inner, float p_drop, unsigned long long seed, void* ws,
+                      size_t ws_bytes, void* stream);
+
 /* ---- K-groups: launch sequencing on the C side (one forward and one backward symbol per fused-op group) --
  * Each group runs the kernels above in the order tvqaplus_amd/ops.py would, as ONE call (csrc/groups.hip); fp32 storage.
  * Memory protocol: `arena` (stage_grp_*_arena_bytes) = what the forward keeps for the backward, carved deterministically;
@@ -501,6 +514,16 @@ int stage_cat3_dx_ln_bwd_rag(const float* dy, const unsigned* relu_mask, const f
                              const float* mean, const float* rstd, const float* gamma, float* da, float* db_fc, float* dgamma,
                              float* dbeta, const int* gdesc, const int* wtab, long long rows, long long fc_rows, int D, int groups,
                              int max_frames, int Lqa, float p_drop, unsigned long long seed, void* ws, size_t ws_bytes, void* stream);
+/* the ragged backward with the Linear's gradients inside (csrc/cat3_bwd_dw.hip; see stage_cat3_bwd_dw): wtab is REQUIRED and built
+ * for stage_cat3_bwd_dw_rag_work_groups() workgroups (= what stage_cat3_rag_work_groups() returns while this path is enabled) */
+int stage_cat3_bwd_dw_rag_supported(long long rows, long long fc_rows, int D, int groups, int max_frames, int Lqa);
+int stage_cat3_bwd_dw_rag_work_groups(void);
+size_t stage_cat3_bwd_dw_rag_ws_bytes(int groups, int Lqa);
+int stage_cat3_bwd_dw_rag(const float* dy, const unsigned* relu_mask, const float* W, const float* a, const float* b_fc,
+                          const float* mean, const float* rstd, const float* gamma, const float* beta, float* da, float* db_fc,
+                          float* dgamma, float* dbeta, float* dW, float* dc, const int* gdesc, const int* wtab, long long rows,
+                          long long fc_rows, int D, int groups, int max_frames, int Lqa, float p_drop, unsigned long long seed,
+                          void* ws, size_t ws_bytes, void* stream);
 /* encoder block pieces on ragged sequences (model/encoder.py:35-52; model/stage.py:503 for the pooled LayerNorm) */
 int stage_ln_dwconv_rag_fwd(const float* x, const float* res, const float* pe, float* sum_out, const float* gamma,
                             const float* beta, const float* w, const float* bias, float* h, float* mean, float* rstd,

@@ -41,7 +41,7 @@ def test_header_symbols_exported(built_lib):
     # one number in three places: the header's macro (what the library returns), the Python binding's constant, this test
     import re
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "stage_hip.h")).read()
-    assert int(re.search(r"#define STAGE_HIP_ABI_VERSION (\d+)", hdr).group(1)) == built_lib.ABI_VERSION == lib.stage_hip_abi_version() == 4
+    assert int(re.search(r"#define STAGE_HIP_ABI_VERSION (\d+)", hdr).group(1)) == built_lib.ABI_VERSION == lib.stage_hip_abi_version() == 5
     assert lib.stage_hip_error_string(-1).decode().startswith("stage_hip")
 
 

@@ -76,3 +76,27 @@ def fwd_fused():
 fwd_unfused(); fwd_fused(); torch.cuda.synchronize()
 print("forward: max|y - y'| %.3e of %.3e, z equal up to %.3e" % (float((y - y2).abs().max()), float(y.abs().max()), float((z - z2).abs().max())))
 timeit(fwd_unfused, "LayerNorm forward + GEMM"); timeit(fwd_fused, "fused forward")
+# ---- round 6: the backward with the Linear's gradients inside (csrc/cat3_bwd_dw.hip) and the forward without the z store ----
+if lib.stage_cat3_bwd_dw_supported(U, D, rep, inner):
+    da3 = torch.empty_like(a); db3 = torch.empty_like(b); dg3 = torch.empty(3 * D, device=dev); dbt3 = torch.empty(3 * D, device=dev)
+    dW3 = torch.empty(D, 3 * D, device=dev); dc3 = torch.empty(D, device=dev)
+    dW0 = torch.empty(D, 3 * D, device=dev); dc0 = torch.empty(D, device=dev)
+    wsb3 = lib.stage_cat3_bwd_dw_ws_bytes(U, D, rep, inner); ws3 = torch.empty(wsb3, dtype=torch.uint8, device=dev)
+    wsb0 = lib.stage_gemm_tn_ws_bytes(U, D, 3 * D); ws0 = torch.empty(wsb0, dtype=torch.uint8, device=dev)
+    def dw_inside():
+        _lib.check(lib.stage_cat3_bwd_dw(dy.data_ptr(), mask.data_ptr(), W.data_ptr(), a.data_ptr(), b.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                   gamma.data_ptr(), beta.data_ptr(), da3.data_ptr(), db3.data_ptr(), dg3.data_ptr(), dbt3.data_ptr(), dW3.data_ptr(), dc3.data_ptr(),
+                   U, D, rep, inner, p, seed, ws3.data_ptr(), wsb3, st), "dw inside")
+    def tn_on_z():
+        _lib.check(lib.stage_gemm_tn_mask(dy.data_ptr(), mask.data_ptr(), z.data_ptr(), dW0.data_ptr(), dc0.data_ptr(), U, D, 3 * D, ws0.data_ptr(), wsb0, st), "tn")
+    fwd_unfused(); dw_inside(); tn_on_z(); torch.cuda.synchronize()
+    for nm, x, y3 in (("da", da2, da3), ("db", db2, db3), ("dgamma", dg2, dg3), ("dbeta", dbt2, dbt3), ("dW", dW0, dW3), ("dc", dc0, dc3)):
+        print("dW-inside %-7s max|diff| %.3e  of scale %.3e" % (nm, float((x - y3).abs().max()), float(x.abs().max())))
+    ref = (dy * (((mask.unsqueeze(-1) >> torch.arange(32, device=dev, dtype=torch.int32)) & 1).permute(1, 0, 2).reshape(U, D).float())).double().t() @ z.double()
+    print("dW vs fp64: TN on z %.3e, inside %.3e (scale %.3e)" % (float((dW0.double() - ref).abs().max()), float((dW3.double() - ref).abs().max()), float(ref.abs().max())))
+    del ref
+    timeit(tn_on_z, "weight-gradient GEMM on z"); timeit(dw_inside, "backward with dW inside (incl. weight image + reductions)")
+    def fwd_fused_noz():
+        _lib.check(lib.stage_cat3_ln_gemm_fwd(a.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), W.data_ptr(), bias.data_ptr(), None, mean2.data_ptr(),
+                   rstd2.data_ptr(), y2.data_ptr(), mask2.data_ptr(), U, D, rep, inner, 1e-5, p, seed, fws.data_ptr(), fwsb, st), "fused fwd no z")
+    timeit(fwd_fused_noz, "fused forward without the z store")

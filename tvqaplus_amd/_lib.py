@@ -98,6 +98,9 @@ SIGNATURES = {
     "stage_cat3_dx_ln_bwd_supported": (I, [LL, I, I, I]),
     "stage_cat3_dx_ln_bwd_ws_bytes": (SZ, [LL, I, I, I]),
     "stage_cat3_dx_ln_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, U64, P, SZ, P]),
+    "stage_cat3_bwd_dw_supported": (I, [LL, I, I, I]),
+    "stage_cat3_bwd_dw_ws_bytes": (SZ, [LL, I, I, I]),
+    "stage_cat3_bwd_dw": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, U64, P, SZ, P]),
     "stage_cat3_ln_gemm_fwd_supported": (I, [LL, I, I, I]),
     "stage_cat3_ln_gemm_fwd_ws_bytes": (SZ, []),
     "stage_cat3_ln_gemm_fwd": (I, [P, P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, F, U64, P, SZ, P]),
@@ -151,6 +154,10 @@ SIGNATURES = {
     "stage_cat3_dx_ln_bwd_rag_supported": (I, [LL, LL, I, I, I, I]),
     "stage_cat3_dx_ln_bwd_rag_ws_bytes": (SZ, [I, I, I]),
     "stage_cat3_rag_work_groups": (I, []),
+    "stage_cat3_bwd_dw_rag_supported": (I, [LL, LL, I, I, I, I]),
+    "stage_cat3_bwd_dw_rag_work_groups": (I, []),
+    "stage_cat3_bwd_dw_rag_ws_bytes": (SZ, [I, I]),
+    "stage_cat3_bwd_dw_rag": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, LL, LL, I, I, I, I, F, U64, P, SZ, P]),
     "stage_cat3_dx_ln_bwd_rag": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, LL, LL, I, I, I, I, F, U64, P, SZ, P]),
     "stage_ln_dwconv_rag_fwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, F, U64, P]),
     "stage_ln_dwconv_rag_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, U64, P, SZ, P]),
@@ -167,7 +174,7 @@ SIGNATURES = {
     "stage_grp_encoder_rag_bwd": (I, [P, P, P, P, P, P, P, SZ, P, P, SZ, LL, LL, LL, LL, I, I, I, I, F, P, P]),
 }
 
-ABI_VERSION = 4    # include/stage_hip.h: STAGE_HIP_ABI_VERSION (tests/test_abi.py holds the two together)
+ABI_VERSION = 5    # include/stage_hip.h: STAGE_HIP_ABI_VERSION (tests/test_abi.py holds the two together)
 
 _lib = None
 

@@ -2,7 +2,7 @@
 #include "common.h"
 #include "../../include/stage_hip.h"
 
-extern "C" int stage_hip_abi_version(void) { return STAGE_HIP_ABI_VERSION; }   // 2: round 4 (ragged token rows: stage_rag_*, *_fc, *_rag); 3: balanced work table (wtab) of stage_cat3_dx_ln_bwd_rag, T[5]; 4: round 5 (stage_ts_loss na_total, stage_mha_core_qkv_*)
+extern "C" int stage_hip_abi_version(void) { return STAGE_HIP_ABI_VERSION; }   // 2: round 4 (ragged token rows: stage_rag_*, *_fc, *_rag); 3: balanced work table (wtab) of stage_cat3_dx_ln_bwd_rag, T[5]; 4: round 5 (stage_ts_loss na_total, stage_mha_core_qkv_*); 5: round 6 (stage_cat3_bwd_dw*: the [a,b,a*b] backward with the Linear's gradients inside, z optional in stage_cat3_ln_gemm_fwd*)
 
 extern "C" const char* stage_hip_error_string(int code) {
     if (code == 0) return "success";

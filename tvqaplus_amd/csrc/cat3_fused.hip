@@ -599,6 +599,11 @@ extern "C" int stage_cat3_dx_ln_bwd(const float* dy, const unsigned* relu_mask, 
 }
 
 // ---- ragged token rows (MODE 3) -------------------------------------------------------------------------------------
+// persistent workgroups of the balanced ragged launch: what the work table is built for.  With the dW-inside backward enabled
+// (cat3_bwd_dw.hip: one workgroup per compute unit) both kernels take ITS count, so that one table serves either.
+static int cf_rag_wgs() {
+    return stage_cat3_bwd_dw_rag_supported(1, 1, CF_D, 1, 1, 1) ? stage_cat3_bwd_dw_rag_work_groups() : CF_RAG_WGS;
+}
 extern "C" int stage_cat3_dx_ln_bwd_rag_supported(long long rows, long long fc_rows, int D, int groups, int max_frames, int Lqa) {
     if (getenv("STAGE_NO_CAT3_FUSED")) return 0;
     return (D == CF_D && rows >= 1 && rows * (long long)D * 4 < (1ll << 31) && fc_rows * (long long)D * 4 < (1ll << 31) && groups >= 1 &&
@@ -608,13 +613,13 @@ extern "C" size_t stage_cat3_dx_ln_bwd_rag_ws_bytes(int groups, int max_frames, 
     int CH, fpc;
     cf_chunks(groups, max_frames, 2, &CH, &fpc);
     size_t wg = (size_t)groups * CH;
-    if (wg < (size_t)CF_RAG_WGS + groups) wg = (size_t)CF_RAG_WGS + groups;      // the balanced launch: <= CF_RAG_WGS + groups slabs
+    if (wg < (size_t)cf_rag_wgs() + groups) wg = (size_t)cf_rag_wgs() + groups;  // the balanced launch: <= work groups + groups slabs
     size_t b = cf_align((size_t)CF_WFRAG * sizeof(uint4)) + 256;
     b += cf_align(wg * 2 * 3 * CF_D * sizeof(float));
     b += cf_align(wg * (size_t)Lqa * CF_D * sizeof(float));
     return b;
 }
-extern "C" int stage_cat3_rag_work_groups(void) { return CF_RAG_WGS; }
+extern "C" int stage_cat3_rag_work_groups(void) { return cf_rag_wgs(); }
 // As stage_cat3_dx_ln_bwd with a broadcast `a`, on ragged token rows: dy / relu_mask / mean / rstd are compact (rows), b_fc and db_fc
 // rows of the frame-compact tensor (fc_rows; db_fc may be b_fc itself), a and da (groups, Lqa, D); gdesc: see cf_bwd_kernel MODE 3.
 // wtab (may be NULL: one workgroup per (group, chunk of max_frames)): the balanced work table for stage_cat3_rag_work_groups()
@@ -639,8 +644,8 @@ extern "C" int stage_cat3_dx_ln_bwd_rag(const float* dy, const unsigned* relu_ma
     const int K3 = 3 * CF_D;
     int CH, fpc;
     cf_chunks(groups, max_frames, 2, &CH, &fpc);
-    const int grid = wtab ? CF_RAG_WGS : groups * CH;
-    const size_t slabs = wtab ? (size_t)CF_RAG_WGS + groups : (size_t)grid;
+    const int grid = wtab ? cf_rag_wgs() : groups * CH;
+    const size_t slabs = wtab ? (size_t)cf_rag_wgs() + groups : (size_t)grid;
     float* part = (float*)wsp;
     wsp += cf_align(slabs * 2 * K3 * sizeof(float));
     float* da_out = (float*)wsp;                               // slabs [G][CH][Lqa][D] / one per segment
@@ -657,7 +662,7 @@ extern "C" int stage_cat3_dx_ln_bwd_rag(const float* dy, const unsigned* relu_ma
     if (!wtab) return stage_reduce_rep(da_out, da, groups, CH, (long long)Lqa * CF_D, st);
     const long inner4 = (long)Lqa * CF_D / 4;
     hipLaunchKernelGGL(cf_reduce_seg_kernel, dim3(stage_grid_for((long long)groups * inner4, 256, 4096)), dim3(256), 0, st, da_out, da,
-                       reinterpret_cast<const int2*>(wtab + CF_WTAB_GSEG(CF_RAG_WGS)), (long)groups, inner4);
+                       reinterpret_cast<const int2*>(wtab + CF_WTAB_GSEG(cf_rag_wgs())), (long)groups, inner4);
     STAGE_LAUNCH_CHECK();
     return 0;
 }
@@ -824,8 +829,9 @@ __global__ __launch_bounds__(256, 3) void cff_fwd_kernel(const float* __restrict
                 o[t].w = (v[t].w - mu) * rs * gm[t].w + bt[t].w;
                 if (DROP) o[t] = f4mul(o[t], drop4(seed, (uint64_t)row * K4 + (uint64_t)(t * D4 + sl), th, inv_keep));
                 if (!ok) o[t] = f4zero();
-                // z is written once: the weight-gradient GEMM of the backward contracts over it (rows past the end: dropped by bounds)
-                __builtin_amdgcn_raw_buffer_store_b128((cf_u4){__float_as_uint(o[t].x), __float_as_uint(o[t].y), __float_as_uint(o[t].z), __float_as_uint(o[t].w)},
+                // z is written once: the weight-gradient GEMM of the backward contracts over it (rows past the end: dropped by bounds).
+                // z == NULL (uniform): the backward rebuilds it (cat3_bwd_dw.hip) -- nothing is stored
+                if (z) __builtin_amdgcn_raw_buffer_store_b128((cf_u4){__float_as_uint(o[t].x), __float_as_uint(o[t].y), __float_as_uint(o[t].z), __float_as_uint(o[t].w)},
                                                        rs_z, (sj * K3 + t * CF_D + 4 * sl) * 4, (int)((t0 + 8 * pass) * K3 * 4), CFF_NT);
                 m = h_amax3(h_amax3(m, o[t].x, o[t].y), o[t].z, o[t].w);
             }

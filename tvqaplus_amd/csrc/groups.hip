@@ -420,6 +420,7 @@ QaTmp qa_tmp(void* base, int N, int NA, int Li, int Lqa, int Lr, int D) {
     t.wsb = umax(t.wsb, stage_cat3_layernorm_bwd_reduced_ws_bytes((long long)U, D, Li, Lqa));
     t.wsb = umax(t.wsb, umax(stage_str_attn_bwd_fused_ws_bytes(N, NA, Li, Lqa, D), stage_str_attn_bwd_ws_bytes(N, NA, Lqa, D)));
     t.wsb = umax(t.wsb, stage_cat3_dx_ln_bwd_ws_bytes((long long)U, D, Li, Lqa));
+    t.wsb = umax(t.wsb, stage_cat3_bwd_dw_ws_bytes((long long)U, D, Li, Lqa));
     t.ws = b.take<char>(t.wsb);
     t.bytes = b.off;
     return t;
@@ -439,10 +440,12 @@ extern "C" int stage_grp_qa_ctx_fwd(const float* qa, const float* ctx, const flo
     TRY(stage_l2norm_fwd(qa, a.Cn, nullptr, (long long)N * NA * Lqa, D, EPS_L2, p, seeds[0], st));
     TRY(stage_str_attn_fwd(a.Cn, ctx, qa_mask, ctx_mask, a.A, S_raw, S_norm, N, NA, Li, Lqa, Lr, D, scale, p, seeds[1], st));
     if (stage_cat3_ln_gemm_fwd_supported(U, D, Li, Lqa) && lin_wants_mask(a.z, P[2], U, D, 3 * D, 1)) {
-        // LayerNorm + dropout + Linear + ReLU in one pass (csrc/cat3_fused.hip); fwd_ws: scratch for its pre-split weight image
-        const int rc = stage_cat3_ln_gemm_fwd(qa, a.A, P[0], P[1], P[2], P[3], a.z, a.mean, a.rstd, mixed, a.mask, U, D, Li, Lqa, EPS_LN, p,
-                                              seeds[2], a.fwd_ws, stage_cat3_ln_gemm_fwd_ws_bytes(), st);
-        if (rc == 0) { flags[0] = 1; return 0; }
+        // LayerNorm + dropout + Linear + ReLU in one pass (csrc/cat3_fused.hip); fwd_ws: scratch for its pre-split weight image.
+        // flags[0] = 2: z was NOT written -- the backward rebuilds it and forms the Linear's gradients itself (csrc/cat3_bwd_dw.hip)
+        const bool dw = stage_cat3_bwd_dw_supported(U, D, Li, Lqa) != 0;
+        const int rc = stage_cat3_ln_gemm_fwd(qa, a.A, P[0], P[1], P[2], P[3], dw ? nullptr : a.z, a.mean, a.rstd, mixed, a.mask, U, D, Li, Lqa,
+                                              EPS_LN, p, seeds[2], a.fwd_ws, stage_cat3_ln_gemm_fwd_ws_bytes(), st);
+        if (rc == 0) { flags[0] = dw ? 2 : 1; return 0; }
         if (rc != STAGE_ERR_SHAPE) return rc;
     }
     TRY(stage_cat3_layernorm_fwd(qa, a.A, P[0], P[1], a.z, a.mean, a.rstd, U, D, Li, Lqa, EPS_LN, p, seeds[2], st));
@@ -471,7 +474,11 @@ extern "C" int stage_grp_qa_ctx_bwd(const float* d_mixed, const float* dS_ext, c
     // Linear(3D -> D) + ReLU, LayerNorm over [a, b, a*b].  With the ReLU bit mask at hand the Linear's input gradient never
     // exists as a tensor (csrc/cat3_fused.hip); otherwise: dX GEMM, then the LayerNorm backward with the broadcast reduction
     bool reduced = false, fused = false;
-    if (flags[0] && al16(d_mixed) && stage_cat3_dx_ln_bwd_supported(U, D, Li, Lqa)) {
+    if (flags[0] == 2) {                                  // no saved z: everything in one kernel
+        TRY(stage_cat3_bwd_dw(d_mixed, a.mask, P[2], qa, a.A, a.mean, a.rstd, P[0], P[1], d_qa, t.dA, G[0], G[1], G[2], G[3], U, D, Li, Lqa, p,
+                              seeds[2], t.ws, stage_cat3_bwd_dw_ws_bytes(U, D, Li, Lqa), st));
+        fused = reduced = true;
+    } else if (flags[0] && al16(d_mixed) && stage_cat3_dx_ln_bwd_supported(U, D, Li, Lqa)) {
         TRY(lin_bwd(d_mixed, a.z, mixed, a.mask, flags[0], 1, P[2], t.wt, nullptr, G[2], G[3], U, D, 3 * D, t.ws, t.wsb, st));
         const int rc = stage_cat3_dx_ln_bwd(d_mixed, a.mask, P[2], qa, a.A, a.mean, a.rstd, P[0], d_qa, t.dA, G[0], G[1], U, D, Li, Lqa, p,
                                             seeds[2], t.ws, stage_cat3_dx_ln_bwd_ws_bytes(U, D, Li, Lqa), st);
@@ -533,6 +540,7 @@ FcTmp fc_tmp(void* base, long long U, int D) {
     t.wt = b.take<float>((size_t)3 * D * D);
     t.wsb = umax(umax(lin_bwd_ws(U, D, 3 * D), stage_ln_bwd_ws_bytes(3 * D)), stage_ln_bwd_ws_bytes(D));
     t.wsb = umax(t.wsb, stage_cat3_dx_ln_bwd_ws_bytes(U, D, 1, 1));
+    t.wsb = umax(t.wsb, stage_cat3_bwd_dw_ws_bytes(U, D, 1, 1));
     t.ws = b.take<char>(t.wsb);
     t.bytes = b.off;
     return t;
@@ -550,9 +558,10 @@ extern "C" int stage_grp_concat_fc_fwd(const float* s, const float* v, const flo
     if (arena_bytes < a.bytes) return STAGE_ERR_WORKSPACE;
     bool fused = false;
     if (stage_cat3_ln_gemm_fwd_supported(U, D, 1, 1) && lin_wants_mask(a.z, P[2], U, D, 3 * D, 1)) {
-        const int rc = stage_cat3_ln_gemm_fwd(s, v, P[0], P[1], P[2], P[3], a.z, a.mean3, a.rstd3, a.h, a.mask, U, D, 1, 1, EPS_LN, p, seeds[0],
-                                              a.fwd_ws, stage_cat3_ln_gemm_fwd_ws_bytes(), st);
-        if (rc == 0) { flags[0] = 1; fused = true; }
+        const bool dw = stage_cat3_bwd_dw_supported(U, D, 1, 1) != 0;          // flags[0] = 2: z not written (see G3)
+        const int rc = stage_cat3_ln_gemm_fwd(s, v, P[0], P[1], P[2], P[3], dw ? nullptr : a.z, a.mean3, a.rstd3, a.h, a.mask, U, D, 1, 1, EPS_LN,
+                                              p, seeds[0], a.fwd_ws, stage_cat3_ln_gemm_fwd_ws_bytes(), st);
+        if (rc == 0) { flags[0] = dw ? 2 : 1; fused = true; }
         else if (rc != STAGE_ERR_SHAPE) return rc;
     }
     if (!fused) {
@@ -570,6 +579,9 @@ extern "C" int stage_grp_concat_fc_bwd(const float* dout, const float* s, const 
     FcTmp t = fc_tmp(tmp, U, D);
     if (arena_bytes < a.bytes || tmp_bytes < t.bytes) return STAGE_ERR_WORKSPACE;
     TRY(stage_layernorm_bwd(dout, a.h, a.mean, a.rstd, P[4], t.dh, nullptr, G[4], G[5], U, D, 0.f, 0ull, t.ws, stage_ln_bwd_ws_bytes(D), st));
+    if (flags[0] == 2)                                    // no saved z: the Linear's gradients come out of the same kernel
+        return stage_cat3_bwd_dw(t.dh, a.mask, P[2], s, v, a.mean3, a.rstd3, P[0], P[1], ds, dv, G[0], G[1], G[2], G[3], U, D, 1, 1, p, seeds[0],
+                                 t.ws, stage_cat3_bwd_dw_ws_bytes(U, D, 1, 1), st);
     if (flags[0] && stage_cat3_dx_ln_bwd_supported(U, D, 1, 1)) {      // no 3D-wide gradient tensor (csrc/cat3_fused.hip)
         TRY(lin_bwd(t.dh, a.z, a.h, a.mask, flags[0], 1, P[2], t.wt, nullptr, G[2], G[3], U, D, 3 * D, t.ws, t.wsb, st));
         const int rc = stage_cat3_dx_ln_bwd(t.dh, a.mask, P[2], s, v, a.mean3, a.rstd3, P[0], ds, dv, G[0], G[1], U, D, 1, 1, p, seeds[0],
@@ -700,6 +712,7 @@ QaRagTmp qa_rag_tmp(void* base, int N, int NA, int Li, int Lqa, int Lr, int D, l
     t.dCn = b.take<float>((size_t)N * NA * Lqa * D);
     t.wt = b.take<float>((size_t)3 * D * D);
     t.wsb = umax(lin_bwd_ws(Ucap, D, 3 * D), stage_cat3_dx_ln_bwd_rag_ws_bytes(N * NA, Li, Lqa));
+    t.wsb = umax(t.wsb, stage_cat3_bwd_dw_rag_ws_bytes(N * NA, Lqa));
     t.wsb = umax(t.wsb, stage_str_attn_bwd_fused_ws_bytes(N, NA, Li, Lqa, D));
     t.ws = b.take<char>(t.wsb);
     t.bytes = b.off;
@@ -733,9 +746,12 @@ extern "C" int stage_grp_qa_ctx_rag_fwd(const float* qa, const float* ctx, const
     if (arena_bytes < a.bytes) return STAGE_ERR_WORKSPACE;
     TRY(stage_l2norm_fwd(qa, a.Cn, nullptr, (long long)N * NA * Lqa, D, EPS_L2, p, seeds[0], st));
     TRY(stage_str_attn_fwd_fc(a.Cn, ctx, qa_mask, ctx_mask, a.A, S_raw, S_norm, T[0], T[4], N, NA, Li, Lqa, Lr, D, scale, p, seeds[1], st));
-    TRY(stage_cat3_ln_gemm_fwd_rag(qa, a.A, P[0], P[1], P[2], P[3], a.z, a.mean, a.rstd, mixed, a.mask, T[3], U, (long long)N * NA * Lqa, Fc,
-                                   D, EPS_LN, p, seeds[2], a.fwd_ws, stage_cat3_ln_gemm_fwd_ws_bytes(), st));
-    flags[0] = 1;
+    // flags[0] = 2: z is not written -- the backward rebuilds it and forms the Linear's gradients itself (csrc/cat3_bwd_dw.hip; needs
+    // the balanced work table T[5])
+    const bool dw = T[5] != nullptr && stage_cat3_bwd_dw_rag_supported(U, Fc, D, N * NA, Li, Lqa) != 0;
+    TRY(stage_cat3_ln_gemm_fwd_rag(qa, a.A, P[0], P[1], P[2], P[3], dw ? nullptr : a.z, a.mean, a.rstd, mixed, a.mask, T[3], U,
+                                   (long long)N * NA * Lqa, Fc, D, EPS_LN, p, seeds[2], a.fwd_ws, stage_cat3_ln_gemm_fwd_ws_bytes(), st));
+    flags[0] = dw ? 2 : 1;
     return 0;
 }
 
@@ -746,7 +762,6 @@ extern "C" int stage_grp_qa_ctx_rag_bwd(const float* d_mixed, const float* dS_ex
                                         size_t arena_bytes, const int* flags, void* tmp, size_t tmp_bytes, int N, int NA, int Li,
                                         int Lqa, int Lr, int D, long long U, long long Ucap, long long Fc, long long Uc, float scale,
                                         float p, const unsigned long long* seeds, void* st) {
-    (void)flags;
     QaRagArena a = qa_rag_layout(arena, N, NA, Lqa, D, Ucap, Fc);
     QaRagTmp t = qa_rag_tmp(tmp, N, NA, Li, Lqa, Lr, D, Ucap, Uc);
     if (arena_bytes < a.bytes || tmp_bytes < t.bytes) return STAGE_ERR_WORKSPACE;
@@ -754,9 +769,14 @@ extern "C" int stage_grp_qa_ctx_rag_bwd(const float* d_mixed, const float* dS_ex
     const long long Crows = (long long)N * NA * Lqa, Qrows = Uc;
     // weight / bias gradient of the Linear (contracts over the saved normalised concat), then its input gradient fused with the
     // LayerNorm backward: da accumulated over the live frames, db written over the attention output it came from
-    TRY(lin_bwd(d_mixed, a.z, mixed, a.mask, 1, 1, P[2], t.wt, nullptr, G[2], G[3], U, D, 3 * D, t.ws, t.wsb, st));
-    TRY(stage_cat3_dx_ln_bwd_rag(d_mixed, a.mask, P[2], qa, a.A, a.mean, a.rstd, P[0], d_qa, a.A, G[0], G[1], T[1], T[5], U, Fc, D, N * NA, Li,
-                                 Lqa, p, seeds[2], t.ws, stage_cat3_dx_ln_bwd_rag_ws_bytes(N * NA, Li, Lqa), st));
+    if (flags[0] == 2) {
+        TRY(stage_cat3_bwd_dw_rag(d_mixed, a.mask, P[2], qa, a.A, a.mean, a.rstd, P[0], P[1], d_qa, a.A, G[0], G[1], G[2], G[3], T[1], T[5], U, Fc,
+                                  D, N * NA, Li, Lqa, p, seeds[2], t.ws, stage_cat3_bwd_dw_rag_ws_bytes(N * NA, Lqa), st));
+    } else {
+        TRY(lin_bwd(d_mixed, a.z, mixed, a.mask, 1, 1, P[2], t.wt, nullptr, G[2], G[3], U, D, 3 * D, t.ws, t.wsb, st));
+        TRY(stage_cat3_dx_ln_bwd_rag(d_mixed, a.mask, P[2], qa, a.A, a.mean, a.rstd, P[0], d_qa, a.A, G[0], G[1], T[1], T[5], U, Fc, D, N * NA,
+                                     Li, Lqa, p, seeds[2], t.ws, stage_cat3_dx_ln_bwd_rag_ws_bytes(N * NA, Li, Lqa), st));
+    }
     TRY(stage_rag_zero_dump(a.A, T[0], N, NA, Li, Lqa, D, st));
     TRY(stage_l2norm_fwd(ctx, t.Qn, nullptr, Qrows, D, EPS_L2, p, seeds[1], st));
     TRY(stage_str_attn_bwd_fused_fc(a.A, dS_ext, a.Cn, ctx, t.Qn, S_norm, ctx_mask, d_ctx, t.dQn, t.dCn, T[0], T[4], N, NA, Li, Lqa, Lr, D, scale,
