@@ -76,6 +76,7 @@ def fwd_fused():
 fwd_unfused(); fwd_fused(); torch.cuda.synchronize()
 print("forward: max|y - y'| %.3e of %.3e, z equal up to %.3e" % (float((y - y2).abs().max()), float(y.abs().max()), float((z - z2).abs().max())))
 timeit(fwd_unfused, "LayerNorm forward + GEMM"); timeit(fwd_fused, "fused forward")
+os.environ.setdefault("STAGE_CAT3_DW", "1")
 # ---- round 6: the backward with the Linear's gradients inside (csrc/cat3_bwd_dw.hip) and the forward without the z store ----
 if lib.stage_cat3_bwd_dw_supported(U, D, rep, inner):
     da3 = torch.empty_like(a); db3 = torch.empty_like(b); dg3 = torch.empty(3 * D, device=dev); dbt3 = torch.empty(3 * D, device=dev)

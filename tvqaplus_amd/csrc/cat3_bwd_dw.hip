@@ -6,28 +6,29 @@
 //
 // One persistent workgroup of EIGHT waves per compute unit, two per SIMD with different jobs (the 128 x 384 weight gradient is 192
 // accumulator registers per lane at four waves: next to the LayerNorm epilogue's own registers it fits no single wave, not even with
-// the whole 512-entry file -- so the two halves of the register file get one job each):
-//   * E waves 0..3 (cf_bwd_kernel's structure; tile = four passes of 8 rows, wave w owns columns 32 w .. 32 w + 31 of each third):
-//     stage the dy tile (ReLU gate, one power-of-two scale per row, two fp16 planes, row-major in LDS), dX product
-//     (v_mfma_f32_32x32x16_f16, two-way fp16 split / three products; weight fragments from an L2-resident image), LayerNorm backward
-//     on the accumulators, row statistics exchanged through LDS, db / da out; and they REBUILD z (a, b, saved row statistics, gamma /
-//     beta, the dropout stream) and leave it in LDS as B-operand fragments: z in the C/D layout IS the B operand of a contraction over
-//     the tile's rows under the k-slot permutation (k-step s, lane half h, element e) <-> row 16 s + 8 (e >> 2) + (e & 3) + 4 h.
-//   * W waves 4..7: the dW product of the PREVIOUS tile while the E waves work on the current one -- A operand dy^T out of the
-//     row-major planes through ds_read_b64_tr_b16 (same permutation), B operand from the z fragments of "their" E wave -- into
-//     accumulators that live for the whole launch; and the memory side: every byte a tile needs (dy rows, mask words, b rows, mean,
-//     rstd) is brought into LDS by buffer_load ... lds (no registers, bounds-checked) one tile ahead.
+// the whole 512-entry file -- so the two halves of the register file get one job each, and the vector work is split between them: a
+// lone wave issues at most every other cycle of its SIMD):
+//   * E waves 0..3 (tile = four passes of 8 rows as in cf_bwd_kernel, wave w owns columns 32 w .. 32 w + 31 of each third): dX product
+//     (v_mfma_f32_32x32x16_f16, two-way fp16 split / three products; A = the gated dy tile as row-major fp16 planes in LDS, B = weight
+//     fragments from an L2-resident image), LayerNorm backward on the accumulators (row statistics exchanged through LDS), db / da out.
+//   * W waves 4..7: everything else.  (1) the memory side: every byte a tile needs (dy rows, mask words, rows of b (and a), mean, rstd)
+//     comes into LDS by buffer_load ... lds (no registers, bounds-checked) two tiles ahead; (2) staging of the next tile: ReLU gate, one
+//     power-of-two scale per row, two fp16 planes, row-major; the dropout hashes of the next tile (handed to the E waves through LDS,
+//     kept in registers for (3)); the bias gradient; (3) the dW product of the PREVIOUS tile: z is rebuilt from a, b, the saved row
+//     statistics, gamma / beta and the dropout bits directly in the B-operand layout of a contraction over the tile's rows (lane = column,
+//     k-slot (k-step s, lane half h, element e) <-> row 16 s + 8 (e >> 2) + (e & 3) + 4 h); the A operand (dy^T) comes out of the
+//     row-major planes through ds_read_b64_tr_b16 under the same permutation; accumulators live for the whole launch.
 //   The dy planes carry one scale per ROW (fp16 range), which a contraction over rows cannot factor out: 2^(E - up_row) goes into z,
 //   E = the smallest scale field the workgroup has seen so far; when a tile lowers it the W waves rescale their accumulators (a
 //   wave-uniform branch); the final store divides 2^(E - 127) and z's own column scale out again.
-// Barriers per tile (all eight waves): B1 planes + row scales ready | B2 row statistics ready, dW of the previous tile done | B3 z
-// fragments + epilogue reads done, the next tile's LDS-DMA landed.
+// Two barriers per tile (all eight waves): Ba(i) planes / row scales / dropout bits of tile i ready | Bb(i) row statistics of tile i
+// ready, dW of tile i - 1 done (its planes are free), the LDS-DMA of tile i + 1 landed.
 #include "common.h"
 #include "../../include/stage_hip.h"
 
 #ifndef CW_ABL
-#define CW_ABL 0      // developer ablation bits (timing only, results wrong): 1 no dX MFMAs, 2 no dW MFMAs, 4 no dropout hashes
-#endif
+#define CW_ABL 0      // developer ablation bits (timing only, results wrong): 1 no dX MFMAs, 2 no dW MFMAs, 4 no dropout hashes, 8 no
+#endif                // LayerNorm epilogue (both halves), 16 no staging arithmetic, 32 no z rebuild
 namespace {
 constexpr int CW_D = 128, CW_K3 = 384;
 constexpr int CW_KS = CW_D / 16;                      // k-steps of the dX product
@@ -36,18 +37,18 @@ constexpr int CW_PITCH = 320;                         // bytes per row of a row-
                                                       // 16-lane groups a ds_read_b64_tr_b16 serves together sit on 32 different bank pairs
 constexpr int CW_RP = 2 * 32 * CW_PITCH;              // row-major planes of one tile [plane][row][pitch]
 constexpr int CW_TILE = 32 * CW_D * 4;                // one 32-row tile of a (rows, D) fp32 tensor
-constexpr int CW_ZW = 3 * 2 * 2 * 4 * 64 * 4;         // z fragments of one E wave [third][k-step][plane][component][lane] dwords
 constexpr int CW_OFF_RP = 0;                          // [2 buffers] dy planes
-constexpr int CW_OFF_ZB = CW_OFF_RP + 2 * CW_RP;      // [4 E waves] z fragments
-constexpr int CW_OFF_RAW = CW_OFF_ZB + 4 * CW_ZW;     // [32][128] float   the next tile's dy rows (LDS-DMA)
-constexpr int CW_OFF_BT = CW_OFF_RAW + CW_TILE;       // [2 buffers][32][128] float  the tile's rows of b
-constexpr int CW_OFF_AT = CW_OFF_BT + 2 * CW_TILE;    // [40][128] float   the group's block of the broadcast operand
-constexpr int CW_OFF_MK = CW_OFF_AT + 40 * CW_D * 4;  // [4 words][64] u32 the next tile's ReLU mask words
-constexpr int CW_OFF_MS = CW_OFF_MK + 4 * 64 * 4;     // [2 buffers][mean | rstd][64] float
-constexpr int CW_OFF_UP = CW_OFF_MS + 2 * 2 * 64 * 4; // [32] int          row scale exponent fields
-constexpr int CW_OFF_TE = CW_OFF_UP + 32 * 4;         // [2] int tile minimum of the scale fields | [2] int running minimum handed to the W waves
-constexpr int CW_OFF_ST = CW_OFF_TE + 16;             // [4 waves][32][2] float  partial row statistics
-constexpr int CW_LDS = CW_OFF_ST + 4 * 32 * 8;
+constexpr int CW_OFF_RAW = CW_OFF_RP + 2 * CW_RP;     // [32][128] float   dy rows in flight (LDS-DMA; W wave v: rows 8 v .. 8 v + 7)
+constexpr int CW_OFF_BT = CW_OFF_RAW + CW_TILE;       // [3 buffers][32][128] float  rows of b
+constexpr int CW_OFF_AT = CW_OFF_BT + 3 * CW_TILE;    // [3 buffers][32][128] float  rows of a (flat) / [40][128] the group's block (broadcast)
+constexpr int CW_OFF_MK = CW_OFF_AT + 3 * CW_TILE;    // [4 W waves][4 words][8 rows] u32  ReLU mask words in flight
+constexpr int CW_OFF_MS = CW_OFF_MK + 4 * 32 * 4;     // [3 buffers][mean | rstd][32] float
+constexpr int CW_OFF_UP = CW_OFF_MS + 3 * 64 * 4;     // [3 buffers][32] int         row scale exponent fields
+constexpr int CW_OFF_KB = CW_OFF_UP + 3 * 32 * 4;     // [4 E waves][2][64] u32      dropout bits of the tile (three nibbles per pass)
+constexpr int CW_OFF_TE = CW_OFF_KB + 4 * 2 * 64 * 4; // [3] int (+ pad)             tile minimum of the scale fields
+constexpr int CW_OFF_ST = CW_OFF_TE + 16;             // [4 E waves][32][2] float    partial row statistics
+constexpr int CW_OFF_GZ = CW_OFF_ST + 4 * 32 * 8;     // [2][384] float              z's column scale folded into gamma / beta (W waves)
+constexpr int CW_LDS = CW_OFF_GZ + 2 * CW_K3 * 4;
 static_assert(CW_LDS <= 160 * 1024, "LDS budget");
 #define CW_WTAB_GSEG(W) ((((W) + 1) + 3) & ~3)
 #define CW_WTAB_SEG(W, G) (CW_WTAB_GSEG(W) + ((2 * (G) + 3) & ~3))
@@ -109,10 +110,6 @@ __device__ __forceinline__ int cw_zfield(float g, float b, float inv_keep) {
     const int ebb = ((int)(__float_as_uint(bound) >> 23) & 0xff) + 1;
     return max(1, min(268 - ebb, 254));
 }
-// workgroup barrier that does NOT drain the vector-memory counter (an LDS-DMA in flight stays in flight): LDS traffic only
-__device__ __forceinline__ void cw_barrier_lds() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 
 // MODE 0: rep == 1, tiles of 32 consecutive rows, grid-stride.  MODE 1: rep > 1, inner <= 32: one tile per frame.  MODE 2: rep > 1,
 // inner == 40: per four frames four main tiles + one rest tile.  MODE 3: ragged token rows with the balanced work table `wtab`
@@ -147,9 +144,20 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
     const __amdgpu_buffer_rsrc_t rs_db = __builtin_amdgcn_make_buffer_rsrc((void*)db, 0, (int)((RAG ? b_rows : M) * CW_D * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_da = __builtin_amdgcn_make_buffer_rsrc((void*)da, 0, REP ? 0 : (int)(M * CW_D * 4), 0x00020000);
     int* const row_up = reinterpret_cast<int*>(smem + CW_OFF_UP);
-    int* const tileE = reinterpret_cast<int*>(smem + CW_OFF_TE);          // [0..1] tile minimum, [2..3] running minimum for the W waves
+    int* const tmin = reinterpret_cast<int*>(smem + CW_OFF_TE);
     float* const st_part = reinterpret_cast<float*>(smem + CW_OFF_ST);
-    if (tid < 2) tileE[tid] = 254;
+    if (tid < 3) tmin[tid] = 254;
+    __syncthreads();
+    if (is_w) {                                           // z's column scale folded into gamma / beta: read back per use (registers are for accW)
+        float* gzl = reinterpret_cast<float*>(smem + CW_OFF_GZ);
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const float g_ = gamma[t * CW_D + c], b_ = beta[t * CW_D + c];
+            const float zc = __uint_as_float((unsigned)cw_zfield(g_, b_, inv_keep) << 23) * inv_keep;
+            gzl[t * CW_D + c] = g_ * zc;
+            gzl[K3 + t * CW_D + c] = b_ * zc;
+        }
+    }
     __syncthreads();
 
     // ---- work of this workgroup (every wave walks the same tiles: the control flow below is uniform over the workgroup) ----
@@ -253,9 +261,10 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
         return true;
     };
 
+
     if (is_w) {
         // =============================================================================================================
-        // W waves: LDS-DMA of the next tile, dW product of the previous one
+        // W waves: LDS-DMA two tiles ahead, staging + dropout hashes of the next tile, z and the dW product of the previous one
         // =============================================================================================================
         f32x16 accW[4][3];                                // dW rows 32 nt + (C/D row), column 128 t + c
 #pragma unroll
@@ -264,10 +273,12 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
             for (int t = 0; t < 3; t++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) accW[nt][t][r] = 0.f;
-        int E_acc = 254;                                  // scale field the accumulators are held at (uniform)
-        // LDS-DMA of a tile: wave wv brings pass wv (8 rows) of dy and b, mask word wv of the 32 rows, wave 0 / 1 the means / rstds.
-        // Rows past the end of a tensor read zeros (buffer bounds check); rows past the end of their pass are masked by the E waves.
-        auto dma_tile = [&](const int (&pb)[4], const int (&pbB)[4], int nbuf) {
+        int E_acc = 254;                                  // scale field the accumulators are held at = running minimum (uniform)
+        float dbs[4] = {0.f, 0.f, 0.f, 0.f};
+        unsigned kbA0 = 0xffffffu, kbA1 = 0xffffffu, kbN0 = 0xffffffu, kbN1 = 0xffffffu;   // dropout bits: tile whose dW is pending / newest
+        // LDS-DMA of a tile: wave wv brings pass wv (8 rows) of dy, b (and a), its 32 mask words; wave 0 / 1 the means / rstds.
+        // Rows past the end of a tensor read zeros (buffer bounds check); rows past the end of their pass are masked on use.
+        auto dma_tile = [&](const int (&pb)[4], const int (&pbB)[4], int nb3) {
             const int pbw = wv == 0 ? pb[0] : (wv == 1 ? pb[1] : (wv == 2 ? pb[2] : pb[3]));
             const int pbBw = wv == 0 ? pbB[0] : (wv == 1 ? pbB[1] : (wv == 2 ? pbB[2] : pbB[3]));
             const int vo = (h * CW_D + 4 * l31) * 4;      // row lane >> 5 of a pair of rows, float4 lane & 31
@@ -275,25 +286,87 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
             for (int k = 0; k < 4; k++) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (cw_lds_ptr)(smem + CW_OFF_RAW + (8 * wv + 2 * k) * (CW_D * 4)), 16, vo,
                                                          (pbw + 2 * k) * (CW_D * 4), 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (cw_lds_ptr)(smem + CW_OFF_BT + nbuf * CW_TILE + (8 * wv + 2 * k) * (CW_D * 4)), 16, vo,
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (cw_lds_ptr)(smem + CW_OFF_BT + nb3 * CW_TILE + (8 * wv + 2 * k) * (CW_D * 4)), 16, vo,
                                                          (pbBw + 2 * k) * (CW_D * 4), 0, 0);
+                if (!REP)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (cw_lds_ptr)(smem + CW_OFF_AT + nb3 * CW_TILE + (8 * wv + 2 * k) * (CW_D * 4)), 16,
+                                                             vo, (pbBw + 2 * k) * (CW_D * 4), 0, 0);
             }
-            // per-row words: lane < 32 = tile row `lane` = row (lane & 7) of pass lane >> 3; lanes 32..63 fetch nothing (out of range)
-            const int pr = l31 >> 3;
-            const int prow = (pr == 0 ? pb[0] : (pr == 1 ? pb[1] : (pr == 2 ? pb[2] : pb[3]))) + (l31 & 7);
-            const int vrow = h ? 0x7ffffff0 : prow * 4;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_mk, (cw_lds_ptr)(smem + CW_OFF_MK + wv * 256), 4, h ? 0x7ffffff0 : (int)(((long)wv * M + prow) * 4),
-                                                     0, 0, 0);
-            if (wv == 0)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_mean, (cw_lds_ptr)(smem + CW_OFF_MS + nbuf * 512), 4, vrow, 0, 0, 0);
-            if (wv == 1)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_rstd, (cw_lds_ptr)(smem + CW_OFF_MS + nbuf * 512 + 256), 4, vrow, 0, 0, 0);
+            // the 4-byte words: 32 per instruction, by the lower lane half only (an inactive lane writes nothing; an active lane whose
+            // offset is out of range would write a ZERO to its slot -- the next array)
+            if (h == 0) {
+                // its own mask words: word lane >> 3 of row lane & 7
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_mk, (cw_lds_ptr)(smem + CW_OFF_MK + wv * 128), 4,
+                                                         (int)(((long)(l31 >> 3) * M + (l31 & 7)) * 4), pbw * 4, 0, 0);
+                // per-row statistics of the 32 rows: tile row `lane` = row (lane & 7) of pass lane >> 3
+                const int pr = l31 >> 3;
+                const int prow = (pr == 0 ? pb[0] : (pr == 1 ? pb[1] : (pr == 2 ? pb[2] : pb[3]))) + (l31 & 7);
+                if (wv == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_mean, (cw_lds_ptr)(smem + CW_OFF_MS + nb3 * 256), 4, prow * 4, 0, 0, 0);
+                if (wv == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_rstd, (cw_lds_ptr)(smem + CW_OFF_MS + nb3 * 256 + 128), 4, prow * 4, 0, 0, 0);
+            }
         };
-        // dW product of one tile: planes `Rp`, z fragments of E wave wv, scale field `Et` the E waves built z with
+        // staging of a tile (this wave: its pass): gate by the ReLU bits, one power-of-two scale per row, two fp16 planes, row-major; the
+        // bias gradient; the tile's smallest scale field
+        auto stage_tile = [&](const int (&nv)[4], int pbuf, int nb3) {
+            const int nvw = wv == 0 ? nv[0] : (wv == 1 ? nv[1] : (wv == 2 ? nv[2] : nv[3]));
+            unsigned char* const Rp = smem + CW_OFF_RP + pbuf * CW_RP;
+            const float* raw = reinterpret_cast<const float*>(smem + CW_OFF_RAW) + (8 * wv + h) * CW_D + 4 * l31;
+            const unsigned* mk = reinterpret_cast<const unsigned*>(smem + CW_OFF_MK) + wv * 32 + (l31 >> 3) * 8 + h;
+#pragma unroll 1                                           // (rolled, like the hashes below: these waves have the time, not the registers -- an
+            for (int k = 0; k < ((CW_ABL & 16) ? 0 : 4); k++) {   //  unrolled body makes the allocator park all of accW in scratch around it)
+                const int rl = 8 * wv + 2 * k + h;
+                const bool ok = 2 * k + h < nvw;
+                const unsigned wbits = mk[2 * k] >> (4 * (l31 & 7));      // the bits of this lane's 4 columns
+                float4 v = *reinterpret_cast<const float4*>(raw + 2 * k * CW_D);
+                v.x = (ok && (wbits & 1u)) ? v.x : 0.f;
+                v.y = (ok && (wbits & 2u)) ? v.y : 0.f;
+                v.z = (ok && (wbits & 4u)) ? v.z : 0.f;
+                v.w = (ok && (wbits & 8u)) ? v.w : 0.f;
+                dbs[0] += v.x; dbs[1] += v.y; dbs[2] += v.z; dbs[3] += v.w;
+                float m = h_amax3(h_amax3(v.x, v.y, v.z), v.w, v.w);
+                m = group_max(m, 32);
+                const int up = h_up_field((int)(__float_as_uint(m) >> 23) & 0xff);
+                const float sc = __uint_as_float((unsigned)up << 23);
+                unsigned h01, l01, h23, l23;
+                h_split2(v.x, v.y, sc, h01, l01);
+                h_split2(v.z, v.w, sc, h23, l23);
+                *reinterpret_cast<uint2*>(Rp + rl * CW_PITCH + 8 * l31) = make_uint2(h01, h23);
+                *reinterpret_cast<uint2*>(Rp + 32 * CW_PITCH + rl * CW_PITCH + 8 * l31) = make_uint2(l01, l23);
+                if (l31 == 0) {
+                    row_up[nb3 * 32 + rl] = up;
+                    atomicMin(&tmin[nb3], up);
+                }
+            }
+        };
+        // dropout stream of stage_cat3_layernorm_fwd: element row * 3D + t * D + c, one hash per 4 consecutive columns = the 4 lanes of
+        // a quad: quad lane q hashes for the C/D registers 4 j + q (row pb[j] + q + 4 h); three keep nibbles per pass j, two passes per word
+        auto hash_tile = [&](const int (&pb)[4]) {
+            unsigned w0 = 0u, w1 = 0u;
+            if (DROP && !(CW_ABL & 4)) {
+                const unsigned drop_lane = (unsigned)(((l31 & 3) + h4) * (K3 / 4) + (c >> 2));
+#pragma unroll 1
+                for (int jt = 0; jt < 12; jt++) {         // pass j = jt / 3, third t = jt % 3
+                    const int j = jt / 3, t = jt - 3 * j;
+                    const int pbj = j == 0 ? pb[0] : (j == 1 ? pb[1] : (j == 2 ? pb[2] : pb[3]));
+                    const uint64_t base = (uint64_t)pbj * (uint64_t)(K3 / 4) + (uint64_t)drop_lane + (uint64_t)(t * (CW_D / 4));
+                    const unsigned bits = drop4_bits(seed, base, th) << (12 * (j & 1) + 4 * t);
+                    if (j < 2) w0 |= bits; else w1 |= bits;
+                }
+            } else {
+                w0 = w1 = 0xffffffu;
+            }
+            kbN0 = w0;
+            kbN1 = w1;
+            unsigned* kbp = reinterpret_cast<unsigned*>(smem + CW_OFF_KB) + wv * 128 + lane;
+            kbp[0] = kbN0;
+            kbp[64] = kbN1;
+        };
+        // z and the dW product of one tile: planes `pbuf`, operand buffers `nb3`, dropout bits kbA, pass lengths nvp
         const int G = lane >> 4, i16 = lane & 15;
         const int tr_off = (4 * (G >> 1) + (i16 >> 2)) * CW_PITCH + (16 * (G & 1) + 4 * (i16 & 3)) * 2;
-        const unsigned* const zb = reinterpret_cast<const unsigned*>(smem + CW_OFF_ZB + wv * CW_ZW) + lane;
-        auto dw_tile = [&](int pbuf, int Et) {
+        const int q = l31 & 3;
+        auto dw_tile = [&](int pbuf, int nb3, const int (&nvp)[4], bool restp) {
+            const int Et = __builtin_amdgcn_readfirstlane(tmin[nb3]);
             if (Et < E_acc) {                             // (uniform, rare) a row larger than anything so far: bring the accumulators along
                 const int d = Et - E_acc;
 #pragma unroll
@@ -305,14 +378,53 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
                 E_acc = Et;
             }
             const unsigned char* const trow = smem + CW_OFF_RP + pbuf * CW_RP + tr_off;
+            const float* const bt_h = reinterpret_cast<const float*>(smem + CW_OFF_BT + nb3 * CW_TILE) + h4 * CW_D + c;
+            const float* const at_h = reinterpret_cast<const float*>(smem + CW_OFF_AT + (REP ? 0 : nb3 * CW_TILE)) + h4 * CW_D + c;
+            const int* const up_h = row_up + nb3 * 32 + h4;
+            const float* const mu_h = reinterpret_cast<const float*>(smem + CW_OFF_MS + nb3 * 256) + h4;
+            const float* const gz_c = reinterpret_cast<const float*>(smem + CW_OFF_GZ) + c;
 #pragma unroll
             for (int s = 0; s < ((CW_ABL & 2) ? 0 : 2); s++) {
+                // z of the 8 rows of k-step s in this lane's column of each third (element e = C/D register r = 8 s + e), split pair by
+                // pair into the B operands
+                uint4 zh[3], zl[3];
+                float zprev[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int r = 8 * s + e, rl = 8 * (r >> 2) + (r & 3);       // + 4 h
+                    const bool valid = h4 < nvp[r >> 2] - (r & 3);
+                    int upv = up_h[rl];
+                    asm volatile("" : "+v"(upv));
+                    const float f = valid ? __builtin_ldexpf(1.0f, E_acc - upv) : 0.f;
+                    const float mu = mu_h[rl], rsv = mu_h[32 + rl];
+                    const float rs = valid ? rsv : 0.f;
+                    const float bvr = bt_h[rl * CW_D];
+                    const float avr = at_h[((REP && MODE >= 2 && restp) ? 32 + (r & 3) : rl) * CW_D];
+                    unsigned bw = 0xfffu;
+                    if (DROP) bw = cw_quad_bcast(((r >> 3) ? kbA1 : kbA0) >> (12 * ((r >> 2) & 1)), r & 3) >> q;
+#pragma unroll
+                    for (int t = 0; t < 3; t++) {
+                        const float x = t == 0 ? avr : (t == 1 ? bvr : avr * bvr);
+                        const float xh = (x - mu) * rs;
+                        const float zv = (!(CW_ABL & 32) && ((bw >> (4 * t)) & 1u)) ? (xh * gz_c[t * CW_D] + gz_c[K3 + t * CW_D]) * f : 0.f;
+                        if (e & 1) {
+                            unsigned hi, lo;
+                            h_split2(zprev[t], zv, 1.0f, hi, lo);
+                            if ((e >> 1) == 0) { zh[t].x = hi; zl[t].x = lo; }
+                            else if ((e >> 1) == 1) { zh[t].y = hi; zl[t].y = lo; }
+                            else if ((e >> 1) == 2) { zh[t].z = hi; zl[t].z = lo; }
+                            else { zh[t].w = hi; zl[t].w = lo; }
+                        } else zprev[t] = zv;
+                    }
+                    if (e & 1) __builtin_amdgcn_sched_barrier(0);     // a pair of rows at a time: the accumulators leave few registers
+                }
                 sf16x8 vzh[3], vzl[3];
 #pragma unroll
                 for (int t = 0; t < 3; t++) {
-                    const unsigned* zp = zb + ((t * 2 + s) * 2) * 256;
-                    vzh[t] = __builtin_bit_cast(sf16x8, make_uint4(zp[0], zp[64], zp[128], zp[192]));
-                    vzl[t] = __builtin_bit_cast(sf16x8, make_uint4(zp[256], zp[320], zp[384], zp[448]));
+                    h_operands_ready(zh[t].x, zh[t].y, zh[t].z, zh[t].w);
+                    h_operands_ready(zl[t].x, zl[t].y, zl[t].z, zl[t].w);
+                    vzh[t] = __builtin_bit_cast(sf16x8, zh[t]);
+                    vzl[t] = __builtin_bit_cast(sf16x8, zl[t]);
                 }
 #pragma unroll
                 for (int nt = 0; nt < 4; nt++) {
@@ -332,36 +444,52 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
                 }
             }
         };
-        bool have_prev = false;
-        int buf = 0;
+        int tc = 0;                                       // tiles so far: tile tc uses planes tc & 1, operand buffers tc % 3
         while (next_segment()) {
             if (REP) { __syncthreads(); __syncthreads(); }    // (the E waves copy the group's block of `a` between these two)
-            if (n_tiles > 0) {                            // the first tile of the segment: nothing was requested ahead
-                int pb[4], pbB[4], nv[4];
-                bool rest;
-                geom(0, pb, pbB, nv, rest);
-                dma_tile(pb, pbB, buf);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();                          // S: the first tile's rows are in LDS
+            if (n_tiles <= 0) continue;
+            int pb[4], pbB[4], nv[4], nvp[4] = {0, 0, 0, 0};
+            bool rest, restp = false;
+            // prologue: tile 0 of the segment is brought in and staged, tile 1 requested
+            geom(0, pb, pbB, nv, rest);
+            dma_tile(pb, pbB, tc % 3);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                              // P1 (its mask words / rows are this wave's own; b / a / statistics: for the E waves)
+            stage_tile(nv, tc & 1, tc % 3);
+            hash_tile(pb);
+            if (n_tiles > 1) {
+                int pbn[4], pbBn[4], nvn[4];
+                bool restn;
+                geom(1, pbn, pbBn, nvn, restn);
+                dma_tile(pbn, pbBn, (tc + 1) % 3);
             }
-            for (long it = 0; it < n_tiles; it++) {
-                cw_barrier_lds();                         // B1
-                if (have_prev) dw_tile(buf ^ 1, tileE[2 + (buf ^ 1)]);
-                // (the DMA behind the product: the compiler orders every LDS read behind a pending LDS-DMA with vmcnt(0))
+            // (ONE call site of the product inside the loop -- with a second one the allocator parks all of accW in scratch between
+            // them: the last tile of a segment is drained by an extra trip that runs the product only)
+            for (long it = 0;; it++) {
+                if (it < n_tiles) __syncthreads();        // Ba(it)
+                if (it > 0) dw_tile((tc - 1) & 1, (tc + 2) % 3, nvp, restp);       // tile tc - 1
+                if (it >= n_tiles) break;
+                if (tid == 256) tmin[(tc + 1) % 3] = 254; // (the word of tile tc + 1 = of tile tc - 2: read in the previous slot, written behind Bb)
+                kbA0 = kbN0; kbA1 = kbN1;                 // (the bits of tile tc: pending from here on)
+#pragma unroll
+                for (int p2 = 0; p2 < 4; p2++) nvp[p2] = nv[p2];
+                restp = rest;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the rows of tile tc + 1 have landed
+                __syncthreads();                          // Bb(it)
                 if (it + 1 < n_tiles) {
-                    int pbn[4], pbBn[4], nvn[4];
-                    bool restn;
-                    geom(it + 1, pbn, pbBn, nvn, restn);
-                    dma_tile(pbn, pbBn, buf ^ 1);
+                    geom(it + 1, pb, pbB, nv, rest);
+                    stage_tile(nv, (tc + 1) & 1, (tc + 1) % 3);
+                    hash_tile(pb);
+                    if (it + 2 < n_tiles) {
+                        int pbn[4], pbBn[4], nvn[4];
+                        bool restn;
+                        geom(it + 2, pbn, pbBn, nvn, restn);
+                        dma_tile(pbn, pbBn, (tc + 2) % 3);
+                    }
                 }
-                cw_barrier_lds();                         // B2
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();                          // B3: the next tile's rows have landed
-                have_prev = true;
-                buf ^= 1;
+                tc++;
             }
         }
-        if (have_prev) dw_tile(buf ^ 1, tileE[2 + (buf ^ 1)]);
         // weight gradient in true units: the accumulators hold dW * 2^(zf_t - 127) * 2^(E_acc - 127)
         float* pw = partW + (size_t)blockIdx.x * CW_D * K3;
 #pragma unroll
@@ -373,33 +501,34 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
                 for (int r = 0; r < 16; r++)
                     pw[(size_t)(32 * nt + 8 * (r >> 2) + (r & 3) + h4) * K3 + t * CW_D + c] = __builtin_ldexpf(accW[nt][t][r], e);
         }
-        __syncthreads();                                  // (the E waves' final reductions: two barriers)
+        // bias gradient of the Linear: the 8 staging rows (4 waves x 2 lane halves) of a column meet in LDS
+        __syncthreads();                                  // (every wave is past its last tile: the planes are reduction scratch)
+        float* red = reinterpret_cast<float*>(smem + CW_OFF_RP);          // [8][128]
+        *reinterpret_cast<float4*>(red + (2 * wv + h) * CW_D + 4 * l31) = make_float4(dbs[0], dbs[1], dbs[2], dbs[3]);
         __syncthreads();
+        if (tid - 256 < CW_D) {
+            float sm = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; r++) sm += red[r * CW_D + (tid - 256)];
+            partB[(size_t)blockIdx.x * CW_D + (tid - 256)] = sm;
+        }
         return;
     }
 
     // =================================================================================================================
-    // E waves: staging, dX product, LayerNorm backward, z fragments
+    // E waves: dX product, LayerNorm backward
     // =================================================================================================================
     const int w_up = w_up_p[0];
     const float invK = 1.0f / (float)K3;
-    float gm[3], bt[3], gz[3], bz[3], ag[3] = {0.f, 0.f, 0.f}, ab[3] = {0.f, 0.f, 0.f};
+    float gm[3], ag[3] = {0.f, 0.f, 0.f}, ab[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 3; t++) {
-        gm[t] = gamma[t * CW_D + c];
-        bt[t] = beta[t * CW_D + c];
-        const float zc = __uint_as_float((unsigned)cw_zfield(gm[t], bt[t], inv_keep) << 23) * inv_keep;
-        gz[t] = gm[t] * zc;
-        bz[t] = bt[t] * zc;
-    }
+    for (int t = 0; t < 3; t++) gm[t] = gamma[t * CW_D + c];
     const int vo_row = (h4 * CW_D + c) * 4;               // byte offset of (row 4 h, column c) in a (rows, D) tensor
-    const int sj = tid >> 5, sl = tid & 31;               // staging role: row tid >> 5 of every pass, float4 index tid & 31
     // gradient of the broadcast operand: slot r of a main tile = position 8 (r >> 2) + (r & 3) + 4 h; the rest tile adds its registers
     // r, r + 4, r + 8, r + 12 (four frames) into slot r & 3 = position 32 + (r & 3) + 4 h
-    float dacc[16], dacc_rest[4] = {0.f, 0.f, 0.f, 0.f}, dbs[4] = {0.f, 0.f, 0.f, 0.f};
+    float dacc[16], dacc_rest[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 16; r++) dacc[r] = 0.f;
-    int E = 254;                                          // running minimum of the row scale fields (uniform)
     auto write_slab = [&](int slab) {                     // da slab [inner][D] of an item / segment
         float* dst = da + (size_t)slab * inner * CW_D;
 #pragma unroll
@@ -413,8 +542,7 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
                 if (32 + r + h4 < inner) dst[(32 + r + h4) * CW_D + c] = dacc_rest[r];
         }
     };
-    unsigned* const zw = reinterpret_cast<unsigned*>(smem + CW_OFF_ZB + wv * CW_ZW) + lane;
-    int buf = 0;
+    int tc = 0;
     while (next_segment()) {
         if (REP) {
             // the group's block of the broadcast operand -> LDS (behind a barrier: a slower wave may still read the previous one)
@@ -424,72 +552,22 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
             for (int e = tid; e < 40 * (CW_D / 4); e += 256) dst[e] = e < inner * (CW_D / 4) ? src[e] : f4zero();   // (slots past the last
             __syncthreads();                              //  position read zeros: their gradients are masked, not their values)
         }
-        if (n_tiles > 0) __syncthreads();                 // S: the first tile's rows are in LDS (W waves)
+        if (n_tiles <= 0) continue;
+        __syncthreads();                                  // P1
         for (long it = 0; it < n_tiles; it++) {
             int pb[4], pbB[4], nv[4];
             bool rest;
             geom(it, pb, pbB, nv, rest);
-            unsigned char* const Rp = smem + CW_OFF_RP + buf * CW_RP;
-            const float* const bt_b = reinterpret_cast<const float*>(smem + CW_OFF_BT + buf * CW_TILE);
-            const float* const ms_b = reinterpret_cast<const float*>(smem + CW_OFF_MS + buf * 512);
-            // ---- stage the dy tile: gate by the ReLU bits, one power-of-two scale per row, two fp16 planes, row-major ----
-            {
-                const float* raw = reinterpret_cast<const float*>(smem + CW_OFF_RAW);
-                const unsigned* mk = reinterpret_cast<const unsigned*>(smem + CW_OFF_MK);
-#pragma unroll
-                for (int pass = 0; pass < 4; pass++) {
-                    const int rl = 8 * pass + sj;
-                    const bool ok = sj < nv[pass];
-                    const unsigned wbits = mk[(sl >> 3) * 64 + rl] >> (4 * (sl & 7));      // the bits of this lane's 4 columns
-                    float4 v = *reinterpret_cast<const float4*>(raw + rl * CW_D + 4 * sl);
-                    v.x = (ok && (wbits & 1u)) ? v.x : 0.f;
-                    v.y = (ok && (wbits & 2u)) ? v.y : 0.f;
-                    v.z = (ok && (wbits & 4u)) ? v.z : 0.f;
-                    v.w = (ok && (wbits & 8u)) ? v.w : 0.f;
-                    dbs[0] += v.x; dbs[1] += v.y; dbs[2] += v.z; dbs[3] += v.w;
-                    float m = h_amax3(h_amax3(v.x, v.y, v.z), v.w, v.w);
-                    m = group_max(m, 32);
-                    const int up = h_up_field((int)(__float_as_uint(m) >> 23) & 0xff);
-                    const float sc = __uint_as_float((unsigned)up << 23);
-                    unsigned h01, l01, h23, l23;
-                    h_split2(v.x, v.y, sc, h01, l01);
-                    h_split2(v.z, v.w, sc, h23, l23);
-                    *reinterpret_cast<uint2*>(Rp + rl * CW_PITCH + 8 * sl) = make_uint2(h01, h23);
-                    *reinterpret_cast<uint2*>(Rp + 32 * CW_PITCH + rl * CW_PITCH + 8 * sl) = make_uint2(l01, l23);
-                    if (sl == 0) {
-                        row_up[rl] = up;
-                        atomicMin(&tileE[buf], up);
-                    }
-                }
-            }
-            __syncthreads();                              // B1: planes and row scales of the tile
-            // ---- the running scale of the dW contraction ----
-            {
-                const int Et = __builtin_amdgcn_readfirstlane(tileE[buf]);
-                E = min(E, Et);
-                if (tid == 0) {
-                    tileE[buf ^ 1] = 254;                 // (the next tile's word: its staging starts behind B3)
-                    tileE[2 + buf] = E;                   // what z of this tile is scaled with: the W waves rescale to it
-                }
-            }
-            float avf[REP ? 1 : 16];                      // flat `a`: one value per slot, requested ahead of the product, used in both
-            if (!REP) {                                   // halves of the epilogue
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    avf[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_a, vo_row, pbB[r >> 2] * (CW_D * 4) + (r & 3) * (CW_D * 4), 0));
-            }
-            // dropout stream of stage_cat3_layernorm_fwd: element row * 3D + t * D + c, one hash per 4 consecutive columns = the 4 lanes
-            // of a quad: quad lane q hashes for the registers 4 j + q (row pb[j] + q + 4 h); kbits[j] = the three thirds' keep nibbles
-            unsigned kbits[4] = {0u, 0u, 0u, 0u};
-            if (DROP && !(CW_ABL & 4)) {
-                const unsigned drop_lane = (unsigned)(((l31 & 3) + h4) * (K3 / 4) + (c >> 2));
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint64_t base = (uint64_t)pb[j] * (uint64_t)(K3 / 4) + (uint64_t)drop_lane;
-#pragma unroll
-                    for (int t = 0; t < 3; t++) kbits[j] |= drop4_bits(seed, base + (uint64_t)(t * (CW_D / 4)), th) << (4 * t);
-                    __builtin_amdgcn_sched_barrier(0);    // three hashes in flight, not twelve (64-bit temporaries)
-                }
+            const int nb3 = tc % 3;
+            const unsigned char* const Rp = smem + CW_OFF_RP + (tc & 1) * CW_RP;
+            const float* const bt_b = reinterpret_cast<const float*>(smem + CW_OFF_BT + nb3 * CW_TILE);
+            const float* const ms_b = reinterpret_cast<const float*>(smem + CW_OFF_MS + nb3 * 256);
+            __syncthreads();                              // Ba: planes, row scales, dropout bits of the tile
+            unsigned kb0 = 0xffffffu, kb1 = 0xffffffu;
+            if (DROP) {
+                const unsigned* kbp = reinterpret_cast<const unsigned*>(smem + CW_OFF_KB) + wv * 128 + lane;
+                kb0 = kbp[0];
+                kb1 = kbp[64];
             }
             // ---- dX product: acc[third] = dy tile (32 x 128) . W[:, columns 32 w .. 32 w + 31 of each third].  A operand lane (row l31,
             // h), k-step ks = 16 bytes at column 16 ks + 8 h of its row (a 4-way bank conflict on 16 reads per tile: the pitch serves the
@@ -531,16 +609,16 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
                 }
             }
             // ---- LayerNorm backward, first half: gradient of the LayerNorm output in true units, row statistics.  Slot r = tile row
-            // 8 (r >> 2) + (r & 3) + 4 h, column c of each third; a / b values from the LDS tiles (flat `a`: straight from memory) ----
+            // 8 (r >> 2) + (r & 3) + 4 h, column c of each third; a / b values from the LDS tiles ----
             const float* const bt_h = bt_b + h4 * CW_D + c;
-            const float* const at_h = reinterpret_cast<const float*>(smem + CW_OFF_AT) + h4 * CW_D + c;
-            const int* const up_h = row_up + h4;
+            const float* const at_h = reinterpret_cast<const float*>(smem + CW_OFF_AT + (REP ? 0 : nb3 * CW_TILE)) + h4 * CW_D + c;
+            const int* const up_h = row_up + nb3 * 32 + h4;
             const float* const mu_h = ms_b + h4;
             float* const stw_h = st_part + (wv * 32 + h4) * 2;
             const float* const sta_h = st_part + h4 * 2;
             const int q = l31 & 3;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
+            for (int r = 0; r < ((CW_ABL & 8) ? 0 : 16); r++) {
                 const int rl = 8 * (r >> 2) + (r & 3);    // + 4 h
                 const bool valid = h4 < nv[r >> 2] - (r & 3);
                 int upv = up_h[rl];
@@ -548,13 +626,13 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
                 float un = valid ? __builtin_ldexpf(1.0f, 254 - upv - w_up) : 0.f;
                 unsigned bw = 0xfffu;
                 if (DROP) {
-                    bw = cw_quad_bcast(kbits[r >> 2], r & 3) >> q;
+                    bw = cw_quad_bcast(((r >> 3) ? kb1 : kb0) >> (12 * ((r >> 2) & 1)), r & 3) >> q;
                     un *= inv_keep;
                 }
-                const float mu = mu_h[rl], rsv = mu_h[64 + rl];
+                const float mu = mu_h[rl], rsv = mu_h[32 + rl];
                 const float rs = valid ? rsv : 0.f;
                 const float bvr = bt_h[rl * CW_D];
-                const float avr = REP ? at_h[((MODE >= 2 && rest) ? 32 + (r & 3) : rl) * CW_D] : avf[REP ? 0 : r];
+                const float avr = at_h[((REP && MODE >= 2 && rest) ? 32 + (r & 3) : rl) * CW_D];
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int t = 0; t < 3; t++) {
@@ -573,12 +651,10 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
                 *reinterpret_cast<float2*>(stw_h + rl * 2) = make_float2(s1, s2);      // (all 32 lanes of the half: the same value)
                 if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four rows in flight at a time: bounded register pressure
             }
-            __syncthreads();                              // B2: the partial statistics of all four E waves
-            // ---- second half: dz, the gradients of a and b, and z itself (scaled for the row contraction), pair by pair into the
-            // fragments of the W waves: k-step s = r >> 3, element e = r & 7, component e >> 1 ----
-            float zprev[3] = {0.f, 0.f, 0.f};
+            __syncthreads();                              // Bb: the partial statistics of all four E waves
+            // ---- second half: dz and the gradients of a and b ----
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
+            for (int r = 0; r < ((CW_ABL & 8) ? 0 : 16); r++) {
                 const int rl = 8 * (r >> 2) + (r & 3);
                 const bool valid = h4 < nv[r >> 2] - (r & 3);
                 float s1 = 0.f, s2 = 0.f;
@@ -590,29 +666,16 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
                 }
                 s1 *= invK;
                 s2 *= invK;
-                const float mu = mu_h[rl], rsv = mu_h[64 + rl];
+                const float mu = mu_h[rl], rsv = mu_h[32 + rl];
                 const float rs = valid ? rsv : 0.f;
-                int upv = up_h[rl];
-                asm volatile("" : "+v"(upv));
-                const float f = valid ? __builtin_ldexpf(1.0f, E - upv) : 0.f;
                 const float bvr = bt_h[rl * CW_D];
-                const float avr = REP ? at_h[((MODE >= 2 && rest) ? 32 + (r & 3) : rl) * CW_D] : avf[REP ? 0 : r];
-                unsigned bw = 0xfffu;
-                if (DROP) bw = cw_quad_bcast(kbits[r >> 2], r & 3) >> q;
+                const float avr = at_h[((REP && MODE >= 2 && rest) ? 32 + (r & 3) : rl) * CW_D];
                 float dz[3];
 #pragma unroll
                 for (int t = 0; t < 3; t++) {
                     const float x = t == 0 ? avr : (t == 1 ? bvr : avr * bvr);
                     const float xh = (x - mu) * rs;
                     dz[t] = rs * (acc[t][r] * gm[t] - s1 - xh * s2);
-                    const float zv = ((bw >> (4 * t)) & 1u) ? (xh * gz[t] + bz[t]) * f : 0.f;
-                    if (r & 1) {
-                        unsigned hi, lo;
-                        h_split2(zprev[t], zv, 1.0f, hi, lo);
-                        unsigned* zp = zw + ((t * 2 + (r >> 3)) * 2) * 256 + ((r & 7) >> 1) * 64;
-                        zp[0] = hi;
-                        zp[256] = lo;
-                    } else zprev[t] = zv;
                 }
                 // z = [a, b, a*b]:  da = dz0 + dz2 * b ; db = dz1 + dz2 * a
                 const float da_v = dz[0] + dz[2] * bvr, db_v = dz[1] + dz[2] * avr;
@@ -624,8 +687,7 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
                 else dacc[r] += valid ? da_v : 0.f;
                 if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
-            __syncthreads();                              // B3: z fragments complete, the epilogue's LDS reads done
-            buf ^= 1;
+            tc++;
         }
         if (REP) {
             write_slab(sg);
@@ -635,8 +697,8 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
             for (int r = 0; r < 4; r++) dacc_rest[r] = 0.f;
         }
     }
-    // ---- what the E waves summed over their rows ----
-    // column partials of d gamma / d beta: the two lane halves hold different rows of the same columns
+    // ---- what the E waves summed over their rows: column partials of d gamma / d beta (the two lane halves hold different rows of
+    // the same columns) ----
     {
         float* prow = part + (size_t)blockIdx.x * 2 * K3;
 #pragma unroll
@@ -648,19 +710,8 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
             }
         }
     }
-    // bias gradient of the Linear: the 8 staging rows of a column meet in LDS (the statistics / tile regions are free now)
+    __syncthreads();                                      // (the W waves' bias-gradient reduction: two barriers)
     __syncthreads();
-    {
-        float* red = reinterpret_cast<float*>(smem + CW_OFF_BT);          // [8][128]
-        *reinterpret_cast<float4*>(red + sj * CW_D + 4 * sl) = make_float4(dbs[0], dbs[1], dbs[2], dbs[3]);
-        __syncthreads();
-        if (tid < CW_D) {
-            float s = 0.f;
-#pragma unroll
-            for (int r = 0; r < 8; r++) s += red[r * CW_D + tid];
-            partB[(size_t)blockIdx.x * CW_D + tid] = s;
-        }
-    }
 }
 
 inline size_t cw_align(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -687,8 +738,15 @@ void cw_chunks(long long groups, int rep, int mode, int* CH, int* fpc) {
     *fpc = f;
     *CH = (rep + f - 1) / f;
 }
-bool cw_enabled() {                                       // (read on every call: the tests switch it inside one process)
-    return getenv("STAGE_NO_CAT3_DW") == nullptr && getenv("STAGE_NO_CAT3_FUSED") == nullptr;
+// OPT-IN (STAGE_CAT3_DW=1): measured on MI355X at 960 000 rows (profiles/r06_cat3_dw_ab.txt) this kernel takes 1.97 ms (broadcast a) /
+// 1.69 ms (flat) against 0.92 ms + 0.42-0.56 ms for cf_bwd_kernel + the weight-gradient GEMM on the saved z, and the forward without
+// the z store saves 0.15 ms: a net loss of 0.3-0.5 ms per instance.  One E and one W wave per SIMD are two dependency chains of ~9 us per
+// tile each (dX is bound by the L2 bandwidth of the weight image, 192 KB per 32 rows; the epilogue and the z rebuild by LDS / VALU
+// latency of a single wave), where cf_bwd_kernel keeps two independent tiles in flight per compute unit.  (Read on every call: the tests
+// switch it inside one process.)
+bool cw_enabled() {
+    const char* e = getenv("STAGE_CAT3_DW");
+    return e != nullptr && e[0] == '1' && getenv("STAGE_NO_CAT3_FUSED") == nullptr;
 }
 template <typename K>
 void cw_set_lds(K kern) {
