@@ -55,6 +55,38 @@ def _centred_oracle_grads(fx):
     return {k: v.grad for k, v in P.items() if v.grad is not None}
 
 
+PRODUCT_ROWS = 200000      # tvqaplus_amd/stage.py: the default of STAGE.ragged_min_rows (tests/conftest.py forces 0 for the rest of the suite)
+
+
+@pytest.mark.parametrize("name", [n for n in MODEL_CASES if n.endswith("_train")][:4])
+def test_golden_train_under_product_defaults(hip_device, name):
+    """the suite runs with STAGE_RAGGED_MIN_ROWS=0 (every batch takes the ragged layout); a deployment keeps the default --
+    below 200 000 padded statement rows the step runs DENSE statement rows + the context-bucket fallback.  The reference fixtures once
+    under exactly that configuration (logits, losses, every parameter gradient)."""
+    fx = Fixture(name)
+    model = _model_from(fx, hip_device)
+    model.ragged_min_rows = PRODUCT_ROWS
+    exp = fx.group("out")
+    batch = fx.batch().to(hip_device)
+    model.train()
+    if "att_seed" in fx.z.files:
+        torch.manual_seed(int(fx["att_seed"]))
+    (out, targets), att_loss, _, t_loss, t_scores, other = model.forward_main(batch)
+    assert model.last_ragged is None                      # (the fixtures are far below the threshold: the dense-row path ran)
+    assert torch.equal(targets.cpu(), exp["targets"]), "proposal set differs"
+    loss = F.cross_entropy(out, targets, reduction="sum") * (len(batch.qid) / len(targets)) + 0.5 * t_loss
+    if fx.opt.use_sup_att:
+        loss = loss + 0.1 * att_loss
+    loss.backward()
+    assert rel_err(out, exp["logits"]) < TOL and rel_err(t_scores, exp["t_scores"]) < TOL and rel_err(loss, exp["loss"]) < TOL
+    G = fx.group("grad")
+    for k, p in model.named_parameters():
+        if k in UNDEFINED_GRADS.get(name, ()):
+            continue
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert rel_err(got, G[k]) < GTOL, (k, rel_err(got, G[k]))
+
+
 @pytest.mark.parametrize("name", MODEL_CASES)
 def test_golden_whole_model(hip_device, name):
     fx = Fixture(name)

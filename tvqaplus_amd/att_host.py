@@ -192,8 +192,15 @@ class AttPairs:
             self.flat = t
         if target_dev is not None:
             n2 = 2 * self.m
-            ca = target_dev.to(self.flat.device).clamp(0, NA - 1).index_select(0, self.flat[n2:])     # (the kernels gather unchecked)
+            tdev = target_dev.to(self.flat.device)
+            ca = tdev.clamp(0, NA - 1).index_select(0, self.flat[n2:])     # (the kernels gather unchecked: the clamp is for memory safety)
             self.flat = self.flat[:n2] + ca * (Li * Lqa * Lr)
+            # an answer index outside [0, NA) is an ERROR in the reference (scores[batch_idx, ca_idx] raises, model/stage.py:645) and on
+            # the host path above; here nothing can raise without a read-back, so the loss is poisoned instead: get_att_loss multiplies
+            # by this factor (1.0, or NaN when any target was out of range) -- the step fails loudly, not silently on the wrong candidate
+            self.poison = torch.where(((tdev < 0) | (tdev >= NA)).any(), float("nan"), 1.0).to(torch.float32)
+        else:
+            self.poison = None
         self.stage = stage
 
 
@@ -217,7 +224,8 @@ def get_att_loss(model, scores: torch.Tensor, batch, pairs=None):
         # gather + loss + per-pair gradient coefficients in one kernel; the backward zero-fills and scatters (csrc/groups.hip)
         from . import groups
         try:
-            return groups.att_loss(scores.contiguous(), pairs.flat, pairs.m, model.att_loss_type, model.alpha, model.margin), None
+            loss = groups.att_loss(scores.contiguous(), pairs.flat, pairs.m, model.att_loss_type, model.alpha, model.margin)
+            return (loss if pairs.poison is None else loss * pairs.poison), None
         except groups.Unsupported:
             pass      # the plain gather below
     # ONE flat gather: the gradient reaches raw_s as a sparse scatter
@@ -229,6 +237,8 @@ def get_att_loss(model, scores: torch.Tensor, batch, pairs=None):
         loss = torch.log1p(torch.exp(model.alpha * (s_neg - s_pos))).sum()
     else:
         raise NotImplementedError("Only support hinge and lse")
+    if pairs.poison is not None:
+        loss = loss * pairs.poison
     return loss, None  # att_predictions are only produced outside training in the reference (:702)
 
 

@@ -204,6 +204,11 @@ class FlatGradBucket:
         view of ``flat`` (parameters without a gradient hold zeros there), so the total 2-norm is ONE reduction and the scaling ONE
         multiply -- three small kernels instead of torch's per-tensor norms / stack / norm / clamp / multi-tensor multiply (0.4 ms of
         host time per step: it decides the step when a rank holds two examples).  Same value up to summation order; returns the norm."""
+        # precondition: every gradient IS a view of ``flat`` (pack() / all_reduce() ran after this step's backward).  Called earlier --
+        # or after a backward that produced fresh p.grad tensors -- the norm would be the previous step's buffer and the real
+        # gradients would stay unclipped: pack first (pointer comparisons only, no device work when the precondition holds)
+        if any(p.grad is not None and p.grad.data_ptr() != v.data_ptr() for v, p in zip(self.views, self.params)):
+            self.pack()
         total = torch.linalg.vector_norm(self.flat)
         self.flat.mul_(torch.clamp(float(max_norm) / (total + eps), max=1.0))
         return total

@@ -156,17 +156,27 @@ def _block_params(blk):
     K-groups take them.  Cached on the block (plain attribute): the Parameter OBJECTS never change (``.to()`` / the optimizer update them
     in place), and walking ``nn.Module.__getattr__`` / ``ModuleList.__getitem__`` for 14 parameters per call is host time the small-batch
     step is bound by."""
-    ps = blk.__dict__.get("_stage_plist")
-    if ps is not None and ps[-1] is not blk.final_layer_norm._parameters["bias"]:
-        ps = None                                   # a parameter object was replaced (rare: surgery on the module) -> rebuild
-    if ps is None:
-        ps = []
+    cached = blk.__dict__.get("_stage_plist")
+    if cached is not None:
+        ps, owners = cached
+        # every entry is checked against the module that owns it (dict look-ups, no __getattr__ walk): a replaced Parameter object
+        # (per-layer surgery, parametrize, a swapped nn.Parameter) must not leave the K-groups computing with the old tensor
+        for p, (params, key) in zip(ps, owners):
+            if params[key] is not p:
+                cached = None
+                break
+    if cached is None:
+        ps, owners = [], []
         for i in range(blk.n_conv):
             c = blk.conv[i]
-            ps += [blk.layer_norm[i].weight, blk.layer_norm[i].bias, c.depthwise_conv.weight, c.depthwise_conv.bias,
-                   c.pointwise_conv.weight, c.pointwise_conv.bias]
-        ps += [blk.final_layer_norm.weight, blk.final_layer_norm.bias]
-        blk.__dict__["_stage_plist"] = ps
+            for m in (blk.layer_norm[i], c.depthwise_conv, c.pointwise_conv):
+                for key in ("weight", "bias"):
+                    ps.append(m._parameters[key])
+                    owners.append((m._parameters, key))
+        for key in ("weight", "bias"):
+            ps.append(blk.final_layer_norm._parameters[key])
+            owners.append((blk.final_layer_norm._parameters, key))
+        blk.__dict__["_stage_plist"] = (ps, owners)
     return ps
 
 
@@ -175,6 +185,7 @@ class STAGE(nn.Module):
         super().__init__()
         self.opt = opt
         self.inference_mode = False
+        self._qkv_cache = {}
         self.sub_flag = opt.sub_flag
         self.vfeat_flag = opt.vfeat_flag
         self.vfeat_size = opt.vfeat_size
@@ -370,8 +381,14 @@ class STAGE(nn.Module):
                 # one dX GEMM (no sum of three input gradients), one weight-gradient GEMM; the attention core reads / writes the thirds
                 # of the fused tensors in place (round 5; the stacked weight is a 192 KB torch.cat whose backward hands each
                 # Linear its slice of the gradient)
-                w_qkv = torch.cat([self._g(mha.linears[j].weight) for j in range(3)], dim=0)
-                b_qkv = torch.cat([self._g(mha.linears[j].bias) for j in range(3)], dim=0)
+                # (stacked ONCE per step and module -- _open_gates, on the main stream before the branches fork: the shared encoder
+                # is applied to three streams and several length buckets)
+                ck = self._qkv_cache.get(id(mha))
+                if ck is None:
+                    ck = (torch.cat([self._g(mha.linears[j].weight) for j in range(3)], dim=0),
+                          torch.cat([self._g(mha.linears[j].bias) for j in range(3)], dim=0))
+                    self._qkv_cache[id(mha)] = ck
+                w_qkv, b_qkv = ck
                 qkv = ops.linear(y, w_qkv, b_qkv)
                 a = ops.mha_core_qkv(qkv, mask, mha.nh, p=p_attn, seed=self._seed() if p_attn > 0 else 0)
             else:
@@ -819,6 +836,17 @@ class STAGE(nn.Module):
         """The parameter, or its alias of this step when its module is gated (groups.gate)."""
         return self._gate_map.get(id(w), w)
 
+    def _stack_qkv(self):
+        """The stacked Q / K / V projection weights of every attention block of this step (model/self_attention.py:35-44 as one
+        Linear(D -> 3D)): built here, on the main stream, from the step's gate aliases."""
+        self._qkv_cache = {}
+        for enc in (self.input_encoder, self.cls_encoder):
+            for blk in enc.stacked_encoderBlocks:
+                if blk.num_heads != 0:
+                    mha = blk.multi_head_attn
+                    self._qkv_cache[id(mha)] = (torch.cat([self._g(mha.linears[j].weight) for j in range(3)], dim=0),
+                                                torch.cat([self._g(mha.linears[j].bias) for j in range(3)], dim=0))
+
     def _open_gates(self):
         # modules applied to two or three streams (model/stage.py:226-269): their parameter gradients leave the graph once
         self._gate_map = {}
@@ -830,9 +858,31 @@ class STAGE(nn.Module):
         if self.flag_cnt == 2:
             mods.append(self.c2q_down_projection)
         for m in mods:
-            ps = m.__dict__.get("_stage_gated")        # (cached: m.parameters() walks named_modules() on every call)
-            if ps is None or any(not w.requires_grad for w in ps):
-                ps = m.__dict__["_stage_gated"] = [w for w in m.parameters() if w.requires_grad]
+            # (cached: m.parameters() walks named_modules() on every call.  Keyed on the parameter COUNT of the module's direct
+            # children and the requires_grad flags: a parameter added, replaced by surgery or (un)frozen rebuilds the list)
+            cached = m.__dict__.get("_stage_gated")
+            ps = None
+            if cached is not None:
+                ps, owners = cached
+                for w, (params, key) in zip(ps, owners):
+                    if params.get(key) is not w or not w.requires_grad:
+                        ps = None
+                        break
+                if ps is not None and m.__dict__.get("_stage_gated_frozen"):
+                    ps = None if any(w.requires_grad for w in m.__dict__["_stage_gated_frozen"]) else ps
+            if ps is None:
+                ps, owners, frozen = [], [], []
+                for sub in m.modules():
+                    for key, w in sub._parameters.items():
+                        if w is None:
+                            continue
+                        if w.requires_grad:
+                            ps.append(w)
+                            owners.append((sub._parameters, key))
+                        else:
+                            frozen.append(w)
+                m.__dict__["_stage_gated"] = (ps, owners)
+                m.__dict__["_stage_gated_frozen"] = frozen
             if ps:
                 for w, a in zip(ps, groups.gate(ps)):
                     self._gate_map[id(w)] = a
@@ -841,9 +891,11 @@ class STAGE(nn.Module):
         """model/stage.py:199-348."""
         try:
             self._open_gates()
+            self._stack_qkv()
             return self._forward_main(batch)
         finally:
             self._gate_map = {}
+            self._qkv_cache = {}
 
     def _forward_main(self, batch):
         ops.new_step()
