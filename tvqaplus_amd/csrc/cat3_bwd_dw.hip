@@ -111,6 +111,33 @@ __device__ __forceinline__ int cw_zfield(float g, float b, float inv_keep) {
     return max(1, min(268 - ebb, 254));
 }
 
+// LDS-DMA (buffer_load ... lds: 16 / 4 bytes per lane straight into LDS at M0 + 16 / 4 * lane, bounds-checked against the descriptor) as
+// inline assembly: the compiler orders every LDS read behind a pending LDS-DMA it KNOWS of with s_waitcnt vmcnt(0) -- the loads would
+// be drained at the first ds_read of the next phase instead of landing behind it.  Hidden from its counters they are waited for by
+// hand (cw_dma_wait) before the barrier that publishes them.  M0 is compiler-reserved: saved and restored inside the statement.
+typedef int cw_i4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ cw_i4 cw_rsrc(const void* p, long bytes) {
+    const unsigned long long pa = (unsigned long long)p;
+    return (cw_i4){(int)(unsigned)pa, (int)(unsigned)((pa >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ void cw_dma16(cw_i4 rsrc, unsigned lds, int voff, int soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void cw_dma4(cw_i4 rsrc, unsigned lds, int voff, int soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void cw_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// the lane id, RECOMPUTED (two mbcnt instructions on an opaque all-ones mask) instead of kept: see dma_tile
+__device__ __forceinline__ int cw_lane() {
+    unsigned m = ~0u;
+    asm volatile("" : "+s"(m));
+    return (int)__builtin_amdgcn_mbcnt_hi(m, __builtin_amdgcn_mbcnt_lo(m, 0u));
+}
+
 // MODE 0: rep == 1, tiles of 32 consecutive rows, grid-stride.  MODE 1: rep > 1, inner <= 32: one tile per frame.  MODE 2: rep > 1,
 // inner == 40: per four frames four main tiles + one rest tile.  MODE 3: ragged token rows with the balanced work table `wtab`
 // (cat3_fused.hip: cf_bwd_kernel).  MODE 1 / 2: the workgroup walks the (group, chunk of frames) items blockIdx.x, + gridDim.x, ...
@@ -278,36 +305,42 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
         unsigned kbA0 = 0xffffffu, kbA1 = 0xffffffu, kbN0 = 0xffffffu, kbN1 = 0xffffffu;   // dropout bits: tile whose dW is pending / newest
         // LDS-DMA of a tile: wave wv brings pass wv (8 rows) of dy, b (and a), its 32 mask words; wave 0 / 1 the means / rstds.
         // Rows past the end of a tensor read zeros (buffer bounds check); rows past the end of their pass are masked on use.
+        const cw_i4 d_dy = cw_rsrc(dy, M * CW_D * 4), d_b = cw_rsrc(b, (RAG ? b_rows : M) * CW_D * 4),
+                    d_a = cw_rsrc(a, (RAG ? a_rows : (REP ? M / rep : M)) * CW_D * 4), d_mk = cw_rsrc(rmask, M * (CW_D / 32) * 4),
+                    d_mean = cw_rsrc(mean, M * 4), d_rstd = cw_rsrc(rstd, M * 4);
+        const unsigned lds0 = (unsigned)(size_t)(cw_lds_ptr)smem;
         auto dma_tile = [&](const int (&pb)[4], const int (&pbB)[4], int nb3) {
             const int pbw = wv == 0 ? pb[0] : (wv == 1 ? pb[1] : (wv == 2 ? pb[2] : pb[3]));
             const int pbBw = wv == 0 ? pbB[0] : (wv == 1 ? pbB[1] : (wv == 2 ? pbB[2] : pbB[3]));
+            // (every per-lane constant below is re-derived from an OPAQUE copy of the lane id: hoisted out of the tile loop they are a
+            // dozen loop invariants next to 192 accumulator registers -- the allocator parks them in scratch and every reload is a memory
+            // round trip that nothing overlaps in a wave that is alone on its SIMD)
+            const int lane_o = cw_lane();
+            const int l31 = lane_o & 31, h = lane_o >> 5;
             const int vo = (h * CW_D + 4 * l31) * 4;      // row lane >> 5 of a pair of rows, float4 lane & 31
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (cw_lds_ptr)(smem + CW_OFF_RAW + (8 * wv + 2 * k) * (CW_D * 4)), 16, vo,
-                                                         (pbw + 2 * k) * (CW_D * 4), 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (cw_lds_ptr)(smem + CW_OFF_BT + nb3 * CW_TILE + (8 * wv + 2 * k) * (CW_D * 4)), 16, vo,
-                                                         (pbBw + 2 * k) * (CW_D * 4), 0, 0);
-                if (!REP)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (cw_lds_ptr)(smem + CW_OFF_AT + nb3 * CW_TILE + (8 * wv + 2 * k) * (CW_D * 4)), 16,
-                                                             vo, (pbBw + 2 * k) * (CW_D * 4), 0, 0);
+                cw_dma16(d_dy, lds0 + CW_OFF_RAW + (8 * wv + 2 * k) * (CW_D * 4), vo, (pbw + 2 * k) * (CW_D * 4));
+                cw_dma16(d_b, lds0 + CW_OFF_BT + nb3 * CW_TILE + (8 * wv + 2 * k) * (CW_D * 4), vo, (pbBw + 2 * k) * (CW_D * 4));
+                if (!REP) cw_dma16(d_a, lds0 + CW_OFF_AT + nb3 * CW_TILE + (8 * wv + 2 * k) * (CW_D * 4), vo, (pbBw + 2 * k) * (CW_D * 4));
             }
             // the 4-byte words: 32 per instruction, by the lower lane half only (an inactive lane writes nothing; an active lane whose
             // offset is out of range would write a ZERO to its slot -- the next array)
             if (h == 0) {
                 // its own mask words: word lane >> 3 of row lane & 7
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_mk, (cw_lds_ptr)(smem + CW_OFF_MK + wv * 128), 4,
-                                                         (int)(((long)(l31 >> 3) * M + (l31 & 7)) * 4), pbw * 4, 0, 0);
+                cw_dma4(d_mk, lds0 + CW_OFF_MK + wv * 128, (int)(((long)(l31 >> 3) * M + (l31 & 7)) * 4), pbw * 4);
                 // per-row statistics of the 32 rows: tile row `lane` = row (lane & 7) of pass lane >> 3
                 const int pr = l31 >> 3;
                 const int prow = (pr == 0 ? pb[0] : (pr == 1 ? pb[1] : (pr == 2 ? pb[2] : pb[3]))) + (l31 & 7);
-                if (wv == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_mean, (cw_lds_ptr)(smem + CW_OFF_MS + nb3 * 256), 4, prow * 4, 0, 0, 0);
-                if (wv == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_rstd, (cw_lds_ptr)(smem + CW_OFF_MS + nb3 * 256 + 128), 4, prow * 4, 0, 0, 0);
+                if (wv == 0) cw_dma4(d_mean, lds0 + CW_OFF_MS + nb3 * 256, prow * 4, 0);
+                if (wv == 1) cw_dma4(d_rstd, lds0 + CW_OFF_MS + nb3 * 256 + 128, prow * 4, 0);
             }
         };
         // staging of a tile (this wave: its pass): gate by the ReLU bits, one power-of-two scale per row, two fp16 planes, row-major; the
         // bias gradient; the tile's smallest scale field
         auto stage_tile = [&](const int (&nv)[4], int pbuf, int nb3) {
+            const int lane_o = cw_lane();
+            const int l31 = lane_o & 31, h = lane_o >> 5;
             const int nvw = wv == 0 ? nv[0] : (wv == 1 ? nv[1] : (wv == 2 ? nv[2] : nv[3]));
             unsigned char* const Rp = smem + CW_OFF_RP + pbuf * CW_RP;
             const float* raw = reinterpret_cast<const float*>(smem + CW_OFF_RAW) + (8 * wv + h) * CW_D + 4 * l31;
@@ -342,6 +375,8 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
         // a quad: quad lane q hashes for the C/D registers 4 j + q (row pb[j] + q + 4 h); three keep nibbles per pass j, two passes per word
         auto hash_tile = [&](const int (&pb)[4]) {
             unsigned w0 = 0u, w1 = 0u;
+            const int lane_o = cw_lane();
+            const int l31 = lane_o & 31, h4 = 4 * (lane_o >> 5), c = 32 * wv + l31;
             if (DROP && !(CW_ABL & 4)) {
                 const unsigned drop_lane = (unsigned)(((l31 & 3) + h4) * (K3 / 4) + (c >> 2));
 #pragma unroll 1
@@ -357,15 +392,16 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
             }
             kbN0 = w0;
             kbN1 = w1;
-            unsigned* kbp = reinterpret_cast<unsigned*>(smem + CW_OFF_KB) + wv * 128 + lane;
+            unsigned* kbp = reinterpret_cast<unsigned*>(smem + CW_OFF_KB) + wv * 128 + lane_o;
             kbp[0] = kbN0;
             kbp[64] = kbN1;
         };
         // z and the dW product of one tile: planes `pbuf`, operand buffers `nb3`, dropout bits kbA, pass lengths nvp
-        const int G = lane >> 4, i16 = lane & 15;
-        const int tr_off = (4 * (G >> 1) + (i16 >> 2)) * CW_PITCH + (16 * (G & 1) + 4 * (i16 & 3)) * 2;
-        const int q = l31 & 3;
         auto dw_tile = [&](int pbuf, int nb3, const int (&nvp)[4], bool restp) {
+            const int lane_o = cw_lane();
+            const int l31 = lane_o & 31, h4 = 4 * (lane_o >> 5), c = 32 * wv + l31, q = l31 & 3;
+            const int G = lane_o >> 4, i16 = lane_o & 15;
+            const int tr_off = (4 * (G >> 1) + (i16 >> 2)) * CW_PITCH + (16 * (G & 1) + 4 * (i16 & 3)) * 2;
             const int Et = __builtin_amdgcn_readfirstlane(tmin[nb3]);
             if (Et < E_acc) {                             // (uniform, rare) a row larger than anything so far: bring the accumulators along
                 const int d = Et - E_acc;
@@ -453,7 +489,7 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
             // prologue: tile 0 of the segment is brought in and staged, tile 1 requested
             geom(0, pb, pbB, nv, rest);
             dma_tile(pb, pbB, tc % 3);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            cw_dma_wait();
             __syncthreads();                              // P1 (its mask words / rows are this wave's own; b / a / statistics: for the E waves)
             stage_tile(nv, tc & 1, tc % 3);
             hash_tile(pb);
@@ -474,7 +510,7 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
 #pragma unroll
                 for (int p2 = 0; p2 < 4; p2++) nvp[p2] = nv[p2];
                 restp = rest;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the rows of tile tc + 1 have landed
+                cw_dma_wait();                            // the rows of tile tc + 1 have landed
                 __syncthreads();                          // Bb(it)
                 if (it + 1 < n_tiles) {
                     geom(it + 1, pb, pbB, nv, rest);
