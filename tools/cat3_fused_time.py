@@ -101,3 +101,14 @@ if lib.stage_cat3_bwd_dw_supported(U, D, rep, inner):
         _lib.check(lib.stage_cat3_ln_gemm_fwd(a.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), W.data_ptr(), bias.data_ptr(), None, mean2.data_ptr(),
                    rstd2.data_ptr(), y2.data_ptr(), mask2.data_ptr(), U, D, rep, inner, 1e-5, p, seed, fws.data_ptr(), fwsb, st), "fused fwd no z")
     timeit(fwd_fused_noz, "fused forward without the z store")
+    if os.environ.get("CW_PROF"):                         # developer build -DCW_PROF: cycles per phase of workgroup 0
+        import ctypes
+        raw = ctypes.CDLL(_lib.LIB_PATH)
+        buf = (ctypes.c_ulonglong * 32)()
+        dw_inside(); torch.cuda.synchronize()
+        raw.stage_cw_prof(buf)
+        names_w = ["prologue", "wait Ba", "z + dW", "DMA wait", "wait Bb", "geom + staging", "hashes", "DMA issue"]
+        names_e = ["prologue", "geom", "wait Ba", "dX product", "LN bwd 1", "wait Bb", "LN bwd 2"]
+        tiles = (U // 32 + 255) // 256
+        print("W wave (cycles per tile, ~%d tiles):" % tiles, ", ".join("%s %d" % (n, buf[i] // tiles) for i, n in enumerate(names_w)), " total", sum(buf[:8]) // tiles)
+        print("E wave (cycles per tile):", ", ".join("%s %d" % (n, buf[16 + i] // tiles) for i, n in enumerate(names_e)), " total", sum(buf[16:23]) // tiles)

@@ -122,11 +122,15 @@ __device__ __forceinline__ cw_i4 cw_rsrc(const void* p, long bytes) {
 }
 __device__ __forceinline__ void cw_dma16(cw_i4 rsrc, unsigned lds, int voff, int soff) {
     unsigned keep;
+    lds = __builtin_amdgcn_readfirstlane(lds);        // (uniform by construction; the allocator does not always keep them scalar)
+    soff = __builtin_amdgcn_readfirstlane(soff);
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(lds), "s"(rsrc), "s"(soff) : "memory");
 }
 __device__ __forceinline__ void cw_dma4(cw_i4 rsrc, unsigned lds, int voff, int soff) {
     unsigned keep;
+    lds = __builtin_amdgcn_readfirstlane(lds);        // (uniform by construction; the allocator does not always keep them scalar)
+    soff = __builtin_amdgcn_readfirstlane(soff);
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(lds), "s"(rsrc), "s"(soff) : "memory");
 }
@@ -137,6 +141,18 @@ __device__ __forceinline__ int cw_lane() {
     asm volatile("" : "+s"(m));
     return (int)__builtin_amdgcn_mbcnt_hi(m, __builtin_amdgcn_mbcnt_lo(m, 0u));
 }
+// developer build -DCW_PROF: shader-clock cycles per phase of workgroup 0's first W wave (slots 0..) and first E wave (16..), read back
+// through stage_cw_prof(); the product build compiles none of it
+#ifdef CW_PROF
+__device__ unsigned long long cw_prof_buf[32];
+#define CW_PROF_DECL unsigned long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt = __builtin_readcyclecounter()
+#define CW_MARK(slot) do { const unsigned long long t_ = __builtin_readcyclecounter(); pf[slot] += t_ - pt; pt = t_; } while (0)
+#define CW_PROF_OUT(base, who) do { if (blockIdx.x == 0 && tid == (who)) for (int i_ = 0; i_ < 10; i_++) cw_prof_buf[(base) + i_] = pf[i_]; } while (0)
+#else
+#define CW_PROF_DECL
+#define CW_MARK(slot)
+#define CW_PROF_OUT(base, who)
+#endif
 
 // MODE 0: rep == 1, tiles of 32 consecutive rows, grid-stride.  MODE 1: rep > 1, inner <= 32: one tile per frame.  MODE 2: rep > 1,
 // inner == 40: per four frames four main tiles + one rest tile.  MODE 3: ragged token rows with the balanced work table `wtab`
@@ -392,7 +408,9 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
             }
             kbN0 = w0;
             kbN1 = w1;
-            unsigned* kbp = reinterpret_cast<unsigned*>(smem + CW_OFF_KB) + wv * 128 + lane_o;
+        };
+        auto publish_bits = [&]() {                       // the newest bits -> LDS for the E waves (behind Bb: they read a tile's bits right after Ba)
+            unsigned* kbp = reinterpret_cast<unsigned*>(smem + CW_OFF_KB) + wv * 128 + cw_lane();
             kbp[0] = kbN0;
             kbp[64] = kbN1;
         };
@@ -419,6 +437,15 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
             const int* const up_h = row_up + nb3 * 32 + h4;
             const float* const mu_h = reinterpret_cast<const float*>(smem + CW_OFF_MS + nb3 * 256) + h4;
             const float* const gz_c = reinterpret_cast<const float*>(smem + CW_OFF_GZ) + c;
+            // (gamma' / beta' of this lane's three columns: read HERE and pinned -- left inside the keep-select below the compiler turns
+            // every one of the 48 elements into a branch with two LDS reads and their full latency inside)
+            float gzv[3], bzv[3];
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                gzv[t] = gz_c[t * CW_D];
+                bzv[t] = gz_c[K3 + t * CW_D];
+                asm volatile("" : "+v"(gzv[t]), "+v"(bzv[t]));
+            }
 #pragma unroll
             for (int s = 0; s < ((CW_ABL & 2) ? 0 : 2); s++) {
                 // z of the 8 rows of k-step s in this lane's column of each third (element e = C/D register r = 8 s + e), split pair by
@@ -442,7 +469,9 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
                     for (int t = 0; t < 3; t++) {
                         const float x = t == 0 ? avr : (t == 1 ? bvr : avr * bvr);
                         const float xh = (x - mu) * rs;
-                        const float zv = (!(CW_ABL & 32) && ((bw >> (4 * t)) & 1u)) ? (xh * gz_c[t * CW_D] + gz_c[K3 + t * CW_D]) * f : 0.f;
+                        float zfull = (xh * gzv[t] + bzv[t]) * f;
+                        asm volatile("" : "+v"(zfull));
+                        const float zv = (!(CW_ABL & 32) && ((bw >> (4 * t)) & 1u)) ? zfull : 0.f;
                         if (e & 1) {
                             unsigned hi, lo;
                             h_split2(zprev[t], zv, 1.0f, hi, lo);
@@ -481,6 +510,7 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
             }
         };
         int tc = 0;                                       // tiles so far: tile tc uses planes tc & 1, operand buffers tc % 3
+        CW_PROF_DECL;
         while (next_segment()) {
             if (REP) { __syncthreads(); __syncthreads(); }    // (the E waves copy the group's block of `a` between these two)
             if (n_tiles <= 0) continue;
@@ -493,6 +523,7 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
             __syncthreads();                              // P1 (its mask words / rows are this wave's own; b / a / statistics: for the E waves)
             stage_tile(nv, tc & 1, tc % 3);
             hash_tile(pb);
+            publish_bits();
             if (n_tiles > 1) {
                 int pbn[4], pbBn[4], nvn[4];
                 bool restn;
@@ -501,31 +532,45 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
             }
             // (ONE call site of the product inside the loop -- with a second one the allocator parks all of accW in scratch between
             // them: the last tile of a segment is drained by an extra trip that runs the product only)
+            CW_MARK(0);                                   // (segment prologue)
             for (long it = 0;; it++) {
                 if (it < n_tiles) __syncthreads();        // Ba(it)
+                CW_MARK(1);
                 if (it > 0) dw_tile((tc - 1) & 1, (tc + 2) % 3, nvp, restp);       // tile tc - 1
+                CW_MARK(2);
                 if (it >= n_tiles) break;
                 if (tid == 256) tmin[(tc + 1) % 3] = 254; // (the word of tile tc + 1 = of tile tc - 2: read in the previous slot, written behind Bb)
                 kbA0 = kbN0; kbA1 = kbN1;                 // (the bits of tile tc: pending from here on)
 #pragma unroll
                 for (int p2 = 0; p2 < 4; p2++) nvp[p2] = nv[p2];
                 restp = rest;
-                cw_dma_wait();                            // the rows of tile tc + 1 have landed
-                __syncthreads();                          // Bb(it)
-                if (it + 1 < n_tiles) {
+                // the dropout hashes of tile tc + 1 go HERE, next to the E waves' product (their slot behind Bb is the short one); the
+                // bits stay in registers until Bb
+                if (MODE == 0 || it + 1 < n_tiles) {      // (MODE 0: one segment -- the one wasted hash keeps the allocator's plan of the loop)
                     geom(it + 1, pb, pbB, nv, rest);
-                    stage_tile(nv, (tc + 1) & 1, (tc + 1) % 3);
                     hash_tile(pb);
+                }
+                CW_MARK(6);
+                cw_dma_wait();                            // the rows of tile tc + 1 have landed
+                CW_MARK(3);
+                __syncthreads();                          // Bb(it)
+                CW_MARK(4);
+                if (it + 1 < n_tiles) {
+                    stage_tile(nv, (tc + 1) & 1, (tc + 1) % 3);
+                    publish_bits();
+                    CW_MARK(5);
                     if (it + 2 < n_tiles) {
                         int pbn[4], pbBn[4], nvn[4];
                         bool restn;
                         geom(it + 2, pbn, pbBn, nvn, restn);
                         dma_tile(pbn, pbBn, (tc + 2) % 3);
                     }
+                    CW_MARK(7);
                 }
                 tc++;
             }
         }
+        CW_PROF_OUT(0, 256);
         // weight gradient in true units: the accumulators hold dW * 2^(zf_t - 127) * 2^(E_acc - 127)
         float* pw = partW + (size_t)blockIdx.x * CW_D * K3;
 #pragma unroll
@@ -579,6 +624,7 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
         }
     };
     int tc = 0;
+    CW_PROF_DECL;
     while (next_segment()) {
         if (REP) {
             // the group's block of the broadcast operand -> LDS (behind a barrier: a slower wave may still read the previous one)
@@ -590,6 +636,7 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
         }
         if (n_tiles <= 0) continue;
         __syncthreads();                                  // P1
+        CW_MARK(0);
         for (long it = 0; it < n_tiles; it++) {
             int pb[4], pbB[4], nv[4];
             bool rest;
@@ -598,7 +645,9 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
             const unsigned char* const Rp = smem + CW_OFF_RP + (tc & 1) * CW_RP;
             const float* const bt_b = reinterpret_cast<const float*>(smem + CW_OFF_BT + nb3 * CW_TILE);
             const float* const ms_b = reinterpret_cast<const float*>(smem + CW_OFF_MS + nb3 * 256);
+            CW_MARK(1);
             __syncthreads();                              // Ba: planes, row scales, dropout bits of the tile
+            CW_MARK(2);
             unsigned kb0 = 0xffffffu, kb1 = 0xffffffu;
             if (DROP) {
                 const unsigned* kbp = reinterpret_cast<const unsigned*>(smem + CW_OFF_KB) + wv * 128 + lane;
@@ -644,6 +693,7 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
                     mul_b(bfb, ks + 1);
                 }
             }
+            CW_MARK(3);
             // ---- LayerNorm backward, first half: gradient of the LayerNorm output in true units, row statistics.  Slot r = tile row
             // 8 (r >> 2) + (r & 3) + 4 h, column c of each third; a / b values from the LDS tiles ----
             const float* const bt_h = bt_b + h4 * CW_D + c;
@@ -687,7 +737,9 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
                 *reinterpret_cast<float2*>(stw_h + rl * 2) = make_float2(s1, s2);      // (all 32 lanes of the half: the same value)
                 if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four rows in flight at a time: bounded register pressure
             }
+            CW_MARK(4);
             __syncthreads();                              // Bb: the partial statistics of all four E waves
+            CW_MARK(5);
             // ---- second half: dz and the gradients of a and b ----
 #pragma unroll
             for (int r = 0; r < ((CW_ABL & 8) ? 0 : 16); r++) {
@@ -723,6 +775,7 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
                 else dacc[r] += valid ? da_v : 0.f;
                 if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
+            CW_MARK(6);
             tc++;
         }
         if (REP) {
@@ -733,6 +786,7 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
             for (int r = 0; r < 4; r++) dacc_rest[r] = 0.f;
         }
     }
+    CW_PROF_OUT(16, 0);
     // ---- what the E waves summed over their rows: column partials of d gamma / d beta (the two lane halves hold different rows of
     // the same columns) ----
     {
@@ -933,3 +987,10 @@ extern "C" int stage_cat3_bwd_dw_rag(const float* dy, const unsigned* relu_mask,
     STAGE_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef CW_PROF
+extern "C" int stage_cw_prof(unsigned long long* out32) {
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(cw_prof_buf), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
