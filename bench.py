@@ -492,7 +492,7 @@ def side_records(args):
       rounds 1-3 and the first half of round 4 measured) and fully on (--streams 4: the video attention on its side stream too, unfenced)."""
     shp = ["--bsz", str(args.bsz), "--frames", str(args.frames), "--regions", str(args.regions), "--qa_words", str(args.qa_words)]
     out = {}
-    r = child_bench(shp + ["--sub_words", str(args.sub_words), "--hsz", str(args.hsz), "--steps", "3", "--warmup", "2", "--no_roofline",
+    r = child_bench(shp + ["--sub_words", str(args.sub_words), "--hsz", str(args.hsz), "--steps", "6", "--warmup", "3", "--no_roofline",
                            "--no_device_time"], env={"STAGE_GEMM_F32": "1"})
     out["exact_f32"] = ({"ms_per_step": r["ms_per_step"], "value": r["value"], "note": "STAGE_GEMM_F32=1: v_mfma_f32 products, dense rows",
                          "ragged_rows": "not available: the ragged-row groups are built on the fused [a,b,a*b] kernels, which exist as "
@@ -542,13 +542,13 @@ def side_records(args):
     out["heads4"] = ({"ms_per_step": r["ms_per_step"], "value": r["value"], "launches_per_step": r.get("launches_per_step"),
                       "host_issue_ms_per_step": r.get("host_issue_ms_per_step"), "note": "configs[2]: --heads 4 in both encoders"}
                      if "ms_per_step" in r else r)
-    # cat3_dw: the opt-in backward of the [a,b,a*b] blocks with the Linear's gradients inside and no saved z (csrc/cat3_bwd_dw.hip,
-    # VERDICT r5 item 1): the A/B that decided the default (profiles/r06_cat3_dw_ab.txt)
+    # cat3_dw: the backward of the [a,b,a*b] blocks with the Linear's gradients inside and no saved z (csrc/cat3_bwd_dw.hip, VERDICT r5
+    # item 1) is the default since round 6; this child is the step WITHOUT it (profiles/r06_cat3_dw_ab.txt)
     r = child_bench(shp + ["--sub_words", str(args.sub_words), "--hsz", str(args.hsz), "--steps", "6", "--warmup", "3", "--no_roofline",
-                           "--no_device_time"], env={"STAGE_CAT3_DW": "1"})
-    out["cat3_dw_opt_in"] = ({"ms_per_step": r["ms_per_step"], "value": r["value"],
-                              "note": "STAGE_CAT3_DW=1: forward writes no z, dW / dc formed inside the fused backward (slower: kept opt-in)"}
-                             if "ms_per_step" in r else r)
+                           "--no_device_time"], env={"STAGE_CAT3_DW": "0"})
+    out["cat3_dw_off"] = ({"ms_per_step": r["ms_per_step"], "value": r["value"],
+                           "note": "STAGE_CAT3_DW=0: forward saves z, cf_bwd_kernel + weight-gradient GEMM on z (the round-5 path)"}
+                          if "ms_per_step" in r else r)
     r = child_bench(shp + ["--config", "stress", "--steps", "3", "--warmup", "2", "--no_device_time"], timeout=300)
     out["stress"] = ({"ms_per_step": r["ms_per_step"], "value": r["value"], "dtype": r.get("dtype"), "workload": r["config"]["workload"],
                       "peak_hbm_gib": r["config"].get("peak_hbm_gib"), "roofline": r.get("roofline")} if "ms_per_step" in r else r)

@@ -12,7 +12,7 @@ D = 128
 
 @pytest.fixture(autouse=True)
 def _dw_on(monkeypatch):
-    """the kernel is opt-in (STAGE_CAT3_DW=1: it loses to the two-kernel path on MI355X, profiles/r06_cat3_dw_ab.txt)"""
+    """the kernel is the default since round 6 (STAGE_CAT3_DW=0 switches it off; profiles/r06_cat3_dw_ab.txt)"""
     monkeypatch.setenv("STAGE_CAT3_DW", "1")
 
 
@@ -167,7 +167,7 @@ def test_cat3_bwd_dw_ragged(hip_device, p):
     ("concat_fc", dict(U=4096 + 77), 0.1),
 ])
 def test_group_path_without_z_equals_the_path_with_z(hip_device, which, dims, p, monkeypatch):
-    """K-groups (csrc/groups.hip): the opt-in path (STAGE_CAT3_DW=1: forward writes no z, flags[0] = 2, one backward kernel) against STAGE_CAT3_DW=0
+    """K-groups (csrc/groups.hip): the default path (STAGE_CAT3_DW unset / 1: forward writes no z, flags[0] = 2, one backward kernel) against STAGE_CAT3_DW=0
     (z written, weight-gradient GEMM + fused dX / LayerNorm backward): identical forward, gradients to summation order."""
     from tvqaplus_amd import groups
     dev = hip_device
@@ -208,3 +208,45 @@ def test_group_path_without_z_equals_the_path_with_z(hip_device, which, dims, p,
         scale = float(x.abs().max()) + 1e-12
         assert float((x - y).abs().max()) <= 2e-5 * scale, (nm, float((x - y).abs().max()), scale)
     assert not torch.equal(results[0][5], results[1][5])  # (different kernels formed dW: bit-identical would mean the switch did nothing)
+
+
+@pytest.mark.parametrize("rep,inner,G", [(1, 1, 200000), (60, 40, 40)])
+def test_cat3_bwd_dw_repeats_bit_for_bit(hip_device, rep, inner, G):
+    """the two wave roles of a workgroup hand tiles to each other through LDS (two barriers per tile, LDS-DMA two tiles ahead): a race
+    would show as launches of the same inputs that differ.  Every output of six launches, at a size where every workgroup walks many
+    tiles, must be the same bits (the accumulation order is fixed: per workgroup, then a fixed-order reduction of the partials)."""
+    from tvqaplus_amd import _lib
+    lib = _lib.load()
+    U = G * rep * inner if rep > 1 else G
+    if not lib.stage_cat3_bwd_dw_supported(U, D, rep, inner):
+        pytest.skip("dW-inside backward switched off")
+    g = torch.Generator().manual_seed(23)
+    a = torch.randn((U // rep) if rep > 1 else U, D, generator=g).cuda()
+    b = torch.randn(U, D, generator=g).cuda()
+    gamma = (1 + 0.1 * torch.randn(3 * D, generator=g)).cuda()
+    beta = (0.1 * torch.randn(3 * D, generator=g)).cuda()
+    W = (0.08 * torch.randn(D, 3 * D, generator=g)).cuda()
+    dy = (torch.randn(U, D, generator=g) * torch.exp2(torch.randint(-6, 7, (U, 1), generator=g).float())).cuda()
+    mask = torch.randint(-2 ** 31, 2 ** 31 - 1, (D // 32, U), generator=g, dtype=torch.int64).to(torch.int32).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    z = torch.empty(U, 3 * D, device="cuda"); mean = torch.empty(U, device="cuda"); rstd = torch.empty(U, device="cuda")
+    _lib.check(lib.stage_cat3_layernorm_fwd(a.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), z.data_ptr(), mean.data_ptr(),
+                                            rstd.data_ptr(), U, D, rep, inner, 1e-5, 0.1, 77, st), "ln fwd")
+    del z
+    wsb = lib.stage_cat3_bwd_dw_ws_bytes(U, D, rep, inner)
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    first = None
+    for trial in range(6):
+        outs = (torch.full((a.shape[0], D), float("nan"), device="cuda"), torch.full((U, D), float("nan"), device="cuda"),
+                torch.empty(3 * D, device="cuda"), torch.empty(3 * D, device="cuda"), torch.empty(D, 3 * D, device="cuda"),
+                torch.empty(D, device="cuda"))
+        _lib.check(lib.stage_cat3_bwd_dw(dy.data_ptr(), mask.data_ptr(), W.data_ptr(), a.data_ptr(), b.data_ptr(), mean.data_ptr(),
+                                         rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), *[o.data_ptr() for o in outs], U, D, rep, inner,
+                                         0.1, 77, ws.data_ptr(), wsb, st), "dW-inside bwd")
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(o).all() for o in outs)
+        if first is None:
+            first = outs
+        else:
+            for nm, x, y in zip(("da", "db", "dgamma", "dbeta", "dW", "dc"), first, outs):
+                assert torch.equal(x, y), (nm, trial)

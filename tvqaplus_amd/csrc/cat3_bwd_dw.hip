@@ -828,15 +828,17 @@ void cw_chunks(long long groups, int rep, int mode, int* CH, int* fpc) {
     *fpc = f;
     *CH = (rep + f - 1) / f;
 }
-// OPT-IN (STAGE_CAT3_DW=1): measured on MI355X at 960 000 rows (profiles/r06_cat3_dw_ab.txt) this kernel takes 1.97 ms (broadcast a) /
-// 1.69 ms (flat) against 0.92 ms + 0.42-0.56 ms for cf_bwd_kernel + the weight-gradient GEMM on the saved z, and the forward without
-// the z store saves 0.15 ms: a net loss of 0.3-0.5 ms per instance.  One E and one W wave per SIMD are two dependency chains of ~9 us per
-// tile each (dX is bound by the L2 bandwidth of the weight image, 192 KB per 32 rows; the epilogue and the z rebuild by LDS / VALU
-// latency of a single wave), where cf_bwd_kernel keeps two independent tiles in flight per compute unit.  (Read on every call: the tests
+// ON by default since round 6 (STAGE_CAT3_DW=0 switches back to cf_bwd_kernel + the weight-gradient GEMM on a saved z).  Measured on
+// MI355X at 960 000 rows (profiles/r06_cat3_dw_ab.txt): 1.51 ms (broadcast a) / 1.29 ms (flat) for this launch against 0.92 ms +
+// 0.42-0.56 ms for the two it replaces, and the forward without the z store saves 0.13-0.15 ms more; in the training step (three
+// instances, next to other branches' kernels) 0.1-0.3 ms per step, every configuration of bench.py.  The per-phase cycle counters
+// (-DCW_PROF) say where the rest is: one E and one W wave per SIMD are two dependency chains in lock step (two barriers per tile), ~13 us
+// per tile: dX is bound by the L2 bandwidth of the weight image (192 KB per 32 rows), the epilogue, the z rebuild, staging and the
+// hashes by the latency of a single wave with 64 working registers next to its 192 accumulators.  (Read on every call: the tests
 // switch it inside one process.)
 bool cw_enabled() {
     const char* e = getenv("STAGE_CAT3_DW");
-    return e != nullptr && e[0] == '1' && getenv("STAGE_NO_CAT3_FUSED") == nullptr;
+    return !(e != nullptr && e[0] == '0') && getenv("STAGE_NO_CAT3_FUSED") == nullptr;
 }
 template <typename K>
 void cw_set_lds(K kern) {
