@@ -481,7 +481,7 @@ def test_k1_golden(ops, name):
     check("dC", Cd.grad.view_as(C), C.grad, 1e-3)
     check("dQ", Qd.grad.view_as(Q), Q.grad, 1e-3)
     # the public operator: a gradient on the normalised scores as well -- the REFERENCE's own gradients of the fixture
-    # (model/context_query_attention.py:61 is differentiable; STAGE never uses it, a user of torch.ops.stage_hip may)
+    # (model/context_query_attention.py:61 is differentiable; STAGE never uses it, a caller of ops.structured_attention may)
     if "dC" in fx.z.files and "gSn" in fx.z.files:
         _, _, _, Cd, Qd = _k1_run(ops, t("C"), t("Q"), t("c_mask"), t("q_mask"), float(fx["scale"]), t("gA"), t("gS"), t("gSn"))
         check("dC (with dS_norm)", Cd.grad.view_as(C), t("dC"), 1e-3)
@@ -708,29 +708,6 @@ def test_dropout_stream_is_uniform_and_uncorrelated(ops):
         m2 = mask(other)
         assert not torch.equal(m, m2)
         assert corr(c, m2 - m2.mean()) < tol * 1.1, hex(other)
-
-
-def test_torch_ops_namespace_runs_the_hip_kernels(ops):
-    """torch.ops.stage_hip.structured_attention / .linear / .layernorm: same results and gradients as the wrappers (they ARE
-    the wrappers behind the dispatcher), autograd included."""
-    g = torch.Generator().manual_seed(2)
-    N, Li, Lr, Lqa, D = 2, 3, 20, 40, 128
-    C = torch.randn(N, 5, Lqa, D, generator=g).cuda().requires_grad_()
-    Q = torch.randn(N, Li, Lr, D, generator=g).cuda().requires_grad_()
-    cm, qm = torch.ones(N, 5, Lqa).cuda(), torch.ones(N, Li, Lr).cuda()
-    A1, S1, Sn1 = torch.ops.stage_hip.structured_attention(C, Q, cm, qm, 10.0)
-    A1.sum().backward()
-    gC, gQ = C.grad.clone(), Q.grad.clone()
-    C.grad = Q.grad = None
-    A2, S2, Sn2 = ops.structured_attention(C, Q, cm, qm, 10.0)
-    A2.sum().backward()
-    assert torch.equal(A1, A2) and torch.equal(S1, S2) and torch.equal(Sn1, Sn2)
-    assert torch.equal(gC, C.grad) and torch.equal(gQ, Q.grad)
-    x = torch.randn(300, 128, generator=g).cuda()
-    w, b = torch.randn(64, 128, generator=g).cuda(), torch.randn(64, generator=g).cuda()
-    assert torch.equal(torch.ops.stage_hip.linear(x, w, b, True), ops.linear(x, w, b, True))
-    y, s = torch.ops.stage_hip.layernorm(x, torch.ones(128).cuda(), torch.zeros(128).cuda())
-    assert s is None and torch.equal(y, ops.layernorm(x, torch.ones(128).cuda(), torch.zeros(128).cuda())[0])
 
 
 # ---------------------------------------------------------------------------------------------------------------

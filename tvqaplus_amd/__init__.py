@@ -5,7 +5,7 @@ Layout (only what the path needs):
 * ``csrc/``        hand-written HIP kernels + the C-ABI (``include/stage_hip.h``), built into ``libstage_hip.so``
 * ``_lib.py``      ctypes binding of that C-ABI (fails loudly if the library is missing)
 * ``ops.py``       autograd wrappers around the C-ABI entry points
-* ``torch_ops.py`` the same groups as ``torch.ops.stage_hip.*``
+* ``groups.py``    one autograd node per fused-op group (the K-group entry points ``stage_grp_*``): the model's default path
 * ``stage.py``     ``STAGE``: constructor / forward / state_dict compatible with the reference's model/stage.py
 * ``att_host.py``  host side of the supervised-attention loss (reference model/stage.py:344-407)
 * ``parallel.py``  one-process-per-GPU sharding of the batch and of the 5 answer candidates, flat gradient bucket
@@ -15,6 +15,3 @@ Layout (only what the path needs):
 
 Nothing here imports ``oracle/`` (test infrastructure).
 """
-from . import torch_ops as _torch_ops  # noqa: E402
-
-_torch_ops.register()      # torch.ops.stage_hip.* (tvqaplus_amd/torch_ops.py)
