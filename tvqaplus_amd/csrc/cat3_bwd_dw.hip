@@ -305,6 +305,40 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
     };
 
 
+    // LDS-DMA of a tile: wave wv OF EITHER ROLE brings pass wv (8 rows) of dy, b (and a), its 32 mask words; wave 0 / 1 the means / rstds
+    // (the W waves for the first tile of a segment, the E waves -- who have the idle cycles -- for every later one).
+    // Rows past the end of a tensor read zeros (buffer bounds check); rows past the end of their pass are masked on use.
+    const cw_i4 d_dy = cw_rsrc(dy, M * CW_D * 4), d_b = cw_rsrc(b, (RAG ? b_rows : M) * CW_D * 4),
+                d_a = cw_rsrc(a, (RAG ? a_rows : (REP ? M / rep : M)) * CW_D * 4), d_mk = cw_rsrc(rmask, M * (CW_D / 32) * 4),
+                d_mean = cw_rsrc(mean, M * 4), d_rstd = cw_rsrc(rstd, M * 4);
+    const unsigned lds0 = (unsigned)(size_t)(cw_lds_ptr)smem;
+    auto dma_tile = [&](const int (&pb)[4], const int (&pbB)[4], int nb3) {
+        const int pbw = wv == 0 ? pb[0] : (wv == 1 ? pb[1] : (wv == 2 ? pb[2] : pb[3]));
+        const int pbBw = wv == 0 ? pbB[0] : (wv == 1 ? pbB[1] : (wv == 2 ? pbB[2] : pbB[3]));
+        // (every per-lane constant below is re-derived from an OPAQUE copy of the lane id: hoisted out of the tile loop they are a
+        // dozen loop invariants next to 192 accumulator registers -- the allocator parks them in scratch and every reload is a memory
+        // round trip that nothing overlaps in a wave that is alone on its SIMD)
+        const int lane_o = cw_lane();
+        const int l31 = lane_o & 31, h = lane_o >> 5;
+        const int vo = (h * CW_D + 4 * l31) * 4;      // row lane >> 5 of a pair of rows, float4 lane & 31
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            cw_dma16(d_dy, lds0 + CW_OFF_RAW + (8 * wv + 2 * k) * (CW_D * 4), vo, (pbw + 2 * k) * (CW_D * 4));
+            cw_dma16(d_b, lds0 + CW_OFF_BT + nb3 * CW_TILE + (8 * wv + 2 * k) * (CW_D * 4), vo, (pbBw + 2 * k) * (CW_D * 4));
+            if (!REP) cw_dma16(d_a, lds0 + CW_OFF_AT + nb3 * CW_TILE + (8 * wv + 2 * k) * (CW_D * 4), vo, (pbBw + 2 * k) * (CW_D * 4));
+        }
+        // the 4-byte words: 32 per instruction, by the lower lane half only (an inactive lane writes nothing; an active lane whose
+        // offset is out of range would write a ZERO to its slot -- the next array)
+        if (h == 0) {
+            // its own mask words: word lane >> 3 of row lane & 7
+            cw_dma4(d_mk, lds0 + CW_OFF_MK + wv * 128, (int)(((long)(l31 >> 3) * M + (l31 & 7)) * 4), pbw * 4);
+            // per-row statistics of the 32 rows: tile row `lane` = row (lane & 7) of pass lane >> 3
+            const int pr = l31 >> 3;
+            const int prow = (pr == 0 ? pb[0] : (pr == 1 ? pb[1] : (pr == 2 ? pb[2] : pb[3]))) + (l31 & 7);
+            if (wv == 0) cw_dma4(d_mean, lds0 + CW_OFF_MS + nb3 * 256, prow * 4, 0);
+            if (wv == 1) cw_dma4(d_rstd, lds0 + CW_OFF_MS + nb3 * 256 + 128, prow * 4, 0);
+        }
+    };
     if (is_w) {
         // =============================================================================================================
         // W waves: LDS-DMA two tiles ahead, staging + dropout hashes of the next tile, z and the dW product of the previous one
@@ -319,39 +353,6 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
         int E_acc = 254;                                  // scale field the accumulators are held at = running minimum (uniform)
         float dbs[4] = {0.f, 0.f, 0.f, 0.f};
         unsigned kbA0 = 0xffffffu, kbA1 = 0xffffffu, kbN0 = 0xffffffu, kbN1 = 0xffffffu;   // dropout bits: tile whose dW is pending / newest
-        // LDS-DMA of a tile: wave wv brings pass wv (8 rows) of dy, b (and a), its 32 mask words; wave 0 / 1 the means / rstds.
-        // Rows past the end of a tensor read zeros (buffer bounds check); rows past the end of their pass are masked on use.
-        const cw_i4 d_dy = cw_rsrc(dy, M * CW_D * 4), d_b = cw_rsrc(b, (RAG ? b_rows : M) * CW_D * 4),
-                    d_a = cw_rsrc(a, (RAG ? a_rows : (REP ? M / rep : M)) * CW_D * 4), d_mk = cw_rsrc(rmask, M * (CW_D / 32) * 4),
-                    d_mean = cw_rsrc(mean, M * 4), d_rstd = cw_rsrc(rstd, M * 4);
-        const unsigned lds0 = (unsigned)(size_t)(cw_lds_ptr)smem;
-        auto dma_tile = [&](const int (&pb)[4], const int (&pbB)[4], int nb3) {
-            const int pbw = wv == 0 ? pb[0] : (wv == 1 ? pb[1] : (wv == 2 ? pb[2] : pb[3]));
-            const int pbBw = wv == 0 ? pbB[0] : (wv == 1 ? pbB[1] : (wv == 2 ? pbB[2] : pbB[3]));
-            // (every per-lane constant below is re-derived from an OPAQUE copy of the lane id: hoisted out of the tile loop they are a
-            // dozen loop invariants next to 192 accumulator registers -- the allocator parks them in scratch and every reload is a memory
-            // round trip that nothing overlaps in a wave that is alone on its SIMD)
-            const int lane_o = cw_lane();
-            const int l31 = lane_o & 31, h = lane_o >> 5;
-            const int vo = (h * CW_D + 4 * l31) * 4;      // row lane >> 5 of a pair of rows, float4 lane & 31
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                cw_dma16(d_dy, lds0 + CW_OFF_RAW + (8 * wv + 2 * k) * (CW_D * 4), vo, (pbw + 2 * k) * (CW_D * 4));
-                cw_dma16(d_b, lds0 + CW_OFF_BT + nb3 * CW_TILE + (8 * wv + 2 * k) * (CW_D * 4), vo, (pbBw + 2 * k) * (CW_D * 4));
-                if (!REP) cw_dma16(d_a, lds0 + CW_OFF_AT + nb3 * CW_TILE + (8 * wv + 2 * k) * (CW_D * 4), vo, (pbBw + 2 * k) * (CW_D * 4));
-            }
-            // the 4-byte words: 32 per instruction, by the lower lane half only (an inactive lane writes nothing; an active lane whose
-            // offset is out of range would write a ZERO to its slot -- the next array)
-            if (h == 0) {
-                // its own mask words: word lane >> 3 of row lane & 7
-                cw_dma4(d_mk, lds0 + CW_OFF_MK + wv * 128, (int)(((long)(l31 >> 3) * M + (l31 & 7)) * 4), pbw * 4);
-                // per-row statistics of the 32 rows: tile row `lane` = row (lane & 7) of pass lane >> 3
-                const int pr = l31 >> 3;
-                const int prow = (pr == 0 ? pb[0] : (pr == 1 ? pb[1] : (pr == 2 ? pb[2] : pb[3]))) + (l31 & 7);
-                if (wv == 0) cw_dma4(d_mean, lds0 + CW_OFF_MS + nb3 * 256, prow * 4, 0);
-                if (wv == 1) cw_dma4(d_rstd, lds0 + CW_OFF_MS + nb3 * 256 + 128, prow * 4, 0);
-            }
-        };
         // staging of a tile (this wave: its pass): gate by the ReLU bits, one power-of-two scale per row, two fp16 planes, row-major; the
         // bias gradient; the tile's smallest scale field
         auto stage_tile = [&](const int (&nv)[4], int pbuf, int nb3) {
@@ -524,12 +525,6 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
             stage_tile(nv, tc & 1, tc % 3);
             hash_tile(pb);
             publish_bits();
-            if (n_tiles > 1) {
-                int pbn[4], pbBn[4], nvn[4];
-                bool restn;
-                geom(1, pbn, pbBn, nvn, restn);
-                dma_tile(pbn, pbBn, (tc + 1) % 3);
-            }
             // (ONE call site of the product inside the loop -- with a second one the allocator parks all of accW in scratch between
             // them: the last tile of a segment is drained by an extra trip that runs the product only)
             CW_MARK(0);                                   // (segment prologue)
@@ -551,21 +546,12 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
                     hash_tile(pb);
                 }
                 CW_MARK(6);
-                cw_dma_wait();                            // the rows of tile tc + 1 have landed
-                CW_MARK(3);
-                __syncthreads();                          // Bb(it)
+                __syncthreads();                          // Bb(it): the rows of tile tc + 1 have landed (requested and awaited by the E waves)
                 CW_MARK(4);
                 if (it + 1 < n_tiles) {
                     stage_tile(nv, (tc + 1) & 1, (tc + 1) % 3);
                     publish_bits();
                     CW_MARK(5);
-                    if (it + 2 < n_tiles) {
-                        int pbn[4], pbBn[4], nvn[4];
-                        bool restn;
-                        geom(it + 2, pbn, pbBn, nvn, restn);
-                        dma_tile(pbn, pbBn, (tc + 2) % 3);
-                    }
-                    CW_MARK(7);
                 }
                 tc++;
             }
@@ -693,6 +679,14 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
                     mul_b(bfb, ks + 1);
                 }
             }
+            // the LDS-DMA of tile it + 1 (staged by the W waves behind Bb(it)): requested here, behind this tile's weight-fragment loads
+            // (vmcnt retires in order: in front of them it would put an HBM round trip into the product loop), awaited before Bb
+            if (it + 1 < n_tiles) {
+                int pbn[4], pbBn[4], nvn[4];
+                bool restn;
+                geom(it + 1, pbn, pbBn, nvn, restn);
+                dma_tile(pbn, pbBn, (tc + 1) % 3);
+            }
             CW_MARK(3);
             // ---- LayerNorm backward, first half: gradient of the LayerNorm output in true units, row statistics.  Slot r = tile row
             // 8 (r >> 2) + (r & 3) + 4 h, column c of each third; a / b values from the LDS tiles ----
@@ -737,8 +731,9 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
                 *reinterpret_cast<float2*>(stw_h + rl * 2) = make_float2(s1, s2);      // (all 32 lanes of the half: the same value)
                 if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four rows in flight at a time: bounded register pressure
             }
+            cw_dma_wait();
             CW_MARK(4);
-            __syncthreads();                              // Bb: the partial statistics of all four E waves
+            __syncthreads();                              // Bb: the partial statistics of all four E waves; tile it + 1's rows in LDS
             CW_MARK(5);
             // ---- second half: dz and the gradients of a and b ----
 #pragma unroll
