@@ -312,7 +312,9 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
                 d_a = cw_rsrc(a, (RAG ? a_rows : (REP ? M / rep : M)) * CW_D * 4), d_mk = cw_rsrc(rmask, M * (CW_D / 32) * 4),
                 d_mean = cw_rsrc(mean, M * 4), d_rstd = cw_rsrc(rstd, M * 4);
     const unsigned lds0 = (unsigned)(size_t)(cw_lds_ptr)smem;
-    auto dma_tile = [&](const int (&pb)[4], const int (&pbB)[4], int nb3) {
+    // (pieces: bit k < 4 = the row pairs 2 k, 2 k + 1 of the pass, bit 4 = the 4-byte words.  Spreading the pieces over the E waves'
+    // epilogue -- so that the four of them do not queue 48 KB on the CU's address path at once -- cost more in spills than it saved)
+    auto dma_tile = [&](const int (&pb)[4], const int (&pbB)[4], int nb3, int pieces) {
         const int pbw = wv == 0 ? pb[0] : (wv == 1 ? pb[1] : (wv == 2 ? pb[2] : pb[3]));
         const int pbBw = wv == 0 ? pbB[0] : (wv == 1 ? pbB[1] : (wv == 2 ? pbB[2] : pbB[3]));
         // (every per-lane constant below is re-derived from an OPAQUE copy of the lane id: hoisted out of the tile loop they are a
@@ -323,13 +325,14 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
         const int vo = (h * CW_D + 4 * l31) * 4;      // row lane >> 5 of a pair of rows, float4 lane & 31
 #pragma unroll
         for (int k = 0; k < 4; k++) {
+            if (!((pieces >> k) & 1)) continue;
             cw_dma16(d_dy, lds0 + CW_OFF_RAW + (8 * wv + 2 * k) * (CW_D * 4), vo, (pbw + 2 * k) * (CW_D * 4));
             cw_dma16(d_b, lds0 + CW_OFF_BT + nb3 * CW_TILE + (8 * wv + 2 * k) * (CW_D * 4), vo, (pbBw + 2 * k) * (CW_D * 4));
             if (!REP) cw_dma16(d_a, lds0 + CW_OFF_AT + nb3 * CW_TILE + (8 * wv + 2 * k) * (CW_D * 4), vo, (pbBw + 2 * k) * (CW_D * 4));
         }
         // the 4-byte words: 32 per instruction, by the lower lane half only (an inactive lane writes nothing; an active lane whose
         // offset is out of range would write a ZERO to its slot -- the next array)
-        if (h == 0) {
+        if (h == 0 && (pieces & 16)) {
             // its own mask words: word lane >> 3 of row lane & 7
             cw_dma4(d_mk, lds0 + CW_OFF_MK + wv * 128, (int)(((long)(l31 >> 3) * M + (l31 & 7)) * 4), pbw * 4);
             // per-row statistics of the 32 rows: tile row `lane` = row (lane & 7) of pass lane >> 3
@@ -396,13 +399,27 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
             const int l31 = lane_o & 31, h4 = 4 * (lane_o >> 5), c = 32 * wv + l31;
             if (DROP && !(CW_ABL & 4)) {
                 const unsigned drop_lane = (unsigned)(((l31 & 3) + h4) * (K3 / 4) + (c >> 2));
+                // mix64(seed, idx) = finish(seed + (idx + 1) * C0): the three thirds of a pass are idx, idx + D/4, idx + 2 D/4 -- one 64-bit
+                // multiply per pass and two 64-bit adds of constants instead of three multiplies (same values: arithmetic mod 2^64)
+                constexpr uint64_t C0 = 0x9E3779B97F4A7C15ull;
 #pragma unroll 1
-                for (int jt = 0; jt < 12; jt++) {         // pass j = jt / 3, third t = jt % 3
-                    const int j = jt / 3, t = jt - 3 * j;
+                for (int j = 0; j < 4; j++) {             // pass j (rolled: these waves have the time, not the registers)
                     const int pbj = j == 0 ? pb[0] : (j == 1 ? pb[1] : (j == 2 ? pb[2] : pb[3]));
-                    const uint64_t base = (uint64_t)pbj * (uint64_t)(K3 / 4) + (uint64_t)drop_lane + (uint64_t)(t * (CW_D / 4));
-                    const unsigned bits = drop4_bits(seed, base, th) << (12 * (j & 1) + 4 * t);
-                    if (j < 2) w0 |= bits; else w1 |= bits;
+                    const uint64_t zj = seed + ((uint64_t)pbj * (uint64_t)(K3 / 4) + (uint64_t)drop_lane + 1ull) * C0;
+                    unsigned bj = 0u;
+#pragma unroll
+                    for (int t = 0; t < 3; t++) {
+                        uint64_t z = zj + (uint64_t)(t * (CW_D / 4)) * C0;
+                        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+                        const uint64_t hh = z ^ (z >> 31);
+                        const unsigned lo = (unsigned)hh, hi = (unsigned)(hh >> 32);
+                        const unsigned bits = ((lo & 0xFFFFu) >= th ? 1u : 0u) | ((lo >> 16) >= th ? 2u : 0u) | ((hi & 0xFFFFu) >= th ? 4u : 0u) |
+                                              ((hi >> 16) >= th ? 8u : 0u);
+                        bj |= bits << (4 * t);
+                    }
+                    bj <<= 12 * (j & 1);
+                    if (j < 2) w0 |= bj; else w1 |= bj;
                 }
             } else {
                 w0 = w1 = 0xffffffu;
@@ -519,7 +536,7 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
             bool rest, restp = false;
             // prologue: tile 0 of the segment is brought in and staged, tile 1 requested
             geom(0, pb, pbB, nv, rest);
-            dma_tile(pb, pbB, tc % 3);
+            dma_tile(pb, pbB, tc % 3, 31);
             cw_dma_wait();
             __syncthreads();                              // P1 (its mask words / rows are this wave's own; b / a / statistics: for the E waves)
             stage_tile(nv, tc & 1, tc % 3);
@@ -685,7 +702,7 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
                 int pbn[4], pbBn[4], nvn[4];
                 bool restn;
                 geom(it + 1, pbn, pbBn, nvn, restn);
-                dma_tile(pbn, pbBn, (tc + 1) % 3);
+                dma_tile(pbn, pbBn, (tc + 1) % 3, 31);
             }
             CW_MARK(3);
             // ---- LayerNorm backward, first half: gradient of the LayerNorm output in true units, row statistics.  Slot r = tile row
