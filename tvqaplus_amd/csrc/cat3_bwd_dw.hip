@@ -911,11 +911,42 @@ __global__ __launch_bounds__(256) void cw_reduce_seg_kernel(const float* __restr
         st4(out + e * 4, acc);
     }
 }
-// the ordered sums of the workgroup partials
+// the ordered sums of the workgroup partials, ONE launch for the four of them (dW: 50 MB of partials at one workgroup per CU -- the
+// generic 4-byte column reduction took 45 us for it): a workgroup = 64 column quads x 16 interleaved partial groups, 16-byte loads,
+// fixed order (partials b = g, g + 16, ... per group, then the 16 groups in order)
+struct CwFin { const float* src[4]; float* dst[4]; long stride[4]; int quads[4]; int blk0[5]; };
+__global__ __launch_bounds__(1024) void cw_finish_kernel(CwFin f, int nb) {
+    __shared__ float4 sm[16][64];
+    const int x = threadIdx.x & 63, g = threadIdx.x >> 6;
+    int sidx = 0;
+#pragma unroll
+    for (int i = 1; i < 4; i++) sidx = (int)blockIdx.x >= f.blk0[i] ? i : sidx;
+    const int qd = ((int)blockIdx.x - f.blk0[sidx]) * 64 + x;
+    const bool ok = qd < f.quads[sidx];
+    float4 acc = f4zero();
+    if (ok) {
+        const float* p = f.src[sidx] + (size_t)qd * 4;
+#pragma unroll 4
+        for (int b = g; b < nb; b += 16) acc = f4add(acc, ld4(p + (size_t)b * f.stride[sidx]));
+    }
+    sm[g][x] = acc;
+    __syncthreads();
+    if (g == 0 && ok) {
+        float4 t = sm[0][x];
+#pragma unroll
+        for (int j = 1; j < 16; j++) t = f4add(t, sm[j][x]);
+        st4(f.dst[sidx] + (size_t)qd * 4, t);
+    }
+}
 int cw_finish(const CwWs& w, int grid, float* dgamma, float* dbeta, float* dW, float* dc, hipStream_t st) {
-    stage_colreduce2(w.part, dgamma, 2 * CW_K3, CW_K3, w.part + CW_K3, dbeta, 2 * CW_K3, CW_K3, grid, st);
-    STAGE_LAUNCH_CHECK();
-    stage_colreduce2(w.partW, dW, (long)CW_D * CW_K3, CW_D * CW_K3, w.partB, dc, CW_D, CW_D, grid, st);
+    CwFin f;
+    f.src[0] = w.partW; f.dst[0] = dW; f.stride[0] = (long)CW_D * CW_K3; f.quads[0] = CW_D * CW_K3 / 4;
+    f.src[1] = w.partB; f.dst[1] = dc; f.stride[1] = CW_D; f.quads[1] = CW_D / 4;
+    f.src[2] = w.part; f.dst[2] = dgamma; f.stride[2] = 2 * CW_K3; f.quads[2] = CW_K3 / 4;
+    f.src[3] = w.part + CW_K3; f.dst[3] = dbeta; f.stride[3] = 2 * CW_K3; f.quads[3] = CW_K3 / 4;
+    f.blk0[0] = 0;
+    for (int i = 0; i < 4; i++) f.blk0[i + 1] = f.blk0[i] + (f.quads[i] + 63) / 64;
+    hipLaunchKernelGGL(cw_finish_kernel, dim3(f.blk0[4]), dim3(1024), 0, st, f, grid);
     STAGE_LAUNCH_CHECK();
     return 0;
 }
