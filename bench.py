@@ -341,8 +341,8 @@ def k1k2_roofline(args, device, model):
     # priced against the dense fp32 matrix-core peak (the products run as fp16 pairs, three MFMAs each: fp32-equivalent FLOPs)
     flops = 2.0 * U * (3 * D) * D + 2.0 * 2.0 * U * Lr * D
     tf = flops / (avg_ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "K1 + K2 group forward (stage_grp_qa_ctx_fwd: str_attn_fwd + cff_fwd_kernel; the 1.47 GB normalised "
-            "concat is still written once for the weight gradient)", "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s",
+    return {"bound": "mfma", "kernel": "K1 + K2 group forward (stage_grp_qa_ctx_fwd: str_attn_fwd + cff_fwd_kernel; since round 6 the 1.47 GB "
+            "normalised concat is not written: the backward rebuilds it, csrc/cat3_bwd_dw.hip)", "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s",
             "frac": round(tf / 157.3, 4), "flops_fp32_equivalent": flops,
             # the same time against the pipe the instructions actually issue on: three v_mfma_f32_32x32x16_f16 per fp32 product
             "mfma_issued_tflops_f16": round(3.0 * tf, 1), "peak_f16": 2500.0, "frac_of_f16_peak": round(3.0 * tf / 2500.0, 4),
