@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--adam", choices=["fused", "foreach"], default="fused", help="torch.optim.Adam implementation (same update)")
     ap.add_argument("--clip", choices=["flat", "torch"], default="flat", help="clip_grad_norm_(10): on the packed gradient buffer "
                     "(parallel.FlatGradBucket.clip_grad_norm_: one reduction + one multiply) or torch.nn.utils.clip_grad_norm_ (same update)")
+    ap.add_argument("--loss", choices=["fused", "eager"], default="fused", help="the training loop's loss line (main.py:55-60): "
+                    "tvqaplus_amd.stage.reference_loss (one launch forward, the same value) or the eager torch expression (child record eager_loss)")
     ap.add_argument("--dump_steps", action="store_true", help="developer: add every timed step's duration (ms) to the record")
     ap.add_argument("--no_device_time", action="store_true", help="skip the torch.profiler pass behind device_ms_per_step")
     ap.add_argument("--only_roofline", action="store_true")
@@ -92,6 +94,7 @@ def parse():
     return args
 
 
+EAGER_LOSS = False    # --loss fused|eager: the caller's loss line (main.py:55-60) as tvqaplus_amd.stage.reference_loss (one launch) or as the eager torch expression
 CLIP_FLAT = True      # --clip flat|torch: clip_grad_norm_ on the flat gradient buffer (one norm + one multiply) or torch's per-tensor form
 
 
@@ -101,7 +104,11 @@ def train_step(model, batch, bucket, params, optimizer, n_examples, world=1):
     (out, targets), att_loss, _, t_loss, _ = model(batch)
     # main.py:59 -- len(qids) / len(targets) of the gathered batch (N_new is data dependent with add_local)
     scale = (1.0 * n_examples / len(targets)) if world == 1 else parallel.global_loss_scale(n_examples, len(targets), out.device, as_tensor=True)
-    loss = F.cross_entropy(out, targets, reduction="sum") * scale + 0.1 * att_loss + 0.5 * t_loss   # att_weight 0.1, ts_weight 0.5 (config.py)
+    if EAGER_LOSS or out.dtype != torch.float32:
+        loss = F.cross_entropy(out, targets, reduction="sum") * scale + 0.1 * att_loss + 0.5 * t_loss   # att_weight 0.1, ts_weight 0.5 (config.py)
+    else:   # the same value in one launch (tvqaplus_amd.stage.reference_loss; --loss eager runs the line above: child record eager_loss)
+        from tvqaplus_amd.stage import reference_loss
+        loss = reference_loss(out, targets, att_loss, t_loss, n_examples, 0.1, 0.5, scale=scale)
     loss.backward()
     bucket.all_reduce()
     if CLIP_FLAT:
@@ -546,6 +553,11 @@ def side_records(args):
     # item 1) is the default since round 6; this child is the step WITHOUT it (profiles/r06_cat3_dw_ab.txt)
     r = child_bench(shp + ["--sub_words", str(args.sub_words), "--hsz", str(args.hsz), "--steps", "6", "--warmup", "3", "--no_roofline",
                            "--no_device_time"], env={"STAGE_CAT3_DW": "0"})
+    r = child_bench(shp + ["--sub_words", str(args.sub_words), "--hsz", str(args.hsz), "--steps", "6", "--warmup", "3", "--no_roofline",
+                           "--no_device_time", "--loss", "eager"])
+    out["eager_loss"] = ({"ms_per_step": r["ms_per_step"], "value": r["value"],
+                          "note": "--loss eager: the loss line of main.py:55-60 as the eager torch expression (~20 small launches behind the "
+                                  "proposal read-back) instead of tvqaplus_amd.stage.reference_loss"} if "ms_per_step" in r else r)
     out["cat3_dw_off"] = ({"ms_per_step": r["ms_per_step"], "value": r["value"],
                            "note": "STAGE_CAT3_DW=0: forward saves z, cf_bwd_kernel + weight-gradient GEMM on z (the round-5 path)"}
                           if "ms_per_step" in r else r)
@@ -656,8 +668,9 @@ def cpu_baseline(args, opt):
 
 def main():
     args = parse()
-    global CLIP_FLAT
+    global CLIP_FLAT, EAGER_LOSS
     CLIP_FLAT = args.clip == "flat"
+    EAGER_LOSS = args.loss == "eager"
     from tvqaplus_amd import parallel
     from tvqaplus_amd.stage import STAGE
     from tvqaplus_amd.synth import make_batch, make_opt
@@ -956,7 +969,7 @@ def main():
                                                "pairs with algorithmic_bytes of the same launch")
                         if r.get("algorithmic_bytes"):
                             r["traffic_over_algorithmic"] = round(r["traffic"] / float(r["algorithmic_bytes"]), 3)
-        rec["config"]["harness"] = {"gc": args.gc, "adam": args.adam, "clip": args.clip, "ragged_rows": lay is not None,
+        rec["config"]["harness"] = {"gc": args.gc, "adam": args.adam, "clip": args.clip, "loss": args.loss, "ragged_rows": lay is not None,
                                     "branch_streams": int(model.use_streams)}
         if args.storage == "bf16":
             rec["config"]["harness"]["resident_features"] = "fp32" if args.fp32_inputs else "bf16 (as the bf16-staging prefetcher delivers them)"

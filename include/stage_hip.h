@@ -433,6 +433,11 @@ int stage_gt_spans(const float* t_scores, const long long* target, const long lo
  * model's candidate count over all ranks (a target outside [0, na_total) makes the loss NaN; <= 0: cand_offset + NA)        */
 int stage_ts_loss(const float* t_scores, const long long* target, const long long* lab_st, const long long* lab_ed, float* loss,
                   float* grad, float* scratch, int N, int NA, int Li, int cand_offset, int na_total, void* stream);
+/* The caller's loss line (main.py:55-60) in one launch: loss[0] = CE_sum(logits (P, C), targets (P)) * scale + att_w * att_loss[0] +
+ * ts_w * t_loss[0] (att_loss / t_loss may be NULL), dlogits (P, C) = scale * (softmax - onehot) = the gradient of the first term.
+ * scale = scale_dev[0] if scale_dev != NULL (multi-GPU: a device word), else scale_host.  Negative targets are ignored (ignore_index). */
+int stage_train_loss(const float* logits, const long long* targets, const float* att_loss, const float* t_loss, const float* scale_dev,
+                     float scale_host, float att_w, float ts_w, float* loss, float* dlogits, int P, int C, void* stream);
 /* supervised attention loss (model/stage.py:738-745) over M (positive, negative) pairs: flat = 2M int64 indices into scores
  * (positives, then negatives); hinge != 0: max(0, margin + s_neg - s_pos), else log1p(exp(alpha (s_neg - s_pos))).  coef (M) is
  * kept for the backward, which zero-fills dS (n_scores floats) and scatters gout[0] * coef into it.                          */

@@ -312,3 +312,40 @@ def test_gradient_sink_orders_contributions_across_streams(hip_device):
         assert float(res[1].min()) == float(res[1].max()) == 6.0, (trial, float(res[1].min()), float(res[1].max()))
         assert float(res[2].min()) == float(res[2].max()) == 60.0, (trial, float(res[2].min()), float(res[2].max()))
         assert sink.acc == [None, None]
+
+
+@pytest.mark.parametrize("P,C,with_att,with_ts,dev_scale,ignored", [(19, 5, True, True, False, 0), (32, 5, True, False, True, 3),
+                                                                  (1, 5, False, True, False, 0), (300, 7, True, True, False, 11)])
+def test_reference_loss_matches_the_eager_lines(hip_device, P, C, with_att, with_ts, dev_scale, ignored):
+    """tvqaplus_amd.stage.reference_loss (csrc/groups.hip: train_loss_kernel, one launch) against the eager lines of the reference's
+    training loop (main.py:55-60: CrossEntropyLoss(reduction="sum") * len(qids) / len(targets) + weighted side losses): value and
+    every gradient.  fp32 against fp32: 1e-6 relative (the order of the row sums differs)."""
+    from tvqaplus_amd.stage import reference_loss
+    g = torch.Generator().manual_seed(P * 7 + C)
+    logits = (3.0 * torch.randn(P, C, generator=g)).cuda()
+    targets = torch.randint(0, C, (P,), generator=g).cuda()
+    if ignored:
+        targets[torch.randperm(P, generator=g)[:ignored].cuda()] = -100
+    att = torch.rand((), generator=g).cuda() * 4 if with_att else 0
+    ts = torch.rand((), generator=g).cuda() * 9 if with_ts else 0
+    n_examples = 16
+    sc = float(n_examples) / P
+    scale = torch.tensor(sc, device="cuda") if dev_scale else None
+    grads = []
+    for fused in (False, True):
+        x = logits.clone().requires_grad_()
+        a = att.clone().requires_grad_() if with_att else 0
+        t = ts.clone().requires_grad_() if with_ts else 0
+        if fused:
+            loss = reference_loss(x, targets, a, t, n_examples, 0.1, 0.5, scale=scale)
+        else:
+            loss = F.cross_entropy(x, targets, reduction="sum") * (scale if dev_scale else sc) + 0.1 * a + 0.5 * t
+        (loss * 1.7).backward()
+        grads.append((loss.detach(), x.grad, a.grad if with_att else None, t.grad if with_ts else None))
+    (l0, gx0, ga0, gt0), (l1, gx1, ga1, gt1) = grads
+    assert abs(float(l0) - float(l1)) <= 1e-6 * (1 + abs(float(l0)))
+    assert float((gx0 - gx1).abs().max()) <= 1e-6 * (1 + float(gx0.abs().max()))
+    if with_att:
+        assert abs(float(ga0) - float(ga1)) <= 1e-7
+    if with_ts:
+        assert abs(float(gt0) - float(gt1)) <= 1e-7

@@ -12,7 +12,7 @@ print({k:r[k] for k in ("value","ms_per_step","host_issue_ms_per_step","device_m
 for k in ("roofline","roofline_dense","roofline_sub","roofline_bwd","roofline_sub_bwd"):
     if k in r: print(k, {x:r[k].get(x) for x in ("frac","avg_us","algorithmic_bytes","traffic","traffic_over_algorithmic")})
 print("step_roofline", r.get("step_roofline"))
-for k in ("heads4","cat3_dw_off","strong_n2_sim","one_stream","exact_f32","dense","reference_batch","stress"):
+for k in ("heads4","cat3_dw_off","eager_loss","strong_n2_sim","one_stream","exact_f32","dense","reference_batch","stress"):
     v=r.get(k); print(k, {x:v.get(x) for x in ("ms_per_step","value","host_issue_ms_per_step","predicted_8gpu_value","error")} if isinstance(v,dict) else v)
 print("cpu", r.get("cpu_baseline"))
 PY

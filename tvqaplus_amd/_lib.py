@@ -131,6 +131,7 @@ SIGNATURES = {
     "stage_tscores_bwd": (I, [P, P, P, P, I, I, I, P]),
     "stage_gt_spans": (I, [P, P, P, P, P, I, I, I, P]),
     "stage_ts_loss": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "stage_train_loss": (I, [P, P, P, P, P, F, F, F, P, P, I, I, P]),
     "stage_att_loss_fwd": (I, [P, P, LL, I, F, F, P, P, P]),
     "stage_att_loss_bwd": (I, [P, P, P, LL, P, LL, P]),
     "stage_grp_pool_cls_arena_bytes": (SZ, [LL, I, I]),

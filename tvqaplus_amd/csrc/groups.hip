@@ -1216,6 +1216,44 @@ extern "C" int stage_ts_loss(const float* t_scores, const long long* target, con
     STAGE_LAUNCH_CHECK();
     return 0;
 }
+// The caller's loss line (main.py:55-60): loss = CE_sum(logits, targets) * scale + att_w * att_loss + ts_w * t_loss, and the gradient
+// of the cross entropy w.r.t. the logits (scale * (softmax - onehot)) in the same pass -- one launch instead of the ~20 tiny ones of
+// the eager expression and its backward, which arrive one host call at a time right behind the step's only read-back, while the
+// device has nothing else queued (profiles/r06_step_idle_gaps.txt).  One workgroup: P = proposals (<= 2 N), C = candidates.
+// scale: scale_dev[0] if given (multi-GPU: the global N / N_new as a device word), else scale_host.  A target outside [0, C) is
+// ignored like F.cross_entropy's ignore_index (-100) when negative, NaN otherwise (the eager call raises).
+__global__ __launch_bounds__(256) void train_loss_kernel(const float* __restrict__ logits, const long long* __restrict__ targets,
+                                                         const float* __restrict__ att_loss, const float* __restrict__ t_loss,
+                                                         const float* __restrict__ scale_dev, float scale_host, float att_w, float ts_w,
+                                                         float* __restrict__ loss, float* __restrict__ dlogits, int P, int C) {
+    __shared__ float sh[4];
+    const int tid = threadIdx.x;
+    const float scale = scale_dev ? scale_dev[0] : scale_host;
+    float ce = 0.f;
+    for (int r = tid; r < P; r += 256) {
+        const float* x = logits + (long)r * C;
+        float m = -INFINITY;
+        for (int c = 0; c < C; c++) m = fmaxf(m, x[c]);
+        float sum = 0.f;
+        for (int c = 0; c < C; c++) sum += expf(x[c] - m);
+        const float lse = m + logf(sum);
+        const long long t = targets[r];
+        const bool ign = t < 0;
+        for (int c = 0; c < C; c++) dlogits[(long)r * C + c] = ign ? 0.f : scale * (expf(x[c] - lse) - (c == (int)t ? 1.f : 0.f));
+        ce += ign ? 0.f : (t < C ? lse - x[(int)t] : NAN);
+    }
+    ce = block_sum256(ce, sh);
+    if (tid == 0) loss[0] = ce * scale + (att_loss ? att_w * att_loss[0] : 0.f) + (t_loss ? ts_w * t_loss[0] : 0.f);
+}
+extern "C" int stage_train_loss(const float* logits, const long long* targets, const float* att_loss, const float* t_loss,
+                                const float* scale_dev, float scale_host, float att_w, float ts_w, float* loss, float* dlogits, int P, int C,
+                                void* st) {
+    if (P <= 0 || C <= 0 || C > 4096) return STAGE_ERR_SHAPE;
+    hipLaunchKernelGGL(train_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)st, logits, targets, att_loss, t_loss, scale_dev, scale_host,
+                       att_w, ts_w, loss, dlogits, P, C);
+    STAGE_LAUNCH_CHECK();
+    return 0;
+}
 // flat: 2M int64 indices into `scores` (M positives, then M negatives); coef (M) is kept for the backward
 extern "C" int stage_att_loss_fwd(const float* scores, const long long* flat, long long M, int hinge, float alpha, float margin,
                                   float* coef, float* loss, void* st) {

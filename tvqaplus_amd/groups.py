@@ -684,6 +684,39 @@ def ts_loss(t_scores, target, lab_st, lab_ed, cand_offset: int = 0, na_total: in
     return _TsLoss.apply(t_scores, target, lab_st, lab_ed, cand_offset, na_total)
 
 
+class _TrainLoss(torch.autograd.Function):
+    @_on_device
+    def forward(ctx, logits, targets, att_loss, t_loss, scale, att_w: float, ts_w: float):
+        x = _chk(logits, "logits")
+        P, C = x.shape
+        targets = _chk(targets, "targets", torch.int64)
+        dev = x.device
+        att = _chk(att_loss.reshape(1), "att_loss") if torch.is_tensor(att_loss) else None
+        ts = _chk(t_loss.reshape(1), "t_loss") if torch.is_tensor(t_loss) else None
+        sdev = _chk(scale.reshape(1), "scale") if torch.is_tensor(scale) else None
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        grad = torch.empty_like(x)
+        _rc(_lib.load().stage_train_loss(x.data_ptr(), targets.data_ptr(), att.data_ptr() if att is not None else None,
+                                         ts.data_ptr() if ts is not None else None, sdev.data_ptr() if sdev is not None else None,
+                                         0.0 if sdev is not None else float(scale), float(att_w), float(ts_w), loss.data_ptr(),
+                                         grad.data_ptr(), P, C, _stream()), "stage_train_loss")
+        ctx.save_for_backward(grad)
+        ctx.w = (float(att_w) if att is not None else None, float(ts_w) if ts is not None else None)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        aw, tw = ctx.w
+        return grad * g, None, (g * aw if aw is not None else None), (g * tw if tw is not None else None), None, None, None
+
+
+def train_loss(logits, targets, att_loss, t_loss, scale, att_w: float, ts_w: float):
+    """CE_sum(logits, targets) * scale + att_w * att_loss + ts_w * t_loss (main.py:55-60) and the cross entropy's gradient in ONE
+    launch.  att_loss / t_loss: 0-d tensors, or anything else (a Python 0) = absent; scale: float or a 0-d device tensor."""
+    return _TrainLoss.apply(logits, targets, att_loss, t_loss, scale, att_w, ts_w)
+
+
 class _AttLoss(torch.autograd.Function):
     @_on_device
     def forward(ctx, scores, flat, M: int, hinge: bool, alpha: float, margin: float):

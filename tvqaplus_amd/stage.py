@@ -151,6 +151,22 @@ class _ConvLinearParams(nn.Module):
 # ---------------------------------------------------------------------------------------------------------------
 # the model
 # ---------------------------------------------------------------------------------------------------------------
+def reference_loss(outputs, targets, att_loss, temporal_loss, n_examples: int, att_weight: float = 0.1, ts_weight: float = 0.5, scale=None):
+    """The training loss of the reference's driver (main.py:55-60) for the outputs of ``STAGE.forward`` in training mode:
+
+        criterion(outputs, targets) * (len(qids) / len(targets)) + att_weight * att_loss + ts_weight * temporal_loss
+
+    (criterion = CrossEntropyLoss(reduction="sum"), main.py:188) -- in ONE kernel launch forward and one small multiply backward
+    (csrc/groups.hip: train_loss_kernel) instead of the ~20 launches of the eager expression and its autograd nodes.  It matters because
+    of WHERE they sit: right behind the proposal read-back of ``get_proposals``, the one point of the step where the device has nothing
+    queued and waits for the host call by call (profiles/r06_step_idle_gaps.txt).  A drop-in for those four lines of a training loop,
+    optional: the eager lines give the same value (tests/test_hip_groups.py::test_reference_loss_matches_the_eager_lines).
+    ``scale``: overrides len(qids) / len(targets) (multi-GPU: ``parallel.global_loss_scale(..., as_tensor=True)``)."""
+    if scale is None:
+        scale = float(n_examples) / len(targets)
+    return groups.train_loss(outputs, targets, att_loss, temporal_loss, scale, att_weight, ts_weight)
+
+
 def _block_params(blk):
     """[ln.w, ln.b, dw.w, dw.b, pw.w, pw.b] per conv layer + the final LayerNorm's pair of an encoder block, in the order the encoder
     K-groups take them.  Cached on the block (plain attribute): the Parameter OBJECTS never change (``.to()`` / the optimizer update them
