@@ -660,9 +660,6 @@ class STAGE(nn.Module):
             arrived = torch.cuda.Event()
             arrived.record(torch.cuda.current_stream(dev))
             glob, idx_g = groups.masked_max_raw(x, m)       # queued behind the copy: runs while the host reads the spans
-            ea = getattr(self, "_ts_early_args", None)
-            if ea is not None:                              # the temporal loss needs t_scores only: launched before the host waits
-                self._ts_early = (t_scores, self.get_ts_loss(t_scores, ea[0], ea[1], ea[2]))
             arrived.synchronize()
         host = self._span_host.tolist()
         src, wins, inv = [], [], [-1] * (2 * N)
@@ -1063,16 +1060,6 @@ class STAGE(nn.Module):
                 att_pairs = AttPairs(pos, neg, (N, NA, Li_v, batch.qas_mask.shape[-1], Lr_v), batch.vid.device,
                                      getattr(self, "_att_stage", None), target_dev=batch.target if on_dev else None)
                 self._att_stage = att_pairs.stage
-        # The supervised attention loss itself needs the raw scores only: launched HERE, in front of the classifier head, whose proposal
-        # read-back is the one point of the step where the device runs dry (profiles/r06_step_idle_gaps.txt) -- every host call that can
-        # be made before it is one the device does not wait for behind it.  (Same value: the reference computes it after the head.)
-        att_loss_early = None
-        early = os.environ.get("STAGE_LATE_LOSSES") is None     # (developer switch: the reference's order, for the A/B)
-        if early and att_pairs is not None and self.use_sup_att and self.training and self.vfeat_flag and not self.inference_mode:
-            from .att_host import get_att_loss
-            att_loss_early = get_att_loss(self, other_outputs["vid_raw_s"], batch, pairs=att_pairs)
-        self._ts_early = None
-        self._ts_early_args = (batch.ts_label, batch.target, cand_offset) if (early and self.training and not self.inference_mode) else None
         ctx_m = vid_mask if self.vfeat_flag else sub_mask       # the statement mask's context side (model/stage.py:386)
         factors = ((qas_mask != 0).any(-1), ctx_m.sum(-1) != 0)
         out, target, t_scores = self.classfier_head_multi_proposal(
@@ -1094,16 +1081,10 @@ class STAGE(nn.Module):
 
         att_loss = 0
         att_predictions = None
-        if att_loss_early is not None:
-            att_loss, att_predictions = att_loss_early
-        elif self.use_sup_att and self.training and self.vfeat_flag:
+        if self.use_sup_att and self.training and self.vfeat_flag:
             from .att_host import get_att_loss
             att_loss, att_predictions = get_att_loss(self, other_outputs["vid_raw_s"], batch, pairs=att_pairs)
-        ts_early, self._ts_early, self._ts_early_args = self._ts_early, None, None
-        if ts_early is not None and ts_early[0] is t_scores:
-            temporal_loss = ts_early[1]                     # launched in front of the proposal read-back (_proposals_grouped)
-        else:
-            temporal_loss = self.get_ts_loss(t_scores, batch.ts_label, batch.target, cand_offset)
+        temporal_loss = self.get_ts_loss(t_scores, batch.ts_label, batch.target, cand_offset)
         if self.training:
             return [out, target], att_loss, att_predictions, temporal_loss, t_scores, other_outputs
         return out, att_loss, att_predictions, temporal_loss, F.softmax(t_scores, dim=2), other_outputs
