@@ -794,6 +794,8 @@ __global__ __launch_bounds__(256, 3) void cff_fwd_kernel(const float* __restrict
             ra[pass] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, ao, 0, 0);
             rb[pass] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (sj * CF_D + 4 * sl) * 4, (int)((t0 + 8 * pass) * CF_D * 4), 0);
         }
+        // dropout counter of (row t0 + sj, third 0, this lane's column quad): every hash of the tile is this plus a constant (common.h)
+        const uint64_t zlin = mix64_lin(seed, (uint64_t)(t0 + sj) * K4 + (uint64_t)sl);
 #pragma unroll
         for (int pass = 0; pass < 4; pass++) {
             const int rl = 8 * pass + sj;
@@ -827,7 +829,7 @@ __global__ __launch_bounds__(256, 3) void cff_fwd_kernel(const float* __restrict
                 o[t].y = (v[t].y - mu) * rs * gm[t].y + bt[t].y;
                 o[t].z = (v[t].z - mu) * rs * gm[t].z + bt[t].z;
                 o[t].w = (v[t].w - mu) * rs * gm[t].w + bt[t].w;
-                if (DROP) o[t] = f4mul(o[t], drop4(seed, (uint64_t)row * K4 + (uint64_t)(t * D4 + sl), th, inv_keep));
+                if (DROP) o[t] = f4mul(o[t], drop4_fin(zlin + (uint64_t)(pass * 8 * K4 + t * D4) * MIX64_C0, th, inv_keep));   // idx = row * K4 + t * D4 + sl
                 if (!ok) o[t] = f4zero();
                 // z is written once: the weight-gradient GEMM of the backward contracts over it (rows past the end: dropped by bounds).
                 // z == NULL (uniform): the backward rebuilds it (cat3_bwd_dw.hip) -- nothing is stored

@@ -150,6 +150,25 @@ __device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t idx) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
+// mix64 in two stages: the first is LINEAR in idx -- a kernel whose hashes of a tile sit at idx0 + (compile-time constant) pays one 64-bit
+// multiply per tile (mix64_lin) and a 64-bit add of a constant per hash instead of a multiply each:
+//     mix64(seed, idx0 + c) == mix64_fin(mix64_lin(seed, idx0) + c * MIX64_C0)          (arithmetic mod 2^64: the same bits)
+#define MIX64_C0 0x9E3779B97F4A7C15ull
+__device__ __forceinline__ uint64_t mix64_lin(uint64_t seed, uint64_t idx) { return seed + (idx + 1) * MIX64_C0; }
+__device__ __forceinline__ uint64_t mix64_fin(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float4 drop4_fin(uint64_t z_lin, uint32_t thresh16, float inv_keep) {
+    const uint64_t h = mix64_fin(z_lin);
+    float4 m;
+    m.x = ((uint32_t)(h) & 0xFFFFu) >= thresh16 ? inv_keep : 0.f;
+    m.y = ((uint32_t)(h >> 16) & 0xFFFFu) >= thresh16 ? inv_keep : 0.f;
+    m.z = ((uint32_t)(h >> 32) & 0xFFFFu) >= thresh16 ? inv_keep : 0.f;
+    m.w = ((uint32_t)(h >> 48) & 0xFFFFu) >= thresh16 ? inv_keep : 0.f;
+    return m;
+}
 // multipliers (0 or 1/(1-p)) for the 4 elements starting at element index 4*idx4
 __device__ __forceinline__ float4 drop4(uint64_t seed, uint64_t idx4, uint32_t thresh16, float inv_keep) {
     uint64_t h = mix64(seed, idx4);
