@@ -22,6 +22,9 @@
 #include "common.h"
 #include "../../include/stage_hip.h"
 
+#ifndef CFF_ABL
+#define CFF_ABL 0     // the same for cff_fwd_kernel: 1 no weight-fragment loads / MFMAs, 2 no dropout hashes, 4 no y stores
+#endif
 #ifndef CF_ABL
 #define CF_ABL 0      // developer ablation bits (timing only, results wrong): 1 no weight-fragment loads / MFMAs, 2 no LayerNorm epilogue
 #endif                // (statistics + output pass), 4 no staging of the dy tile, 8 output pass without the second a / b read
@@ -829,7 +832,7 @@ __global__ __launch_bounds__(256, 3) void cff_fwd_kernel(const float* __restrict
                 o[t].y = (v[t].y - mu) * rs * gm[t].y + bt[t].y;
                 o[t].z = (v[t].z - mu) * rs * gm[t].z + bt[t].z;
                 o[t].w = (v[t].w - mu) * rs * gm[t].w + bt[t].w;
-                if (DROP) o[t] = f4mul(o[t], drop4_fin(zlin + (uint64_t)(pass * 8 * K4 + t * D4) * MIX64_C0, th, inv_keep));   // idx = row * K4 + t * D4 + sl
+                if (DROP && !(CFF_ABL & 2)) o[t] = f4mul(o[t], drop4_fin(zlin + (uint64_t)(pass * 8 * K4 + t * D4) * MIX64_C0, th, inv_keep));   // idx = row * K4 + t * D4 + sl
                 if (!ok) o[t] = f4zero();
                 // z is written once: the weight-gradient GEMM of the backward contracts over it (rows past the end: dropped by bounds).
                 // z == NULL (uniform): the backward rebuilds it (cat3_bwd_dw.hip) -- nothing is stored
@@ -880,7 +883,7 @@ __global__ __launch_bounds__(256, 3) void cff_fwd_kernel(const float* __restrict
             sf16x8 bfa[4][2], bfb[4][2];
             load_b(bfa, 0);
 #pragma unroll 1
-            for (int kg = 0; kg < CFF_KS / 4; kg += 2) {
+            for (int kg = 0; kg < ((CFF_ABL & 1) ? 0 : CFF_KS / 4); kg += 2) {
                 load_b(bfb, kg + 1);
                 mul_b(bfa, kg, 0);
                 load_b(bfa, kg + 2 < CFF_KS / 4 ? kg + 2 : 0);
@@ -904,7 +907,7 @@ __global__ __launch_bounds__(256, 3) void cff_fwd_kernel(const float* __restrict
         const long mrow = t0 + 4 * h + (l31 & 3) + 8 * ((l31 & 15) >> 2);
         if (l31 < 16 && mrow < M) mask_out[(long)wave * M + mrow] = myw;      // [word][row]
 #pragma unroll
-        for (int r = 0; r < 16; r++)
+        for (int r = 0; r < ((CFF_ABL & 4) ? 1 : 16); r++)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), rs_y, (4 * h * CF_D + n) * 4,
                                                   (int)((t0 + (r & 3) + 8 * (r >> 2)) * CF_D * 4), 0);
     }
