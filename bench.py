@@ -553,14 +553,14 @@ def side_records(args):
     # item 1) is the default since round 6; this child is the step WITHOUT it (profiles/r06_cat3_dw_ab.txt)
     r = child_bench(shp + ["--sub_words", str(args.sub_words), "--hsz", str(args.hsz), "--steps", "6", "--warmup", "3", "--no_roofline",
                            "--no_device_time"], env={"STAGE_CAT3_DW": "0"})
+    out["cat3_dw_off"] = ({"ms_per_step": r["ms_per_step"], "value": r["value"],
+                           "note": "STAGE_CAT3_DW=0: forward saves z, cf_bwd_kernel + weight-gradient GEMM on z (the round-5 path)"}
+                          if "ms_per_step" in r else r)
     r = child_bench(shp + ["--sub_words", str(args.sub_words), "--hsz", str(args.hsz), "--steps", "6", "--warmup", "3", "--no_roofline",
                            "--no_device_time", "--loss", "eager"])
     out["eager_loss"] = ({"ms_per_step": r["ms_per_step"], "value": r["value"],
                           "note": "--loss eager: the loss line of main.py:55-60 as the eager torch expression (~20 small launches behind the "
                                   "proposal read-back) instead of tvqaplus_amd.stage.reference_loss"} if "ms_per_step" in r else r)
-    out["cat3_dw_off"] = ({"ms_per_step": r["ms_per_step"], "value": r["value"],
-                           "note": "STAGE_CAT3_DW=0: forward saves z, cf_bwd_kernel + weight-gradient GEMM on z (the round-5 path)"}
-                          if "ms_per_step" in r else r)
     r = child_bench(shp + ["--config", "stress", "--steps", "3", "--warmup", "2", "--no_device_time"], timeout=300)
     out["stress"] = ({"ms_per_step": r["ms_per_step"], "value": r["value"], "dtype": r.get("dtype"), "workload": r["config"]["workload"],
                       "peak_hbm_gib": r["config"].get("peak_hbm_gib"), "roofline": r.get("roofline")} if "ms_per_step" in r else r)
