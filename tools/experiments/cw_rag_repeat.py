@@ -1,0 +1,53 @@
+"""Repeat-launch determinism of the RAGGED entry point stage_cat3_bwd_dw_rag (mode 3: balanced work table, many short segments per
+workgroup) with a poisoned workspace and other kernels between the launches."""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from tvqaplus_amd import _lib, ragged
+lib = _lib.load()
+D = 128
+rng = np.random.default_rng(int(os.environ.get("SEED", 3)))
+N, NA, Li, Lqa = int(os.environ.get("N", 4)), 5, int(os.environ.get("LI", 48)), 40
+qa = np.zeros((N, NA, Lqa), bool)
+for n in range(N):
+    for ai in range(NA):
+        qa[n, ai, :rng.integers(0, Lqa + 1)] = True
+qa[0, 0, :] = True
+fl = rng.random((N, Li)) < 0.8
+tab = ragged.RaggedTables(qa, fl, 4)
+lay = ragged.RaggedLayout(tab, torch.device("cuda"))
+U, Fc, G = lay.U, lay.Fc, N * NA
+assert lib.stage_cat3_bwd_dw_rag_supported(U, Fc, D, G, Li, Lqa) and lay.wtab is not None
+g = torch.Generator().manual_seed(5)
+dy = torch.randn(U, D, generator=g).cuda(); W = (0.08 * torch.randn(D, 3 * D, generator=g)).cuda(); bias = (0.1 * torch.randn(D, generator=g)).cuda()
+a = torch.randn(G * Lqa, D, generator=g).cuda(); b_fc = torch.randn(Fc, D, generator=g).cuda()
+gamma = (1 + 0.1 * torch.randn(3 * D, generator=g)).cuda(); beta = (0.1 * torch.randn(3 * D, generator=g)).cuda()
+st = torch.cuda.current_stream().cuda_stream
+p = 0.1
+mean = torch.empty(U, device="cuda"); rstd = torch.empty(U, device="cuda"); y = torch.empty(U, D, device="cuda"); mask = torch.zeros(D // 32, U, dtype=torch.int32, device="cuda")
+fwsb = lib.stage_cat3_ln_gemm_fwd_ws_bytes(); fws = torch.empty(fwsb, dtype=torch.uint8, device="cuda")
+_lib.check(lib.stage_cat3_ln_gemm_fwd_rag(a.data_ptr(), b_fc.data_ptr(), gamma.data_ptr(), beta.data_ptr(), W.data_ptr(), bias.data_ptr(), None, mean.data_ptr(), rstd.data_ptr(),
+                                          y.data_ptr(), mask.data_ptr(), lay.rowinfo.data_ptr(), U, G * Lqa, Fc, D, 1e-5, p, 4321, fws.data_ptr(), fwsb, st), "fwd")
+wsb = lib.stage_cat3_bwd_dw_rag_ws_bytes(G, Lqa); ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+names = ("da", "db", "dgamma", "dbeta", "dW", "dc")
+noise_x = torch.randn(2048, 2048, device="cuda")
+def run(t):
+    if os.environ.get("POISON"): ws.view(torch.float32).uniform_(-1e3, 1e3)
+    if os.environ.get("NOISE"):
+        yv = (noise_x * (1.0 + t)) @ noise_x; torch.sort(yv.view(-1)[: 1 << 20]); torch.cumsum(yv, 1)
+    outs = (torch.full((G * Lqa, D), float("nan"), device="cuda"), torch.zeros(Fc, D, device="cuda"), torch.empty(3 * D, device="cuda"),
+            torch.empty(3 * D, device="cuda"), torch.empty(D, 3 * D, device="cuda"), torch.empty(D, device="cuda"))
+    _lib.check(lib.stage_cat3_bwd_dw_rag(dy.data_ptr(), mask.data_ptr(), W.data_ptr(), a.data_ptr(), b_fc.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                         beta.data_ptr(), *[o.data_ptr() for o in outs], lay.gdesc.data_ptr(), lay.wtab.data_ptr(), U, Fc, D, G, Li, Lqa, p, 4321,
+                                         ws.data_ptr(), wsb, st), "bwd rag")
+    torch.cuda.synchronize()
+    return outs
+ref = run(0)
+bad = {}
+for t in range(int(os.environ.get("TRIALS", 100))):
+    cur = run(t + 1)
+    for nm, x, yv in zip(names, ref, cur):
+        if not torch.equal(x, yv):
+            d = (x != yv)
+            rows = d.view(d.shape[0], -1).any(-1).nonzero().flatten() if d.dim() > 1 else d.nonzero().flatten()
+            bad.setdefault(nm, []).append((int(d.sum()), rows[:8].tolist(), float((x - yv).abs().max()), float(x.abs().max())))
+print("U", U, "Fc", Fc, "groups", G, "n_wg", lay.n_wg, "launches that differ:", {k: (len(v), v[:3]) for k, v in bad.items()} or "none")
