@@ -622,3 +622,35 @@ def test_branch_streams_change_nothing_but_the_schedule(hip_device, train, varia
             assert len(cur) == len(ref)
             for i, (a, b) in enumerate(zip(cur, ref)):
                 assert torch.equal(a, b), (rep, level, i)
+
+
+def test_small_ragged_training_step_repeats_bit_for_bit(hip_device):
+    """Sixty training steps of the same small batch from the same state (ragged layout: conftest sets STAGE_RAGGED_MIN_ROWS=0; one or two
+    tiles per workgroup of the persistent `[a,b,a*b]` backward, csrc/cat3_bwd_dw.hip) on ONE stream must give the same bits every time.
+    The kernel tests run that backward at sizes where its two wave roles have comfortable margins between their LDS handoffs; this is
+    the size at which a faster epilogue once came out different in 2-5 % of the steps (DESIGN / docs/findings.md, finding 62)."""
+    from tvqaplus_amd.stage import STAGE
+    from tvqaplus_amd.synth import make_batch, make_opt
+    torch.manual_seed(11)
+    opt = make_opt(hsz=128, embedding_size=96, vfeat_size=64, dropout=0.1, add_local=True, use_sup_att=True)
+    model = STAGE(opt).to(hip_device).train()
+    model.use_streams = 0
+    batch = make_batch(N=4, Li=48, Lr=20, Lw=30, Lqa=40, wd_size=96, vfeat_size=64, seed=3, att_imgs=3, att_words=2).to(hip_device)
+
+    def run():
+        model._seed_state = None
+        for p in model.parameters():
+            p.grad = None
+        torch.manual_seed(5)
+        (out, targets), att_loss, _, t_loss, t_scores, other = model.forward_main(batch)
+        assert model.last_ragged is not None
+        loss = F.cross_entropy(out, targets, reduction="sum") + 0.5 * t_loss + 0.1 * att_loss
+        loss.backward()
+        torch.cuda.synchronize()
+        return [out.detach().clone(), loss.detach().clone()] + [p.grad.clone() for p in model.parameters() if p.grad is not None]
+
+    ref = run()
+    for rep in range(60):
+        cur = run()
+        for i, (a, b) in enumerate(zip(cur, ref)):
+            assert torch.equal(a, b), (rep, i)

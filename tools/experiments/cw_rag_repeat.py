@@ -10,10 +10,10 @@ N, NA, Li, Lqa = int(os.environ.get("N", 4)), 5, int(os.environ.get("LI", 48)), 
 qa = np.zeros((N, NA, Lqa), bool)
 for n in range(N):
     for ai in range(NA):
-        qa[n, ai, :rng.integers(0, Lqa + 1)] = True
+        qa[n, ai, :(Lqa if os.environ.get("FULL") else rng.integers(0, Lqa + 1))] = True
 qa[0, 0, :] = True
 fl = rng.random((N, Li)) < 0.8
-tab = ragged.RaggedTables(qa, fl, 4)
+tab = ragged.RaggedTables(qa, fl, Lqa if os.environ.get("FULL") else 4)
 lay = ragged.RaggedLayout(tab, torch.device("cuda"))
 U, Fc, G = lay.U, lay.Fc, N * NA
 assert lib.stage_cat3_bwd_dw_rag_supported(U, Fc, D, G, Li, Lqa) and lay.wtab is not None
@@ -30,13 +30,21 @@ _lib.check(lib.stage_cat3_ln_gemm_fwd_rag(a.data_ptr(), b_fc.data_ptr(), gamma.d
 wsb = lib.stage_cat3_bwd_dw_rag_ws_bytes(G, Lqa); ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
 names = ("da", "db", "dgamma", "dbeta", "dW", "dc")
 noise_x = torch.randn(2048, 2048, device="cuda")
+side = torch.cuda.Stream()
+big = torch.randn(64 << 20, device="cuda")
 def run(t):
     if os.environ.get("POISON"): ws.view(torch.float32).uniform_(-1e3, 1e3)
     if os.environ.get("NOISE"):
         yv = (noise_x * (1.0 + t)) @ noise_x; torch.sort(yv.view(-1)[: 1 << 20]); torch.cumsum(yv, 1)
-    outs = (torch.full((G * Lqa, D), float("nan"), device="cuda"), torch.zeros(Fc, D, device="cuda"), torch.empty(3 * D, device="cuda"),
+    if os.environ.get("CONC"):
+        with torch.cuda.stream(side):                       # other kernels DURING the launch: HBM and L2 traffic, compute units taken
+            for _ in range(1 + t % 3):
+                big.mul_(1.0000001); (noise_x @ noise_x)
+    alias = bool(os.environ.get("ALIAS"))
+    b_in = b_fc.clone() if alias else b_fc               # the model passes ONE buffer as b and db (the gradient is written over the saved A)
+    outs = (torch.full((G * Lqa, D), float("nan"), device="cuda"), b_in if alias else torch.zeros(Fc, D, device="cuda"), torch.empty(3 * D, device="cuda"),
             torch.empty(3 * D, device="cuda"), torch.empty(D, 3 * D, device="cuda"), torch.empty(D, device="cuda"))
-    _lib.check(lib.stage_cat3_bwd_dw_rag(dy.data_ptr(), mask.data_ptr(), W.data_ptr(), a.data_ptr(), b_fc.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+    _lib.check(lib.stage_cat3_bwd_dw_rag(dy.data_ptr(), mask.data_ptr(), W.data_ptr(), a.data_ptr(), b_in.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
                                          beta.data_ptr(), *[o.data_ptr() for o in outs], lay.gdesc.data_ptr(), lay.wtab.data_ptr(), U, Fc, D, G, Li, Lqa, p, 4321,
                                          ws.data_ptr(), wsb, st), "bwd rag")
     torch.cuda.synchronize()

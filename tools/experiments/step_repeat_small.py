@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from tvqaplus_amd.stage import STAGE
 from tvqaplus_amd.synth import make_batch, make_opt
 torch.manual_seed(11)
-opt = make_opt(hsz=128, embedding_size=96, vfeat_size=64, dropout=0.1, add_local=True, use_sup_att=True)
+kw = dict(input_encoder_n_heads=4, cls_encoder_n_heads=4) if os.environ.get("HEADS") else {}
+opt = make_opt(hsz=128, embedding_size=96, vfeat_size=64, dropout=0.1, add_local=True, use_sup_att=True, **kw)
 model = STAGE(opt).cuda().train()
 batch = make_batch(N=4, Li=48, Lr=20, Lw=30, Lqa=40, wd_size=96, vfeat_size=64, seed=3, att_imgs=3, att_words=2).to("cuda")
 model.use_streams = int(os.environ.get("STREAMS", 0))

@@ -1,5 +1,7 @@
 #!/bin/bash
-export TMPDIR=/tmp
-STAGE_RAGGED_MIN_ROWS=0 TRIALS=300 LEVELS=0 timeout 600 python tools/experiments/step_repeat_small.py 2>&1 | grep -E "repeats that differ" | cut -c1-60
-STAGE_RAGGED_MIN_ROWS=0 NOSYNC=1 TRIALS=300 timeout 600 python tools/experiments/step_repeat_small.py 2>&1 | grep -E "repeats that differ" | cut -c1-60
-for i in 1 2 3 4 5 6 7 8 9 10; do timeout 300 python -m pytest "tests/test_hip_stage.py::test_branch_streams_change_nothing_but_the_schedule" -x -q -k "True-groups" 2>&1 | grep -E "passed|failed" ; done
+export TMPDIR=/tmp STAGE_RAGGED_MIN_ROWS=0
+echo "heads, mixed levels"; HEADS=1 TRIALS=3000 timeout 900 python tools/experiments/step_repeat_small.py 2>&1 | grep -E "repeats that differ" | cut -c1-50
+echo "groups, mixed levels"; TRIALS=3000 timeout 900 python tools/experiments/step_repeat_small.py 2>&1 | grep -E "repeats that differ" | cut -c1-50
+echo "groups, level 0"; LEVELS=0 TRIALS=1500 timeout 900 python tools/experiments/step_repeat_small.py 2>&1 | grep -E "repeats that differ" | cut -c1-50
+timeout 600 python -m pytest tests/test_hip_cat3_dw.py -x -q 2>&1 | tail -1
+REP=300 python tools/cat3_fused_time.py 2>&1 | grep "backward with dW"; REP=1 python tools/cat3_fused_time.py 2>&1 | grep "backward with dW"

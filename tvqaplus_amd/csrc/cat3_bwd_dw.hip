@@ -715,105 +715,77 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
             const float* const sta_h = st_part + h4 * 2;
             const int q = l31 & 3;
 #pragma unroll
-            for (int g4 = 0; g4 < ((CW_ABL & 8) ? 0 : 4); g4++) {
-                // the per-row inputs of the group's four slots are requested TOGETHER and waited for once (a wave alone on its SIMD pays
-                // every LDS round trip it waits for in full: per slot that was two of them, 32 per tile)
-                int upq[4];
-                float muq[4], rsq[4], bq[4], aq[4];
-#pragma unroll
-                for (int q4 = 0; q4 < 4; q4++) {
-                    const int rl = 8 * g4 + q4;           // + 4 h   (slot r = 4 g4 + q4)
-                    upq[q4] = up_h[rl];
-                    muq[q4] = mu_h[rl];
-                    rsq[q4] = mu_h[32 + rl];
-                    bq[q4] = bt_h[rl * CW_D];
-                    aq[q4] = at_h[((REP && MODE >= 2 && rest) ? 32 + q4 : rl) * CW_D];
+            for (int r = 0; r < ((CW_ABL & 8) ? 0 : 16); r++) {
+                const int rl = 8 * (r >> 2) + (r & 3);    // + 4 h
+                const bool valid = h4 < nv[r >> 2] - (r & 3);
+                int upv = up_h[rl];
+                asm volatile("" : "+v"(upv));             // (keeps the load out of the select: no branch per slot)
+                float un = valid ? __builtin_ldexpf(1.0f, 254 - upv - w_up) : 0.f;
+                unsigned bw = 0xfffu;
+                if (DROP) {
+                    bw = cw_quad_bcast(((r >> 3) ? kb1 : kb0) >> (12 * ((r >> 2) & 1)), r & 3) >> q;
+                    un *= inv_keep;
                 }
-                asm volatile("" : "+v"(upq[0]), "+v"(upq[1]), "+v"(upq[2]), "+v"(upq[3]));   // (keeps the loads out of the selects: no branches)
+                const float mu = mu_h[rl], rsv = mu_h[32 + rl];
+                const float rs = valid ? rsv : 0.f;
+                const float bvr = bt_h[rl * CW_D];
+                const float avr = at_h[((REP && MODE >= 2 && rest) ? 32 + (r & 3) : rl) * CW_D];
+                float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int q4 = 0; q4 < 4; q4++) {
-                    const int r = 4 * g4 + q4, rl = 8 * g4 + q4;
-                    const bool valid = h4 < nv[g4] - q4;
-                    float un = valid ? __builtin_ldexpf(1.0f, 254 - upq[q4] - w_up) : 0.f;
-                    unsigned bw = 0xfffu;
-                    if (DROP) {
-                        bw = cw_quad_bcast(((r >> 3) ? kb1 : kb0) >> (12 * ((r >> 2) & 1)), r & 3) >> q;
-                        un *= inv_keep;
-                    }
-                    const float mu = muq[q4];
-                    const float rs = valid ? rsq[q4] : 0.f;
-                    const float bvr = bq[q4], avr = aq[q4];
-                    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                    for (int t = 0; t < 3; t++) {
-                        const float dd = ((bw >> (4 * t)) & 1u) ? acc[t][r] * un : 0.f;
-                        acc[t][r] = dd;
-                        const float x = t == 0 ? avr : (t == 1 ? bvr : avr * bvr);
-                        const float xh = (x - mu) * rs;
-                        const float gq = dd * gm[t];
-                        s1 += gq;
-                        s2 += gq * xh;
-                        ag[t] += dd * xh;
-                        ab[t] += dd;
-                    }
-                    s1 = group_sum(s1, 32);
-                    s2 = group_sum(s2, 32);
-                    *reinterpret_cast<float2*>(stw_h + rl * 2) = make_float2(s1, s2);      // (all 32 lanes of the half: the same value)
+                for (int t = 0; t < 3; t++) {
+                    const float dd = ((bw >> (4 * t)) & 1u) ? acc[t][r] * un : 0.f;
+                    acc[t][r] = dd;
+                    const float x = t == 0 ? avr : (t == 1 ? bvr : avr * bvr);
+                    const float xh = (x - mu) * rs;
+                    const float gq = dd * gm[t];
+                    s1 += gq;
+                    s2 += gq * xh;
+                    ag[t] += dd * xh;
+                    ab[t] += dd;
                 }
-                __builtin_amdgcn_sched_barrier(0);        // four rows in flight at a time: bounded register pressure
+                s1 = group_sum(s1, 32);
+                s2 = group_sum(s2, 32);
+                *reinterpret_cast<float2*>(stw_h + rl * 2) = make_float2(s1, s2);      // (all 32 lanes of the half: the same value)
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four rows in flight at a time: bounded register pressure
             }
             cw_dma_wait();
             CW_MARK(4);
             __syncthreads();                              // Bb: the partial statistics of all four E waves; tile it + 1's rows in LDS
             CW_MARK(5);
-            // ---- second half: dz and the gradients of a and b (inputs of four slots requested together, as above) ----
+            // ---- second half: dz and the gradients of a and b ----
 #pragma unroll
-            for (int g4 = 0; g4 < ((CW_ABL & 8) ? 0 : 4); g4++) {
-                float2 pq[4][4];
-                float muq[4], rsq[4], bq[4], aq[4];
+            for (int r = 0; r < ((CW_ABL & 8) ? 0 : 16); r++) {
+                const int rl = 8 * (r >> 2) + (r & 3);
+                const bool valid = h4 < nv[r >> 2] - (r & 3);
+                float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int q4 = 0; q4 < 4; q4++) {
-                    const int rl = 8 * g4 + q4;
-#pragma unroll
-                    for (int w2 = 0; w2 < 4; w2++) pq[q4][w2] = *reinterpret_cast<const float2*>(sta_h + (w2 * 32 + rl) * 2);
-                    muq[q4] = mu_h[rl];
-                    rsq[q4] = mu_h[32 + rl];
-                    bq[q4] = bt_h[rl * CW_D];
-                    aq[q4] = at_h[((REP && MODE >= 2 && rest) ? 32 + q4 : rl) * CW_D];
+                for (int w2 = 0; w2 < 4; w2++) {          // fixed order: identical totals in all four waves
+                    const float2 p = *reinterpret_cast<const float2*>(sta_h + (w2 * 32 + rl) * 2);
+                    s1 += p.x;
+                    s2 += p.y;
                 }
-                asm volatile("" : "+v"(rsq[0]), "+v"(rsq[1]), "+v"(rsq[2]), "+v"(rsq[3]));
+                s1 *= invK;
+                s2 *= invK;
+                const float mu = mu_h[rl], rsv = mu_h[32 + rl];
+                const float rs = valid ? rsv : 0.f;
+                const float bvr = bt_h[rl * CW_D];
+                const float avr = at_h[((REP && MODE >= 2 && rest) ? 32 + (r & 3) : rl) * CW_D];
+                float dz[3];
 #pragma unroll
-                for (int q4 = 0; q4 < 4; q4++) {
-                    const int r = 4 * g4 + q4;
-                    const bool valid = h4 < nv[g4] - q4;
-                    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                    for (int w2 = 0; w2 < 4; w2++) {      // fixed order: identical totals in all four waves
-                        s1 += pq[q4][w2].x;
-                        s2 += pq[q4][w2].y;
-                    }
-                    s1 *= invK;
-                    s2 *= invK;
-                    const float mu = muq[q4];
-                    const float rs = valid ? rsq[q4] : 0.f;
-                    const float bvr = bq[q4], avr = aq[q4];
-                    float dz[3];
-#pragma unroll
-                    for (int t = 0; t < 3; t++) {
-                        const float x = t == 0 ? avr : (t == 1 ? bvr : avr * bvr);
-                        const float xh = (x - mu) * rs;
-                        dz[t] = rs * (acc[t][r] * gm[t] - s1 - xh * s2);
-                    }
-                    // z = [a, b, a*b]:  da = dz0 + dz2 * b ; db = dz1 + dz2 * a
-                    const float da_v = dz[0] + dz[2] * bvr, db_v = dz[1] + dz[2] * avr;
-                    const int so = pbB[g4] * (CW_D * 4) + q4 * (CW_D * 4);
-                    // an invalid slot (a row of the next frame / past the end) gets an out-of-range lane offset: dropped by the bounds check
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(db_v), rs_db, valid ? vo_row : 0x7ffffff0, so, 0);
-                    if (!REP) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(da_v), rs_da, valid ? vo_row : 0x7ffffff0, so, 0);
-                    else if (MODE >= 2 && rest) dacc_rest[q4] += valid ? da_v : 0.f;
-                    else dacc[r] += valid ? da_v : 0.f;
+                for (int t = 0; t < 3; t++) {
+                    const float x = t == 0 ? avr : (t == 1 ? bvr : avr * bvr);
+                    const float xh = (x - mu) * rs;
+                    dz[t] = rs * (acc[t][r] * gm[t] - s1 - xh * s2);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                // z = [a, b, a*b]:  da = dz0 + dz2 * b ; db = dz1 + dz2 * a
+                const float da_v = dz[0] + dz[2] * bvr, db_v = dz[1] + dz[2] * avr;
+                const int so = pbB[r >> 2] * (CW_D * 4) + (r & 3) * (CW_D * 4);
+                // an invalid slot (a row of the next frame / past the end) gets an out-of-range lane offset: dropped by the bounds check
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(db_v), rs_db, valid ? vo_row : 0x7ffffff0, so, 0);
+                if (!REP) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(da_v), rs_da, valid ? vo_row : 0x7ffffff0, so, 0);
+                else if (MODE >= 2 && rest) dacc_rest[r & 3] += valid ? da_v : 0.f;
+                else dacc[r] += valid ? da_v : 0.f;
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
             CW_MARK(6);
             tc++;
