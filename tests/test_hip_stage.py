@@ -624,20 +624,23 @@ def test_branch_streams_change_nothing_but_the_schedule(hip_device, train, varia
                 assert torch.equal(a, b), (rep, level, i)
 
 
-def test_small_ragged_training_step_repeats_bit_for_bit(hip_device):
+@pytest.mark.parametrize("heads,levels", [(0, (0,)), (0, (2, 4, 3, 1, 0)), (4, (2, 4, 3, 1, 0))])
+def test_small_ragged_training_step_repeats_bit_for_bit(hip_device, heads, levels):
     """Sixty training steps of the same small batch from the same state (ragged layout: conftest sets STAGE_RAGGED_MIN_ROWS=0; one or two
-    tiles per workgroup of the persistent `[a,b,a*b]` backward, csrc/cat3_bwd_dw.hip) on ONE stream must give the same bits every time.
+    tiles per workgroup of the persistent `[a,b,a*b]` backward, csrc/cat3_bwd_dw.hip) must give the same bits every time -- on one stream,
+    with the branch-stream level cycling, and with self-attention encoders (whole 40-word sequences: every group walks rest tiles).
     The kernel tests run that backward at sizes where its two wave roles have comfortable margins between their LDS handoffs; this is
     the size at which a faster epilogue once came out different in 2-5 % of the steps (DESIGN / docs/findings.md, finding 62)."""
     from tvqaplus_amd.stage import STAGE
     from tvqaplus_amd.synth import make_batch, make_opt
     torch.manual_seed(11)
-    opt = make_opt(hsz=128, embedding_size=96, vfeat_size=64, dropout=0.1, add_local=True, use_sup_att=True)
+    kw = dict(input_encoder_n_heads=heads, cls_encoder_n_heads=heads) if heads else {}
+    opt = make_opt(hsz=128, embedding_size=96, vfeat_size=64, dropout=0.1, add_local=True, use_sup_att=True, **kw)
     model = STAGE(opt).to(hip_device).train()
-    model.use_streams = 0
     batch = make_batch(N=4, Li=48, Lr=20, Lw=30, Lqa=40, wd_size=96, vfeat_size=64, seed=3, att_imgs=3, att_words=2).to(hip_device)
 
-    def run():
+    def run(level=0):
+        model.use_streams = level
         model._seed_state = None
         for p in model.parameters():
             p.grad = None
@@ -651,6 +654,6 @@ def test_small_ragged_training_step_repeats_bit_for_bit(hip_device):
 
     ref = run()
     for rep in range(60):
-        cur = run()
+        cur = run(levels[rep % len(levels)])
         for i, (a, b) in enumerate(zip(cur, ref)):
-            assert torch.equal(a, b), (rep, i)
+            assert torch.equal(a, b), (rep, levels[rep % len(levels)], i)

@@ -29,7 +29,10 @@ for t in range(int(os.environ.get("TRIALS", 40))):
     bad = [k for k in ref if not torch.equal(ref[k], cur[k])]
     if bad:
         nbad += 1
-        for k in bad: cnt[k] = cnt.get(k, 0) + 1
+        for k in bad:
+            cnt[k] = cnt.get(k, 0) + 1
+            d = (ref[k] != cur[k]).flatten()
+            if len(bad) <= 3: print("  step", t, "level", model.use_streams, k, "elements", int(d.sum()), "idx", d.nonzero().flatten()[:12].tolist(), "max|diff|", float((ref[k] - cur[k]).abs().max()), "of", float(ref[k].abs().max()))
 print("STAGE_CAT3_DW", os.environ.get("STAGE_CAT3_DW"), "repeats that differ:", nbad, "equal everywhere:", sorted(set(ref) - set(cnt)))
 print("differ:", cnt)
 print("levels", levels)

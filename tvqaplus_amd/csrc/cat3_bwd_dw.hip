@@ -141,26 +141,6 @@ __device__ __forceinline__ int cw_lane() {
     asm volatile("" : "+s"(m));
     return (int)__builtin_amdgcn_mbcnt_hi(m, __builtin_amdgcn_mbcnt_lo(m, 0u));
 }
-// Transposing reduction of EIGHT values over the 32 lanes of a lane half: three halving steps (lane bits 0, 1, 2: a lane keeps the half
-// of the values its bit selects and adds its partner's copy of them), then the plain butterfly over bits 3 and 4.  33 instructions
-// instead of 8 x 10 for eight group_sum(.., 32); lane l ends with the total of value id = 4 (l & 1) + (l & 2) + ((l >> 2) & 1), the
-// same in the four lanes that differ in bits 3 / 4 only.
-__device__ __forceinline__ float cw_xor4(float x) {                 // lane ^ 4 inside a 16-lane row: two bank-masked row shifts
-    unsigned r = __builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x104, 0xf, 0x5, false);   // banks 0, 2 <- lane + 4
-    r = __builtin_amdgcn_update_dpp(r, __float_as_uint(x), 0x114, 0xf, 0xa, false);             // banks 1, 3 <- lane - 4
-    return __uint_as_float(r);
-}
-__device__ __forceinline__ float cw_treduce8(const float (&v)[8], int lane) {
-    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
-    float w[4], x[2];
-#pragma unroll
-    for (int i = 0; i < 4; i++) w[i] = (b0 ? v[i + 4] : v[i]) + dpp_mov<0xB1>(b0 ? v[i] : v[i + 4]);
-#pragma unroll
-    for (int i = 0; i < 2; i++) x[i] = (b1 ? w[i + 2] : w[i]) + dpp_mov<0x4E>(b1 ? w[i] : w[i + 2]);
-    float y = (b2 ? x[1] : x[0]) + cw_xor4(b2 ? x[0] : x[1]);
-    y += dpp_mov<0x128>(y);                                          // row_ror:8 = lane ^ 8 inside the row
-    return xsum16(y, y);
-}
 // developer build -DCW_PROF: shader-clock cycles per phase of workgroup 0's first W wave (slots 0..) and first E wave (16..), read back
 // through stage_cw_prof(); the product build compiles none of it
 #ifdef CW_PROF
@@ -734,7 +714,6 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
             float* const stw_h = st_part + (wv * 32 + h4) * 2;
             const float* const sta_h = st_part + h4 * 2;
             const int q = l31 & 3;
-            float sv[8];
 #pragma unroll
             for (int r = 0; r < ((CW_ABL & 8) ? 0 : 16); r++) {
                 const int rl = 8 * (r >> 2) + (r & 3);    // + 4 h
@@ -764,15 +743,10 @@ __global__ __launch_bounds__(512, 2) void cw_bwd_kernel(const float* __restrict_
                     ag[t] += dd * xh;
                     ab[t] += dd;
                 }
-                sv[2 * (r & 3)] = s1;
-                sv[2 * (r & 3) + 1] = s2;
-                if ((r & 3) == 3) {
-                    // the eight row sums of the group over this half's 32 columns in one transposing reduction; lane -> its value
-                    const int lo = cw_lane();
-                    const int id = 4 * (lo & 1) + (lo & 2) + ((lo >> 2) & 1);          // value id = 2 (r & 3) + (0: s1, 1: s2)
-                    stw_h[16 * (r >> 2) + id] = cw_treduce8(sv, lo);                   // (the four lanes that hold a value store the same word)
-                    __builtin_amdgcn_sched_barrier(0);    // four rows in flight at a time: bounded register pressure
-                }
+                s1 = group_sum(s1, 32);
+                s2 = group_sum(s2, 32);
+                *reinterpret_cast<float2*>(stw_h + rl * 2) = make_float2(s1, s2);      // (all 32 lanes of the half: the same value)
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four rows in flight at a time: bounded register pressure
             }
             cw_dma_wait();
             CW_MARK(4);
