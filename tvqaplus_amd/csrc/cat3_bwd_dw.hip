@@ -841,9 +841,11 @@ void cw_chunks(long long groups, int rep, int mode, int* CH, int* fpc) {
     *CH = (rep + f - 1) / f;
 }
 // ON by default since round 6 (STAGE_CAT3_DW=0 switches back to cf_bwd_kernel + the weight-gradient GEMM on a saved z).  Measured on
-// MI355X at 960 000 rows (profiles/r06_cat3_dw_ab.txt): 1.51 ms (broadcast a) / 1.29 ms (flat) for this launch against 0.92 ms +
+// MI355X at 960 000 rows (profiles/r06_cat3_dw_ab.txt): 1.43 ms (broadcast a) / 1.27 ms (flat) for this launch against 0.92 ms +
 // 0.42-0.56 ms for the two it replaces, and the forward without the z store saves 0.13-0.15 ms more; in the training step (three
-// instances, next to other branches' kernels) 0.1-0.3 ms per step, every configuration of bench.py.  The per-phase cycle counters
+// instances, next to other branches' kernels) 0.4-0.85 ms per step in the round's bench runs.  EVERY change of this kernel goes
+// through tools/experiments/step_repeat_small.py at >= 6000 steps (docs/findings.md, finding 62: two faster epilogue forms lost bit
+// repeatability once in 200 / 2000 training steps and were withdrawn).  The per-phase cycle counters
 // (-DCW_PROF) say where the rest is: one E and one W wave per SIMD are two dependency chains in lock step (two barriers per tile), ~13 us
 // per tile: dX is bound by the L2 bandwidth of the weight image (192 KB per 32 rows), the epilogue, the z rebuild, staging and the
 // hashes by the latency of a single wave with 64 working registers next to its 192 accumulators.  (Read on every call: the tests
