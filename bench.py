@@ -556,7 +556,7 @@ def side_records(args):
     out["cat3_dw_off"] = ({"ms_per_step": r["ms_per_step"], "value": r["value"],
                            "note": "STAGE_CAT3_DW=0: forward saves z, cf_bwd_kernel + weight-gradient GEMM on z (the round-5 path)"}
                           if "ms_per_step" in r else r)
-    r = child_bench(shp + ["--sub_words", str(args.sub_words), "--hsz", str(args.hsz), "--steps", "6", "--warmup", "3", "--no_roofline",
+    r = child_bench(shp + ["--sub_words", str(args.sub_words), "--hsz", str(args.hsz), "--steps", "12", "--warmup", "6", "--no_roofline",
                            "--no_device_time", "--loss", "eager"])
     out["eager_loss"] = ({"ms_per_step": r["ms_per_step"], "value": r["value"],
                           "note": "--loss eager: the loss line of main.py:55-60 as the eager torch expression (~20 small launches behind the "
